@@ -1,0 +1,154 @@
+"""Pin the CPU oracle (oracle/phylk_oracle.c) to golden vectors dumped from the REAL reference.
+
+Known answers (reference AVX build):
+    examples/nucleic GTR+G4 a=1  BioNJ  lnL = -5870.539924060607518
+    examples/proteic LG+G4  a=1  BioNJ  lnL = -12569.851977923575760
+Everything else in tests/golden/*.phyg was produced by oracle/ref_driver.c linked against the
+reference's own objects (tests/golden/make_golden.py holds the commands).
+"""
+import numpy as np
+import pytest
+
+import orc
+from conftest import FIXTURES
+
+KNOWN = {"nucleic_gtr_g4": -5870.539924060607518, "proteic_lg_g4": -12569.851977923575760}
+
+
+@pytest.fixture(scope="module")
+def evaluated(golden):
+    cache = {}
+
+    def get(name, arith=1):
+        key = (name, arith)
+        if key not in cache:
+            d = golden(name)
+            t = orc.tree_from_golden(d, arith=arith)
+            lnl = t.lk(None, both_sides=True)
+            cache[key] = (d, t, lnl, t.c_lnL_sorted.copy(), t.fact_sum_scale.copy(), t.unscaled_site_lk_cat.copy(),
+                          t.cur_site_lk.copy())
+        return cache[key]
+    return get
+
+
+@pytest.mark.parametrize("name", list(KNOWN))
+def test_known_answer_lnl(name, evaluated):
+    d, t, lnl, *_ = evaluated(name)
+    assert abs(lnl - KNOWN[name]) / abs(KNOWN[name]) < 1e-14
+    assert abs(d["lnL"][0] - KNOWN[name]) / abs(KNOWN[name]) < 1e-14
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_tip_encoding(name, golden):
+    d = golden(name)
+    m = orc.Model(d)
+    for k in range(int(d["n_otu"][0])):
+        v, ds, amb = orc.init_tip(m.datatype, d["tip_chars"][k])
+        mask = (v * (1 << np.arange(m.ns))).sum(1).astype(np.int64)
+        assert np.array_equal(mask, d["tip_mask"][k])
+        assert np.array_equal(amb, d["tip_is_ambigu"][k])
+        una = amb == 0
+        assert np.array_equal(ds[una], d["tip_d_state"][k][una])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_pmatrices_bit_exact(name, golden):
+    d = golden(name)
+    t = orc.tree_from_golden(d)
+    npm = d["Pij_rr"].shape[0]
+    assert npm > 0
+    assert np.array_equal(t.pm[:npm], d["Pij_rr"])
+    # rows are renormalised, entries floored at 1e-100 (src/models.c:293-298)
+    assert np.all(t.pm >= 1e-100 * (1 - 1e-12))
+    assert np.allclose(t.pm.sum(-1), 1.0, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_lnl_and_site_outputs(name, evaluated):
+    d, t, lnl, site, fact, unscaled, cur = evaluated(name)
+    w = d["wght"] > 0
+    assert abs(lnl - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-14
+    assert np.array_equal(fact[w], d["fact_sum_scale"][w])
+    assert np.max(np.abs(site[w] - d["c_lnL_sorted"][w])) < 1e-12
+    assert np.allclose(unscaled[w], d["unscaled_site_lk_cat"][w], rtol=1e-13, atol=0)
+    assert np.allclose(cur[w], d["cur_site_lk"][w], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_partials_bit_exact_and_digests(name, evaluated):
+    d, t, *_ = evaluated(name)
+    w = d["wght"] > 0
+    n_full = 0
+    for e in d["full_edges"]:
+        for side, nm in ((0, "left"), (1, "rght")):
+            key = f"p_lk_{nm}_{e}"
+            if key in d:
+                assert np.array_equal(t.plk[(int(e), side)][w], d[key][w]), (name, e, nm)
+                assert np.array_equal(t.scale[(int(e), side)][w], d[f"sum_scale_{nm}_{e}"][w])
+                n_full += 1
+    assert n_full >= 1
+    # every edge side of the tree through its digest (sum, sum of squares, sum of scale exponents)
+    n_chk = 0
+    for e in range(t.ne):
+        for side in (0, 1):
+            if d["side_valid"][e, side]:
+                a = t.plk[(e, side)][w]
+                got = np.array([a.sum(), (a * a).sum(), t.scale[(e, side)][w].sum()])
+                assert np.allclose(got, d["side_digest"][e, side], rtol=1e-11, atol=0), (name, e, side)
+                n_chk += 1
+    assert n_chk == 2 * (t.ne - t.n)   # every internal edge side (tips hold no partial vector)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_lnl_at_every_edge(name, evaluated):
+    """Pulley principle with both sides filled: Lk(b) for every b (src/lk.c:2642-2684)."""
+    d, t, *_ = evaluated(name)
+    got = np.array([t.lk(e, refresh_pmat=False) for e in range(t.ne)])
+    assert np.max(np.abs(got - d["edge_lnL"]) / np.abs(d["edge_lnL"])) < 1e-13
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_eigen_lr_and_dlk(name, evaluated):
+    d, t, *_ = evaluated(name)
+    w = d["wght"] > 0
+    for k, e in enumerate(d["eigen_edges"]):
+        e = int(e)
+        t.lk(e, refresh_pmat=False)          # leaves fact_sum_scale of this edge behind
+        t.update_eigen_lr(e)
+        ref = d[f"dot_prod_{e}"]
+        assert np.allclose(t.dot_prod[w], ref[w], rtol=1e-12, atol=1e-300)
+        assert np.array_equal(t.fact_sum_scale[w], d[f"eig_fact_sum_scale_{e}"][w])
+        for j in range(3):
+            l_in, lnl_ref, dlnl_ref = d["dlk_triples"][k, j]
+            l_out, lnl, dlnl = t.dlk(l_in)
+            assert l_out == l_in
+            assert abs(lnl - lnl_ref) / abs(lnl_ref) < 1e-13
+            assert abs(dlnl - dlnl_ref) <= 1e-10 * max(1.0, abs(dlnl_ref))
+        lnl_e = t.lk_eigen(t.len[e])
+        assert abs(lnl_e - d[f"eig_lnL_{e}"][0]) / abs(lnl_e) < 1e-13
+
+
+@pytest.mark.parametrize("name", ["nucleic_gtr_g4", "synth_aa_90x24"])
+def test_scalar_order_agrees(name, evaluated):
+    """The reference's scalar kernels (no FMA) and its AVX kernels agree to ~1e-15."""
+    d, t, lnl, *_ = evaluated(name, arith=1)
+    _, t0, lnl0, *_ = evaluated(name, arith=0)
+    assert abs(lnl - lnl0) / abs(lnl) < 1e-13
+    assert np.array_equal(t.fact_sum_scale, t0.fact_sum_scale)
+
+
+def test_rescaling_is_exercised(golden):
+    assert set(np.unique(golden("synth_nt_300x40")["fact_sum_scale"])) >= {0, 256, 512}
+    assert 256 in np.unique(golden("synth_aa_90x24")["fact_sum_scale"])
+    assert (golden("nucleic_zero_w")["wght"] == 0).sum() > 50
+    assert golden("nucleic_gtr_g4_inv")["invar_model"][0] == 1
+
+
+def test_update_order_counts(golden):
+    d = golden("nucleic_gtr_g4")
+    t = orc.tree_from_golden(d)
+    t.lk(None, both_sides=False)
+    assert t.n_updates == t.n - 2              # n-2 site-updates per pattern, SURVEY 8d
+    t.n_updates = 0
+    t.lk(None, both_sides=True)
+    assert t.n_updates == 3 * (t.n - 2)
