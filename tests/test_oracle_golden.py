@@ -96,7 +96,7 @@ def test_partials_bit_exact_and_digests(name, evaluated):
                 got = np.array([a.sum(), (a * a).sum(), t.scale[(e, side)][w].sum()])
                 assert np.allclose(got, d["side_digest"][e, side], rtol=1e-11, atol=0), (name, e, side)
                 n_chk += 1
-    assert n_chk == 2 * (t.ne - t.n)   # every internal edge side (tips hold no partial vector)
+    assert n_chk == 3 * (t.n - 2)   # every internal edge side: 2(2n-3) sides minus n tip sides
 
 
 @pytest.mark.parametrize("name", FIXTURES)
