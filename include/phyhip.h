@@ -1,0 +1,223 @@
+/*
+ * phyhip.h -- C ABI of the MI355X-native Felsenstein-pruning likelihood engine (libphyhip.so).
+ *
+ * This is the drop-in boundary of SURVEY.md section 8b: PhyML's only accelerator seam is the
+ * `#ifdef BEAGLE` hook (src/lk.c:1300-1302, :585-587, :2327-2367; src/beagle_utils.c), whose foreign
+ * calls are the BEAGLE C API.  Every entry point below names the call of that seam it replaces
+ * (reference file:line) and keeps its argument order and meaning, so the glue a PhyML maintainer adds
+ * is a rename.  The numerical semantics, however, are those of PhyML's own AVX path
+ * (src/avx.c, src/lk.c) -- in particular PhyML's power-of-two rescaling rule (threshold 2^-256, factor
+ * 2^256, one int per pattern and partial buffer: src/avx.c:460-513) instead of BEAGLE's scale
+ * buffers, the 1e-100 floor / row renormalisation of transition matrices (src/models.c:293-298) and
+ * the [l_min,l_max] clamp of rate-scaled branch lengths (src/lk.c:2296-2300) -- because the parity
+ * target is the AVX path, not BEAGLE (the manual quotes 1e-4 disagreement for the latter).
+ *
+ * Plain C: ints, doubles, pointers and sizes only.  One host thread drives one instance (the
+ * reference is single-threaded and non re-entrant).  All functions return
+ * PHYHIP_SUCCESS (0) or a negative PHYHIP_ERROR_* code; phyhip_get_last_error() gives the text.
+ * The glue prints it and calls Exit(), as src/beagle_utils.c:246-249 does.
+ *
+ * Data layouts (identical to the reference's host buffers, so uploads/downloads are memcpys):
+ *   partials buffer   [pattern][category][state]  double     (t_edge::p_lk_left/p_lk_rght)
+ *   tip partials      [pattern][state]            double 0/1 (t_edge::p_lk_tip_r)
+ *   scale factors     [pattern]                   int        (t_edge::sum_scale_left/rght)
+ *   transition matrix [category][from][to]        double     (t_edge::Pij_rr)
+ *
+ * Buffer index space (as in src/beagle_utils.c:108-113, lk.c:2221-2230): partial-buffer indices
+ * 0..tipCount-1 are the tips, tipCount..partialsBufferCount-1 are internal edge sides.
+ *
+ * Execution model: phyhip_update_partials() only *queues* operations; the queue is flushed as ONE
+ * kernel launch (the whole post-order traversal for every pattern tile) by the first call that needs
+ * results: phyhip_calculate_edge_log_likelihoods*, phyhip_get_*, phyhip_update_eigen_lr,
+ * phyhip_synchronize.  Callers need not know this; results are as if every call were synchronous.
+ */
+#ifndef PHYHIP_H
+#define PHYHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHYHIP_SUCCESS                         0
+#define PHYHIP_ERROR_GENERAL                  (-1)
+#define PHYHIP_ERROR_OUT_OF_MEMORY            (-2)
+#define PHYHIP_ERROR_UNIDENTIFIED_EXCEPTION   (-3)
+#define PHYHIP_ERROR_UNINITIALIZED_INSTANCE   (-4)
+#define PHYHIP_ERROR_OUT_OF_RANGE             (-5)
+#define PHYHIP_ERROR_NO_RESOURCE              (-6)   /* no gfx950 device visible */
+#define PHYHIP_ERROR_NO_IMPLEMENTATION        (-7)
+#define PHYHIP_ERROR_FLOATING_POINT           (-8)
+
+#define PHYHIP_OP_NONE (-1)   /* BEAGLE_OP_NONE */
+
+/* BeagleOperation (src/beagle_utils.c:243).  The two scale-index fields are accepted and ignored:
+   scale vectors are implicit, one per partials buffer, as in PhyML. */
+typedef struct
+{
+  int destinationPartials;
+  int destinationScaleWrite;
+  int destinationScaleRead;
+  int child1Partials;
+  int child1TransitionMatrix;
+  int child2Partials;
+  int child2TransitionMatrix;
+} phyhip_operation;
+
+/* BeagleInstanceDetails (src/beagle_utils.c:84-95) */
+typedef struct
+{
+  int  resourceNumber;     /* HIP device ordinal */
+  char resourceName[64];   /* e.g. "AMD Instinct MI355X" */
+  char implName[64];       /* "phyhip-gfx950" */
+  long flags;
+  int  computeUnits;
+  long long globalMemBytes;
+} phyhip_instance_details;
+
+/* ---- instance lifetime ------------------------------------------------------------------ */
+
+/* replaces beagleCreateInstance, src/beagle_utils.c:119-133.
+   compactBufferCount, scaleBufferCount, preferenceFlags, requirementFlags are accepted for signature
+   compatibility; resourceList[0] (if given) is the HIP device ordinal, else env PHYHIP_DEVICE, else 0.
+   Returns the instance id (>= 0) or a negative error. */
+int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
+                           int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
+                           int scaleBufferCount, const int *resourceList, int resourceCount,
+                           long preferenceFlags, long requirementFlags, phyhip_instance_details *returnInfo);
+
+/* replaces beagleFinalizeInstance, src/beagle_utils.c:266 */
+int phyhip_finalize_instance(int instance);
+
+const char *phyhip_get_last_error(void);
+
+/* ---- inputs ---------------------------------------------------------------------------------- */
+
+/* replaces beagleSetTipPartials, src/beagle_utils.c:153.  inPartials is [pattern][state] with 0/1
+   entries (src/lk.c:26-161); it is stored on the device as one byte per pattern (an index into a
+   table of allowed-state masks).  Entries other than 0 and 1 are rejected (PHYHIP_ERROR_OUT_OF_RANGE). */
+int phyhip_set_tip_partials(int instance, int tipIndex, const double *inPartials);
+
+/* replaces beagleSetTipStates (BEAGLE compact form): state in [0,stateCount) or >= stateCount for a
+   fully ambiguous character. */
+int phyhip_set_tip_states(int instance, int tipIndex, const int *inStates);
+
+/* replaces beagleSetPartials: upload an internal partials buffer ([pattern][category][state]). */
+int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials);
+
+/* replaces beagleSetPatternWeights, src/beagle_utils.c:165 (re-callable: bootstrap re-weights,
+   src/utilities.c:3945-3955).  Patterns with weight <= DBL_MIN are skipped in every sum. */
+int phyhip_set_pattern_weights(int instance, const double *inPatternWeights);
+
+/* replaces beagleSetCategoryRates / beagleSetCategoryWeights, src/beagle_utils.c:281-305 */
+int phyhip_set_category_rates(int instance, const double *inCategoryRates);
+int phyhip_set_category_weights(int instance, int categoryWeightsIndex, const double *inCategoryWeights);
+
+/* replaces beagleSetStateFrequencies, src/beagle_utils.c:322-325 */
+int phyhip_set_state_frequencies(int instance, int stateFrequenciesIndex, const double *inStateFrequencies);
+
+/* replaces beagleSetEigenDecomposition, src/beagle_utils.c:383-386.  inEigenVectors = r_e_vect,
+   inInverseEigenVectors = l_e_vect (row-major [state][state]); inEigenValues are the RAW eigenvalues
+   of Q (mod->eigen->e_val, src/models.c:275 -- the log() in beagle_utils.c:376 is stale). */
+int phyhip_set_eigen_decomposition(int instance, int eigenIndex, const double *inEigenVectors,
+                                   const double *inInverseEigenVectors, const double *inEigenValues);
+
+/* PhyML-specific knobs the BEAGLE API has no slot for.
+   l_min,l_max: mod->l_min/l_max (src/init.c:711-714); br_len_mult: mod->br_len_mult->v;
+   apply_lk_scaling: tree->apply_lk_scaling (src/utilities.h:993). */
+int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br_len_mult, int apply_lk_scaling);
+
+/* +I model: mod->ras->invar, mod->ras->pinvar->v, data->invar[pattern] (src/lk.c:820-842,1226-1273).
+   invar may be NULL when invar_model == 0. */
+int phyhip_set_invariant_sites(int instance, int invar_model, double pinvar, const short *invar);
+
+/* ---- transition matrices --------------------------------------------------------------------- */
+
+/* replaces beagleUpdateTransitionMatrices, src/lk.c:2344.  For each i < count builds, on the device,
+   all categories of matrix probabilityIndices[i] for edge length edgeLengths[i] (= b->l->v; the MAX(0,.)
+   x rate x br_len_mult product and the clamp of src/lk.c:2296-2300 are applied here), with the
+   floor / renormalise post-processing of src/models.c:293-298.  Derivative indices must be NULL. */
+int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *probabilityIndices,
+                                      const int *firstDerivativeIndices, const int *secondDerivativeIndices,
+                                      const double *edgeLengths, int count);
+
+/* replaces beagleSetTransitionMatrix, src/lk.c:2360: upload b->Pij_rr ([category][from][to]) as computed
+   by the host's own PMat() -- the bit-exact route. */
+int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *inMatrix, double paddedValue);
+
+/* replaces beagleGetTransitionMatrix, src/lk.c:2351 */
+int phyhip_get_transition_matrix(int instance, int matrixIndex, double *outMatrix);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+
+/* replaces beagleUpdatePartials, src/beagle_utils.c:245 (i.e. the body of Update_Partial_Lk,
+   src/lk.c:1300-1302 -> src/avx.c:301-522).  Operations are executed in order; an operation may read
+   the destination of an earlier one.  cumulativeScaleIndex is ignored. */
+int phyhip_update_partials(int instance, const phyhip_operation *operations, int operationCount,
+                           int cumulativeScaleIndex);
+
+/* replaces beagleCalculateEdgeLogLikelihoods, src/beagle_utils.c:344 (i.e. the site loop of Lk(),
+   src/lk.c:590-645 + Lk_Core :767-861).  count must be 1.  parentBufferIndices[0] is b->p_lk_left,
+   childBufferIndices[0] the right side (tip index if b->rght->tax), probabilityIndices[0] b->Pij_rr.
+   Derivative outputs must be NULL (PhyML differentiates in the eigen basis: phyhip_calculate_eigen_*). */
+int phyhip_calculate_edge_log_likelihoods(int instance, const int *parentBufferIndices,
+                                          const int *childBufferIndices, const int *probabilityIndices,
+                                          const int *firstDerivativeIndices, const int *secondDerivativeIndices,
+                                          const int *categoryWeightsIndices, const int *stateFrequenciesIndices,
+                                          const int *cumulativeScaleIndices, int count,
+                                          double *outSumLogLikelihood, double *outSumFirstDerivative,
+                                          double *outSumSecondDerivative);
+
+/* Same evaluation, but the per-shard sum stays in device memory (deviceOut[0] = lnL) and the call does
+   not synchronise: the multi-GPU path all-reduces deviceOut over RCCL on the same stream. */
+int phyhip_calculate_edge_log_likelihoods_device(int instance, int parentBufferIndex, int childBufferIndex,
+                                                 int probabilityIndex, double *deviceOut);
+
+/* replaces beagleGetSiteLogLikelihoods, src/beagle_utils.c:355 (log-likelihood per pattern,
+   tree->c_lnL_sorted) */
+int phyhip_get_site_log_likelihoods(int instance, double *outLogLikelihoods);
+
+/* The other per-pattern outputs of Lk_Core that host readers use (src/lk.c:855-857, 2791, 2801);
+   any pointer may be NULL. */
+int phyhip_get_site_outputs(int instance, double *c_lnL_sorted, double *cur_site_lk,
+                            double *unscaled_site_lk_cat, int *fact_sum_scale);
+
+/* replaces beagleGetPartials, src/beagle_utils.c:252 (download hook for ancestral.c, cv.c, m4.c ...) */
+int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *outPartials);
+
+/* sum_scale_left/rght of a partials buffer ([pattern] ints) */
+int phyhip_get_scale_factors(int instance, int bufferIndex, int *outScaleFactors);
+int phyhip_set_scale_factors(int instance, int bufferIndex, const int *inScaleFactors);
+
+/* tree->numerical_warning of the last edge evaluation (src/lk.c:847-851) */
+int phyhip_get_numerical_warning(int instance, int *outWarning);
+
+/* ---- eigen-basis branch-length derivative (no BEAGLE counterpart in the seam) ---------------- */
+
+/* Update_Eigen_Lr(b,tree), src/lk.c:1038-1114 / src/avx.c:21-105: fills the instance's dot_prod
+   [pattern][category][state] from the two sides of an edge (either side may be a tip). */
+int phyhip_update_eigen_lr(int instance, int leftBufferIndex, int rightBufferIndex);
+
+/* dLk(&l,b,tree), src/lk.c:655-753: clamps *l to [l_min,l_max], returns lnL and dlnL/dl from dot_prod
+   and the fact_sum_scale left by the preceding edge evaluation. */
+int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, double *outDLnL);
+
+/* Lk(b,tree) with use_eigen_lr == YES, src/lk.c:592-603,625-629,866-950 */
+int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL);
+
+int phyhip_get_dot_prod(int instance, double *outDotProd);
+
+/* ---- stream / timing plumbing ---------------------------------------------------------------- */
+
+/* Run on the caller's HIP stream (e.g. torch's current stream) instead of the instance's own. */
+int phyhip_set_stream(int instance, void *hipStream);
+int phyhip_synchronize(int instance);
+
+/* Kernel timing with HIP events on the instance's stream, around the traversal kernel only.
+   enable != 0 starts (and resets) accumulation. */
+int phyhip_profile(int instance, int enable);
+int phyhip_profile_read(int instance, double *outTraversalMs, int *outLaunches, double *outSiteUpdates);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYHIP_H */

@@ -1,0 +1,233 @@
+"""ctypes binding of libphyhip.so (the C ABI in include/phyhip.h).
+
+Python is only the test / benchmark harness here; the product is the shared library.  Loading fails
+loudly when the library has not been built (`python -c 'import __graft_entry__ as g; g.build()'`);
+there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libphyhip.so")
+
+
+class PhyhipError(RuntimeError):
+    pass
+
+
+class Operation(C.Structure):
+    _fields_ = [("destinationPartials", C.c_int), ("destinationScaleWrite", C.c_int), ("destinationScaleRead", C.c_int),
+                ("child1Partials", C.c_int), ("child1TransitionMatrix", C.c_int),
+                ("child2Partials", C.c_int), ("child2TransitionMatrix", C.c_int)]
+
+
+class InstanceDetails(C.Structure):
+    _fields_ = [("resourceNumber", C.c_int), ("resourceName", C.c_char * 64), ("implName", C.c_char * 64),
+                ("flags", C.c_long), ("computeUnits", C.c_int), ("globalMemBytes", C.c_longlong)]
+
+
+# every symbol include/phyhip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "phyhip_create_instance", "phyhip_finalize_instance", "phyhip_get_last_error", "phyhip_set_tip_partials",
+    "phyhip_set_tip_states", "phyhip_set_partials", "phyhip_set_pattern_weights", "phyhip_set_category_rates",
+    "phyhip_set_category_weights", "phyhip_set_state_frequencies", "phyhip_set_eigen_decomposition",
+    "phyhip_set_phyml_options", "phyhip_set_invariant_sites", "phyhip_update_transition_matrices",
+    "phyhip_set_transition_matrix", "phyhip_get_transition_matrix", "phyhip_update_partials",
+    "phyhip_calculate_edge_log_likelihoods", "phyhip_calculate_edge_log_likelihoods_device",
+    "phyhip_get_site_log_likelihoods", "phyhip_get_site_outputs", "phyhip_get_partials", "phyhip_get_scale_factors",
+    "phyhip_set_scale_factors", "phyhip_get_numerical_warning", "phyhip_update_eigen_lr",
+    "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
+    "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PhyhipError(f"{LIB_PATH} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        L = C.CDLL(LIB_PATH)
+        L.phyhip_get_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc < 0:
+        raise PhyhipError(f"phyhip error {rc}: {load().phyhip_get_last_error().decode()}")
+    return rc
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Instance:
+    """Thin object wrapper: one method per C entry point, numpy in / numpy out."""
+
+    def __init__(self, tip_count, partials_buffer_count, state_count, pattern_count, matrix_buffer_count,
+                 category_count, device=None):
+        L = load()
+        self.L = L
+        self.tips, self.nbuf, self.S, self.P, self.nmat, self.C = (tip_count, partials_buffer_count, state_count,
+                                                                  pattern_count, matrix_buffer_count, category_count)
+        self.details = InstanceDetails()
+        res = (C.c_int * 1)(device if device is not None else 0)
+        self.id = _chk(L.phyhip_create_instance(tip_count, partials_buffer_count, 0, state_count, pattern_count, 1,
+                                                matrix_buffer_count, category_count, 0,
+                                                res if device is not None else None, 1 if device is not None else 0,
+                                                C.c_long(0), C.c_long(0), C.byref(self.details)))
+
+    def close(self):
+        if self.id is not None:
+            self.L.phyhip_finalize_instance(self.id)
+            self.id = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs
+    def set_tip_partials(self, tip, partials):
+        a = _f64(partials); assert a.size == self.P * self.S
+        _chk(self.L.phyhip_set_tip_partials(self.id, tip, _ptr(a)))
+
+    def set_tip_states(self, tip, states):
+        a = np.ascontiguousarray(states, dtype=np.int32); assert a.size == self.P
+        _chk(self.L.phyhip_set_tip_states(self.id, tip, _ptr(a)))
+
+    def set_partials(self, buf, partials):
+        a = _f64(partials); assert a.size == self.P * self.C * self.S
+        _chk(self.L.phyhip_set_partials(self.id, buf, _ptr(a)))
+
+    def set_pattern_weights(self, w):
+        a = _f64(w); assert a.size == self.P
+        _chk(self.L.phyhip_set_pattern_weights(self.id, _ptr(a)))
+
+    def set_category_rates(self, r):
+        a = _f64(r); assert a.size == self.C
+        _chk(self.L.phyhip_set_category_rates(self.id, _ptr(a)))
+
+    def set_category_weights(self, w):
+        a = _f64(w); assert a.size == self.C
+        _chk(self.L.phyhip_set_category_weights(self.id, 0, _ptr(a)))
+
+    def set_state_frequencies(self, pi):
+        a = _f64(pi); assert a.size == self.S
+        _chk(self.L.phyhip_set_state_frequencies(self.id, 0, _ptr(a)))
+
+    def set_eigen_decomposition(self, evec, ivec, evals):
+        a, b, c = _f64(evec), _f64(ivec), _f64(evals)
+        assert a.size == self.S * self.S and b.size == self.S * self.S and c.size == self.S
+        _chk(self.L.phyhip_set_eigen_decomposition(self.id, 0, _ptr(a), _ptr(b), _ptr(c)))
+
+    def set_phyml_options(self, l_min=1e-8, l_max=100.0, br_len_mult=1.0, apply_lk_scaling=1):
+        _chk(self.L.phyhip_set_phyml_options(self.id, C.c_double(l_min), C.c_double(l_max), C.c_double(br_len_mult),
+                                             int(apply_lk_scaling)))
+
+    def set_invariant_sites(self, invar_model, pinvar, invar):
+        a = None if invar is None else np.ascontiguousarray(invar, dtype=np.int16)
+        _chk(self.L.phyhip_set_invariant_sites(self.id, int(invar_model), C.c_double(pinvar), _ptr(a)))
+
+    # -- matrices
+    def update_transition_matrices(self, indices, lengths):
+        i = np.ascontiguousarray(indices, dtype=np.int32); l = _f64(lengths); assert i.size == l.size
+        _chk(self.L.phyhip_update_transition_matrices(self.id, 0, _ptr(i), None, None, _ptr(l), int(i.size)))
+
+    def set_transition_matrix(self, idx, mat):
+        a = _f64(mat); assert a.size == self.C * self.S * self.S
+        _chk(self.L.phyhip_set_transition_matrix(self.id, int(idx), _ptr(a), C.c_double(0.0)))
+
+    def get_transition_matrix(self, idx):
+        out = np.zeros((self.C, self.S, self.S))
+        _chk(self.L.phyhip_get_transition_matrix(self.id, int(idx), _ptr(out)))
+        return out
+
+    # -- hot path
+    def update_partials(self, ops):
+        """ops: iterable of (dest, child1, pm1, child2, pm2)."""
+        ops = list(ops)
+        arr = (Operation * len(ops))()
+        for k, (d, c1, m1, c2, m2) in enumerate(ops):
+            arr[k] = Operation(d, -1, -1, c1, m1, c2, m2)
+        _chk(self.L.phyhip_update_partials(self.id, arr, len(ops), -1))
+
+    def edge_lnl(self, parent, child, pm):
+        out = C.c_double(0)
+        p = (C.c_int * 1)(parent); c = (C.c_int * 1)(child); m = (C.c_int * 1)(pm); z = (C.c_int * 1)(0)
+        _chk(self.L.phyhip_calculate_edge_log_likelihoods(self.id, p, c, m, None, None, z, z, None, 1, C.byref(out), None, None))
+        return out.value
+
+    def edge_lnl_device(self, parent, child, pm, device_ptr):
+        _chk(self.L.phyhip_calculate_edge_log_likelihoods_device(self.id, parent, child, pm, C.c_void_p(device_ptr)))
+
+    def site_log_likelihoods(self):
+        out = np.zeros(self.P)
+        _chk(self.L.phyhip_get_site_log_likelihoods(self.id, _ptr(out)))
+        return out
+
+    def site_outputs(self):
+        a = np.zeros(self.P); b = np.zeros(self.P); c = np.zeros((self.P, self.C)); f = np.zeros(self.P, np.int32)
+        _chk(self.L.phyhip_get_site_outputs(self.id, _ptr(a), _ptr(b), _ptr(c), _ptr(f)))
+        return a, b, c, f
+
+    def get_partials(self, buf):
+        out = np.zeros((self.P, self.C * self.S))
+        _chk(self.L.phyhip_get_partials(self.id, int(buf), -1, _ptr(out)))
+        return out
+
+    def get_scale_factors(self, buf):
+        out = np.zeros(self.P, np.int32)
+        _chk(self.L.phyhip_get_scale_factors(self.id, int(buf), _ptr(out)))
+        return out
+
+    def numerical_warning(self):
+        w = C.c_int(0)
+        _chk(self.L.phyhip_get_numerical_warning(self.id, C.byref(w)))
+        return w.value
+
+    # -- eigen basis
+    def update_eigen_lr(self, left, rght):
+        _chk(self.L.phyhip_update_eigen_lr(self.id, int(left), int(rght)))
+
+    def eigen_lnl_dlnl(self, l):
+        lv = C.c_double(l); a = C.c_double(0); b = C.c_double(0)
+        _chk(self.L.phyhip_calculate_eigen_lnl_dlnl(self.id, C.byref(lv), C.byref(a), C.byref(b)))
+        return lv.value, a.value, b.value
+
+    def eigen_lnl(self, l):
+        a = C.c_double(0)
+        _chk(self.L.phyhip_calculate_eigen_lnl(self.id, C.c_double(l), C.byref(a)))
+        return a.value
+
+    def get_dot_prod(self):
+        out = np.zeros((self.P, self.C * self.S))
+        _chk(self.L.phyhip_get_dot_prod(self.id, _ptr(out)))
+        return out
+
+    # -- plumbing
+    def set_stream(self, stream_handle):
+        _chk(self.L.phyhip_set_stream(self.id, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        _chk(self.L.phyhip_synchronize(self.id))
+
+    def profile(self, enable):
+        _chk(self.L.phyhip_profile(self.id, int(enable)))
+
+    def profile_read(self):
+        ms = C.c_double(0); n = C.c_int(0); u = C.c_double(0)
+        _chk(self.L.phyhip_profile_read(self.id, C.byref(ms), C.byref(n), C.byref(u)))
+        return ms.value, n.value, u.value

@@ -1,0 +1,928 @@
+// phyhip.hip -- host side of libphyhip.so: instance table, device memory, the deferred operation
+// queue and the C ABI declared in include/phyhip.h.  gfx950 only; no CPU fallback: every entry point
+// fails with PHYHIP_ERROR_NO_RESOURCE when no device is visible.
+#include "../../include/phyhip.h"
+#include "phyhip_kernels.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace phyhip;
+
+namespace
+{
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+  char    buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(call)                                                                                         \
+  do                                                                                                         \
+  {                                                                                                          \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ != hipSuccess)                                                                                    \
+      return fail(e_ == hipErrorOutOfMemory ? PHYHIP_ERROR_OUT_OF_MEMORY : PHYHIP_ERROR_GENERAL,             \
+                  "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);                 \
+  } while (0)
+
+// Pinned staging ring for small host->device payloads (operation lists, transition matrices, edge
+// lengths).  A chunk is recycled only after the copies issued from it have executed.
+struct StagingRing
+{
+  static constexpr int kChunks = 8;
+  size_t               chunk_bytes = 0;
+  char                *base        = nullptr;
+  hipEvent_t           ev[kChunks];
+  bool                 pending[kChunks];
+  int                  cur  = 0;
+  size_t               used = 0;
+
+  int init(size_t bytes)
+  {
+    chunk_bytes = (bytes + 255) & ~size_t(255);
+    HIPCHK(hipHostMalloc((void **)&base, chunk_bytes * kChunks, hipHostMallocDefault));
+    for (int i = 0; i < kChunks; ++i)
+    {
+      HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+      pending[i] = false;
+    }
+    return 0;
+  }
+  void destroy()
+  {
+    if (!base) return;
+    for (int i = 0; i < kChunks; ++i) (void)hipEventDestroy(ev[i]);
+    (void)hipHostFree(base);
+    base = nullptr;
+  }
+  // reserve `bytes` (<= chunk_bytes) of pinned memory that stays valid until the stream reaches `seal`
+  int alloc(size_t bytes, hipStream_t s, void **out)
+  {
+    bytes = (bytes + 15) & ~size_t(15);
+    if (bytes > chunk_bytes) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "staging request of %zu bytes too large", bytes);
+    if (used + bytes > chunk_bytes)
+    {
+      HIPCHK(hipEventRecord(ev[cur], s));
+      pending[cur] = true;
+      cur          = (cur + 1) % kChunks;
+      used         = 0;
+      if (pending[cur])
+      {
+        HIPCHK(hipEventSynchronize(ev[cur]));
+        pending[cur] = false;
+      }
+    }
+    *out = base + (size_t)cur * chunk_bytes + used;
+    used += bytes;
+    return 0;
+  }
+};
+
+struct Instance
+{
+  int         dev        = 0;
+  hipStream_t stream     = nullptr;
+  bool        own_stream = true;
+  int         tips = 0, nbuf = 0, S = 0, C = 0, CP = 0, nmat = 0;
+  long long   P = 0;
+
+  double   *d_partials = nullptr;
+  int      *d_scales   = nullptr;
+  uint8_t  *d_tipcodes = nullptr;
+  uint32_t *d_masks    = nullptr;
+  double   *d_pmats    = nullptr;
+  double   *d_wght     = nullptr;
+  short    *d_invar    = nullptr;
+  double   *d_model    = nullptr; // pi[S] catw[C] catr[C] eval[S] evec[S*S] ivec[S*S]
+  double   *d_pi, *d_catw, *d_catr, *d_eval, *d_evec, *d_ivec;
+  double   *d_site_lnl = nullptr, *d_site_lk = nullptr, *d_site_cat = nullptr, *d_dot = nullptr;
+  int      *d_fact     = nullptr;
+  double   *d_block    = nullptr; // [2][grid]
+  double   *d_result   = nullptr; // [2]
+  double   *h_result   = nullptr; // pinned, device-visible
+  int      *d_warn     = nullptr;
+  int      *h_warn     = nullptr;
+  void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
+  int       pm_scratch_cap = 0;
+  DevOp    *d_ops      = nullptr; // ring of op lists on the device
+  int       ops_cap = 0, ops_slots = 4, ops_slot = 0;
+  int       grid = 0;
+
+  std::vector<DevOp>                     pending;
+  std::vector<unsigned char>             mat_in_queue; // matrix index referenced by a queued op
+  std::vector<uint32_t>                  masks;
+  std::unordered_map<uint32_t, int>      mask_code;
+  bool                                   masks_dirty = false;
+  std::vector<double>                    h_rates, h_eval;
+  StagingRing                            ring;
+
+  double l_min = 1.e-8, l_max = 100., br_len_mult = 1.0, pinvar = 0.0; // src/init.c:711-714
+  int    apply_scaling = 1, invar_model = 0;
+  bool   want_site_outputs = true;
+
+  bool       prof = false;
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pairs;
+  double     prof_ms = 0.0, prof_updates = 0.0;
+  int        prof_n = 0;
+};
+
+std::mutex              g_mu;
+std::vector<Instance *> g_inst;
+
+Instance *get(int id)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (id < 0 || id >= (int)g_inst.size()) return nullptr;
+  return g_inst[id];
+}
+
+#define GET_INST(I, id)                                                                                      \
+  Instance *I = get(id);                                                                                     \
+  if (!I) return fail(PHYHIP_ERROR_UNINITIALIZED_INSTANCE, "instance %d does not exist", id);                 \
+  HIPCHK(hipSetDevice(I->dev))
+
+int next_pow2(int x)
+{
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+size_t buf_elems(const Instance *I) { return (size_t)I->P * I->C * I->S; }
+
+TreeParams base_params(Instance *I)
+{
+  TreeParams q;
+  memset(&q, 0, sizeof q);
+  q.partials = I->d_partials; q.scales = I->d_scales; q.tip_codes = I->d_tipcodes; q.code_masks = I->d_masks;
+  q.pmats = I->d_pmats; q.wght = I->d_wght; q.P = I->P; q.C = I->C; q.tip_count = I->tips;
+  q.apply_scaling = I->apply_scaling; q.pi = I->d_pi; q.cat_w = I->d_catw; q.invar_model = I->invar_model;
+  q.pinvar = I->pinvar; q.invar = I->d_invar; q.block_sums = I->d_block; q.warn = I->d_warn; q.fact = I->d_fact;
+  return q;
+}
+
+template <typename F> int dispatch_shape(const Instance *I, F &&f)
+{
+  // (S, CP) instantiations: nucleotides / amino acids x category count padded to a power of two
+#define CASE(S_, CP_)                                                                                        \
+  if (I->S == S_ && I->CP == CP_) return f(std::integral_constant<int, S_>(), std::integral_constant<int, CP_>());
+  CASE(4, 1) CASE(4, 2) CASE(4, 4) CASE(4, 8) CASE(20, 1) CASE(20, 2) CASE(20, 4) CASE(20, 8)
+#undef CASE
+  return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "no kernel for %d states x %d categories", I->S, I->C);
+}
+
+int upload_masks(Instance *I)
+{
+  if (!I->masks_dirty) return 0;
+  if (I->masks.size() > 256) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "more than 256 distinct tip state sets");
+  HIPCHK(hipMemcpyAsync(I->d_masks, I->masks.data(), I->masks.size() * sizeof(uint32_t), hipMemcpyHostToDevice, I->stream));
+  HIPCHK(hipStreamSynchronize(I->stream));
+  I->masks_dirty = false;
+  return 0;
+}
+
+struct EdgeEval
+{
+  int     parent, child, pm;
+  double *dev_out;  // optional user device pointer
+  bool    to_host;
+};
+
+// Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
+int flush(Instance *I, const EdgeEval *ee)
+{
+  const int n_ops = (int)I->pending.size();
+  if (n_ops == 0 && !ee) return 0;
+  int rc = upload_masks(I);
+  if (rc) return rc;
+
+  TreeParams q = base_params(I);
+  if (n_ops > 0)
+  {
+    void *st = nullptr;
+    rc = I->ring.alloc(sizeof(DevOp) * n_ops, I->stream, &st);
+    if (rc) return rc;
+    memcpy(st, I->pending.data(), sizeof(DevOp) * n_ops);
+    DevOp *dst = I->d_ops + (size_t)I->ops_slot * I->ops_cap;
+    I->ops_slot = (I->ops_slot + 1) % I->ops_slots;
+    HIPCHK(hipMemcpyAsync(dst, st, sizeof(DevOp) * n_ops, hipMemcpyHostToDevice, I->stream));
+    q.ops = dst;
+    q.n_ops = n_ops;
+  }
+  if (ee)
+  {
+    q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
+    if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
+    HIPCHK(hipMemsetAsync(I->d_warn, 0, sizeof(int), I->stream));
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (I->prof)
+  {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, I->stream));
+  }
+  rc = dispatch_shape(I, [&](auto s, auto cp) {
+    constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    hipLaunchKernelGGL((traverse_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q);
+    return 0;
+  });
+  if (rc) return rc;
+  if (I->prof)
+  {
+    HIPCHK(hipEventRecord(e1, I->stream));
+    I->prof_pairs.emplace_back(e0, e1);
+    I->prof_updates += (double)n_ops * (double)I->P;
+  }
+  HIPCHK(hipGetLastError());
+  if (ee)
+  {
+    double *out = ee->dev_out ? ee->dev_out : I->d_result;
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 1,
+                       I->grid, out, ee->to_host ? I->h_result : (double *)nullptr);
+    HIPCHK(hipGetLastError());
+  }
+  I->pending.clear();
+  std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
+  return 0;
+}
+
+int flush_sync(Instance *I)
+{
+  int rc = flush(I, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(I->stream));
+  return 0;
+}
+
+int check_partial_index(const Instance *I, int idx, bool allow_tip)
+{
+  if (idx < 0 || idx >= I->nbuf || (!allow_tip && idx < I->tips))
+    return fail(PHYHIP_ERROR_OUT_OF_RANGE, "partials buffer index %d out of range [%d,%d)", idx, allow_tip ? 0 : I->tips, I->nbuf);
+  return 0;
+}
+
+int collect_profile(Instance *I)
+{
+  for (auto &pr : I->prof_pairs)
+  {
+    HIPCHK(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    I->prof_ms += ms;
+    I->prof_n += 1;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  I->prof_pairs.clear();
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *phyhip_get_last_error(void) { return g_err.c_str(); }
+
+int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
+                           int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
+                           int scaleBufferCount, const int *resourceList, int resourceCount, long preferenceFlags,
+                           long requirementFlags, phyhip_instance_details *returnInfo)
+{
+  (void)compactBufferCount; (void)eigenBufferCount; (void)scaleBufferCount; (void)preferenceFlags; (void)requirementFlags;
+  if (tipCount < 2 || partialsBufferCount <= tipCount || patternCount < 1 || matrixBufferCount < 1 || categoryCount < 1)
+    return fail(PHYHIP_ERROR_OUT_OF_RANGE, "bad instance dimensions");
+  if (stateCount != 4 && stateCount != 20)
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "stateCount %d: only 4 (nt) and 20 (aa) are built", stateCount);
+  if (categoryCount > 8) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "categoryCount %d > 8", categoryCount);
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(PHYHIP_ERROR_NO_RESOURCE, "no HIP device visible: libphyhip has no CPU fallback");
+  int dev = 0;
+  if (resourceList && resourceCount > 0) dev = resourceList[0];
+  else if (const char *e = getenv("PHYHIP_DEVICE")) dev = atoi(e);
+  if (dev < 0 || dev >= ndev) return fail(PHYHIP_ERROR_NO_RESOURCE, "device %d not present (%d visible)", dev, ndev);
+  HIPCHK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, dev));
+
+  Instance *I = new Instance();
+  I->dev = dev; I->tips = tipCount; I->nbuf = partialsBufferCount; I->S = stateCount; I->C = categoryCount;
+  I->CP = next_pow2(categoryCount); I->P = patternCount; I->nmat = matrixBufferCount;
+  HIPCHK(hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking));
+
+  const size_t n_int = (size_t)(I->nbuf - I->tips);
+  const size_t be    = buf_elems(I);
+  HIPCHK(hipMalloc((void **)&I->d_partials, n_int * be * sizeof(double)));
+  HIPCHK(hipMemset(I->d_partials, 0, n_int * be * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_scales, n_int * I->P * sizeof(int)));
+  HIPCHK(hipMemset(I->d_scales, 0, n_int * I->P * sizeof(int)));
+  HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->P));
+  HIPCHK(hipMemset(I->d_tipcodes, 0, (size_t)I->tips * I->P));
+  HIPCHK(hipMalloc((void **)&I->d_masks, 256 * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void **)&I->d_pmats, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
+  HIPCHK(hipMemset(I->d_pmats, 0, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_wght, I->P * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_invar, I->P * sizeof(short)));
+  HIPCHK(hipMemset(I->d_invar, 0xff, I->P * sizeof(short)));
+  {
+    std::vector<double> ones((size_t)I->P, 1.0);
+    HIPCHK(hipMemcpy(I->d_wght, ones.data(), I->P * sizeof(double), hipMemcpyHostToDevice));
+  }
+  const size_t model_doubles = (size_t)2 * I->S + 2 * I->C + 2 * (size_t)I->S * I->S;
+  HIPCHK(hipMalloc((void **)&I->d_model, model_doubles * sizeof(double)));
+  HIPCHK(hipMemset(I->d_model, 0, model_doubles * sizeof(double)));
+  I->d_pi = I->d_model; I->d_catw = I->d_pi + I->S; I->d_catr = I->d_catw + I->C; I->d_eval = I->d_catr + I->C;
+  I->d_evec = I->d_eval + I->S; I->d_ivec = I->d_evec + (size_t)I->S * I->S;
+  I->h_rates.assign(I->C, 1.0);
+  I->h_eval.assign(I->S, 0.0);
+  HIPCHK(hipMalloc((void **)&I->d_site_lnl, I->P * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_site_lk, I->P * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_site_cat, (size_t)I->P * I->C * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_fact, I->P * sizeof(int)));
+  HIPCHK(hipMemset(I->d_fact, 0, I->P * sizeof(int)));
+  HIPCHK(hipMalloc((void **)&I->d_dot, be * sizeof(double)));
+  HIPCHK(hipMemset(I->d_dot, 0, be * sizeof(double)));
+
+  I->grid = (int)(((long long)I->P * I->CP + 255) / 256);
+  HIPCHK(hipMalloc((void **)&I->d_block, (size_t)2 * I->grid * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_result, 2 * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **)&I->h_result, 2 * sizeof(double), hipHostMallocMapped));
+  HIPCHK(hipMalloc((void **)&I->d_warn, sizeof(int)));
+  HIPCHK(hipMemset(I->d_warn, 0, sizeof(int)));
+  HIPCHK(hipHostMalloc((void **)&I->h_warn, sizeof(int), hipHostMallocDefault));
+
+  I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
+  HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
+  I->ops_cap = 2 * I->nbuf + 8;
+  HIPCHK(hipMalloc((void **)&I->d_ops, (size_t)I->ops_slots * I->ops_cap * sizeof(DevOp)));
+  size_t chunk = std::max<size_t>(64 * 1024, std::max(sizeof(DevOp) * (size_t)I->ops_cap,
+                                                       (size_t)I->C * I->S * I->S * sizeof(double) * 4));
+  int rc = I->ring.init(chunk);
+  if (rc) return rc;
+  I->mat_in_queue.assign(I->nmat, 0);
+
+  // codes 0..S-1 are the single states
+  for (int s = 0; s < I->S; ++s)
+  {
+    I->masks.push_back(1u << s);
+    I->mask_code[1u << s] = s;
+  }
+  I->masks_dirty = true;
+
+  if (returnInfo)
+  {
+    memset(returnInfo, 0, sizeof *returnInfo);
+    returnInfo->resourceNumber = dev;
+    snprintf(returnInfo->resourceName, sizeof returnInfo->resourceName, "%s", prop.name);
+    snprintf(returnInfo->implName, sizeof returnInfo->implName, "phyhip-%s", prop.gcnArchName);
+    returnInfo->computeUnits   = prop.multiProcessorCount;
+    returnInfo->globalMemBytes = (long long)prop.totalGlobalMem;
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (size_t i = 0; i < g_inst.size(); ++i)
+    if (!g_inst[i])
+    {
+      g_inst[i] = I;
+      return (int)i;
+    }
+  g_inst.push_back(I);
+  return (int)g_inst.size() - 1;
+}
+
+int phyhip_finalize_instance(int instance)
+{
+  GET_INST(I, instance);
+  (void)hipStreamSynchronize(I->stream);
+  collect_profile(I);
+  void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
+                  I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
+                  I->d_pmscratch};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (I->h_result) (void)hipHostFree(I->h_result);
+  if (I->h_warn) (void)hipHostFree(I->h_warn);
+  I->ring.destroy();
+  if (I->own_stream && I->stream) (void)hipStreamDestroy(I->stream);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_inst[instance] = nullptr;
+  }
+  delete I;
+  return PHYHIP_SUCCESS;
+}
+
+// ---- inputs --------------------------------------------------------------------------------------
+
+static int set_tip_codes(Instance *I, int tip, const std::vector<uint8_t> &codes)
+{
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(I->d_tipcodes + (size_t)tip * I->P, codes.data(), (size_t)I->P, hipMemcpyHostToDevice));
+  return upload_masks(I);
+}
+
+static int code_for_mask(Instance *I, uint32_t m, int *code)
+{
+  auto it = I->mask_code.find(m);
+  if (it != I->mask_code.end())
+  {
+    *code = it->second;
+    return 0;
+  }
+  if (I->masks.size() >= 256) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "more than 256 distinct tip state sets");
+  *code = (int)I->masks.size();
+  I->masks.push_back(m);
+  I->mask_code[m] = *code;
+  I->masks_dirty  = true;
+  return 0;
+}
+
+int phyhip_set_tip_partials(int instance, int tipIndex, const double *inPartials)
+{
+  GET_INST(I, instance);
+  if (tipIndex < 0 || tipIndex >= I->tips) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip index %d", tipIndex);
+  std::vector<uint8_t> codes((size_t)I->P);
+  for (long long p = 0; p < I->P; ++p)
+  {
+    uint32_t m = 0;
+    for (int s = 0; s < I->S; ++s)
+    {
+      const double x = inPartials[(size_t)p * I->S + s];
+      if (x == 1.0) m |= 1u << s;
+      else if (x != 0.0)
+        return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip %d pattern %lld state %d: partial %g is not 0 or 1", tipIndex, p, s, x);
+    }
+    int code = 0;
+    int rc   = code_for_mask(I, m, &code);
+    if (rc) return rc;
+    codes[(size_t)p] = (uint8_t)code;
+  }
+  return set_tip_codes(I, tipIndex, codes);
+}
+
+int phyhip_set_tip_states(int instance, int tipIndex, const int *inStates)
+{
+  GET_INST(I, instance);
+  if (tipIndex < 0 || tipIndex >= I->tips) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip index %d", tipIndex);
+  std::vector<uint8_t> codes((size_t)I->P);
+  const uint32_t       full = (I->S == 32) ? 0xffffffffu : ((1u << I->S) - 1u);
+  for (long long p = 0; p < I->P; ++p)
+  {
+    const int st = inStates[p];
+    int       code = st;
+    if (st < 0 || st >= I->S)
+    {
+      int rc = code_for_mask(I, full, &code);
+      if (rc) return rc;
+    }
+    codes[(size_t)p] = (uint8_t)code;
+  }
+  return set_tip_codes(I, tipIndex, codes);
+}
+
+int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials)
+{
+  GET_INST(I, instance);
+  int rc = check_partial_index(I, bufferIndex, false);
+  if (rc) return rc;
+  rc = flush_sync(I);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), inPartials, buf_elems(I) * sizeof(double),
+                   hipMemcpyHostToDevice));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_set_pattern_weights(int instance, const double *w)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(I->d_wght, w, I->P * sizeof(double), hipMemcpyHostToDevice));
+  return PHYHIP_SUCCESS;
+}
+
+static int small_upload(Instance *I, double *dst, const double *src, size_t n)
+{
+  int rc = flush_sync(I); // model blocks change rarely; keep it simple and ordered
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_set_category_rates(int instance, const double *r)
+{
+  GET_INST(I, instance);
+  I->h_rates.assign(r, r + I->C);
+  return small_upload(I, I->d_catr, r, I->C);
+}
+
+int phyhip_set_category_weights(int instance, int idx, const double *w)
+{
+  GET_INST(I, instance);
+  if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "categoryWeightsIndex must be 0");
+  return small_upload(I, I->d_catw, w, I->C);
+}
+
+int phyhip_set_state_frequencies(int instance, int idx, const double *pi)
+{
+  GET_INST(I, instance);
+  if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "stateFrequenciesIndex must be 0");
+  return small_upload(I, I->d_pi, pi, I->S);
+}
+
+int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, const double *ivec, const double *eval)
+{
+  GET_INST(I, instance);
+  if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
+  I->h_eval.assign(eval, eval + I->S);
+  int rc = small_upload(I, I->d_evec, evec, (size_t)I->S * I->S);
+  if (rc) return rc;
+  rc = small_upload(I, I->d_ivec, ivec, (size_t)I->S * I->S);
+  if (rc) return rc;
+  return small_upload(I, I->d_eval, eval, I->S);
+}
+
+int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br_len_mult, int apply_lk_scaling)
+{
+  GET_INST(I, instance);
+  int rc = flush(I, nullptr);
+  if (rc) return rc;
+  I->l_min = l_min; I->l_max = l_max; I->br_len_mult = br_len_mult; I->apply_scaling = apply_lk_scaling ? 1 : 0;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_set_invariant_sites(int instance, int invar_model, double pinvar, const short *invar)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  I->invar_model = invar_model ? 1 : 0;
+  I->pinvar      = pinvar;
+  if (invar) HIPCHK(hipMemcpy(I->d_invar, invar, I->P * sizeof(short), hipMemcpyHostToDevice));
+  else if (invar_model) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "invar_model set but invar == NULL");
+  return PHYHIP_SUCCESS;
+}
+
+// ---- transition matrices ---------------------------------------------------------------------------
+
+static int matrices_touch(Instance *I, const int *idx, int count)
+{
+  for (int i = 0; i < count; ++i)
+  {
+    if (idx[i] < 0 || idx[i] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", idx[i]);
+    if (I->mat_in_queue[idx[i]])
+    { // a queued operation still reads the old matrix: launch the queue first (stream order does the rest)
+      int rc = flush(I, nullptr);
+      if (rc) return rc;
+      break;
+    }
+  }
+  return 0;
+}
+
+int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *probabilityIndices,
+                                      const int *firstDerivativeIndices, const int *secondDerivativeIndices,
+                                      const double *edgeLengths, int count)
+{
+  GET_INST(I, instance);
+  if (eigenIndex != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
+  if (firstDerivativeIndices || secondDerivativeIndices)
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "derivative matrices are not used by PhyML's path (see phyhip_calculate_eigen_lnl_dlnl)");
+  if (count <= 0) return PHYHIP_SUCCESS;
+  int rc = matrices_touch(I, probabilityIndices, count);
+  if (rc) return rc;
+  // stage indices + lengths through the pinned ring into a device scratch (stream order keeps
+  // back-to-back calls from clobbering each other)
+  int done = 0;
+  while (done < count)
+  {
+    const int    n  = std::min(count - done, I->pm_scratch_cap);
+    void        *st = nullptr;
+    const size_t bi = (sizeof(int) * n + 15) & ~size_t(15), bl = sizeof(double) * n;
+    rc = I->ring.alloc(bi + bl, I->stream, &st);
+    if (rc) return rc;
+    memcpy(st, probabilityIndices + done, sizeof(int) * n);
+    memcpy((char *)st + bi, edgeLengths + done, bl);
+    HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
+    PmatParams q;
+    q.indices = (const int *)I->d_pmscratch; q.lengths = (const double *)((char *)I->d_pmscratch + bi); q.count = n;
+    q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
+    q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
+    const int threads = std::min(256, ((I->C * I->S + 63) / 64) * 64);
+    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), sizeof(double) * I->C * I->S, I->stream, q);
+    HIPCHK(hipGetLastError());
+    done += n;
+  }
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *inMatrix, double paddedValue)
+{
+  (void)paddedValue;
+  GET_INST(I, instance);
+  int rc = matrices_touch(I, &matrixIndex, 1);
+  if (rc) return rc;
+  const size_t bytes = (size_t)I->C * I->S * I->S * sizeof(double);
+  void        *st    = nullptr;
+  rc = I->ring.alloc(bytes, I->stream, &st);
+  if (rc) return rc;
+  memcpy(st, inMatrix, bytes);
+  HIPCHK(hipMemcpyAsync(I->d_pmats + (size_t)matrixIndex * I->C * I->S * I->S, st, bytes, hipMemcpyHostToDevice, I->stream));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_transition_matrix(int instance, int matrixIndex, double *outMatrix)
+{
+  GET_INST(I, instance);
+  if (matrixIndex < 0 || matrixIndex >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", matrixIndex);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(outMatrix, I->d_pmats + (size_t)matrixIndex * I->C * I->S * I->S, (size_t)I->C * I->S * I->S * sizeof(double),
+                   hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
+// ---- hot path --------------------------------------------------------------------------------------
+
+int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int cumulativeScaleIndex)
+{
+  (void)cumulativeScaleIndex;
+  GET_INST(I, instance);
+  for (int i = 0; i < n; ++i)
+  {
+    const phyhip_operation &o = ops[i];
+    int rc = check_partial_index(I, o.destinationPartials, false);
+    if (rc) return rc;
+    if ((rc = check_partial_index(I, o.child1Partials, true))) return rc;
+    if ((rc = check_partial_index(I, o.child2Partials, true))) return rc;
+    if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= I->nmat || o.child2TransitionMatrix < 0 ||
+        o.child2TransitionMatrix >= I->nmat)
+      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "operation %d: matrix index out of range", i);
+    if ((int)I->pending.size() >= I->ops_cap)
+    {
+      rc = flush(I, nullptr);
+      if (rc) return rc;
+    }
+    I->pending.push_back(DevOp{o.destinationPartials, o.child1Partials, o.child2Partials, o.child1TransitionMatrix,
+                               o.child2TransitionMatrix, 0});
+    I->mat_in_queue[o.child1TransitionMatrix] = 1;
+    I->mat_in_queue[o.child2TransitionMatrix] = 1;
+  }
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const int *child, const int *pm, const int *d1,
+                                          const int *d2, const int *cw, const int *sf, const int *cs, int count,
+                                          double *outSum, double *outD1, double *outD2)
+{
+  (void)cs;
+  GET_INST(I, instance);
+  if (count != 1) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "count must be 1");
+  if (d1 || d2 || outD1 || outD2)
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "derivatives: use phyhip_calculate_eigen_lnl_dlnl (PhyML's dLk path)");
+  if ((cw && cw[0] != 0) || (sf && sf[0] != 0)) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "weights/frequencies index must be 0");
+  int rc = check_partial_index(I, parent[0], true);
+  if (rc) return rc;
+  if ((rc = check_partial_index(I, child[0], true))) return rc;
+  if (pm[0] < 0 || pm[0] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm[0]);
+  EdgeEval ee{parent[0], child[0], pm[0], nullptr, true};
+  rc = flush(I, &ee);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(I->h_warn, I->d_warn, sizeof(int), hipMemcpyDeviceToHost, I->stream));
+  HIPCHK(hipStreamSynchronize(I->stream));
+  *outSum = I->h_result[0];
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_calculate_edge_log_likelihoods_device(int instance, int parent, int child, int pm, double *deviceOut)
+{
+  GET_INST(I, instance);
+  int rc = check_partial_index(I, parent, true);
+  if (rc) return rc;
+  if ((rc = check_partial_index(I, child, true))) return rc;
+  if (pm < 0 || pm >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm);
+  EdgeEval ee{parent, child, pm, deviceOut, false};
+  return flush(I, &ee);
+}
+
+int phyhip_get_site_log_likelihoods(int instance, double *out)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, I->d_site_lnl, I->P * sizeof(double), hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_site_outputs(int instance, double *c_lnL_sorted, double *cur_site_lk, double *unscaled, int *fact)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  if (c_lnL_sorted) HIPCHK(hipMemcpy(c_lnL_sorted, I->d_site_lnl, I->P * sizeof(double), hipMemcpyDeviceToHost));
+  if (cur_site_lk) HIPCHK(hipMemcpy(cur_site_lk, I->d_site_lk, I->P * sizeof(double), hipMemcpyDeviceToHost));
+  if (unscaled) HIPCHK(hipMemcpy(unscaled, I->d_site_cat, (size_t)I->P * I->C * sizeof(double), hipMemcpyDeviceToHost));
+  if (fact) HIPCHK(hipMemcpy(fact, I->d_fact, I->P * sizeof(int), hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *out)
+{
+  (void)scaleIndex;
+  GET_INST(I, instance);
+  int rc = check_partial_index(I, bufferIndex, false);
+  if (rc) return rc;
+  if ((rc = flush_sync(I))) return rc;
+  HIPCHK(hipMemcpy(out, I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), buf_elems(I) * sizeof(double),
+                   hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_scale_factors(int instance, int bufferIndex, int *out)
+{
+  GET_INST(I, instance);
+  int rc = check_partial_index(I, bufferIndex, false);
+  if (rc) return rc;
+  if ((rc = flush_sync(I))) return rc;
+  HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * I->P, I->P * sizeof(int), hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_set_scale_factors(int instance, int bufferIndex, const int *in)
+{
+  GET_INST(I, instance);
+  int rc = check_partial_index(I, bufferIndex, false);
+  if (rc) return rc;
+  if ((rc = flush_sync(I))) return rc;
+  HIPCHK(hipMemcpy(I->d_scales + (size_t)(bufferIndex - I->tips) * I->P, in, I->P * sizeof(int), hipMemcpyHostToDevice));
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_numerical_warning(int instance, int *out)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, I->d_warn, sizeof(int), hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
+// ---- eigen basis -------------------------------------------------------------------------------------
+
+int phyhip_update_eigen_lr(int instance, int left, int rght)
+{
+  GET_INST(I, instance);
+  int rc = check_partial_index(I, left, true);
+  if (rc) return rc;
+  if ((rc = check_partial_index(I, rght, true))) return rc;
+  if ((rc = flush(I, nullptr))) return rc;
+  EigenParams e;
+  e.t = base_params(I); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;
+  rc = dispatch_shape(I, [&](auto s, auto cp) {
+    constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    hipLaunchKernelGGL((eigen_lr_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, e);
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return PHYHIP_SUCCESS;
+}
+
+static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dlnl)
+{
+  if ((size_t)I->C * 2 * I->S > (size_t)kMaxExpl) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "expl table too large");
+  int rc = flush(I, nullptr);
+  if (rc) return rc;
+  DlkParams q;
+  memset(&q, 0, sizeof q);
+  q.dot_prod = I->d_dot; q.wght = I->d_wght; q.fact = I->d_fact; q.cat_w = I->d_catw; q.pi = I->d_pi; q.invar = I->d_invar;
+  q.P = I->P; q.C = I->C; q.invar_model = I->invar_model; q.apply_scaling = I->apply_scaling; q.with_derivative = deriv ? 1 : 0;
+  q.pinvar = I->pinvar; q.block_sums = I->d_block; q.stride = I->grid; q.warn = I->d_warn;
+  for (int c = 0; c < I->C; ++c)
+  {
+    if (deriv)
+    { // src/lk.c:688-726
+      const double rr  = I->h_rates[c] * I->br_len_mult;
+      double       len = l * rr;
+      if (len < I->l_min) len = I->l_min;
+      else if (len > I->l_max) len = I->l_max;
+      for (int s = 0; s < I->S; ++s)
+      {
+        const double ev = I->h_eval[s], ex = exp(ev * len);
+        q.expl[c * 2 * I->S + 2 * s]     = ex;
+        q.expl[c * 2 * I->S + 2 * s + 1] = ex * ev * rr;
+      }
+    }
+    else
+    { // src/lk.c:594-602
+      double len = (l > 0.0 ? l : 0.0) * I->h_rates[c];
+      len *= I->br_len_mult;
+      if (len < I->l_min) len = I->l_min;
+      else if (len > I->l_max) len = I->l_max;
+      for (int s = 0; s < I->S; ++s) q.expl[c * I->S + s] = exp(I->h_eval[s] * len);
+    }
+  }
+  HIPCHK(hipMemsetAsync(I->d_warn, 0, sizeof(int), I->stream));
+  rc = dispatch_shape(I, [&](auto s, auto cp) {
+    constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q);
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 2, I->grid,
+                     I->d_result, I->h_result);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(I->stream));
+  *lnl = I->h_result[0];
+  if (dlnl) *dlnl = I->h_result[1];
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, double *outDLnL)
+{
+  GET_INST(I, instance);
+  if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN"); // src/lk.c:671
+  if (*l < I->l_min) *l = I->l_min;                                                     // src/lk.c:673-674
+  else if (*l > I->l_max) *l = I->l_max;
+  return eigen_eval(I, *l, true, outLnL, outDLnL);
+}
+
+int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL)
+{
+  GET_INST(I, instance);
+  return eigen_eval(I, l, false, outLnL, nullptr);
+}
+
+int phyhip_get_dot_prod(int instance, double *out)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, I->d_dot, buf_elems(I) * sizeof(double), hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
+// ---- plumbing --------------------------------------------------------------------------------------------
+
+int phyhip_set_stream(int instance, void *hipStream)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  if (I->own_stream && I->stream) (void)hipStreamDestroy(I->stream);
+  I->stream     = (hipStream_t)hipStream;
+  I->own_stream = false;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_synchronize(int instance)
+{
+  GET_INST(I, instance);
+  return flush_sync(I);
+}
+
+int phyhip_profile(int instance, int enable)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  collect_profile(I);
+  I->prof = enable != 0;
+  I->prof_ms = 0.0; I->prof_n = 0; I->prof_updates = 0.0;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_profile_read(int instance, double *ms, int *launches, double *updates)
+{
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  if ((rc = collect_profile(I))) return rc;
+  if (ms) *ms = I->prof_ms;
+  if (launches) *launches = I->prof_n;
+  if (updates) *updates = I->prof_updates;
+  return PHYHIP_SUCCESS;
+}
+
+} // extern "C"

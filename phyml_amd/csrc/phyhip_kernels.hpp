@@ -1,0 +1,582 @@
+// phyhip_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for PhyML's likelihood hot path.
+//
+// Work decomposition (DESIGN.md "Kernels"): the unit of parallelism is one (pattern, rate category) pair
+// per lane.  Partial vectors keep the reference's [pattern][category][state] layout
+// (src/lk.c:1474,1520), so consecutive lanes read consecutive 8*S-byte records: a wave's load of one
+// child is ONE contiguous span (2 KiB for S=4), every byte of every fetched line is used, and the
+// device buffers are byte-identical to the host's t_edge::p_lk_* buffers.
+// The CP lanes of one pattern (CP = categories rounded up to a power of two) sit in adjacent lanes, so
+// the per-pattern max-scan of the rescaling rule (src/avx.c:498-510) and the category mixture of
+// Lk_Core (src/lk.c:816-818) are CP-lane cross-lane operations, no LDS, no barrier.
+//
+// One launch executes a whole *list* of update operations (the post-order traversal recorded by the
+// host) for its pattern tile: patterns are independent, so a thread that owns (pattern, category) can
+// walk the entire tree alone and the launch needs no inter-workgroup synchronisation at all.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phyhip
+{
+
+constexpr int    kLarge         = 256;                         // src/utilities.h:507
+constexpr double kTwoToLarge    = 0x1p256;                     // TWO_TO_THE_LARGE
+constexpr double kInvTwoToLarge = 0x1p-256;                    // INV_TWO_TO_THE_LARGE
+constexpr double kSmall         = 2.2250738585072014e-308;     // SMALL = DBL_MIN, src/utilities.h:476
+constexpr double kLog2          = 0.69314718055994528623;      // LOG2, src/utilities.h:267
+constexpr double kSmallPij      = 1.E-100;                     // SMALL_PIJ, src/utilities.h:478
+constexpr int    kMaxExpl       = 2 * 8 * 20;                  // dLk's expl table: [C<=8][2][S<=20]
+
+struct DevOp
+{
+  int dest, c1, c2, pm1, pm2, pad;
+};
+
+// Everything a traversal launch needs.  Passed by value (fits the 4 KiB kernarg segment easily).
+struct TreeParams
+{
+  double         *partials;   // internal buffer b at (b - tip_count) * P * C * S
+  int            *scales;     // internal buffer b at (b - tip_count) * P
+  const uint8_t  *tip_codes;  // tip t at t * P : index into code_masks
+  const uint32_t *code_masks; // allowed-state bit mask per code
+  const double   *pmats;      // matrix m at m * C * S * S, [c][from][to]
+  const double   *wght;       // [P]
+  long long       P;
+  int             C;
+  int             tip_count;
+  int             apply_scaling;
+  const DevOp    *ops;
+  int             n_ops;
+  // fused root-edge evaluation (K2)
+  int             edge_eval;
+  int             e_parent, e_child, e_pm;
+  const double   *pi;
+  const double   *cat_w;
+  int             invar_model;
+  double          pinvar;
+  const short    *invar;
+  double         *site_lnl;   // c_lnL_sorted      (may be null)
+  double         *site_lk;    // cur_site_lk       (may be null)
+  double         *site_cat;   // unscaled_site_lk_cat [P][C] (may be null)
+  int            *fact;       // fact_sum_scale [P] (always written: dLk needs it)
+  double         *block_sums; // [gridDim.x]
+  int            *warn;
+};
+
+// ---------------------------------------------------------------------------------------------
+// cross-lane helpers over the CP adjacent lanes that share a pattern
+// ---------------------------------------------------------------------------------------------
+template <int CP> __device__ __forceinline__ double group_max(double v)
+{
+#pragma unroll
+  for (int off = 1; off < CP; off <<= 1) v = fmax(v, __shfl_xor(v, off, CP));
+  return v;
+}
+template <int CP> __device__ __forceinline__ int group_bcast0(int v) { return CP == 1 ? v : __shfl(v, 0, CP); }
+template <int CP> __device__ __forceinline__ int group_and(int v)
+{
+#pragma unroll
+  for (int off = 1; off < CP; off <<= 1) v &= __shfl_xor(v, off, CP);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// child fetch: tip -> 0/1 vector from its one-byte code; internal -> S contiguous doubles + scale
+// ---------------------------------------------------------------------------------------------
+template <int S, int CP>
+__device__ __forceinline__ void load_side(const TreeParams &q, int idx, long long p, int c, double (&x)[S], int &sc)
+{
+  if (idx < q.tip_count)
+  { // uniform branch: idx is the same for the whole grid
+    const uint32_t m = q.code_masks[q.tip_codes[(size_t)idx * q.P + p]];
+#pragma unroll
+    for (int j = 0; j < S; ++j) x[j] = ((m >> j) & 1u) ? 1.0 : 0.0;
+    sc = 0;
+  }
+  else
+  {
+    const size_t  b   = (size_t)(idx - q.tip_count);
+    const double *src = q.partials + (b * q.P + p) * (size_t)(q.C * S) + (size_t)c * S;
+    static_assert(S % 2 == 0, "state count must be even for 16-byte loads");
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+#pragma unroll
+    for (int j = 0; j < S / 2; ++j)
+    {
+      const double2 v = s2[j];
+      x[2 * j] = v.x;
+      x[2 * j + 1] = v.y;
+    }
+    // the scale word is written by the c==0 lane of the pattern; read it back through the same lane
+    int s = 0;
+    if (c == 0) s = q.scales[b * q.P + p];
+    sc = group_bcast0<CP>(s);
+  }
+}
+
+// u[i] = sum_j M[i*S+j] * x[j] in the reference's AVX order: first product, then an FMA chain over j
+// (src/avx.c:593-616).  Bit-identical to the AVX kernel given the same matrix.
+template <int S>
+__device__ __forceinline__ void matvec_rows(const double *__restrict__ M, const double (&x)[S], double (&u)[S])
+{
+  constexpr int kOuter = (S <= 4) ? S : 1; // wide alphabets: keep one row of the matrix live at a time
+#pragma unroll kOuter
+  for (int i = 0; i < S; ++i)
+  {
+    double a = M[i * S] * x[0];
+#pragma unroll
+    for (int j = 1; j < S; ++j) a = __builtin_fma(M[i * S + j], x[j], a);
+    u[i] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 + K2: traversal kernel
+// ---------------------------------------------------------------------------------------------
+template <int S, int CP>
+__global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q)
+{
+  const long long gl  = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long p0  = gl / CP;
+  const int       c0  = (int)(gl % CP);
+  const bool      act = (p0 < q.P) && (c0 < q.C);
+  const long long p   = (p0 < q.P) ? p0 : (q.P - 1); // clamp so idle lanes read valid memory
+  const int       c   = (c0 < q.C) ? c0 : 0;
+  const int       CS  = q.C * S;
+  const int       MS  = q.C * S * S;
+
+  for (int k = 0; k < q.n_ops; ++k)
+  {
+    const DevOp op = q.ops[k];
+    double      x1[S], x2[S], u1[S], u2[S];
+    int         s1, s2;
+    load_side<S, CP>(q, op.c1, p, c, x1, s1);
+    load_side<S, CP>(q, op.c2, p, c, x2, s2);
+
+    // all-ones shortcut of the Inin kernel (src/avx.c:575-587): exact 1.0 when both children are 1.0
+    bool ones = true;
+#pragma unroll
+    for (int j = 0; j < S; ++j) ones = ones && (x1[j] == 1.0) && (x2[j] == 1.0);
+
+    matvec_rows<S>(q.pmats + (size_t)op.pm1 * MS + (size_t)c * S * S, x1, u1);
+    matvec_rows<S>(q.pmats + (size_t)op.pm2 * MS + (size_t)c * S * S, x2, u2);
+
+    double o[S];
+    double mx = -__builtin_huge_val();
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+    {
+      o[i] = ones ? 1.0 : u1[i] * u2[i];
+      mx   = (o[i] > mx) ? o[i] : mx; // `>` like src/avx.c:500-502: a NaN never becomes the maximum
+    }
+    if (c0 >= q.C) mx = -__builtin_huge_val();
+    mx = group_max<CP>(mx);
+
+    int sc = s1 + s2; // src/avx.c:462-464
+    if (mx < kInvTwoToLarge && q.apply_scaling)
+    { // src/avx.c:504-510; multiplication by 2^256 is exact
+#pragma unroll
+      for (int i = 0; i < S; ++i) o[i] *= kTwoToLarge;
+      sc += kLarge;
+    }
+
+    if (act)
+    {
+      const size_t b   = (size_t)(op.dest - q.tip_count);
+      double2     *dst = reinterpret_cast<double2 *>(q.partials + (b * q.P + p) * (size_t)CS + (size_t)c * S);
+#pragma unroll
+      for (int j = 0; j < S / 2; ++j) dst[j] = make_double2(o[2 * j], o[2 * j + 1]);
+      if (c == 0) q.scales[b * q.P + p] = sc;
+    }
+  }
+
+  if (!q.edge_eval) return;
+
+  // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861) -----------------
+  double contrib = 0.0;
+  {
+    double x[S], y[S];
+    int    sl, sr;
+    load_side<S, CP>(q, q.e_parent, p, c, x, sl);
+    load_side<S, CP>(q, q.e_child, p, c, y, sr);
+    const double *M = q.pmats + (size_t)q.e_pm * MS + (size_t)c * S * S; // rows: right-side state
+    // acc[k] = sum_i P[k][i] x[i] as an FMA chain from zero (src/avx.c:130-145, 191-206);
+    // lk_c = sum_k acc[k] * (y[k]*pi[k]) with the 4-wide horizontal order of AVX_Vect_Norm.
+    double lkc = 0.0;
+    constexpr int kOuter = (S <= 4) ? 1 : 1;
+#pragma unroll kOuter
+    for (int b4 = 0; b4 < S / 4; ++b4)
+    {
+      double t[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+      {
+        const int k = b4 * 4 + kk;
+        double    a = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) a = __builtin_fma(M[k * S + i], x[i], a);
+        t[kk] = a * (y[k] * q.pi[k]);
+      }
+      const double nrm = (t[0] + t[2]) + (t[1] + t[3]);
+      lkc              = (b4 == 0) ? nrm : lkc + nrm;
+    }
+    if (act && q.site_cat) q.site_cat[(size_t)p * q.C + c] = lkc; // Pull_Scaling_Factors copy, src/lk.c:2801
+
+    // mixture over categories in category order (src/lk.c:816-818)
+    const double t    = (c0 < q.C) ? lkc * q.cat_w[c] : 0.0;
+    double       site = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc)
+    {
+      const double tc = (CP == 1) ? t : __shfl(t, cc, CP);
+      if (cc < q.C) site += tc;
+    }
+
+    if (act && c == 0)
+    {
+      const double w = q.wght[p];
+      int          f = q.apply_scaling ? (sl + sr) : 0; // SCALE_FAST, src/lk.c:2777-2794 / :2701-2705
+      if (w > kSmall)
+      {
+        if (q.invar_model)
+        { // src/lk.c:820-842 with Invariant_Lk :1226-1273
+          const int iv  = q.invar[p];
+          double    inv = 0.0;
+          bool      issue = false;
+          if (iv >= 0)
+          {
+            inv = q.pi[iv];
+            if (q.apply_scaling)
+            {
+              int e = f;
+              do
+              {
+                const int piece = e < 63 ? e : 63;
+                inv *= (double)(1ull << piece);
+                e -= piece;
+              } while (e != 0);
+            }
+            issue = isinf(inv);
+          }
+          if (issue)
+          {
+            f    = 0;
+            site = q.pi[iv] * q.pinvar;
+          }
+          else
+            site = site * (1. - q.pinvar) + inv * q.pinvar;
+        }
+        if (site < kSmall)
+        { // src/lk.c:847-851
+          site = kSmall;
+          *q.warn = 1;
+        }
+        const double lsl = log(site) - kLog2 * (double)f; // src/lk.c:854
+        if (q.site_lnl) q.site_lnl[p] = lsl;
+        if (q.site_lk) q.site_lk[p] = exp(lsl);
+        contrib = w * lsl; // src/lk.c:856
+      }
+      q.fact[p] = f;
+    }
+  }
+
+  // deterministic block reduction: fixed shuffle tree per wave, then wave order
+  __shared__ double wsum[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) wsum[wid] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += wsum[w];
+    q.block_sums[blockIdx.x] = s;
+  }
+}
+
+// Second stage: one block sums `n` per-block values of up to two interleaved streams in a fixed order.
+// out[k] = sum_i in[k*stride + i].
+__global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restrict__ in, int n, int nstreams, int stride,
+                                                          double *__restrict__ out, double *__restrict__ out_host)
+{
+  __shared__ double sh[256];
+  for (int k = 0; k < nstreams; ++k)
+  {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += in[(size_t)k * stride + i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1)
+    {
+      if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+      out[k] = sh[0];
+      if (out_host) out_host[k] = sh[0];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: eigen-basis products (src/lk.c:1038-1114, src/avx.c:21-105)
+// ---------------------------------------------------------------------------------------------
+struct EigenParams
+{
+  TreeParams    t;
+  int           left, rght;
+  const double *r_e_vect, *l_e_vect;
+  double       *dot_prod;
+};
+
+template <int S, int CP>
+__global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
+{
+  const TreeParams &q  = e.t;
+  const long long   gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long   p0 = gl / CP;
+  const int         c0 = (int)(gl % CP);
+  const bool        act = (p0 < q.P) && (c0 < q.C);
+  const long long   p   = (p0 < q.P) ? p0 : (q.P - 1);
+  const int         c   = (c0 < q.C) ? c0 : 0;
+  double            x[S], y[S], lp[S];
+  int               sl, sr;
+  load_side<S, CP>(q, e.left, p, c, x, sl);
+  load_side<S, CP>(q, e.rght, p, c, y, sr);
+#pragma unroll
+  for (int i = 0; i < S; ++i) lp[i] = x[i] * q.pi[i]; // src/avx.c:79
+  double d[S];
+#pragma unroll
+  for (int k = 0; k < S; ++k)
+  { // a[k] = sum_i R[i][k] lp[i];  b[k] = sum_i L[k][i] y[i]  (column-wise FMA chains, src/avx.c:81-82)
+    double a = e.r_e_vect[k] * lp[0];
+    double b = e.l_e_vect[k * S] * y[0];
+#pragma unroll
+    for (int i = 1; i < S; ++i)
+    {
+      a = __builtin_fma(e.r_e_vect[i * S + k], lp[i], a);
+      b = __builtin_fma(e.l_e_vect[k * S + i], y[i], b);
+    }
+    d[k] = a * b;
+  }
+  if (act)
+  {
+    double2 *dst = reinterpret_cast<double2 *>(e.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S);
+#pragma unroll
+    for (int j = 0; j < S / 2; ++j) dst[j] = make_double2(d[2 * j], d[2 * j + 1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: lnL and dlnL/dl in the eigen basis (src/lk.c:655-753, 955-1032; src/avx.c:250-276),
+//     and Lk(b) with use_eigen_lr (src/lk.c:866-950, src/avx.c:220-245)
+// ---------------------------------------------------------------------------------------------
+struct DlkParams
+{
+  const double *dot_prod;
+  const double *wght;
+  const int    *fact;
+  const double *cat_w;
+  const double *pi;
+  const short  *invar;
+  long long     P;
+  int           C;
+  int           invar_model;
+  int           apply_scaling;
+  int           with_derivative; // 1: expl is [c][2*S] interleaved (value, derivative); 0: [c][S]
+  double        pinvar;
+  double       *block_sums;      // [2][stride]
+  int           stride;
+  int          *warn;
+  double        expl[kMaxExpl];
+};
+
+template <int S, int CP>
+__global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
+{
+  const long long gl  = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long p0  = gl / CP;
+  const int       c0  = (int)(gl % CP);
+  const bool      act = (p0 < q.P) && (c0 < q.C);
+  const long long p   = (p0 < q.P) ? p0 : (q.P - 1);
+  const int       c   = (c0 < q.C) ? c0 : 0;
+
+  double dp[S];
+  {
+    const double2 *s2 = reinterpret_cast<const double2 *>(q.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S);
+#pragma unroll
+    for (int j = 0; j < S / 2; ++j)
+    {
+      const double2 v = s2[j];
+      dp[2 * j] = v.x;
+      dp[2 * j + 1] = v.y;
+    }
+  }
+  double lkc, dlkc = 0.0;
+  if (q.with_derivative)
+  { // four lanes (lk,dlk,lk,dlk) over pairs of states, then lane0+lane2 / lane1+lane3 (src/avx.c:257-274)
+    const double *ex = q.expl + c * 2 * S;
+    double        z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
+#pragma unroll
+    for (int i = 0; i < S / 2; ++i)
+    {
+      z0 = __builtin_fma(dp[2 * i], ex[4 * i], z0);
+      z1 = __builtin_fma(dp[2 * i], ex[4 * i + 1], z1);
+      z2 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 2], z2);
+      z3 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 3], z3);
+    }
+    lkc  = z0 + z2;
+    dlkc = z1 + z3;
+  }
+  else
+  { // elementwise product, blockwise lane sums, horizontal norm (src/avx.c:227-244)
+    const double *ex = q.expl + c * S;
+    double        l4[4] = {0., 0., 0., 0.};
+#pragma unroll
+    for (int b4 = 0; b4 < S / 4; ++b4)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) l4[kk] = l4[kk] + dp[b4 * 4 + kk] * ex[b4 * 4 + kk];
+    lkc = (l4[0] + l4[2]) + (l4[1] + l4[3]);
+  }
+  const double w  = (c0 < q.C) ? q.cat_w[c] : 0.0;
+  const double t1 = (c0 < q.C) ? lkc * w : 0.0, t2 = (c0 < q.C) ? dlkc * w : 0.0;
+  double       lk = 0.0, dlk = 0.0;
+#pragma unroll
+  for (int cc = 0; cc < CP; ++cc)
+  {
+    const double a = (CP == 1) ? t1 : __shfl(t1, cc, CP);
+    const double b = (CP == 1) ? t2 : __shfl(t2, cc, CP);
+    if (cc < q.C)
+    {
+      lk += a;
+      dlk += b;
+    }
+  }
+  double c_lnl = 0.0, c_dlnl = 0.0;
+  if (act && c == 0)
+  {
+    const double wt = q.wght[p];
+    if (wt > kSmall)
+    {
+      int f = q.fact[p];
+      if (q.invar_model)
+      { // src/lk.c:1005-1025 (dLk) / :910-931 (Lk in the eigen basis)
+        const int iv  = q.invar[p];
+        double    inv = 0.0;
+        bool      issue = false;
+        if (iv >= 0)
+        {
+          inv = q.pi[iv];
+          if (q.apply_scaling)
+          {
+            int e = f;
+            do
+            {
+              const int piece = e < 63 ? e : 63;
+              inv *= (double)(1ull << piece);
+              e -= piece;
+            } while (e != 0);
+          }
+          issue = isinf(inv);
+        }
+        if (issue)
+        {
+          if (q.with_derivative) { lk = inv * q.pinvar; dlk = 0.0; }
+          else { f = 0; lk = q.pi[iv] * q.pinvar; }
+        }
+        else
+        {
+          lk  = lk * (1. - q.pinvar) + inv * q.pinvar;
+          dlk = dlk * (1. - q.pinvar);
+        }
+      }
+      if (lk < kSmall)
+      {
+        lk = kSmall;
+        *q.warn = 1;
+      }
+      c_dlnl = wt * (dlk / lk);                          // src/lk.c:742-744
+      c_lnl  = wt * (log(lk) - kLog2 * (double)f);       // src/lk.c:745
+    }
+  }
+  __shared__ double ws[2][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    c_lnl += __shfl_down(c_lnl, off, 64);
+    c_dlnl += __shfl_down(c_dlnl, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+    ws[0][wid] = c_lnl;
+    ws[1][wid] = c_dlnl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k)
+    {
+      a += ws[0][k];
+      b += ws[1][k];
+    }
+    q.block_sums[blockIdx.x]            = a;
+    q.block_sums[q.stride + blockIdx.x] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: transition matrices on the device (src/models.c:257-326 behind src/lk.c:2280-2316)
+//     one block per matrix; thread (c,i) builds row i of category c
+// ---------------------------------------------------------------------------------------------
+struct PmatParams
+{
+  const int    *indices; // [count]
+  const double *lengths; // [count] raw edge lengths b->l->v
+  int           count;
+  int           S, C;
+  const double *U, *V, *R;   // r_e_vect, l_e_vect, e_val
+  const double *rates;       // gamma_rr
+  double        br_len_mult, l_min, l_max;
+  double       *pmats;
+};
+
+__global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
+{
+  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S]
+  const int    m  = blockIdx.x;
+  const int    S  = q.S, C = q.C;
+  const double l  = q.lengths[m];
+  for (int t = threadIdx.x; t < C * S; t += blockDim.x)
+  {
+    const int c   = t / S, k = t % S;
+    double    len = (l > 0.0 ? l : 0.0) * q.rates[c]; // src/lk.c:2296
+    len *= q.br_len_mult;                             // :2297
+    if (len < q.l_min) len = q.l_min;                 // :2299-2300
+    else if (len > q.l_max) len = q.l_max;
+    expt[t] = exp(q.R[k] * len);                      // src/models.c:275
+  }
+  __syncthreads();
+  double *out = q.pmats + (size_t)q.indices[m] * C * S * S;
+  for (int t = threadIdx.x; t < C * S; t += blockDim.x)
+  {
+    const int c = t / S, i = t % S;
+    double   *row = out + (size_t)c * S * S + (size_t)i * S;
+    double    sum = 0.0;
+    for (int j = 0; j < S; ++j)
+    {
+      double acc = 0.0;
+      for (int k = 0; k < S; ++k) acc = __builtin_fma(q.U[i * S + k] * expt[c * S + k], q.V[k * S + j], acc); // :278-292
+      if (acc < kSmallPij) acc = kSmallPij;                                                                  // :293
+      row[j] = acc;
+      sum += acc;                                                                                            // :296-297
+    }
+    for (int j = 0; j < S; ++j) row[j] /= sum;                                                               // :298
+  }
+}
+
+} // namespace phyhip

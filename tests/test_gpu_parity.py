@@ -1,0 +1,139 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+Bars: partial vectors and scale vectors bit-equal to the oracle when fed the same
+transition matrices; per-site log-likelihoods within 1e-10 absolute; lnL within 1e-10 relative of the
+oracle and 1e-6 relative of the reference's AVX value (north-star tolerance; observed ~1e-15).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import orc
+from conftest import FIXTURES
+from gpu_common import device_tree_from_golden
+
+
+@pytest.fixture(scope="module")
+def evaluated(golden):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            d = golden(name)
+            t, ot = device_tree_from_golden(d)
+            t.Set_Both_Sides(True)
+            lnl = t.Lk(None)
+            ot_lnl = ot.lk(None, both_sides=True)
+            cache[name] = (d, t, ot, lnl, ot_lnl, t.inst.site_outputs())
+        return cache[name]
+    yield get
+    for v in cache.values():
+        v[1].close()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_lnl_matches_reference_and_oracle(name, evaluated):
+    d, t, ot, lnl, ot_lnl, _ = evaluated(name)
+    ref = d["lnL"][0]
+    assert abs(lnl - ref) / abs(ref) < 1e-6          # north-star tolerance
+    assert abs(lnl - ref) / abs(ref) < 1e-12         # what we actually hold
+    assert abs(lnl - ot_lnl) / abs(ot_lnl) < 1e-12
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_site_outputs(name, evaluated):
+    d, t, ot, lnl, _, (site, cur, cat, fact) = evaluated(name)
+    w = d["wght"] > 0
+    assert np.array_equal(fact[w], d["fact_sum_scale"][w])
+    assert np.max(np.abs(site[w] - d["c_lnL_sorted"][w])) < 1e-10
+    assert np.allclose(cat[w], d["unscaled_site_lk_cat"][w], rtol=1e-12, atol=0)
+    assert np.allclose(cur[w], d["cur_site_lk"][w], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_partials_and_scales_bit_equal(name, evaluated):
+    d, t, ot, *_ = evaluated(name)
+    w = d["wght"] > 0
+    n = 0
+    for (e, side), ref in ot.plk.items():
+        got = t.partials(e, side)
+        assert np.array_equal(got[w], ref[w]), (name, e, side)
+        assert np.array_equal(t.scale_factors(e, side)[w], ot.scale[(e, side)][w]), (name, e, side)
+        n += 1
+    assert n == 3 * (t.n - 2)
+    # and against the reference's own dump where it is held in full
+    for e in d["full_edges"]:
+        for side, nm in ((0, "left"), (1, "rght")):
+            key = f"p_lk_{nm}_{e}"
+            if key in d:
+                assert np.array_equal(t.partials(int(e), side)[w], d[key][w])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_lnl_at_every_edge(name, evaluated):
+    d, t, ot, *_ = evaluated(name)
+    got = np.array([t.Lk(e) for e in range(t.ne)])
+    assert np.max(np.abs(got - d["edge_lnL"]) / np.abs(d["edge_lnL"])) < 1e-12
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_eigen_lr_and_dlk(name, evaluated):
+    d, t, ot, *_ = evaluated(name)
+    w = d["wght"] > 0
+    for k, e in enumerate(d["eigen_edges"]):
+        e = int(e)
+        # Br_Len_Opt's call pattern (src/optimiz.c:622-630)
+        t.Set_Update_Eigen_Lr(True); t.Set_Use_Eigen_Lr(False)
+        t.Lk(e)
+        t.Set_Update_Eigen_Lr(False); t.Set_Use_Eigen_Lr(True)
+        dp = t.inst.get_dot_prod()
+        ref = d[f"dot_prod_{e}"]
+        assert np.allclose(dp[w], ref[w], rtol=1e-12, atol=1e-300)
+        for j in range(3):
+            l_in, lnl_ref, dlnl_ref = d["dlk_triples"][k, j]
+            l_out, lnl = t.dLk(l_in, e)
+            assert l_out == l_in
+            assert abs(lnl - lnl_ref) / abs(lnl_ref) < 1e-12
+            assert abs(t.c_dlnL - dlnl_ref) <= 1e-8 * max(1.0, abs(dlnl_ref))
+        assert abs(t.Lk(e) - d[f"eig_lnL_{e}"][0]) / abs(d[f"eig_lnL_{e}"][0]) < 1e-12
+        t.Set_Use_Eigen_Lr(False)
+
+
+@pytest.mark.parametrize("name", ["nucleic_gtr_g4_inv", "synth_aa_90x24"])
+def test_device_pmatrices(name, golden):
+    """phyhip_update_transition_matrices (device PMat) vs the reference's P-matrices: same floor /
+    renormalise rule; only exp() differs (device libm vs glibc), so <= a few ulp."""
+    d = golden(name)
+    t, ot = device_tree_from_golden(d, host_pmat=False)
+    try:
+        lnl = t.Lk(None)
+        npm = d["Pij_rr"].shape[0]
+        for e in range(npm):
+            got = t.inst.get_transition_matrix(e)
+            assert np.allclose(got, d["Pij_rr"][e], rtol=1e-13, atol=1e-300)
+        assert abs(lnl - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-11
+    finally:
+        t.close()
+
+
+def test_deferred_queue_is_transparent(golden):
+    """One-op-at-a-time updates (SPR style) and a batched traversal give identical buffers."""
+    d = golden("nucleic_gtr_g4")
+    t1, ot = device_tree_from_golden(d)
+    t2, _ = device_tree_from_golden(d)
+    try:
+        t1.Lk(None)
+        t2.Update_All_PMat()
+        order = t2._walk(t2._post, t2.tip_root, t2.adj[t2.tip_root][0][0])
+        for (b, dd) in order:
+            t2.Update_Partial_Lk(b, dd)
+            t2.inst.synchronize()            # force a launch per operation
+        b = t2.adj[t2.tip_root][0][1]
+        l2 = t2.inst.edge_lnl(t2.buf[(b, 0)], t2.buf[(b, 1)], b)
+        assert l2 == t1.c_lnL
+        for (b, dd) in order:
+            side = 0 if dd == t1.el[b] else 1
+            assert np.array_equal(t1.partials(b, side), t2.partials(b, side))
+    finally:
+        t1.close(); t2.close()
