@@ -105,7 +105,8 @@ def main():
     t = lktree.LkTree(n, tree.edge_left, tree.edge_rght, tree.edge_len, P, S, C, device=local)
     t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"],
                 float(blk["l_min"][0]), float(blk["l_max"][0]), 1.0, 1)
-    t.set_data(np.ones(P), tip_states=st.astype(np.int32))
+    t.Make_Tree_For_Lk(np.ones(P))
+    t.set_tips(tip_states=st.astype(np.int32))
     dev_lnl = torch.zeros(2, dtype=torch.float64, device=f"cuda:{local}")
     stream = torch.cuda.current_stream()
     t.inst.set_stream(stream.cuda_stream)
@@ -114,11 +115,7 @@ def main():
         if world == 1:
             return t.Lk(None)
         # sharded evaluation: per-shard lnL stays on the device, ONE all-reduce over RCCL, then the host reads it
-        t.Update_All_PMat()
-        r = t.tip_root
-        t.Post_Order_Lk(r, t.adj[r][0][0])
-        b = t.adj[r][0][1]
-        t.inst.edge_lnl_device(t.buf[(b, 0)], t.buf[(b, 1)], b, dev_lnl.data_ptr())
+        t.Lk_Shard_Device(dev_lnl.data_ptr())
         dist.all_reduce(dev_lnl)
         return float(dev_lnl[0].item())
 

@@ -136,6 +136,7 @@ struct Instance
   double l_min = 1.e-8, l_max = 100., br_len_mult = 1.0, pinvar = 0.0; // src/init.c:711-714
   int    apply_scaling = 1, invar_model = 0;
   bool   want_site_outputs = true;
+  bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
 
   bool       prof = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -172,11 +173,18 @@ TreeParams base_params(Instance *I)
 {
   TreeParams q;
   memset(&q, 0, sizeof q);
-  q.partials = I->d_partials; q.scales = I->d_scales; q.tip_codes = I->d_tipcodes; q.code_masks = I->d_masks;
-  q.pmats = I->d_pmats; q.wght = I->d_wght; q.P = I->P; q.C = I->C; q.tip_count = I->tips;
+  q.partials = I->d_partials; q.scales = I->d_scales;
+  q.wght = I->d_wght; q.P = I->P; q.C = I->C; q.tip_count = I->tips;
   q.apply_scaling = I->apply_scaling; q.pi = I->d_pi; q.cat_w = I->d_catw; q.invar_model = I->invar_model;
   q.pinvar = I->pinvar; q.invar = I->d_invar; q.block_sums = I->d_block; q.warn = I->d_warn; q.fact = I->d_fact;
   return q;
+}
+
+RO base_ro(Instance *I, const DevOp *ops)
+{
+  RO r;
+  r.ops = ops; r.pmats = I->d_pmats; r.tip_codes = I->d_tipcodes; r.code_masks = I->d_masks;
+  return r;
 }
 
 template <typename F> int dispatch_shape(const Instance *I, F &&f)
@@ -215,6 +223,7 @@ int flush(Instance *I, const EdgeEval *ee)
   if (rc) return rc;
 
   TreeParams q = base_params(I);
+  RO         ro = base_ro(I, nullptr);
   if (n_ops > 0)
   {
     void *st = nullptr;
@@ -224,7 +233,7 @@ int flush(Instance *I, const EdgeEval *ee)
     DevOp *dst = I->d_ops + (size_t)I->ops_slot * I->ops_cap;
     I->ops_slot = (I->ops_slot + 1) % I->ops_slots;
     HIPCHK(hipMemcpyAsync(dst, st, sizeof(DevOp) * n_ops, hipMemcpyHostToDevice, I->stream));
-    q.ops = dst;
+    ro.ops = dst;
     q.n_ops = n_ops;
   }
   if (ee)
@@ -242,7 +251,16 @@ int flush(Instance *I, const EdgeEval *ee)
   }
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
-    hipLaunchKernelGGL((traverse_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q);
+    if constexpr (S_ == 4)
+    {
+      if (!I->generic_nt)
+      {
+        hipLaunchKernelGGL((traverse_nt_kernel<CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, ro.ops, ro.pmats, ro.tip_codes);
+        return 0;
+      }
+    }
+    hipLaunchKernelGGL((traverse_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, ro.ops, ro.pmats, ro.tip_codes,
+                       ro.code_masks);
     return 0;
   });
   if (rc) return rc;
@@ -380,6 +398,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   int rc = I->ring.init(chunk);
   if (rc) return rc;
   I->mat_in_queue.assign(I->nmat, 0);
+  if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
 
   // codes 0..S-1 are the single states
   for (int s = 0; s < I->S; ++s)
@@ -472,9 +491,12 @@ int phyhip_set_tip_partials(int instance, int tipIndex, const double *inPartials
       else if (x != 0.0)
         return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip %d pattern %lld state %d: partial %g is not 0 or 1", tipIndex, p, s, x);
     }
-    int code = 0;
-    int rc   = code_for_mask(I, m, &code);
-    if (rc) return rc;
+    int code = (int)m; // S <= 8: the byte stored on the device is the allowed-state mask itself
+    if (I->S > 8)
+    {
+      int rc = code_for_mask(I, m, &code);
+      if (rc) return rc;
+    }
     codes[(size_t)p] = (uint8_t)code;
   }
   return set_tip_codes(I, tipIndex, codes);
@@ -489,12 +511,14 @@ int phyhip_set_tip_states(int instance, int tipIndex, const int *inStates)
   for (long long p = 0; p < I->P; ++p)
   {
     const int st = inStates[p];
-    int       code = st;
-    if (st < 0 || st >= I->S)
+    int       code;
+    if (I->S <= 8) code = (st < 0 || st >= I->S) ? (int)full : (1 << st);
+    else if (st < 0 || st >= I->S)
     {
       int rc = code_for_mask(I, full, &code);
       if (rc) return rc;
     }
+    else code = st;
     codes[(size_t)p] = (uint8_t)code;
   }
   return set_tip_codes(I, tipIndex, codes);
@@ -797,7 +821,7 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   if ((rc = check_partial_index(I, rght, true))) return rc;
   if ((rc = flush(I, nullptr))) return rc;
   EigenParams e;
-  e.t = base_params(I); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;
+  e.t = base_params(I); e.ro = base_ro(I, nullptr); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     hipLaunchKernelGGL((eigen_lr_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, e);

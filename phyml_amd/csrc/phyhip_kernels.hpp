@@ -38,15 +38,11 @@ struct TreeParams
 {
   double         *partials;   // internal buffer b at (b - tip_count) * P * C * S
   int            *scales;     // internal buffer b at (b - tip_count) * P
-  const uint8_t  *tip_codes;  // tip t at t * P : index into code_masks
-  const uint32_t *code_masks; // allowed-state bit mask per code
-  const double   *pmats;      // matrix m at m * C * S * S, [c][from][to]
   const double   *wght;       // [P]
   long long       P;
   int             C;
   int             tip_count;
   int             apply_scaling;
-  const DevOp    *ops;
   int             n_ops;
   // fused root-edge evaluation (K2)
   int             edge_eval;
@@ -82,36 +78,78 @@ template <int CP> __device__ __forceinline__ int group_and(int v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// child fetch: tip -> 0/1 vector from its one-byte code; internal -> S contiguous doubles + scale
+// Read-only inputs travel as separate __restrict__ kernel parameters (not inside TreeParams): that
+// gives them the `noalias` attribute, so the compiler may use scalar loads for wave-uniform data (the
+// operation list) and need not order these loads against the partial-vector stores.
 // ---------------------------------------------------------------------------------------------
-template <int S, int CP>
-__device__ __forceinline__ void load_side(const TreeParams &q, int idx, long long p, int c, double (&x)[S], int &sc)
+struct RO
 {
-  if (idx < q.tip_count)
-  { // uniform branch: idx is the same for the whole grid
-    const uint32_t m = q.code_masks[q.tip_codes[(size_t)idx * q.P + p]];
+  const DevOp    *__restrict__ ops;        // operation list
+  const double   *__restrict__ pmats;      // matrix m at m * C * S * S, [c][from][to]
+  const uint8_t  *__restrict__ tip_codes;  // tip t at t * P : index into code_masks
+  const uint32_t *__restrict__ code_masks; // allowed-state bit mask per code
+};
+
+// child fetch in two phases so that ALL loads of an operation are in flight before the first wait:
+//   issue_side  -- only issues the loads (tip: one code byte; internal: S doubles + the scale word)
+//   finish_side -- turns the raw values into the S-vector and the pattern's scale exponent
+template <int S> struct RawSide
+{
+  double2  v[S / 2];
+  int      sc;
+  unsigned code;
+  bool     tip;
+};
+
+template <int S, int CP>
+__device__ __forceinline__ void issue_side(const TreeParams &q, const RO &ro, int idx, long long p, int c, RawSide<S> &r)
+{
+  r.tip = idx < q.tip_count; // uniform: idx is the same for the whole grid
+  r.sc = 0;
+  r.code = 0;
+  if (r.tip)
+    r.code = ro.tip_codes[(size_t)idx * q.P + p];
+  else
+  {
+    const size_t   b  = (size_t)(idx - q.tip_count);
+    const double2 *s2 = reinterpret_cast<const double2 *>(q.partials + (b * q.P + p) * (size_t)(q.C * S) + (size_t)c * S);
+    static_assert(S % 2 == 0, "state count must be even for 16-byte loads");
+#pragma unroll
+    for (int j = 0; j < S / 2; ++j) r.v[j] = s2[j];
+    // the scale word is written by the c==0 lane of the pattern; read it back through the same lane
+    if (c == 0) r.sc = q.scales[b * q.P + p];
+  }
+}
+
+template <int S, int CP>
+__device__ __forceinline__ void finish_side(const RO &ro, const RawSide<S> &r, double (&x)[S], int &sc)
+{
+  if (r.tip)
+  {
+    // S <= 8: the stored byte IS the allowed-state mask; wider alphabets index the mask table
+    const uint32_t m = (S <= 8) ? r.code : ro.code_masks[r.code];
 #pragma unroll
     for (int j = 0; j < S; ++j) x[j] = ((m >> j) & 1u) ? 1.0 : 0.0;
     sc = 0;
   }
   else
   {
-    const size_t  b   = (size_t)(idx - q.tip_count);
-    const double *src = q.partials + (b * q.P + p) * (size_t)(q.C * S) + (size_t)c * S;
-    static_assert(S % 2 == 0, "state count must be even for 16-byte loads");
-    const double2 *s2 = reinterpret_cast<const double2 *>(src);
 #pragma unroll
     for (int j = 0; j < S / 2; ++j)
     {
-      const double2 v = s2[j];
-      x[2 * j] = v.x;
-      x[2 * j + 1] = v.y;
+      x[2 * j]     = r.v[j].x;
+      x[2 * j + 1] = r.v[j].y;
     }
-    // the scale word is written by the c==0 lane of the pattern; read it back through the same lane
-    int s = 0;
-    if (c == 0) s = q.scales[b * q.P + p];
-    sc = group_bcast0<CP>(s);
+    sc = group_bcast0<CP>(r.sc);
   }
+}
+
+template <int S, int CP>
+__device__ __forceinline__ void load_side(const TreeParams &q, const RO &ro, int idx, long long p, int c, double (&x)[S], int &sc)
+{
+  RawSide<S> r;
+  issue_side<S, CP>(q, ro, idx, p, c, r);
+  finish_side<S, CP>(ro, r, x, sc);
 }
 
 // u[i] = sum_j M[i*S+j] * x[j] in the reference's AVX order: first product, then an FMA chain over j
@@ -134,8 +172,12 @@ __device__ __forceinline__ void matvec_rows(const double *__restrict__ M, const 
 // K1 + K2: traversal kernel
 // ---------------------------------------------------------------------------------------------
 template <int S, int CP>
-__global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q)
+__global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const DevOp *__restrict__ ops_,
+                                                       const double *__restrict__ pmats_,
+                                                       const uint8_t *__restrict__ tip_codes_,
+                                                       const uint32_t *__restrict__ code_masks_)
 {
+  const RO ro{ops_, pmats_, tip_codes_, code_masks_};
   const long long gl  = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long p0  = gl / CP;
   const int       c0  = (int)(gl % CP);
@@ -147,19 +189,45 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q)
 
   for (int k = 0; k < q.n_ops; ++k)
   {
-    const DevOp op = q.ops[k];
+    const DevOp op = ro.ops[k];
     double      x1[S], x2[S], u1[S], u2[S];
     int         s1, s2;
-    load_side<S, CP>(q, op.c1, p, c, x1, s1);
-    load_side<S, CP>(q, op.c2, p, c, x2, s2);
+    const double *__restrict__ M1 = ro.pmats + (size_t)op.pm1 * MS + (size_t)c * S * S;
+    const double *__restrict__ M2 = ro.pmats + (size_t)op.pm2 * MS + (size_t)c * S * S;
+    RawSide<S> r1, r2;
+    issue_side<S, CP>(q, ro, op.c1, p, c, r1);
+    issue_side<S, CP>(q, ro, op.c2, p, c, r2);
+    // small alphabets: pull this lane's two 4x4 blocks into registers while the children are in flight
+    double m1[(S <= 4) ? S * S : 1], m2[(S <= 4) ? S * S : 1];
+    if (S <= 4)
+    {
+      const double2 *a = reinterpret_cast<const double2 *>(M1), *b = reinterpret_cast<const double2 *>(M2);
+#pragma unroll
+      for (int j = 0; j < (S * S) / 2; ++j)
+      {
+        const double2 va = a[j], vb = b[j];
+        m1[(2 * j) % (S * S)] = va.x; m1[(2 * j + 1) % (S * S)] = va.y;
+        m2[(2 * j) % (S * S)] = vb.x; m2[(2 * j + 1) % (S * S)] = vb.y;
+      }
+    }
+    finish_side<S, CP>(ro, r1, x1, s1);
+    finish_side<S, CP>(ro, r2, x2, s2);
 
     // all-ones shortcut of the Inin kernel (src/avx.c:575-587): exact 1.0 when both children are 1.0
     bool ones = true;
 #pragma unroll
     for (int j = 0; j < S; ++j) ones = ones && (x1[j] == 1.0) && (x2[j] == 1.0);
 
-    matvec_rows<S>(q.pmats + (size_t)op.pm1 * MS + (size_t)c * S * S, x1, u1);
-    matvec_rows<S>(q.pmats + (size_t)op.pm2 * MS + (size_t)c * S * S, x2, u2);
+    if (S <= 4)
+    {
+      matvec_rows<S>(m1, x1, u1);
+      matvec_rows<S>(m2, x2, u2);
+    }
+    else
+    {
+      matvec_rows<S>(M1, x1, u1);
+      matvec_rows<S>(M2, x2, u2);
+    }
 
     double o[S];
     double mx = -__builtin_huge_val();
@@ -197,9 +265,12 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q)
   {
     double x[S], y[S];
     int    sl, sr;
-    load_side<S, CP>(q, q.e_parent, p, c, x, sl);
-    load_side<S, CP>(q, q.e_child, p, c, y, sr);
-    const double *M = q.pmats + (size_t)q.e_pm * MS + (size_t)c * S * S; // rows: right-side state
+    RawSide<S> rl, rr;
+    issue_side<S, CP>(q, ro, q.e_parent, p, c, rl);
+    issue_side<S, CP>(q, ro, q.e_child, p, c, rr);
+    finish_side<S, CP>(ro, rl, x, sl);
+    finish_side<S, CP>(ro, rr, y, sr);
+    const double *__restrict__ M = ro.pmats + (size_t)q.e_pm * MS + (size_t)c * S * S; // rows: right-side state
     // acc[k] = sum_i P[k][i] x[i] as an FMA chain from zero (src/avx.c:130-145, 191-206);
     // lk_c = sum_k acc[k] * (y[k]*pi[k]) with the 4-wide horizontal order of AVX_Vect_Norm.
     double lkc = 0.0;
@@ -295,6 +366,282 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1 + K2, nucleotide specialisation (S = 4): software-pipelined traversal.
+//
+// The generic kernel above pays one full memory round trip per operation (the chain is latency-,
+// not bandwidth-bound at 50k patterns: ~3 waves per SIMD).  This version
+//   * is branch-free inside the operation loop: tip / internal / forwarded children differ only in
+//     which address the (always issued) loads use and in a wave-uniform select afterwards, so the
+//     compiler keeps every load of an operation in flight together;
+//   * forwards the previous operation's result in registers when it is a child of the next one (in a
+//     post-order walk the parent usually follows its last child immediately), which removes that
+//     read and its store->load round trip;
+//   * issues the loads of operation k+1 (children that are not forwarded, tip bytes, and this lane's
+//     16-byte piece of the two transition matrices) BEFORE computing operation k;
+//   * stages the two matrices of an operation through a per-wave LDS double buffer: one 16-byte
+//     global load per lane instead of sixteen, then broadcast ds_read_b128s.
+// ---------------------------------------------------------------------------------------------
+template <int CP>
+__global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, const DevOp *__restrict__ ops,
+                                                          const double *__restrict__ pmats,
+                                                          const uint8_t *__restrict__ tip_codes)
+{
+  constexpr int S   = 4;
+  constexpr int NCH = (16 * CP + 63) / 64;           // 16-byte matrix pieces per lane and operation
+  __shared__ __attribute__((aligned(16))) double2 lds_p[4][2][16 * CP]; // [wave][buffer][piece]
+
+  const int       lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long long gl   = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long p0   = gl / CP;
+  const int       c0   = (int)(gl % CP);
+  const bool      act  = (p0 < q.P) && (c0 < q.C);
+  // Idle lanes (tail of the last block, categories beyond C) are clamped onto a real (pattern, category):
+  // they compute and STORE exactly what that real lane does -- same value to the same address -- which
+  // keeps every memory instruction in the loop unconditional (exact s_waitcnt counts, no exec branches).
+  const long long p    = (p0 < q.P) ? p0 : (q.P - 1);
+  const int       c    = (c0 < q.C) ? c0 : 0;
+  const int       C    = q.C;
+  const int       CS   = C * S, MS = C * S * S;
+  const int       tips = q.tip_count;
+  const size_t    poff = (size_t)p * CS + (size_t)c * S; // this lane's record inside any partials buffer
+  const double2  *dummy2 = reinterpret_cast<const double2 *>(pmats); // harmless, cached target for unused loads
+
+  struct Raw
+  {
+    double2  a0, a1, b0, b1; // child 1 / child 2 records
+    int      sa, sb;         // scale words (every lane of the pattern reads and writes its own copy)
+    unsigned ca, cb;         // tip bytes
+  };
+
+  // issue every load operation `o` needs; `fwd_dest` is the buffer whose value is live in registers
+  auto issue = [&](const DevOp &o, int fwd_dest, Raw &r, double2 (&pc)[NCH]) {
+    const bool t1 = o.c1 < tips, t2 = o.c2 < tips;
+    const bool l1 = !t1 && o.c1 != fwd_dest, l2 = !t2 && o.c2 != fwd_dest; // really read from memory
+    const size_t   b1 = (size_t)(l1 ? o.c1 - tips : 0), b2 = (size_t)(l2 ? o.c2 - tips : 0);
+    const double2 *s1 = l1 ? reinterpret_cast<const double2 *>(q.partials + b1 * q.P * CS + poff) : dummy2;
+    const double2 *s2 = l2 ? reinterpret_cast<const double2 *>(q.partials + b2 * q.P * CS + poff) : dummy2;
+    r.a0 = s1[0]; r.a1 = s1[1];
+    r.b0 = s2[0]; r.b1 = s2[1];
+    r.sa = q.scales[b1 * q.P + p];
+    r.sb = q.scales[b2 * q.P + p];
+    r.ca = tip_codes[(size_t)(t1 ? o.c1 : 0) * q.P + p];
+    r.cb = tip_codes[(size_t)(t2 ? o.c2 : 0) * q.P + p];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h)
+    {
+      int ch = lane + 64 * h;                    // piece index over [matrix 1 | matrix 2]
+      ch     = (ch < 16 * C) ? ch : 0;
+      const int mat = ch / (8 * C), within = ch - mat * 8 * C;
+      pc[h] = reinterpret_cast<const double2 *>(pmats + (size_t)(mat ? o.pm2 : o.pm1) * MS)[within];
+    }
+  };
+
+  double o_[S] = {0., 0., 0., 0.};
+  int    osc = 0;
+  int    prev_dest = -1;
+
+  if (q.n_ops > 0)
+  {
+    DevOp   cur = ops[0];
+    DevOp   nxt = ops[(1 < q.n_ops) ? 1 : 0];
+    Raw     r;
+    double2 pc[NCH];
+    issue(cur, -1, r, pc);
+
+    for (int k = 0; k < q.n_ops; ++k)
+    {
+      // descriptor of operation k+2 (scalar load, consumed one iteration later)
+      const int   kn2 = (k + 2 < q.n_ops) ? k + 2 : q.n_ops - 1;
+      const DevOp nn  = ops[kn2];
+
+      // stage this operation's matrices into the wave's LDS buffer (same-wave write -> read, in order);
+      // lanes beyond the last piece rewrite piece 0 with the identical bytes they loaded for it
+      double2 *buf = &lds_p[wid][k & 1][0];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+      {
+        const int ch = lane + 64 * h;
+        buf[(ch < 16 * C) ? ch : 0] = pc[h];
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // prefetch everything operation k+1 needs except what operation k is about to produce
+      Raw     rn;
+      double2 pcn[NCH];
+      issue(nxt, cur.dest, rn, pcn);
+
+      // ---- operands of operation k ----
+      const bool t1 = cur.c1 < tips, t2 = cur.c2 < tips;
+      const bool f1 = cur.c1 == prev_dest, f2 = cur.c2 == prev_dest;
+      double     x1[S], x2[S];
+      int        s1, s2;
+      {
+        const unsigned m1 = r.ca, m2 = r.cb; // S <= 8: the byte is the allowed-state mask
+        const double   l1[S] = {r.a0.x, r.a0.y, r.a1.x, r.a1.y}, l2[S] = {r.b0.x, r.b0.y, r.b1.x, r.b1.y};
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+        {
+          x1[j] = t1 ? (((m1 >> j) & 1u) ? 1.0 : 0.0) : (f1 ? o_[j] : l1[j]);
+          x2[j] = t2 ? (((m2 >> j) & 1u) ? 1.0 : 0.0) : (f2 ? o_[j] : l2[j]);
+        }
+        s1 = t1 ? 0 : (f1 ? osc : r.sa);
+        s2 = t2 ? 0 : (f2 ? osc : r.sb);
+      }
+
+      bool ones = true; // all-ones shortcut, src/avx.c:575-587
+#pragma unroll
+      for (int j = 0; j < S; ++j) ones = ones && (x1[j] == 1.0) && (x2[j] == 1.0);
+
+      // ---- this lane's two 4x4 blocks from LDS, then the AVX-ordered products (src/avx.c:593-616) ----
+      double u1[S], u2[S];
+      {
+        const double2 *m = buf + c * 8; // matrix 1, category c: 8 pieces of 16 bytes
+        double         a[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double2 v = m[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
+        matvec_rows<S>(a, x1, u1);
+        m = buf + C * 8 + c * 8;        // matrix 2
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double2 v = m[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
+        matvec_rows<S>(a, x2, u2);
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      double mx = -__builtin_huge_val();
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+      {
+        o_[i] = ones ? 1.0 : u1[i] * u2[i];
+        mx    = (o_[i] > mx) ? o_[i] : mx;
+      }
+      mx  = group_max<CP>(mx);   // clamped lanes hold a copy of a real lane's values: the max is unaffected
+      osc = s1 + s2; // src/avx.c:462-464
+      if (mx < kInvTwoToLarge && q.apply_scaling)
+      { // src/avx.c:504-510
+#pragma unroll
+        for (int i = 0; i < S; ++i) o_[i] *= kTwoToLarge;
+        osc += kLarge;
+      }
+      {
+        const size_t b   = (size_t)(cur.dest - tips);
+        double2     *dst = reinterpret_cast<double2 *>(q.partials + b * q.P * CS + poff);
+        dst[0] = make_double2(o_[0], o_[1]);
+        dst[1] = make_double2(o_[2], o_[3]);
+        q.scales[b * q.P + p] = osc;
+      }
+      prev_dest = cur.dest;
+      cur       = nxt;
+      nxt       = nn;
+      r         = rn;
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) pc[h] = pcn[h];
+    }
+  }
+
+  if (!q.edge_eval) return;
+
+  // ---- K2 (same arithmetic as the generic kernel) ------------------------------------------------
+  double contrib = 0.0;
+  {
+    double x[S], y[S];
+    int    sl, sr;
+    auto side = [&](int idx, double (&v)[S], int &sc) {
+      if (idx < tips)
+      {
+        const unsigned m = tip_codes[(size_t)idx * q.P + p];
+#pragma unroll
+        for (int j = 0; j < S; ++j) v[j] = ((m >> j) & 1u) ? 1.0 : 0.0;
+        sc = 0;
+      }
+      else if (idx == prev_dest)
+      {
+#pragma unroll
+        for (int j = 0; j < S; ++j) v[j] = o_[j];
+        sc = osc;
+      }
+      else
+      {
+        const size_t   b  = (size_t)(idx - tips);
+        const double2 *s2 = reinterpret_cast<const double2 *>(q.partials + b * q.P * CS + poff);
+        const double2  v0 = s2[0], v1 = s2[1];
+        v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
+        sc = q.scales[b * q.P + p];
+      }
+    };
+    side(q.e_parent, x, sl);
+    side(q.e_child, y, sr);
+    const double *__restrict__ M = pmats + (size_t)q.e_pm * MS + (size_t)c * S * S;
+    double t[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+    {
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < S; ++i) a = __builtin_fma(M[kk * S + i], x[i], a);
+      t[kk] = a * (y[kk] * q.pi[kk]);
+    }
+    const double lkc = (t[0] + t[2]) + (t[1] + t[3]);
+    if (act && q.site_cat) q.site_cat[(size_t)p * C + c] = lkc;
+    const double tw   = (c0 < C) ? lkc * q.cat_w[c] : 0.0;
+    double       site = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc)
+    {
+      const double tc = (CP == 1) ? tw : __shfl(tw, cc, CP);
+      if (cc < C) site += tc;
+    }
+    if (act && c == 0)
+    {
+      const double w = q.wght[p];
+      int          f = q.apply_scaling ? (sl + sr) : 0;
+      if (w > kSmall)
+      {
+        if (q.invar_model)
+        {
+          const int iv = q.invar[p];
+          double    inv = 0.0;
+          bool      issue_ = false;
+          if (iv >= 0)
+          {
+            inv = q.pi[iv];
+            if (q.apply_scaling)
+            {
+              int e = f;
+              do
+              {
+                const int piece = e < 63 ? e : 63;
+                inv *= (double)(1ull << piece);
+                e -= piece;
+              } while (e != 0);
+            }
+            issue_ = isinf(inv);
+          }
+          if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
+          else site = site * (1. - q.pinvar) + inv * q.pinvar;
+        }
+        if (site < kSmall) { site = kSmall; *q.warn = 1; }
+        const double lsl = log(site) - kLog2 * (double)f;
+        if (q.site_lnl) q.site_lnl[p] = lsl;
+        if (q.site_lk) q.site_lk[p] = exp(lsl);
+        contrib = w * lsl;
+      }
+      q.fact[p] = f;
+    }
+  }
+  __shared__ double wsum[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+  if (lane == 0) wsum[wid] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += wsum[w];
+    q.block_sums[blockIdx.x] = s;
+  }
+}
+
 // Second stage: one block sums `n` per-block values of up to two interleaved streams in a fixed order.
 // out[k] = sum_i in[k*stride + i].
 __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restrict__ in, int n, int nstreams, int stride,
@@ -327,6 +674,7 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restr
 struct EigenParams
 {
   TreeParams    t;
+  RO            ro;
   int           left, rght;
   const double *r_e_vect, *l_e_vect;
   double       *dot_prod;
@@ -344,8 +692,8 @@ __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
   const int         c   = (c0 < q.C) ? c0 : 0;
   double            x[S], y[S], lp[S];
   int               sl, sr;
-  load_side<S, CP>(q, e.left, p, c, x, sl);
-  load_side<S, CP>(q, e.rght, p, c, y, sr);
+  load_side<S, CP>(q, e.ro, e.left, p, c, x, sl);
+  load_side<S, CP>(q, e.ro, e.rght, p, c, y, sr);
 #pragma unroll
   for (int i = 0; i < S; ++i) lp[i] = x[i] * q.pi[i]; // src/avx.c:79
   double d[S];

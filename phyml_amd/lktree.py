@@ -1,198 +1,252 @@
-"""Host-side mirror of PhyML's likelihood surface on top of the phyhip C ABI (Python harness form).
+"""Python handle on the C host layer (libphyhip_lk.so, include/phyhip_lk.h).
 
-Names and argument meaning follow the reference (src/lk.h:27-159): `Lk(b)`, `dLk(l, b)`,
-`Update_Partial_Lk(b, d)`, `Update_PMat_At_Given_Edge(b)`, `Post_Order_Lk(a, d)`,
-`Pre_Order_Lk(a, d)`, `Update_Eigen_Lr(b)`, `Set_Both_Sides`, so the parity tests read like calls
-into lk.c.  All arithmetic happens in libphyhip.so on the GPU; this module only walks the tree and
-translates (edge, side) to buffer indices -- the job `Set_All_Partial_Lk` does in the reference
-(src/lk.c:2922-3195).
-
-Buffer indices: tips 0..n-1 (as src/lk.c:2229), then one partials buffer per internal edge side, then
-(optionally) spare buffers; one transition-matrix buffer per edge.
+The host side of the likelihood surface -- `Lk`, `dLk`, `Update_Partial_Lk`, `Post_Order_Lk`, ... with
+the reference's names and argument meaning (src/lk.h:27-159) -- is plain C in
+phyml_amd/csrc/host/phl_lk.c, as in the reference.  This module only mirrors its structs with ctypes
+so that the parity tests and bench.py can drive it; no arithmetic and no tree logic lives here.
 """
 from __future__ import annotations
 
-import sys
+import ctypes as C
+import os
 
 import numpy as np
 
 from . import capi
 
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LK_LIB_PATH = os.path.join(_HERE, "lib", "libphyhip_lk.so")
+
+
+class t_node(C.Structure):
+    pass
+
+
+class t_edge(C.Structure):
+    pass
+
+
+t_node._fields_ = [("v", C.POINTER(t_node) * 3), ("b", C.POINTER(t_edge) * 3), ("num", C.c_int), ("tax", C.c_int)]
+t_edge._fields_ = [("left", C.POINTER(t_node)), ("rght", C.POINTER(t_node)), ("num", C.c_int), ("l", C.c_double),
+                   ("Pij_rr_idx", C.c_int), ("p_lk_left_idx", C.c_int), ("p_lk_rght_idx", C.c_int),
+                   ("p_lk_tip_idx", C.c_int), ("update_partial_lk_left", C.c_short),
+                   ("update_partial_lk_rght", C.c_short), ("Pij_rr", C.POINTER(C.c_double))]
+
+
+class t_mod(C.Structure):
+    _fields_ = [("ns", C.c_int), ("n_catg", C.c_int), ("pi", C.POINTER(C.c_double)),
+                ("gamma_rr", C.POINTER(C.c_double)), ("gamma_r_proba", C.POINTER(C.c_double)),
+                ("e_val", C.POINTER(C.c_double)), ("r_e_vect", C.POINTER(C.c_double)),
+                ("l_e_vect", C.POINTER(C.c_double)), ("l_min", C.c_double), ("l_max", C.c_double),
+                ("br_len_mult", C.c_double), ("invar", C.c_int), ("pinvar", C.c_double)]
+
+
+class t_tree(C.Structure):
+    _fields_ = [("a_nodes", C.POINTER(C.POINTER(t_node))), ("a_edges", C.POINTER(C.POINTER(t_edge))),
+                ("mod", C.POINTER(t_mod)), ("n_otu", C.c_int), ("n_pattern", C.c_int),
+                ("wght", C.POINTER(C.c_double)), ("invar", C.POINTER(C.c_short)), ("b_inst", C.c_int),
+                ("tip_root", C.c_int), ("both_sides", C.c_short), ("use_eigen_lr", C.c_short),
+                ("update_eigen_lr", C.c_short), ("apply_lk_scaling", C.c_short), ("numerical_warning", C.c_short),
+                ("host_pmat", C.c_short), ("c_lnL", C.c_double), ("old_lnL", C.c_double), ("c_dlnL", C.c_double),
+                ("n_edges_traversed", C.c_int)]
+
+
+_lib = None
+_errors = []
+
+
+@C.CFUNCTYPE(None, C.c_char_p)
+def _exit_handler(msg):
+    _errors.append(msg.decode(errors="replace"))
+
+
+def load():
+    global _lib
+    if _lib is None:
+        capi.load()  # libphyhip.so first (the host layer links against it)
+        if not os.path.exists(LK_LIB_PATH):
+            raise capi.PhyhipError(f"{LK_LIB_PATH} not built: run __graft_entry__.build()")
+        L = C.CDLL(LK_LIB_PATH)
+        L.Make_Tree_From_Edges.restype = C.POINTER(t_tree)
+        L.Make_Model_Basic.restype = C.POINTER(t_mod)
+        for f in ("Lk", "dLk", "Br_Len_Opt"):
+            getattr(L, f).restype = C.c_double
+        # tests must survive the reference's print-and-Exit() convention
+        L.Set_Exit_Handler(_exit_handler)
+        _lib = L
+    return _lib
+
+
+def _raise_if_error():
+    if _errors:
+        msg = "".join(_errors)
+        _errors.clear()
+        raise capi.PhyhipError(msg.strip())
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
 
 class LkTree:
-    def __init__(self, n_otu, edge_left, edge_rght, edge_len, n_pattern, ns, ncatg, device=None, adjacency=None,
-                 host_pmat=None):
-        self.n = int(n_otu)
-        self.el = np.asarray(edge_left, dtype=np.int64)
-        self.er = np.asarray(edge_rght, dtype=np.int64)
-        self.len = np.array(edge_len, dtype=np.float64)
-        self.ne = len(self.el)
-        self.P, self.S, self.C = int(n_pattern), int(ns), int(ncatg)
-        # (edge, side) -> partials buffer index; side 0 = left, 1 = rght
-        self.buf = {}
-        nxt = self.n
-        for e in range(self.ne):
-            for side, node in ((0, self.el[e]), (1, self.er[e])):
-                if node < self.n:
-                    self.buf[(e, side)] = int(node)      # tip vector lives on the tip's own index
-                else:
-                    self.buf[(e, side)] = nxt
-                    nxt += 1
-        self.n_partials = nxt
-        self.inst = capi.Instance(self.n, self.n_partials, self.S, self.P, self.ne, self.C, device=device)
-        if adjacency is None:
-            adj = [[] for _ in range(2 * self.n - 2)]
-            for e in range(self.ne):
-                adj[self.el[e]].append((int(self.er[e]), e))
-                adj[self.er[e]].append((int(self.el[e]), e))
-            self.adj = adj
-        else:
-            self.adj = adjacency
-        self.tip_root = 0
-        self.both_sides = False
-        self.use_eigen_lr = False
-        self.update_eigen_lr = False
-        self.c_lnL = 0.0
-        self.c_dlnL = 0.0
-        self.host_pmat = host_pmat          # callable(edge_len) -> [C][S][S] for the bit-exact host route
-        self.n_update_calls = 0
+    """Owns a C `t_tree` + `t_mod`.  Methods are one-line forwards to the C functions of the same name."""
 
-    def close(self):
-        self.inst.close()
+    def __init__(self, n_otu, edge_left, edge_rght, edge_len, n_pattern, ns, ncatg, device=None, node_v=None,
+                 node_b=None, host_pmat=False):
+        L = load()
+        self.L = L
+        self.n, self.P, self.S, self.C = int(n_otu), int(n_pattern), int(ns), int(ncatg)
+        el = np.ascontiguousarray(edge_left, dtype=np.int32); er = np.ascontiguousarray(edge_rght, dtype=np.int32)
+        ln = np.ascontiguousarray(edge_len, dtype=np.float64)
+        nv = None if node_v is None else np.ascontiguousarray(node_v, dtype=np.int32)
+        nb = None if node_b is None else np.ascontiguousarray(node_b, dtype=np.int32)
+        self.ne = len(el)
+        self.tree = L.Make_Tree_From_Edges(self.n, el.ctypes.data_as(C.c_void_p), er.ctypes.data_as(C.c_void_p), _dp(ln),
+                                           None if nv is None else nv.ctypes.data_as(C.c_void_p),
+                                           None if nb is None else nb.ctypes.data_as(C.c_void_p))
+        self.mod = L.Make_Model_Basic(self.S, self.C)
+        self.tree.contents.mod = self.mod
+        self.tree.contents.host_pmat = 1 if host_pmat else 0
+        self.device = -1 if device is None else int(device)
+        self._made = False
+        self.inst = None
 
-    # ---- model / data upload (create_beagle_instance + update_beagle_ras/efrqs/eigen) -------------
+    # --- model / data ------------------------------------------------------------------------------
     def set_model(self, pi, gamma_rr, gamma_r_proba, e_val, r_e_vect, l_e_vect, l_min=1e-8, l_max=100.0,
-                  br_len_mult=1.0, apply_lk_scaling=1, invar_model=0, pinvar=0.0, invar=None):
-        i = self.inst
-        i.set_state_frequencies(pi)
-        i.set_category_rates(gamma_rr)
-        i.set_category_weights(gamma_r_proba)
-        i.set_eigen_decomposition(r_e_vect, l_e_vect, e_val)
-        i.set_phyml_options(l_min, l_max, br_len_mult, apply_lk_scaling)
-        i.set_invariant_sites(invar_model, pinvar, invar)
+                  br_len_mult=1.0, apply_lk_scaling=1, invar_model=0, pinvar=0.0):
+        m = self.mod.contents
+        for dst, src, n in ((m.pi, pi, self.S), (m.gamma_rr, gamma_rr, self.C), (m.gamma_r_proba, gamma_r_proba, self.C),
+                            (m.e_val, e_val, self.S), (m.r_e_vect, r_e_vect, self.S * self.S),
+                            (m.l_e_vect, l_e_vect, self.S * self.S)):
+            a = np.ascontiguousarray(src, dtype=np.float64).ravel()
+            assert a.size == n
+            C.memmove(dst, a.ctypes.data, 8 * n)
+        m.l_min, m.l_max, m.br_len_mult = float(l_min), float(l_max), float(br_len_mult)
+        m.invar, m.pinvar = int(invar_model), float(pinvar)
+        self.tree.contents.apply_lk_scaling = int(apply_lk_scaling)
+        if self._made:
+            self.L.Update_Model_On_Device(self.tree)
+            _raise_if_error()
 
-    def set_data(self, wght, tip_partials=None, tip_states=None):
-        self.inst.set_pattern_weights(wght)
+    def Make_Tree_For_Lk(self, wght, invar=None):
+        w = np.ascontiguousarray(wght, dtype=np.float64); assert w.size == self.P
+        iv = None if invar is None else np.ascontiguousarray(invar, dtype=np.int16)
+        self.L.Make_Tree_For_Lk(self.tree, self.P, _dp(w), None if iv is None else iv.ctypes.data_as(C.c_void_p),
+                                self.device)
+        _raise_if_error()
+        self._made = True
+        self.inst = _InstanceView(self.tree.contents.b_inst, self)
+
+    def set_tips(self, tip_partials=None, tip_states=None):
         for t in range(self.n):
             if tip_partials is not None:
-                self.inst.set_tip_partials(t, tip_partials[t])
+                a = np.ascontiguousarray(tip_partials[t], dtype=np.float64); assert a.size == self.P * self.S
+                self.L.Init_Partial_Lk_Tips_Double_One_Tip(self.tree, t, _dp(a))
             else:
-                self.inst.set_tip_states(t, tip_states[t])
+                a = np.ascontiguousarray(tip_states[t], dtype=np.int32); assert a.size == self.P
+                self.L.Init_Partial_Lk_Tips_States_One_Tip(self.tree, t, a.ctypes.data_as(C.c_void_p))
+            _raise_if_error()
 
-    # ---- a12 -------------------------------------------------------------------------------------------
-    def Update_PMat_At_Given_Edge(self, b):
-        if self.host_pmat is not None:
-            self.inst.set_transition_matrix(b, self.host_pmat(self.len[b]))
-        else:
-            self.inst.update_transition_matrices([b], [self.len[b]])
+    def close(self):
+        if self.tree is not None:
+            if self._made:
+                self.L.Free_Tree_Lk(self.tree)
+            self.L.Free_Tree(self.tree)
+            self.L.Free_Model(self.mod)
+            self.tree = None
 
-    def Update_All_PMat(self):
-        if self.host_pmat is not None:
-            for b in range(self.ne):
-                self.inst.set_transition_matrix(b, self.host_pmat(self.len[b]))
-        else:
-            self.inst.update_transition_matrices(np.arange(self.ne), self.len)
+    # --- accessors ---------------------------------------------------------------------------------------
+    def edge(self, e):
+        return self.tree.contents.a_edges[e]
 
-    # ---- a2 / a5 -----------------------------------------------------------------------------------------
-    def _op(self, b, d):
-        dest = self.buf[(b, 0 if d == self.el[b] else 1)]
-        ch = []
-        for (v, be) in self.adj[d]:
-            if be != b:
-                ch.append((self.buf[(be, 1 if d == self.el[be] else 0)], be))
-        assert len(ch) == 2
-        return (dest, ch[0][0], ch[0][1], ch[1][0], ch[1][1])
+    def node(self, k):
+        return self.tree.contents.a_nodes[k]
 
-    def Update_Partial_Lk(self, b, d):
-        if d < self.n:                       # src/lk.c:1297
-            return
-        self.inst.update_partials([self._op(b, d)])
-        self.n_update_calls += 1
+    @property
+    def c_lnL(self):
+        return self.tree.contents.c_lnL
 
-    # ---- a13 ----------------------------------------------------------------------------------------------
-    def _post(self, a, d, out):
-        if d < self.n:
-            return
-        dir_e = None
-        for (v, be) in self.adj[d]:
-            if v != a:
-                self._post(d, v, out)
-            else:
-                dir_e = be
-        out.append((dir_e, d))
+    @property
+    def c_dlnL(self):
+        return self.tree.contents.c_dlnL
 
-    def _pre(self, a, d, out):
-        if d < self.n:
-            return
-        for (v, be) in self.adj[d]:
-            if v != a:
-                out.append((be, d))
-                self._pre(d, v, out)
+    @property
+    def tip_root(self):
+        return self.tree.contents.tip_root
 
-    def _walk(self, fn, a, d):
-        out = []
-        old = sys.getrecursionlimit()
-        sys.setrecursionlimit(max(old, 10 * self.n + 100))
-        try:
-            fn(a, d, out)
-        finally:
-            sys.setrecursionlimit(old)
-        return out
+    @tip_root.setter
+    def tip_root(self, v):
+        self.tree.contents.tip_root = int(v)
 
-    def Post_Order_Lk(self, a, d):
-        order = self._walk(self._post, a, d)
-        self.inst.update_partials([self._op(b, dd) for (b, dd) in order])
-        self.n_update_calls += len(order)
-
-    def Pre_Order_Lk(self, a, d):
-        order = self._walk(self._pre, a, d)
-        self.inst.update_partials([self._op(b, dd) for (b, dd) in order])
-        self.n_update_calls += len(order)
-
-    def Set_Both_Sides(self, yesno):
-        self.both_sides = bool(yesno)
-
-    def Set_Use_Eigen_Lr(self, yesno):
-        self.use_eigen_lr = bool(yesno)
-
-    def Set_Update_Eigen_Lr(self, yesno):
-        self.update_eigen_lr = bool(yesno)
-
-    # ---- a1 ---------------------------------------------------------------------------------------------------
+    # --- the surface (same names as src/lk.h) ------------------------------------------------------------------
     def Lk(self, b=None):
-        if b is None:
-            self.Update_All_PMat()
-            r = self.tip_root
-            v0 = self.adj[r][0][0]
-            self.Post_Order_Lk(r, v0)
-            if self.both_sides:
-                self.Pre_Order_Lk(r, v0)
-            b = self.adj[r][0][1]
-        elif not self.use_eigen_lr:
-            self.Update_PMat_At_Given_Edge(b)
-        if self.update_eigen_lr:
-            self.Update_Eigen_Lr(b)
-        if self.use_eigen_lr:
-            self.c_lnL = self.inst.eigen_lnl(self.len[b])
-        else:
-            self.c_lnL = self.inst.edge_lnl(self.buf[(b, 0)], self.buf[(b, 1)], b)
-        return self.c_lnL
-
-    # ---- a10 / a11 -----------------------------------------------------------------------------------------------
-    def Update_Eigen_Lr(self, b):
-        self.inst.update_eigen_lr(self.buf[(b, 0)], self.buf[(b, 1)])
+        v = self.L.Lk(None if b is None else self.edge(b), self.tree)
+        _raise_if_error()
+        return v
 
     def dLk(self, l, b):
-        """Returns (clamped l, lnL); sets c_lnL and c_dlnL like src/lk.c:749-750."""
-        if self.update_eigen_lr:
-            self.Update_Eigen_Lr(b)
-        l2, lnl, dlnl = self.inst.eigen_lnl_dlnl(l)
-        self.c_lnL, self.c_dlnL = lnl, dlnl
-        return l2, lnl
+        lv = C.c_double(l)
+        v = self.L.dLk(C.byref(lv), self.edge(b), self.tree)
+        _raise_if_error()
+        return lv.value, v
 
-    # ---- download hooks ---------------------------------------------------------------------------------------------
+    def Update_Partial_Lk(self, b, d):
+        self.L.Update_Partial_Lk(self.tree, self.edge(b), self.node(d)); _raise_if_error()
+
+    def Update_PMat_At_Given_Edge(self, b):
+        self.L.Update_PMat_At_Given_Edge(self.edge(b), self.tree); _raise_if_error()
+
+    def Post_Order_Lk(self, a, d):
+        self.L.Post_Order_Lk(self.node(a), self.node(d), self.tree); _raise_if_error()
+
+    def Pre_Order_Lk(self, a, d):
+        self.L.Pre_Order_Lk(self.node(a), self.node(d), self.tree); _raise_if_error()
+
+    def Update_All_Partial_Lk(self):
+        self.L.Update_All_Partial_Lk(self.tree); _raise_if_error()
+
+    def Update_Eigen_Lr(self, b):
+        self.L.Update_Eigen_Lr(self.edge(b), self.tree); _raise_if_error()
+
+    def Set_Both_Sides(self, yesno):
+        self.L.Set_Both_Sides(int(bool(yesno)), self.tree)
+
+    def Set_Use_Eigen_Lr(self, yesno):
+        self.L.Set_Use_Eigen_Lr(int(bool(yesno)), self.tree)
+
+    def Set_Update_Eigen_Lr(self, yesno):
+        self.L.Set_Update_Eigen_Lr(int(bool(yesno)), self.tree)
+
+    def Br_Len_Opt(self, b):
+        lv = C.c_double(self.edge(b).contents.l)
+        v = self.L.Br_Len_Opt(C.byref(lv), self.edge(b), self.tree)
+        _raise_if_error()
+        return lv.value, v
+
+    def Lk_Shard_Device(self, device_ptr):
+        self.L.Lk_Shard_Device(self.tree, C.c_void_p(device_ptr)); _raise_if_error()
+
+    # --- download hooks ---------------------------------------------------------------------------------------------
+    def side_buffer(self, b, side):
+        e = self.edge(b).contents
+        return e.p_lk_left_idx if side == 0 else e.p_lk_rght_idx
+
     def partials(self, b, side):
-        return self.inst.get_partials(self.buf[(b, side)])
+        return self.inst.get_partials(self.side_buffer(b, side))
 
     def scale_factors(self, b, side):
-        return self.inst.get_scale_factors(self.buf[(b, side)])
+        return self.inst.get_scale_factors(self.side_buffer(b, side))
+
+
+class _InstanceView(capi.Instance):
+    """capi.Instance methods on an instance id that the C host layer created (no ownership)."""
+
+    def __init__(self, inst_id, tree: LkTree):
+        self.L = capi.load()
+        self.id = inst_id
+        self.tips, self.S, self.P, self.C = tree.n, tree.S, tree.P, tree.C
+        self.nmat = tree.ne
+        self.details = None
+
+    def close(self):
+        self.id = None

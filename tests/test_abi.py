@@ -25,6 +25,20 @@ def test_header_symbols_exported():
         assert hasattr(L, s), s
 
 
+def test_host_layer_exports():
+    """libphyhip_lk.so exports the reference-named surface declared in include/phyhip_lk.h."""
+    L, capi = _lib()
+    from phyml_amd import lktree
+    H = lktree.load()
+    hdr = open(os.path.join(ROOT, "include", "phyhip_lk.h")).read()
+    body = hdr[hdr.index("/* ---- construction"):]
+    names = set(re.findall(r"^[A-Za-z_ \*]*?\b([A-Za-z_]+)\(", body, flags=re.M)) - {"void", "handler"}
+    assert {"Lk", "dLk", "Update_Partial_Lk", "Update_PMat_At_Given_Edge", "Post_Order_Lk", "Pre_Order_Lk",
+            "Update_Eigen_Lr", "Set_Both_Sides", "Br_Len_Opt", "Make_Tree_For_Lk", "Free_Tree_Lk", "PMat"} <= names, names
+    for s in names:
+        assert hasattr(H, s), s
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
