@@ -121,7 +121,8 @@ struct Instance
   int      *h_warn     = nullptr;
   void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
   int       pm_scratch_cap = 0;
-  DevOp    *d_ops      = nullptr; // ring of op lists on the device
+  char     *d_ops      = nullptr; // ring of op lists on the device (slim DevOp or fat IssueRec+ExecRec)
+  size_t    ops_slot_bytes = 0;
   int       ops_cap = 0, ops_slots = 4, ops_slot = 0;
   int       grid = 0;
 
@@ -136,6 +137,8 @@ struct Instance
   double l_min = 1.e-8, l_max = 100., br_len_mult = 1.0, pinvar = 0.0; // src/init.c:711-714
   int    apply_scaling = 1, invar_model = 0;
   bool   want_site_outputs = true;
+  int    ablate = 0;         // PHYHIP_ABLATE: timing-only kernel variants (results invalid)
+  bool   no_loads = false;   // PHYHIP_NOLOADS: zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
 
   bool       prof = false;
@@ -224,16 +227,67 @@ int flush(Instance *I, const EdgeEval *ee)
 
   TreeParams q = base_params(I);
   RO         ro = base_ro(I, nullptr);
+  const bool fat = (I->S == 4) && !I->generic_nt;
+  const IssueRec *d_irec = nullptr;
+  const ExecRec  *d_xrec = nullptr;
+  q.last_dest = -1;
   if (n_ops > 0)
   {
-    void *st = nullptr;
-    rc = I->ring.alloc(sizeof(DevOp) * n_ops, I->stream, &st);
-    if (rc) return rc;
-    memcpy(st, I->pending.data(), sizeof(DevOp) * n_ops);
-    DevOp *dst = I->d_ops + (size_t)I->ops_slot * I->ops_cap;
+    char *dst = I->d_ops + (size_t)I->ops_slot * I->ops_slot_bytes;
     I->ops_slot = (I->ops_slot + 1) % I->ops_slots;
-    HIPCHK(hipMemcpyAsync(dst, st, sizeof(DevOp) * n_ops, hipMemcpyHostToDevice, I->stream));
-    ro.ops = dst;
+    void *st = nullptr;
+    if (!fat)
+    {
+      rc = I->ring.alloc(sizeof(DevOp) * n_ops, I->stream, &st);
+      if (rc) return rc;
+      memcpy(st, I->pending.data(), sizeof(DevOp) * n_ops);
+      HIPCHK(hipMemcpyAsync(dst, st, sizeof(DevOp) * n_ops, hipMemcpyHostToDevice, I->stream));
+      ro.ops = reinterpret_cast<const DevOp *>(dst);
+    }
+    else
+    {
+      // one record pair per operation, all address arithmetic done here once
+      const size_t ib = sizeof(IssueRec) * n_ops, xb = sizeof(ExecRec) * n_ops;
+      rc = I->ring.alloc(ib + xb, I->stream, &st);
+      if (rc) return rc;
+      IssueRec *ir = reinterpret_cast<IssueRec *>(st);
+      ExecRec  *xr = reinterpret_cast<ExecRec *>((char *)st + ib);
+      const size_t   bufbytes = buf_elems(I) * sizeof(double);
+      const unsigned matbytes = (unsigned)((size_t)I->C * I->S * I->S * sizeof(double));
+      auto desc = [](const void *base, size_t bytes, unsigned x) {
+        Desc d;
+        d.base = (unsigned long long)(uintptr_t)base; d.bytes = (unsigned)bytes; d.x = x;
+        return d;
+      };
+      for (int k = 0; k < n_ops; ++k)
+      {
+        const DevOp &o  = I->pending[k];
+        const int    e1 = k >= 1 ? I->pending[k - 1].dest : -1, e2 = k >= 2 ? I->pending[k - 2].dest : -1;
+        unsigned     fl = 0;
+        auto child = [&](int c, unsigned tipbit, unsigned f1bit, unsigned f2bit, Desc &data, Desc &scale, Desc &tip,
+                         unsigned pmoff) {
+          const bool t = c < I->tips;
+          const bool f1 = !t && c == e1, f2 = !t && !f1 && c == e2;
+          const bool ld = !t && !f1 && !f2 && !I->no_loads;
+          if (t) fl |= tipbit;
+          if (f1) fl |= f1bit;
+          if (f2) fl |= f2bit;
+          const size_t b = ld ? (size_t)(c - I->tips) : 0;
+          data  = desc(I->d_partials + b * buf_elems(I), ld ? bufbytes : 0, pmoff);
+          scale = desc(I->d_scales + b * I->P, ld ? (size_t)I->P * 4 : 0, 0);
+          tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->P, t ? (size_t)I->P : 0, 0);
+        };
+        child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes);
+        child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);
+        const size_t b = (size_t)(o.dest - I->tips);
+        xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), bufbytes, fl);
+        xr[k].dst_scale = desc(I->d_scales + b * I->P, (size_t)I->P * 4, 0);
+      }
+      HIPCHK(hipMemcpyAsync(dst, st, ib + xb, hipMemcpyHostToDevice, I->stream));
+      d_irec = reinterpret_cast<const IssueRec *>(dst);
+      d_xrec = reinterpret_cast<const ExecRec *>(dst + ib);
+      q.last_dest = I->pending[n_ops - 1].dest;
+    }
     q.n_ops = n_ops;
   }
   if (ee)
@@ -255,7 +309,18 @@ int flush(Instance *I, const EdgeEval *ee)
     {
       if (!I->generic_nt)
       {
-        hipLaunchKernelGGL((traverse_nt_kernel<CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, ro.ops, ro.pmats, ro.tip_codes);
+        if constexpr (CP_ == 4)
+        {
+          switch (I->ablate)
+          {
+#define ABLCASE(a) case a: hipLaunchKernelGGL((traverse_nt_kernel<CP_, a>), dim3(I->grid), dim3(256), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes); return 0;
+            ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(6) ABLCASE(7)
+#undef ABLCASE
+            default: break;
+          }
+        }
+        hipLaunchKernelGGL((traverse_nt_kernel<CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, d_irec, d_xrec, ro.pmats,
+                           ro.tip_codes);
         return 0;
       }
     }
@@ -331,6 +396,10 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   if (stateCount != 4 && stateCount != 20)
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "stateCount %d: only 4 (nt) and 20 (aa) are built", stateCount);
   if (categoryCount > 8) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "categoryCount %d > 8", categoryCount);
+  if ((double)patternCount * categoryCount * stateCount * 8.0 >= 2147483648.0)
+    return fail(PHYHIP_ERROR_OUT_OF_RANGE, "one partials buffer must stay below 2 GiB (shard the patterns across devices)");
+  if ((double)matrixBufferCount * categoryCount * stateCount * stateCount * 8.0 >= 2147483648.0)
+    return fail(PHYHIP_ERROR_OUT_OF_RANGE, "transition-matrix table must stay below 2 GiB");
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -392,13 +461,16 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
   I->ops_cap = 2 * I->nbuf + 8;
-  HIPCHK(hipMalloc((void **)&I->d_ops, (size_t)I->ops_slots * I->ops_cap * sizeof(DevOp)));
-  size_t chunk = std::max<size_t>(64 * 1024, std::max(sizeof(DevOp) * (size_t)I->ops_cap,
+  I->ops_slot_bytes = (size_t)(I->ops_cap + 1) * (sizeof(IssueRec) + sizeof(ExecRec));
+  HIPCHK(hipMalloc((void **)&I->d_ops, (size_t)I->ops_slots * I->ops_slot_bytes));
+  size_t chunk = std::max<size_t>(64 * 1024, std::max(I->ops_slot_bytes,
                                                        (size_t)I->C * I->S * I->S * sizeof(double) * 4));
   int rc = I->ring.init(chunk);
   if (rc) return rc;
   I->mat_in_queue.assign(I->nmat, 0);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
+  if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
 
   // codes 0..S-1 are the single states
   for (int s = 0; s < I->S; ++s)

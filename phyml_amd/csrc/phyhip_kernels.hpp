@@ -27,10 +27,43 @@ constexpr double kSmall         = 2.2250738585072014e-308;     // SMALL = DBL_MI
 constexpr double kLog2          = 0.69314718055994528623;      // LOG2, src/utilities.h:267
 constexpr double kSmallPij      = 1.E-100;                     // SMALL_PIJ, src/utilities.h:478
 constexpr int    kMaxExpl       = 2 * 8 * 20;                  // dLk's expl table: [C<=8][2][S<=20]
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct DevOp
 {
   int dest, c1, c2, pm1, pm2, pad;
+};
+
+// Host-prepared operation records for the pipelined nucleotide kernel.  All per-operation address
+// arithmetic is done ONCE on the host at flush time (the scalar unit is shared by the four SIMDs of a CU:
+// ~200 SALU instructions per operation were the kernel's bottleneck when descriptors were derived on
+// the device).  A `Desc` is (base address, size in bytes); size 0 disables the load through the
+// hardware bounds check.
+struct Desc
+{
+  unsigned long long base;
+  unsigned           bytes;
+  unsigned           x; // spare word, meaning depends on the slot
+};
+struct IssueRec          // what the load stage of operation k needs (consumed two steps before execution)
+{
+  Desc c1_data;  // x: byte offset of transition matrix 1 inside the matrix table
+  Desc c2_data;  // x: byte offset of transition matrix 2
+  Desc c1_scale;
+  Desc c2_scale;
+  Desc c1_tip;
+  Desc c2_tip;
+};
+struct ExecRec           // what the compute / store stage of operation k needs
+{
+  Desc dst_data; // x: flags
+  Desc dst_scale;
+};
+enum : unsigned
+{
+  kOpTip1 = 1u, kOpTip2 = 2u,   // child is a tip: expand its state byte
+  kOpF11 = 4u, kOpF12 = 8u,     // child 1 is the result of the previous / second-previous operation
+  kOpF21 = 16u, kOpF22 = 32u    // child 2 likewise
 };
 
 // Everything a traversal launch needs.  Passed by value (fits the 4 KiB kernarg segment easily).
@@ -44,6 +77,7 @@ struct TreeParams
   int             tip_count;
   int             apply_scaling;
   int             n_ops;
+  int             last_dest;  // destination buffer of the last queued operation (-1: none)
   // fused root-edge evaluation (K2)
   int             edge_eval;
   int             e_parent, e_child, e_pm;
@@ -382,10 +416,13 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
 //   * stages the two matrices of an operation through a per-wave LDS double buffer: one 16-byte
 //     global load per lane instead of sixteen, then broadcast ds_read_b128s.
 // ---------------------------------------------------------------------------------------------
-template <int CP>
-__global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, const DevOp *__restrict__ ops,
-                                                          const double *__restrict__ pmats,
-                                                          const uint8_t *__restrict__ tip_codes)
+// ABL != 0 builds timing-only ablation variants (PHYHIP_ABLATE): bit0 no stores, bit1 no matrix-vector work,
+// bit2 no LDS staging.  Results are wrong by construction; used to attribute kernel time.
+template <int CP, int ABL = 0>
+__global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+                                                             const ExecRec *__restrict__ xrec,
+                                                             const double *__restrict__ pmats,
+                                                             const uint8_t *__restrict__ tip_codes)
 {
   constexpr int S   = 4;
   constexpr int NCH = (16 * CP + 63) / 64;           // 16-byte matrix pieces per lane and operation
@@ -404,90 +441,106 @@ __global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, co
   const int       C    = q.C;
   const int       CS   = C * S, MS = C * S * S;
   const int       tips = q.tip_count;
-  const size_t    poff = (size_t)p * CS + (size_t)c * S; // this lane's record inside any partials buffer
-  const double2  *dummy2 = reinterpret_cast<const double2 *>(pmats); // harmless, cached target for unused loads
+  // Addressing: every buffer is reached through a 128-bit buffer descriptor held in SGPRs (base and size
+  // come ready-made from the host's operation record) plus ONE 32-bit per-lane byte offset that is the
+  // same for every partials buffer.  A load that is not needed (tip or forwarded child, tip byte of an
+  // internal child) has size 0: the hardware bounds check returns 0 without touching memory, so the loop
+  // body has neither branches nor conditional memory instructions.
+  const unsigned poffb = (unsigned)(((size_t)p * CS + (size_t)c * S) * sizeof(double)); // bytes
+  const unsigned pidx  = (unsigned)p;
+  const size_t   bufsz = (size_t)q.P * CS;                                              // doubles per buffer
 
   struct Raw
   {
-    double2  a0, a1, b0, b1; // child 1 / child 2 records
-    int      sa, sb;         // scale words (every lane of the pattern reads and writes its own copy)
+    u32x4    a0, a1, b0, b1; // child 1 / child 2 records (2 doubles each)
+    unsigned sa, sb;         // scale words (every lane of the pattern reads and writes its own copy)
     unsigned ca, cb;         // tip bytes
   };
+  const __amdgpu_buffer_rsrc_t pm_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pmats), 0, 0x7fffffff, 0x00020000);
+  auto rsrc = [](const Desc &d) {
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
+  };
 
-  // issue every load operation `o` needs; `fwd_dest` is the buffer whose value is live in registers
-  auto issue = [&](const DevOp &o, int fwd_dest, Raw &r, double2 (&pc)[NCH]) {
-    const bool t1 = o.c1 < tips, t2 = o.c2 < tips;
-    const bool l1 = !t1 && o.c1 != fwd_dest, l2 = !t2 && o.c2 != fwd_dest; // really read from memory
-    const size_t   b1 = (size_t)(l1 ? o.c1 - tips : 0), b2 = (size_t)(l2 ? o.c2 - tips : 0);
-    const double2 *s1 = l1 ? reinterpret_cast<const double2 *>(q.partials + b1 * q.P * CS + poff) : dummy2;
-    const double2 *s2 = l2 ? reinterpret_cast<const double2 *>(q.partials + b2 * q.P * CS + poff) : dummy2;
-    r.a0 = s1[0]; r.a1 = s1[1];
-    r.b0 = s2[0]; r.b1 = s2[1];
-    r.sa = q.scales[b1 * q.P + p];
-    r.sb = q.scales[b2 * q.P + p];
-    r.ca = tip_codes[(size_t)(t1 ? o.c1 : 0) * q.P + p];
-    r.cb = tip_codes[(size_t)(t2 ? o.c2 : 0) * q.P + p];
+  // issue every load an operation needs (which ones are live was decided by the host)
+  auto issue = [&](const IssueRec &o, Raw &r, u32x4 (&pc)[NCH]) {
+    const __amdgpu_buffer_rsrc_t d1r = rsrc(o.c1_data), d2r = rsrc(o.c2_data), g1r = rsrc(o.c1_scale),
+                                 g2r = rsrc(o.c2_scale), y1r = rsrc(o.c1_tip), y2r = rsrc(o.c2_tip);
+    r.a0 = __builtin_amdgcn_raw_buffer_load_b128(d1r, poffb, 0, 0);
+    r.a1 = __builtin_amdgcn_raw_buffer_load_b128(d1r, poffb + 16, 0, 0);
+    r.b0 = __builtin_amdgcn_raw_buffer_load_b128(d2r, poffb, 0, 0);
+    r.b1 = __builtin_amdgcn_raw_buffer_load_b128(d2r, poffb + 16, 0, 0);
+    r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, pidx * 4, 0, 0);
+    r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, pidx * 4, 0, 0);
+    r.ca = __builtin_amdgcn_raw_buffer_load_b8(y1r, pidx, 0, 0);
+    r.cb = __builtin_amdgcn_raw_buffer_load_b8(y2r, pidx, 0, 0);
 #pragma unroll
     for (int h = 0; h < NCH; ++h)
     {
       int ch = lane + 64 * h;                    // piece index over [matrix 1 | matrix 2]
       ch     = (ch < 16 * C) ? ch : 0;
-      const int mat = ch / (8 * C), within = ch - mat * 8 * C;
-      pc[h] = reinterpret_cast<const double2 *>(pmats + (size_t)(mat ? o.pm2 : o.pm1) * MS)[within];
+      const int      mat = ch / (8 * C), within = ch - mat * 8 * C;
+      const unsigned off = (mat ? o.c2_data.x : o.c1_data.x) + (unsigned)within * 16u;
+      pc[h] = __builtin_amdgcn_raw_buffer_load_b128(pm_rsrc, off, 0, 0);
     }
   };
+  auto as_d2 = [](const u32x4 &v) { double2 d; __builtin_memcpy(&d, &v, 16); return d; };
 
-  double o_[S] = {0., 0., 0., 0.};
-  int    osc = 0;
-  int    prev_dest = -1;
+  // results of the last two operations stay in registers: F1 = operation k-1 (buffer d1), F2 = k-2 (d2)
+  double F1[S] = {0., 0., 0., 0.}, F2[S] = {0., 0., 0., 0.};
+  int    sc1 = 0, sc2 = 0;
 
   if (q.n_ops > 0)
   {
-    DevOp   cur = ops[0];
-    DevOp   nxt = ops[(1 < q.n_ops) ? 1 : 0];
-    Raw     r;
-    double2 pc[NCH];
-    issue(cur, -1, r, pc);
+    const int last = q.n_ops - 1;
+    Raw       RA, RB;
+    u32x4     PA[NCH], PB[NCH];
+    issue(irec[0], RA, PA);
+    issue(irec[(1 < last) ? 1 : last], RB, PB);
+    ExecRec cur = xrec[0];
 
-    for (int k = 0; k < q.n_ops; ++k)
-    {
-      // descriptor of operation k+2 (scalar load, consumed one iteration later)
-      const int   kn2 = (k + 2 < q.n_ops) ? k + 2 : q.n_ops - 1;
-      const DevOp nn  = ops[kn2];
+    // One pipeline step.  (R, PC) hold the loads of operation k, issued two steps ago; after its operands
+    // are extracted the same registers receive the loads of operation k+2.  The loop below alternates two
+    // register sets, so no loaded value is ever copied (a copy would force a wait on loads still in flight).
+    auto step = [&](const int k, const int parity, Raw &R, u32x4 (&PC)[NCH]) {
+      // scalar loads: load-stage record of operation k+2, compute-stage record of operation k+1
+      const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
+      const ExecRec  nx1 = xrec[(k + 1 < last) ? k + 1 : last];
 
       // stage this operation's matrices into the wave's LDS buffer (same-wave write -> read, in order);
       // lanes beyond the last piece rewrite piece 0 with the identical bytes they loaded for it
-      double2 *buf = &lds_p[wid][k & 1][0];
+      double2 *buf = &lds_p[wid][parity][0];
 #pragma unroll
       for (int h = 0; h < NCH; ++h)
       {
         const int ch = lane + 64 * h;
-        buf[(ch < 16 * C) ? ch : 0] = pc[h];
+        if (!(ABL & 4)) buf[(ch < 16 * C) ? ch : 0] = as_d2(PC[h]);
       }
       __builtin_amdgcn_wave_barrier();
 
-      // prefetch everything operation k+1 needs except what operation k is about to produce
-      Raw     rn;
-      double2 pcn[NCH];
-      issue(nxt, cur.dest, rn, pcn);
-
       // ---- operands of operation k ----
-      const bool t1 = cur.c1 < tips, t2 = cur.c2 < tips;
-      const bool f1 = cur.c1 == prev_dest, f2 = cur.c2 == prev_dest;
-      double     x1[S], x2[S];
+      const unsigned fl = cur.dst_data.x;
+      const bool     t1 = fl & kOpTip1, t2 = fl & kOpTip2;
+      const bool     f11 = fl & kOpF11, f12 = fl & kOpF12, f21 = fl & kOpF21, f22 = fl & kOpF22;
+      double         x1[S], x2[S];
       int        s1, s2;
       {
-        const unsigned m1 = r.ca, m2 = r.cb; // S <= 8: the byte is the allowed-state mask
-        const double   l1[S] = {r.a0.x, r.a0.y, r.a1.x, r.a1.y}, l2[S] = {r.b0.x, r.b0.y, r.b1.x, r.b1.y};
+        const unsigned m1 = R.ca, m2 = R.cb; // S <= 8: the byte is the allowed-state mask
+        const double2  a0 = as_d2(R.a0), a1 = as_d2(R.a1), b0 = as_d2(R.b0), b1 = as_d2(R.b1);
+        const double   l1[S] = {a0.x, a0.y, a1.x, a1.y}, l2[S] = {b0.x, b0.y, b1.x, b1.y};
 #pragma unroll
         for (int j = 0; j < S; ++j)
         {
-          x1[j] = t1 ? (((m1 >> j) & 1u) ? 1.0 : 0.0) : (f1 ? o_[j] : l1[j]);
-          x2[j] = t2 ? (((m2 >> j) & 1u) ? 1.0 : 0.0) : (f2 ? o_[j] : l2[j]);
+          x1[j] = t1 ? (((m1 >> j) & 1u) ? 1.0 : 0.0) : (f11 ? F1[j] : (f12 ? F2[j] : l1[j]));
+          x2[j] = t2 ? (((m2 >> j) & 1u) ? 1.0 : 0.0) : (f21 ? F1[j] : (f22 ? F2[j] : l2[j]));
         }
-        s1 = t1 ? 0 : (f1 ? osc : r.sa);
-        s2 = t2 ? 0 : (f2 ? osc : r.sb);
+        s1 = t1 ? 0 : (f11 ? sc1 : (f12 ? sc2 : (int)R.sa));
+        s2 = t2 ? 0 : (f21 ? sc1 : (f22 ? sc2 : (int)R.sb));
       }
+
+      // prefetch operation k+2 into the registers just freed (the host left out of its record whatever
+      // operations k and k+1 are still to produce: those are forwarded from F1 / F2)
+      issue(nx2, R, PC);
 
       bool ones = true; // all-ones shortcut, src/avx.c:575-587
 #pragma unroll
@@ -495,6 +548,13 @@ __global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, co
 
       // ---- this lane's two 4x4 blocks from LDS, then the AVX-ordered products (src/avx.c:593-616) ----
       double u1[S], u2[S];
+      if (ABL & 2)
+      {
+        const double2 pv = as_d2(PC[0]);
+#pragma unroll
+        for (int i = 0; i < S; ++i) { u1[i] = x1[i] + pv.x; u2[i] = x2[i] + pv.y; }
+      }
+      else
       {
         const double2 *m = buf + c * 8; // matrix 1, category c: 8 pieces of 16 bytes
         double         a[16];
@@ -508,6 +568,7 @@ __global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, co
       }
       __builtin_amdgcn_wave_barrier();
 
+      double o_[S];
       double mx = -__builtin_huge_val();
 #pragma unroll
       for (int i = 0; i < S; ++i)
@@ -515,8 +576,8 @@ __global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, co
         o_[i] = ones ? 1.0 : u1[i] * u2[i];
         mx    = (o_[i] > mx) ? o_[i] : mx;
       }
-      mx  = group_max<CP>(mx);   // clamped lanes hold a copy of a real lane's values: the max is unaffected
-      osc = s1 + s2; // src/avx.c:462-464
+      mx      = group_max<CP>(mx);   // clamped lanes hold a copy of a real lane's values: the max is unaffected
+      int osc = s1 + s2;             // src/avx.c:462-464
       if (mx < kInvTwoToLarge && q.apply_scaling)
       { // src/avx.c:504-510
 #pragma unroll
@@ -524,20 +585,36 @@ __global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, co
         osc += kLarge;
       }
       {
-        const size_t b   = (size_t)(cur.dest - tips);
-        double2     *dst = reinterpret_cast<double2 *>(q.partials + b * q.P * CS + poff);
-        dst[0] = make_double2(o_[0], o_[1]);
-        dst[1] = make_double2(o_[2], o_[3]);
-        q.scales[b * q.P + p] = osc;
+        const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
+        u32x4 w0, w1;
+        const double2 v0 = make_double2(o_[0], o_[1]), v1 = make_double2(o_[2], o_[3]);
+        __builtin_memcpy(&w0, &v0, 16);
+        __builtin_memcpy(&w1, &v1, 16);
+        if (!(ABL & 1))
+        {
+          __builtin_amdgcn_raw_buffer_store_b128(w0, dr, poffb, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(w1, dr, poffb + 16, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)osc, gr, pidx * 4, 0, 0);
+        }
       }
-      prev_dest = cur.dest;
-      cur       = nxt;
-      nxt       = nn;
-      r         = rn;
+      // rotate results and descriptors (computed values and SGPRs only)
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) pc[h] = pcn[h];
+      for (int i = 0; i < S; ++i) { F2[i] = F1[i]; F1[i] = o_[i]; }
+      sc2 = sc1; sc1 = osc;
+      cur = nx1;
+    };
+
+    // An odd operation count runs one extra step, which re-executes the last operation (descriptor
+    // indices are clamped): same inputs, same output, same address -- idempotent.
+    for (int k = 0; k < q.n_ops; k += 2)
+    {
+      step(k, 0, RA, PA);
+      step(k + 1, 1, RB, PB);
     }
   }
+  const int    prev_dest = q.last_dest; // buffer whose value is still live in F1
+  const int    osc = sc1;
+  const double o_[S] = {F1[0], F1[1], F1[2], F1[3]};
 
   if (!q.edge_eval) return;
 
@@ -563,10 +640,10 @@ __global__ __launch_bounds__(256) void traverse_nt_kernel(const TreeParams q, co
       else
       {
         const size_t   b  = (size_t)(idx - tips);
-        const double2 *s2 = reinterpret_cast<const double2 *>(q.partials + b * q.P * CS + poff);
+        const double2 *s2 = reinterpret_cast<const double2 *>(q.partials + b * bufsz + (size_t)p * CS + (size_t)c * S);
         const double2  v0 = s2[0], v1 = s2[1];
         v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
-        sc = q.scales[b * q.P + p];
+        sc = (q.scales + b * q.P)[pidx];
       }
     };
     side(q.e_parent, x, sl);
