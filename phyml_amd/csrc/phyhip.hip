@@ -124,9 +124,11 @@ struct Instance
   char     *d_ops      = nullptr; // ring of op lists on the device (slim DevOp or fat IssueRec+ExecRec)
   size_t    ops_slot_bytes = 0;
   int       ops_cap = 0, ops_slots = 4, ops_slot = 0;
-  int       grid = 0;
+  int       grid = 0, grid_nt = 0, block_nt = 64;
 
   std::vector<DevOp>                     pending;
+  std::vector<std::vector<DevOp>>        slot_ops;  // what each device ring slot currently holds (content cache)
+  std::vector<int>                       slot_kind; // 0 slim, 1 fat dist 1, 2 fat dist 2
   std::vector<unsigned char>             mat_in_queue; // matrix index referenced by a queued op
   std::vector<uint32_t>                  masks;
   std::unordered_map<uint32_t, int>      mask_code;
@@ -137,6 +139,7 @@ struct Instance
   double l_min = 1.e-8, l_max = 100., br_len_mult = 1.0, pinvar = 0.0; // src/init.c:711-714
   int    apply_scaling = 1, invar_model = 0;
   bool   want_site_outputs = true;
+  int    prefetch_dist = 2;  // PHYHIP_DIST: load-stage distance of the nt pipeline (1 or 2)
   int    ablate = 0;         // PHYHIP_ABLATE: timing-only kernel variants (results invalid)
   bool   no_loads = false;   // PHYHIP_NOLOADS: zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
@@ -158,10 +161,18 @@ Instance *get(int id)
   return g_inst[id];
 }
 
+thread_local int g_cur_dev = -1;
+
+// hipSetDevice costs about a microsecond; the surface is entered hundreds of thousands of times per tree
+// search, so only switch when the calling thread is actually on another device
 #define GET_INST(I, id)                                                                                      \
   Instance *I = get(id);                                                                                     \
   if (!I) return fail(PHYHIP_ERROR_UNINITIALIZED_INSTANCE, "instance %d does not exist", id);                 \
-  HIPCHK(hipSetDevice(I->dev))
+  if (g_cur_dev != I->dev)                                                                                   \
+  {                                                                                                          \
+    HIPCHK(hipSetDevice(I->dev));                                                                            \
+    g_cur_dev = I->dev;                                                                                      \
+  }
 
 int next_pow2(int x)
 {
@@ -231,9 +242,33 @@ int flush(Instance *I, const EdgeEval *ee)
   const IssueRec *d_irec = nullptr;
   const ExecRec  *d_xrec = nullptr;
   q.last_dest = -1;
+  const int kind = fat ? I->prefetch_dist : 0;
+  int       hit  = -1;
   if (n_ops > 0)
+  { // an operation list identical to one still sitting in a device slot (repeated Lk(NULL) on one topology) is
+    // neither rebuilt nor re-uploaded
+    for (int sl = 0; sl < I->ops_slots && hit < 0; ++sl)
+      if (I->slot_kind[sl] == kind && I->slot_ops[sl].size() == (size_t)n_ops &&
+          memcmp(I->slot_ops[sl].data(), I->pending.data(), sizeof(DevOp) * n_ops) == 0)
+        hit = sl;
+  }
+  if (n_ops > 0 && hit >= 0)
+  {
+    char *dst = I->d_ops + (size_t)hit * I->ops_slot_bytes;
+    if (!fat) ro.ops = reinterpret_cast<const DevOp *>(dst);
+    else
+    {
+      d_irec = reinterpret_cast<const IssueRec *>(dst);
+      d_xrec = reinterpret_cast<const ExecRec *>(dst + sizeof(IssueRec) * n_ops);
+      q.last_dest = I->pending[n_ops - 1].dest;
+    }
+    q.n_ops = n_ops;
+  }
+  else if (n_ops > 0)
   {
     char *dst = I->d_ops + (size_t)I->ops_slot * I->ops_slot_bytes;
+    I->slot_ops[I->ops_slot]  = I->pending;
+    I->slot_kind[I->ops_slot] = kind;
     I->ops_slot = (I->ops_slot + 1) % I->ops_slots;
     void *st = nullptr;
     if (!fat)
@@ -262,7 +297,8 @@ int flush(Instance *I, const EdgeEval *ee)
       for (int k = 0; k < n_ops; ++k)
       {
         const DevOp &o  = I->pending[k];
-        const int    e1 = k >= 1 ? I->pending[k - 1].dest : -1, e2 = k >= 2 ? I->pending[k - 2].dest : -1;
+        const int    e1 = k >= 1 ? I->pending[k - 1].dest : -1;
+        const int    e2 = (k >= 2 && I->prefetch_dist == 2) ? I->pending[k - 2].dest : -1;
         unsigned     fl = 0;
         auto child = [&](int c, unsigned tipbit, unsigned f1bit, unsigned f2bit, Desc &data, Desc &scale, Desc &tip,
                          unsigned pmoff) {
@@ -294,7 +330,6 @@ int flush(Instance *I, const EdgeEval *ee)
   {
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
     if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
-    HIPCHK(hipMemsetAsync(I->d_warn, 0, sizeof(int), I->stream));
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (I->prof)
@@ -309,17 +344,23 @@ int flush(Instance *I, const EdgeEval *ee)
     {
       if (!I->generic_nt)
       {
+        if (I->prefetch_dist == 1)
+        {
+          hipLaunchKernelGGL((traverse_nt_kernel<CP_, 0, 1>), dim3(I->grid_nt), dim3(I->block_nt), 0, I->stream, q, d_irec, d_xrec, ro.pmats,
+                             ro.tip_codes);
+          return 0;
+        }
         if constexpr (CP_ == 4)
         {
           switch (I->ablate)
           {
-#define ABLCASE(a) case a: hipLaunchKernelGGL((traverse_nt_kernel<CP_, a>), dim3(I->grid), dim3(256), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes); return 0;
+#define ABLCASE(a) case a: hipLaunchKernelGGL((traverse_nt_kernel<CP_, a>), dim3(I->grid_nt), dim3(I->block_nt), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes); return 0;
             ABLCASE(1) ABLCASE(2) ABLCASE(3) ABLCASE(6) ABLCASE(7)
 #undef ABLCASE
             default: break;
           }
         }
-        hipLaunchKernelGGL((traverse_nt_kernel<CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, d_irec, d_xrec, ro.pmats,
+        hipLaunchKernelGGL((traverse_nt_kernel<CP_>), dim3(I->grid_nt), dim3(I->block_nt), 0, I->stream, q, d_irec, d_xrec, ro.pmats,
                            ro.tip_codes);
         return 0;
       }
@@ -339,8 +380,9 @@ int flush(Instance *I, const EdgeEval *ee)
   if (ee)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
-    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 1,
-                       I->grid, out, ee->to_host ? I->h_result : (double *)nullptr);
+    const int nsum = fat ? I->grid_nt : I->grid;
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, nsum, 1,
+                       nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn);
     HIPCHK(hipGetLastError());
   }
   I->pending.clear();
@@ -409,6 +451,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   else if (const char *e = getenv("PHYHIP_DEVICE")) dev = atoi(e);
   if (dev < 0 || dev >= ndev) return fail(PHYHIP_ERROR_NO_RESOURCE, "device %d not present (%d visible)", dev, ndev);
   HIPCHK(hipSetDevice(dev));
+  g_cur_dev = dev;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, dev));
 
@@ -451,12 +494,25 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   HIPCHK(hipMemset(I->d_dot, 0, be * sizeof(double)));
 
   I->grid = (int)(((long long)I->P * I->CP + 255) / 256);
-  HIPCHK(hipMalloc((void **)&I->d_block, (size_t)2 * I->grid * sizeof(double)));
+  // The pipelined nucleotide kernel is instruction-issue bound per CU, so CU-level balance matters more than
+  // workgroup size: one-wave workgroups let the dispatcher spread e.g. 3125 waves as 12-13 per CU instead of
+  // 3-4 four-wave groups (measured: 100 taxa x 50 000 patterns, 288 -> 25x us).
+  I->block_nt = 64;
+  if (const char *e = getenv("PHYHIP_BLOCK")) { int b = atoi(e); if (b == 64 || b == 128 || b == 256) I->block_nt = b; }
+  I->grid_nt = (int)(((long long)I->P * I->CP + I->block_nt - 1) / I->block_nt);
+  {
+    // distance-2 prefetch needs 168 VGPRs (3 waves/SIMD), distance-1 fits 4 waves/SIMD: prefer the deeper
+    // pipeline unless that would leave a nearly empty second residency round
+    const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
+    if (!getenv("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
+  }
+  HIPCHK(hipMalloc((void **)&I->d_block, (size_t)2 * std::max(I->grid, I->grid_nt) * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_result, 2 * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&I->h_result, 2 * sizeof(double), hipHostMallocMapped));
   HIPCHK(hipMalloc((void **)&I->d_warn, sizeof(int)));
   HIPCHK(hipMemset(I->d_warn, 0, sizeof(int)));
-  HIPCHK(hipHostMalloc((void **)&I->h_warn, sizeof(int), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&I->h_warn, sizeof(int), hipHostMallocMapped));
+  *I->h_warn = 0;
 
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
@@ -468,8 +524,11 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   int rc = I->ring.init(chunk);
   if (rc) return rc;
   I->mat_in_queue.assign(I->nmat, 0);
+  I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
+  I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
+  if (const char *e = getenv("PHYHIP_DIST")) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
   if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
 
   // codes 0..S-1 are the single states
@@ -804,7 +863,6 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
   EdgeEval ee{parent[0], child[0], pm[0], nullptr, true};
   rc = flush(I, &ee);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(I->h_warn, I->d_warn, sizeof(int), hipMemcpyDeviceToHost, I->stream));
   HIPCHK(hipStreamSynchronize(I->stream));
   *outSum = I->h_result[0];
   return PHYHIP_SUCCESS;
@@ -879,7 +937,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
-  HIPCHK(hipMemcpy(out, I->d_warn, sizeof(int), hipMemcpyDeviceToHost));
+  *out = *I->h_warn; // written by the final reduction of the last edge evaluation
   return PHYHIP_SUCCESS;
 }
 
@@ -938,7 +996,6 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       for (int s = 0; s < I->S; ++s) q.expl[c * I->S + s] = exp(I->h_eval[s] * len);
     }
   }
-  HIPCHK(hipMemsetAsync(I->d_warn, 0, sizeof(int), I->stream));
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q);
@@ -947,7 +1004,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 2, I->grid,
-                     I->d_result, I->h_result);
+                     I->d_result, I->h_result, I->d_warn, I->h_warn);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(I->stream));
   *lnl = I->h_result[0];

@@ -418,8 +418,8 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
 // ---------------------------------------------------------------------------------------------
 // ABL != 0 builds timing-only ablation variants (PHYHIP_ABLATE): bit0 no stores, bit1 no matrix-vector work,
 // bit2 no LDS staging.  Results are wrong by construction; used to attribute kernel time.
-template <int CP, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+template <int CP, int ABL = 0, int DIST = 2>
+__global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec,
                                                              const double *__restrict__ pmats,
                                                              const uint8_t *__restrict__ tip_codes)
@@ -496,15 +496,17 @@ __global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q,
     Raw       RA, RB;
     u32x4     PA[NCH], PB[NCH];
     issue(irec[0], RA, PA);
-    issue(irec[(1 < last) ? 1 : last], RB, PB);
-    ExecRec cur = xrec[0];
+    if (DIST == 2) issue(irec[(1 < last) ? 1 : last], RB, PB);
+    ExecRec  cur = xrec[0];
+    IssueRec nx2 = irec[(DIST < last) ? DIST : last]; // load-stage record of the operation DIST steps ahead
 
     // One pipeline step.  (R, PC) hold the loads of operation k, issued two steps ago; after its operands
     // are extracted the same registers receive the loads of operation k+2.  The loop below alternates two
     // register sets, so no loaded value is ever copied (a copy would force a wait on loads still in flight).
-    auto step = [&](const int k, const int parity, Raw &R, u32x4 (&PC)[NCH]) {
-      // scalar loads: load-stage record of operation k+2, compute-stage record of operation k+1
-      const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
+    auto step = [&](const int k, const int parity, Raw &R, u32x4 (&PC)[NCH], Raw &Rn, u32x4 (&PCn)[NCH]) {
+      // scalar loads for the NEXT step (their latency hides behind this step's work): load-stage record of
+      // operation k+3, compute-stage record of operation k+1
+      const IssueRec nx3 = irec[(k + DIST + 1 < last) ? k + DIST + 1 : last];
       const ExecRec  nx1 = xrec[(k + 1 < last) ? k + 1 : last];
 
       // stage this operation's matrices into the wave's LDS buffer (same-wave write -> read, in order);
@@ -521,7 +523,8 @@ __global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q,
       // ---- operands of operation k ----
       const unsigned fl = cur.dst_data.x;
       const bool     t1 = fl & kOpTip1, t2 = fl & kOpTip2;
-      const bool     f11 = fl & kOpF11, f12 = fl & kOpF12, f21 = fl & kOpF21, f22 = fl & kOpF22;
+      const bool     f11 = fl & kOpF11, f12 = (DIST == 2) && (fl & kOpF12), f21 = fl & kOpF21,
+                     f22 = (DIST == 2) && (fl & kOpF22);
       double         x1[S], x2[S];
       int        s1, s2;
       {
@@ -540,7 +543,8 @@ __global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q,
 
       // prefetch operation k+2 into the registers just freed (the host left out of its record whatever
       // operations k and k+1 are still to produce: those are forwarded from F1 / F2)
-      issue(nx2, R, PC);
+      if (DIST == 2) issue(nx2, R, PC);   // operation k+2 into the registers just freed
+      else issue(nx2, Rn, PCn);           // operation k+1 into the other register set
 
       bool ones = true; // all-ones shortcut, src/avx.c:575-587
 #pragma unroll
@@ -556,15 +560,21 @@ __global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q,
       }
       else
       {
-        const double2 *m = buf + c * 8; // matrix 1, category c: 8 pieces of 16 bytes
-        double         a[16];
+        // row i of a 4x4 block = two 16-byte pieces; first product, then the FMA chain (src/avx.c:593-616)
+        auto rows = [&](const double2 *m, const double (&x)[S], double (&u)[S]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const double2 v = m[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
-        matvec_rows<S>(a, x1, u1);
-        m = buf + C * 8 + c * 8;        // matrix 2
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const double2 v = m[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
-        matvec_rows<S>(a, x2, u2);
+          for (int i = 0; i < S; ++i)
+          {
+            const double2 lo = m[2 * i], hi = m[2 * i + 1];
+            double        a  = lo.x * x[0];
+            a    = __builtin_fma(lo.y, x[1], a);
+            a    = __builtin_fma(hi.x, x[2], a);
+            a    = __builtin_fma(hi.y, x[3], a);
+            u[i] = a;
+          }
+        };
+        rows(buf + c * 8, x1, u1);          // matrix 1, category c: 8 pieces of 16 bytes
+        rows(buf + C * 8 + c * 8, x2, u2);  // matrix 2
       }
       __builtin_amdgcn_wave_barrier();
 
@@ -599,17 +609,18 @@ __global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q,
       }
       // rotate results and descriptors (computed values and SGPRs only)
 #pragma unroll
-      for (int i = 0; i < S; ++i) { F2[i] = F1[i]; F1[i] = o_[i]; }
+      for (int i = 0; i < S; ++i) { if (DIST == 2) F2[i] = F1[i]; F1[i] = o_[i]; }
       sc2 = sc1; sc1 = osc;
       cur = nx1;
+      nx2 = nx3;
     };
 
     // An odd operation count runs one extra step, which re-executes the last operation (descriptor
     // indices are clamped): same inputs, same output, same address -- idempotent.
     for (int k = 0; k < q.n_ops; k += 2)
     {
-      step(k, 0, RA, PA);
-      step(k + 1, 1, RB, PB);
+      step(k, 0, RA, PA, RB, PB);
+      step(k + 1, 1, RB, PB, RA, PA);
     }
   }
   const int    prev_dest = q.last_dest; // buffer whose value is still live in F1
@@ -722,8 +733,16 @@ __global__ __launch_bounds__(256, 3) void traverse_nt_kernel(const TreeParams q,
 // Second stage: one block sums `n` per-block values of up to two interleaved streams in a fixed order.
 // out[k] = sum_i in[k*stride + i].
 __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restrict__ in, int n, int nstreams, int stride,
-                                                          double *__restrict__ out, double *__restrict__ out_host)
+                                                          double *__restrict__ out, double *__restrict__ out_host,
+                                                          int *warn, int *warn_host)
 {
+  // hand the numerical-warning flag of this evaluation to the host and re-arm it for the next one
+  if (threadIdx.x == 0 && warn)
+  {
+    const int w = *warn;
+    if (warn_host) *warn_host = w;
+    *warn = 0;
+  }
   __shared__ double sh[256];
   for (int k = 0; k < nstreams; ++k)
   {
