@@ -3,6 +3,7 @@
 // fails with PHYHIP_ERROR_NO_RESOURCE when no device is visible.
 #include "../../include/phyhip.h"
 #include "phyhip_kernels.hpp"
+#include "phyhip_aa.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -101,7 +102,10 @@ struct Instance
   hipStream_t stream     = nullptr;
   bool        own_stream = true;
   int         tips = 0, nbuf = 0, S = 0, C = 0, CP = 0, nmat = 0;
-  long long   P = 0;
+  long long   P = 0, Ppad = 0; // Ppad: patterns per buffer as allocated (P, or P rounded up to 16 when perm)
+  bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
+  double     *d_afrag = nullptr;
+  int         grid_aa = 0;
 
   double   *d_partials = nullptr;
   int      *d_scales   = nullptr;
@@ -181,14 +185,14 @@ int next_pow2(int x)
   return p;
 }
 
-size_t buf_elems(const Instance *I) { return (size_t)I->P * I->C * I->S; }
+size_t buf_elems(const Instance *I) { return (size_t)I->Ppad * I->C * I->S; }
 
 TreeParams base_params(Instance *I)
 {
   TreeParams q;
   memset(&q, 0, sizeof q);
   q.partials = I->d_partials; q.scales = I->d_scales;
-  q.wght = I->d_wght; q.P = I->P; q.C = I->C; q.tip_count = I->tips;
+  q.wght = I->d_wght; q.P = I->P; q.Ppad = I->Ppad; q.perm = I->perm ? 1 : 0; q.C = I->C; q.tip_count = I->tips;
   q.apply_scaling = I->apply_scaling; q.pi = I->d_pi; q.cat_w = I->d_catw; q.invar_model = I->invar_model;
   q.pinvar = I->pinvar; q.invar = I->d_invar; q.block_sums = I->d_block; q.warn = I->d_warn; q.fact = I->d_fact;
   return q;
@@ -365,6 +369,15 @@ int flush(Instance *I, const EdgeEval *ee)
         return 0;
       }
     }
+    if constexpr (S_ == 20 && CP_ <= 4)
+    {
+      if (I->perm)
+      {
+        hipLaunchKernelGGL((traverse_aa_kernel<CP_>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, ro.ops,
+                           (const double *)I->d_afrag, ro.tip_codes, ro.code_masks);
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((traverse_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, ro.ops, ro.pmats, ro.tip_codes,
                        ro.code_masks);
     return 0;
@@ -380,7 +393,7 @@ int flush(Instance *I, const EdgeEval *ee)
   if (ee)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
-    const int nsum = fat ? I->grid_nt : I->grid;
+    const int nsum = fat ? I->grid_nt : (I->perm ? I->grid_aa : I->grid);
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, nsum, 1,
                        nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn);
     HIPCHK(hipGetLastError());
@@ -460,12 +473,21 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->CP = next_pow2(categoryCount); I->P = patternCount; I->nmat = matrixBufferCount;
   HIPCHK(hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking));
 
+  I->perm = (I->S == 20) && (I->C <= 4) && !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA")));
+  I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : I->P;
   const size_t n_int = (size_t)(I->nbuf - I->tips);
   const size_t be    = buf_elems(I);
   HIPCHK(hipMalloc((void **)&I->d_partials, n_int * be * sizeof(double)));
   HIPCHK(hipMemset(I->d_partials, 0, n_int * be * sizeof(double)));
-  HIPCHK(hipMalloc((void **)&I->d_scales, n_int * I->P * sizeof(int)));
-  HIPCHK(hipMemset(I->d_scales, 0, n_int * I->P * sizeof(int)));
+  HIPCHK(hipMalloc((void **)&I->d_scales, n_int * I->Ppad * sizeof(int)));
+  HIPCHK(hipMemset(I->d_scales, 0, n_int * I->Ppad * sizeof(int)));
+  if (I->perm)
+  {
+    const size_t fb = (size_t)I->nmat * I->C * 2 * kAaT * 64 * sizeof(double);
+    HIPCHK(hipMalloc((void **)&I->d_afrag, fb));
+    HIPCHK(hipMemset(I->d_afrag, 0, fb));
+    I->grid_aa = (int)(I->Ppad / 16); // one workgroup (C waves) per tile of 16 patterns
+  }
   HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->P));
   HIPCHK(hipMemset(I->d_tipcodes, 0, (size_t)I->tips * I->P));
   HIPCHK(hipMalloc((void **)&I->d_masks, 256 * sizeof(uint32_t)));
@@ -506,7 +528,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
     const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
     if (!getenv("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
   }
-  HIPCHK(hipMalloc((void **)&I->d_block, (size_t)2 * std::max(I->grid, I->grid_nt) * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_block, (size_t)2 * std::max(std::max(I->grid, I->grid_nt), I->grid_aa) * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_result, 2 * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&I->h_result, 2 * sizeof(double), hipHostMallocMapped));
   HIPCHK(hipMalloc((void **)&I->d_warn, sizeof(int)));
@@ -566,7 +588,7 @@ int phyhip_finalize_instance(int instance)
   collect_profile(I);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch};
+                  I->d_pmscratch, I->d_afrag};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
@@ -662,7 +684,17 @@ int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials)
   if (rc) return rc;
   rc = flush_sync(I);
   if (rc) return rc;
-  HIPCHK(hipMemcpy(I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), inPartials, buf_elems(I) * sizeof(double),
+  if (!I->perm)
+  {
+    HIPCHK(hipMemcpy(I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), inPartials, buf_elems(I) * sizeof(double),
+                     hipMemcpyHostToDevice));
+    return PHYHIP_SUCCESS;
+  }
+  std::vector<double> tmp(buf_elems(I), 0.0);
+  for (long long p = 0; p < I->P; ++p)
+    for (int c = 0; c < I->C; ++c)
+      for (int s = 0; s < 20; ++s) tmp[aa_off(p, I->C, c, s)] = inPartials[((size_t)p * I->C + c) * 20 + s];
+  HIPCHK(hipMemcpy(I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), tmp.data(), buf_elems(I) * sizeof(double),
                    hipMemcpyHostToDevice));
   return PHYHIP_SUCCESS;
 }
@@ -786,6 +818,12 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
     const int threads = std::min(256, ((I->C * I->S + 63) / 64) * 64);
     hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), sizeof(double) * I->C * I->S, I->stream, q);
     HIPCHK(hipGetLastError());
+    if (I->perm)
+    { // MFMA A-operand fragments of the matrices just built
+      FragParams f{q.indices, n, I->C, I->d_pmats, I->d_afrag};
+      hipLaunchKernelGGL(aa_frag_kernel, dim3(n), dim3(256), 0, I->stream, f);
+      HIPCHK(hipGetLastError());
+    }
     done += n;
   }
   return PHYHIP_SUCCESS;
@@ -803,6 +841,17 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
   if (rc) return rc;
   memcpy(st, inMatrix, bytes);
   HIPCHK(hipMemcpyAsync(I->d_pmats + (size_t)matrixIndex * I->C * I->S * I->S, st, bytes, hipMemcpyHostToDevice, I->stream));
+  if (I->perm)
+  {
+    void *si = nullptr;
+    rc = I->ring.alloc(16, I->stream, &si);
+    if (rc) return rc;
+    *(int *)si = matrixIndex;
+    HIPCHK(hipMemcpyAsync(I->d_pmscratch, si, sizeof(int), hipMemcpyHostToDevice, I->stream));
+    FragParams f{(const int *)I->d_pmscratch, 1, I->C, I->d_pmats, I->d_afrag};
+    hipLaunchKernelGGL(aa_frag_kernel, dim3(1), dim3(256), 0, I->stream, f);
+    HIPCHK(hipGetLastError());
+  }
   return PHYHIP_SUCCESS;
 }
 
@@ -907,8 +956,18 @@ int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *o
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
   if ((rc = flush_sync(I))) return rc;
-  HIPCHK(hipMemcpy(out, I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), buf_elems(I) * sizeof(double),
+  if (!I->perm)
+  {
+    HIPCHK(hipMemcpy(out, I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), buf_elems(I) * sizeof(double),
+                     hipMemcpyDeviceToHost));
+    return PHYHIP_SUCCESS;
+  }
+  std::vector<double> tmp(buf_elems(I));
+  HIPCHK(hipMemcpy(tmp.data(), I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), buf_elems(I) * sizeof(double),
                    hipMemcpyDeviceToHost));
+  for (long long p = 0; p < I->P; ++p)
+    for (int c = 0; c < I->C; ++c)
+      for (int s = 0; s < 20; ++s) out[((size_t)p * I->C + c) * 20 + s] = tmp[aa_off(p, I->C, c, s)];
   return PHYHIP_SUCCESS;
 }
 
@@ -918,7 +977,7 @@ int phyhip_get_scale_factors(int instance, int bufferIndex, int *out)
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
   if ((rc = flush_sync(I))) return rc;
-  HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * I->P, I->P * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * I->Ppad, I->P * sizeof(int), hipMemcpyDeviceToHost));
   return PHYHIP_SUCCESS;
 }
 
@@ -928,7 +987,7 @@ int phyhip_set_scale_factors(int instance, int bufferIndex, const int *in)
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
   if ((rc = flush_sync(I))) return rc;
-  HIPCHK(hipMemcpy(I->d_scales + (size_t)(bufferIndex - I->tips) * I->P, in, I->P * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(I->d_scales + (size_t)(bufferIndex - I->tips) * I->Ppad, in, I->P * sizeof(int), hipMemcpyHostToDevice));
   return PHYHIP_SUCCESS;
 }
 
@@ -1032,7 +1091,7 @@ int phyhip_get_dot_prod(int instance, double *out)
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
-  HIPCHK(hipMemcpy(out, I->d_dot, buf_elems(I) * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, I->d_dot, (size_t)I->P * I->C * I->S * sizeof(double), hipMemcpyDeviceToHost));
   return PHYHIP_SUCCESS;
 }
 

@@ -73,6 +73,8 @@ struct TreeParams
   int            *scales;     // internal buffer b at (b - tip_count) * P
   const double   *wght;       // [P]
   long long       P;
+  long long       Ppad;       // patterns per scale vector (P, or P rounded up to 16 for the fragment-major layout)
+  int             perm;       // 1: 20-state partials are stored fragment-major (phyhip_aa.hpp)
   int             C;
   int             tip_count;
   int             apply_scaling;
@@ -143,6 +145,20 @@ __device__ __forceinline__ void issue_side(const TreeParams &q, const RO &ro, in
   r.code = 0;
   if (r.tip)
     r.code = ro.tip_codes[(size_t)idx * q.P + p];
+  else if (S == 20 && q.perm)
+  { // fragment-major layout: state s of (p,c) sits at ((tile*C + c)*5 + s/4)*64 + (s%4)*16 + p%16
+    const size_t  b    = (size_t)(idx - q.tip_count);
+    const size_t  nt   = (size_t)((q.P + 15) >> 4);
+    const double *base = q.partials + b * nt * (size_t)q.C * 5 * 64 + ((size_t)(p >> 4) * q.C + c) * 5 * 64 + (size_t)(p & 15);
+#pragma unroll
+    for (int j = 0; j < S / 2; ++j)
+    {
+      const int s0 = 2 * j, s1 = 2 * j + 1;
+      r.v[j].x = base[(size_t)(s0 >> 2) * 64 + (s0 & 3) * 16];
+      r.v[j].y = base[(size_t)(s1 >> 2) * 64 + (s1 & 3) * 16];
+    }
+    if (c == 0) r.sc = q.scales[b * q.Ppad + p];
+  }
   else
   {
     const size_t   b  = (size_t)(idx - q.tip_count);
@@ -151,7 +167,7 @@ __device__ __forceinline__ void issue_side(const TreeParams &q, const RO &ro, in
 #pragma unroll
     for (int j = 0; j < S / 2; ++j) r.v[j] = s2[j];
     // the scale word is written by the c==0 lane of the pattern; read it back through the same lane
-    if (c == 0) r.sc = q.scales[b * q.P + p];
+    if (c == 0) r.sc = q.scales[b * q.Ppad + p];
   }
 }
 
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
       double2     *dst = reinterpret_cast<double2 *>(q.partials + (b * q.P + p) * (size_t)CS + (size_t)c * S);
 #pragma unroll
       for (int j = 0; j < S / 2; ++j) dst[j] = make_double2(o[2 * j], o[2 * j + 1]);
-      if (c == 0) q.scales[b * q.P + p] = sc;
+      if (c == 0) q.scales[b * q.Ppad + p] = sc;
     }
   }
 
