@@ -81,7 +81,11 @@ typedef struct __Tree
   short    host_pmat;      /* YES: PMat() on the host + upload (src/lk.c:2315,2360); NO: device PMat (src/lk.c:2344) */
   phydbl   c_lnL, old_lnL, c_dlnL;
   int      n_edges_traversed; /* counter like src/utilities.h:1018 */
+  int      spare_p_lk_idx;    /* first of PHL_N_SPARE spare partials buffers (extra SPR edges, src/make.c:750) */
+  int      spare_Pij_idx;     /* first of PHL_N_SPARE spare transition-matrix buffers */
 } t_tree;
+
+#define PHL_N_SPARE 4
 
 /* ---- construction ------------------------------------------------------------------------------ */
 
@@ -122,6 +126,18 @@ void   PMat(phydbl l, const t_mod *mod, int pos, phydbl *Pij);
 
 /* sharded evaluation: same as Lk(NULL,tree) but the shard's lnL is left in device memory (no sync) */
 void   Lk_Shard_Device(t_tree *tree, double *device_out);
+
+/* Caller-side counterpart for tree search: replays a recorded stream of surface calls
+   -- the calls spr.c / optimiz.c make through Update_PMat_At_Given_Edge, Update_Partial_Lk, Lk(b), Update_Eigen_Lr
+   and dLk (src/spr.c:543,643-646; src/optimiz.c:622-632) -- at buffer-index level, in one C loop, and records the
+   scalar every call returned.  kind[i]: */
+#define PHL_REC_SET_PMAT 0 /* a = matrix index, x = edge length                               */
+#define PHL_REC_UPDATE   1 /* a = dest, b = child1, c = matrix1, d = child2, e = matrix2       */
+#define PHL_REC_EDGE_LNL 2 /* a = left buffer, b = right buffer or tip, c = matrix -> out = lnL */
+#define PHL_REC_EIGEN_LR 3 /* a = left, b = right                                              */
+#define PHL_REC_DLK      4 /* x = length -> out = lnL, out2 = dlnL                             */
+void Replay_Surface_Trace(t_tree *tree, int n_rec, const int *kind, const int *a, const int *b, const int *c, const int *d,
+                          const int *e, const phydbl *x, phydbl *out, phydbl *out2);
 
 /* download hooks for host readers (ancestral.c, cv.c, io.c) */
 void Get_Partial_Lk(t_tree *tree, t_edge *b, t_node *d, phydbl *p_lk, int *sum_scale);

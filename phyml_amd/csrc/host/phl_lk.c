@@ -194,10 +194,15 @@ void Make_Tree_For_Lk(t_tree *tree, int n_pattern, const phydbl *wght, const sho
     b->p_lk_rght_idx   = b->rght->tax ? b->rght->num : next++;
     b->Pij_rr          = (phydbl *)calloc((size_t)m->n_catg * m->ns * m->ns, sizeof(phydbl));
   }
+  /* spare partials buffers and matrices, the counterpart of the reference's extra SPR edges
+     (Make_Extra_Edge_Lk, src/make.c:750): a regraft candidate is evaluated into these */
+  tree->spare_p_lk_idx = next;
+  tree->spare_Pij_idx  = n_edges;
+  next += PHL_N_SPARE;
   int resource[1] = {device};
   phyhip_instance_details det;
-  int inst = phyhip_create_instance(n, next, 0, m->ns, n_pattern, 1, n_edges, m->n_catg, 0, device >= 0 ? resource : NULL,
-                                    device >= 0 ? 1 : 0, 0, 0, &det);
+  int inst = phyhip_create_instance(n, next, 0, m->ns, n_pattern, 1, n_edges + PHL_N_SPARE, m->n_catg, 0,
+                                    device >= 0 ? resource : NULL, device >= 0 ? 1 : 0, 0, 0, &det);
   if (inst < 0) { Lk_Exit("phyhip_create_instance", phyhip_get_last_error()); return; }
   tree->b_inst = inst;
   CHK(phyhip_set_pattern_weights(inst, tree->wght));
@@ -516,6 +521,80 @@ phydbl Br_Len_Opt(phydbl *l, t_edge *b, t_tree *tree)
     return tree->c_lnL;
   }
   return tree->c_lnL;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* caller-side counterpart: replay of a recorded surface-call stream            */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* Matrix refresh by index (real edge or spare): the body of Update_PMat_At_Given_Edge for a bare length */
+static int Replay_Set_PMat(t_tree *tree, int idx, phydbl l, phydbl *scratch)
+{
+  const t_mod *m = tree->mod;
+  if (tree->host_pmat)
+  {
+    for (int c = 0; c < m->n_catg; ++c)
+    {
+      phydbl len = (l > 0.0 ? l : 0.0) * m->gamma_rr[c];
+      len *= m->br_len_mult;
+      if (len < m->l_min) len = m->l_min;
+      else if (len > m->l_max) len = m->l_max;
+      PMat(len, m, c * m->ns * m->ns, scratch);
+    }
+    return phyhip_set_transition_matrix(tree->b_inst, idx, scratch, -1);
+  }
+  int    i1[1] = {idx};
+  double l1[1] = {l};
+  return phyhip_update_transition_matrices(tree->b_inst, 0, i1, NULL, NULL, l1, 1);
+}
+
+void Replay_Surface_Trace(t_tree *tree, int n_rec, const int *kind, const int *a, const int *b, const int *c, const int *d,
+                          const int *e, const phydbl *x, phydbl *out, phydbl *out2)
+{
+  const t_mod *m = tree->mod;
+  phydbl *scratch = (phydbl *)malloc(sizeof(phydbl) * (size_t)m->n_catg * m->ns * m->ns);
+  int     zero[1] = {0};
+  for (int i = 0; i < n_rec; ++i)
+  {
+    int rc = 0;
+    out[i] = out2[i] = 0.0;
+    switch (kind[i])
+    {
+    case PHL_REC_SET_PMAT: rc = Replay_Set_PMat(tree, a[i], x[i], scratch); break;
+    case PHL_REC_UPDATE:
+    {
+      phyhip_operation op = {a[i], PHYHIP_OP_NONE, PHYHIP_OP_NONE, b[i], c[i], d[i], e[i]};
+      rc = phyhip_update_partials(tree->b_inst, &op, 1, PHYHIP_OP_NONE);
+      tree->n_edges_traversed++;
+      break;
+    }
+    case PHL_REC_EDGE_LNL:
+    {
+      int parent[1] = {a[i]}, child[1] = {b[i]}, pm[1] = {c[i]};
+      double lnl = 0.0;
+      rc = phyhip_calculate_edge_log_likelihoods(tree->b_inst, parent, child, pm, NULL, NULL, zero, zero, NULL, 1, &lnl, NULL, NULL);
+      out[i] = tree->c_lnL = lnl;
+      break;
+    }
+    case PHL_REC_EIGEN_LR: rc = phyhip_update_eigen_lr(tree->b_inst, a[i], b[i]); break;
+    case PHL_REC_DLK:
+    {
+      double l = x[i], lnl = 0.0, dlnl = 0.0;
+      rc = phyhip_calculate_eigen_lnl_dlnl(tree->b_inst, &l, &lnl, &dlnl);
+      out[i] = tree->c_lnL = lnl;
+      out2[i] = tree->c_dlnL = dlnl;
+      break;
+    }
+    default: rc = -1; break;
+    }
+    if (rc < 0)
+    {
+      free(scratch);
+      Lk_Exit("Replay_Surface_Trace", rc == -1 && kind[i] > PHL_REC_DLK ? "unknown record kind" : phyhip_get_last_error());
+      return;
+    }
+  }
+  free(scratch);
 }
 
 /* ------------------------------------------------------------------------------------------------ */

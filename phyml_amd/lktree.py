@@ -48,7 +48,7 @@ class t_tree(C.Structure):
                 ("tip_root", C.c_int), ("both_sides", C.c_short), ("use_eigen_lr", C.c_short),
                 ("update_eigen_lr", C.c_short), ("apply_lk_scaling", C.c_short), ("numerical_warning", C.c_short),
                 ("host_pmat", C.c_short), ("c_lnL", C.c_double), ("old_lnL", C.c_double), ("c_dlnL", C.c_double),
-                ("n_edges_traversed", C.c_int)]
+                ("n_edges_traversed", C.c_int), ("spare_p_lk_idx", C.c_int), ("spare_Pij_idx", C.c_int)]
 
 
 _lib = None
@@ -223,6 +223,26 @@ class LkTree:
         _raise_if_error()
         return lv.value, v
 
+    def Replay_Surface_Trace(self, trace):
+        """trace: dict of equal-length arrays kind,a,b,c,d,e (int32) and x (float64); returns (out, out2)."""
+        n = len(trace["kind"])
+        arr = {k: np.ascontiguousarray(trace[k], dtype=np.int32) for k in ("kind", "a", "b", "c", "d", "e")}
+        x = np.ascontiguousarray(trace["x"], dtype=np.float64)
+        out = np.zeros(n); out2 = np.zeros(n)
+        ip = lambda v: v.ctypes.data_as(C.c_void_p)
+        self.L.Replay_Surface_Trace(self.tree, n, ip(arr["kind"]), ip(arr["a"]), ip(arr["b"]), ip(arr["c"]), ip(arr["d"]),
+                                    ip(arr["e"]), _dp(x), _dp(out), _dp(out2))
+        _raise_if_error()
+        return out, out2
+
+    @property
+    def spare_p_lk_idx(self):
+        return self.tree.contents.spare_p_lk_idx
+
+    @property
+    def spare_Pij_idx(self):
+        return self.tree.contents.spare_Pij_idx
+
     def Lk_Shard_Device(self, device_ptr):
         self.L.Lk_Shard_Device(self.tree, C.c_void_p(device_ptr)); _raise_if_error()
 
@@ -245,7 +265,7 @@ class _InstanceView(capi.Instance):
         self.L = capi.load()
         self.id = inst_id
         self.tips, self.S, self.P, self.C = tree.n, tree.S, tree.P, tree.C
-        self.nmat = tree.ne
+        self.nmat = tree.ne + 4
         self.details = None
 
     def close(self):

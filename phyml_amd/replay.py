@@ -1,0 +1,85 @@
+"""Seeded generator of SPR / branch-length-optimisation surface-call streams (the
+trace-free fallback): the *call pattern* spr.c and optimiz.c drive through the likelihood surface, expressed at
+buffer-index level so it can be replayed by `Replay_Surface_Trace` (device) and by the CPU oracle (tests).
+
+Per regraft candidate (src/spr.c:643-646):   Update_PMat x2 (the two halves of the target edge) ->
+Update_Partial_Lk(b_arrow, n_link) into a spare buffer -> Lk(b_arrow) = Update_PMat(pendant) + edge lnL.
+Every `walk_every` candidates one real edge side is refreshed (the path update of spr.c:543).
+Every `opt_every` candidates a Br_Len_Opt pattern follows (src/optimiz.c:622-632): Update_Eigen_Lr on the
+candidate edge, then `n_dlk` dLk evaluations at different lengths.
+
+The stream is a valid sequence of buffer operations on a tree whose partials are up to date on both sides; it
+does not move subtrees (pruning/regrafting is caller-side pointer surgery, out of scope), so the scalars are
+not the lnL of SPR-rearranged trees -- they are what the same calls return on either engine, which is what
+per-call parity needs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import synth
+
+SET_PMAT, UPDATE, EDGE_LNL, EIGEN_LR, DLK = 0, 1, 2, 3, 4
+
+
+def side_buffer_map(n_otu, edge_left, edge_rght):
+    """(edge, side) -> partials buffer index with the host layer's numbering (tips first, then internal
+    edge sides in edge order; phl_lk.c Make_Tree_For_Lk)."""
+    buf, nxt = {}, n_otu
+    for e in range(len(edge_left)):
+        l, r = int(edge_left[e]), int(edge_rght[e])
+        if l < n_otu and r >= n_otu:
+            l, r = r, l
+        for side, node in ((0, l), (1, r)):
+            if node < n_otu:
+                buf[(e, side)] = node
+            else:
+                buf[(e, side)] = nxt
+                nxt += 1
+    return buf, nxt
+
+
+def make_trace(n_otu, edge_left, edge_rght, edge_len, n_candidates, seed, walk_every=3, opt_every=0, n_dlk=8):
+    el = np.asarray(edge_left); er = np.asarray(edge_rght); ln = np.asarray(edge_len, dtype=np.float64)
+    ne = len(el)
+    buf, n_real = side_buffer_map(n_otu, el, er)
+    spare_buf, spare_mat = n_real, ne
+    adj = [[] for _ in range(2 * n_otu - 2)]
+    for e in range(ne):
+        adj[int(el[e])].append((int(er[e]), e)); adj[int(er[e])].append((int(el[e]), e))
+    internal_edges = [e for e in range(ne) if el[e] >= n_otu and er[e] >= n_otu]
+    rec = {k: [] for k in ("kind", "a", "b", "c", "d", "e", "x")}
+
+    def push(kind, a=0, b=0, c=0, d=0, e=0, x=0.0):
+        for k, v in zip(("kind", "a", "b", "c", "d", "e", "x"), (kind, a, b, c, d, e, x)):
+            rec[k].append(v)
+
+    h = synth.hash_u64(seed, 77, np.arange(4 * n_candidates + 8))
+    for i in range(n_candidates):
+        prune = internal_edges[int(h[4 * i]) % len(internal_edges)]
+        target = int(h[4 * i + 1]) % ne
+        if target == prune:
+            target = (target + 1) % ne
+        u = float(int(h[4 * i + 2]) >> 11) / float(1 << 53)
+        half = 0.5 * max(ln[target], 1e-4) * (0.5 + u)
+        # Update_PMat on the two halves of the target edge, then the new node's partial into a spare buffer
+        push(SET_PMAT, a=spare_mat, x=half)
+        push(SET_PMAT, a=spare_mat + 1, x=max(ln[target], 1e-4) - half if ln[target] > half else half)
+        push(UPDATE, a=spare_buf, b=buf[(target, 0)], c=spare_mat, d=buf[(target, 1)], e=spare_mat + 1)
+        # Lk(b_arrow): refresh the pendant matrix, evaluate against the pruned subtree's partial
+        pend = ln[prune] * (0.5 + u)
+        push(SET_PMAT, a=spare_mat + 2, x=pend)
+        push(EDGE_LNL, a=spare_buf, b=buf[(prune, 1)], c=spare_mat + 2)
+        if walk_every and i % walk_every == walk_every - 1:
+            # path update on a real edge side (recomputes the value it already holds)
+            e = internal_edges[int(h[4 * i + 3]) % len(internal_edges)]
+            d_node = int(el[e])
+            ch = [(buf[(be, 1 if d_node == el[be] else 0)], be) for (v, be) in adj[d_node] if be != e]
+            push(UPDATE, a=buf[(e, 0)], b=ch[0][0], c=ch[0][1], d=ch[1][0], e=ch[1][1])
+        if opt_every and i % opt_every == opt_every - 1:
+            # Br_Len_Opt on the candidate edge: eigen products once, then a series of dLk calls
+            push(EIGEN_LR, a=spare_buf, b=buf[(prune, 1)])
+            for j in range(n_dlk):
+                push(DLK, x=pend * (0.25 + 0.25 * j))
+    out = {k: np.array(v, dtype=np.float64 if k == "x" else np.int32) for k, v in rec.items()}
+    return out
