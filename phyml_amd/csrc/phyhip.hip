@@ -131,6 +131,9 @@ struct Instance
   int       grid = 0, grid_nt = 0, block_nt = 64;
 
   std::vector<DevOp>                     pending;
+  std::vector<int>                       pm_idx;    // queued device-side matrix rebuilds (index, edge length)
+  std::vector<double>                    pm_len;
+  std::vector<int>                       pm_slot;   // matrix index -> position in pm_idx, or -1
   std::vector<std::vector<DevOp>>        slot_ops;  // what each device ring slot currently holds (content cache)
   std::vector<int>                       slot_kind; // 0 slim, 1 fat dist 1, 2 fat dist 2
   std::vector<unsigned char>             mat_in_queue; // matrix index referenced by a queued op
@@ -232,12 +235,50 @@ struct EdgeEval
   bool    to_host;
 };
 
+// Rebuild every queued transition matrix on the device: one staged copy of (index, length) pairs, one launch.
+int flush_pmats(Instance *I)
+{
+  int done = 0, rc = 0;
+  const int count = (int)I->pm_idx.size();
+  while (done < count)
+  {
+    const int    n  = std::min(count - done, I->pm_scratch_cap);
+    void        *st = nullptr;
+    const size_t bi = (sizeof(int) * n + 15) & ~size_t(15), bl = sizeof(double) * n;
+    rc = I->ring.alloc(bi + bl, I->stream, &st);
+    if (rc) return rc;
+    memcpy(st, I->pm_idx.data() + done, sizeof(int) * n);
+    memcpy((char *)st + bi, I->pm_len.data() + done, bl);
+    HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
+    PmatParams q;
+    q.indices = (const int *)I->d_pmscratch; q.lengths = (const double *)((char *)I->d_pmscratch + bi); q.count = n;
+    q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
+    q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
+    const int threads = std::min(256, ((I->C * I->S + 63) / 64) * 64);
+    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), sizeof(double) * I->C * I->S, I->stream, q);
+    HIPCHK(hipGetLastError());
+    if (I->perm)
+    { // MFMA A-operand fragments of the matrices just built
+      FragParams f{q.indices, n, I->C, I->d_pmats, I->d_afrag};
+      hipLaunchKernelGGL(aa_frag_kernel, dim3(n), dim3(256), 0, I->stream, f);
+      HIPCHK(hipGetLastError());
+    }
+    done += n;
+  }
+  for (int m : I->pm_idx) I->pm_slot[m] = -1;
+  I->pm_idx.clear();
+  I->pm_len.clear();
+  return 0;
+}
+
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush(Instance *I, const EdgeEval *ee)
 {
   const int n_ops = (int)I->pending.size();
+  int rc = 0;
+  if (!I->pm_idx.empty() && (rc = flush_pmats(I))) return rc;
   if (n_ops == 0 && !ee) return 0;
-  int rc = upload_masks(I);
+  rc = upload_masks(I);
   if (rc) return rc;
 
   TreeParams q = base_params(I);
@@ -546,6 +587,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   int rc = I->ring.init(chunk);
   if (rc) return rc;
   I->mat_in_queue.assign(I->nmat, 0);
+  I->pm_slot.assign(I->nmat, -1);
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
@@ -798,33 +840,18 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
   if (count <= 0) return PHYHIP_SUCCESS;
   int rc = matrices_touch(I, probabilityIndices, count);
   if (rc) return rc;
-  // stage indices + lengths through the pinned ring into a device scratch (stream order keeps
-  // back-to-back calls from clobbering each other)
-  int done = 0;
-  while (done < count)
+  // Deferred like the partial updates: SPR refreshes three matrices per regraft candidate (src/spr.c:643-646);
+  // they are rebuilt by ONE pmat_kernel launch right before the traversal kernel that reads them.
+  for (int i = 0; i < count; ++i)
   {
-    const int    n  = std::min(count - done, I->pm_scratch_cap);
-    void        *st = nullptr;
-    const size_t bi = (sizeof(int) * n + 15) & ~size_t(15), bl = sizeof(double) * n;
-    rc = I->ring.alloc(bi + bl, I->stream, &st);
-    if (rc) return rc;
-    memcpy(st, probabilityIndices + done, sizeof(int) * n);
-    memcpy((char *)st + bi, edgeLengths + done, bl);
-    HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
-    PmatParams q;
-    q.indices = (const int *)I->d_pmscratch; q.lengths = (const double *)((char *)I->d_pmscratch + bi); q.count = n;
-    q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
-    q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
-    const int threads = std::min(256, ((I->C * I->S + 63) / 64) * 64);
-    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), sizeof(double) * I->C * I->S, I->stream, q);
-    HIPCHK(hipGetLastError());
-    if (I->perm)
-    { // MFMA A-operand fragments of the matrices just built
-      FragParams f{q.indices, n, I->C, I->d_pmats, I->d_afrag};
-      hipLaunchKernelGGL(aa_frag_kernel, dim3(n), dim3(256), 0, I->stream, f);
-      HIPCHK(hipGetLastError());
+    const int m = probabilityIndices[i];
+    if (I->pm_slot[m] >= 0) I->pm_len[I->pm_slot[m]] = edgeLengths[i]; // last length wins
+    else
+    {
+      I->pm_slot[m] = (int)I->pm_idx.size();
+      I->pm_idx.push_back(m);
+      I->pm_len.push_back(edgeLengths[i]);
     }
-    done += n;
   }
   return PHYHIP_SUCCESS;
 }
@@ -835,6 +862,7 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
   GET_INST(I, instance);
   int rc = matrices_touch(I, &matrixIndex, 1);
   if (rc) return rc;
+  if (I->pm_slot[matrixIndex] >= 0 && (rc = flush_pmats(I))) return rc; // keep rebuild-then-upload order
   const size_t bytes = (size_t)I->C * I->S * I->S * sizeof(double);
   void        *st    = nullptr;
   rc = I->ring.alloc(bytes, I->stream, &st);
