@@ -70,6 +70,28 @@ def cpu_baseline(wl, sample_patterns, reps):
                 sample=f"oracle Lk(NULL) x{reps} on {tree.n_otu} taxa x {n_s} patterns", lnL_sample=lnl)
 
 
+def measured_roofline():
+    """HBM streaming rates of this GPU from the repo's micro-benchmark (phyml_amd/lib/membench): the
+    denominator the north star calls the 'measured HBM-read roofline'."""
+    mb = os.path.join(ROOT, "phyml_amd", "lib", "membench")
+    try:
+        out = subprocess.run([mb, "1", "7"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120).stdout
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def pmc_traffic(workload):
+    """HBM bytes per traversal launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/): 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes."""
+    f = os.path.join(ROOT, "profiles", f"r01_pmc_{workload}.json")
+    try:
+        d = json.load(open(f))
+        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +117,7 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    from phyml_amd import lktree, workloads
+    from phyml_amd import lktree, shard, workloads
     wl = workloads.make(args.workload, n_pattern=args.patterns,
                         seed=None if world == 1 else workloads.CONFIGS[args.workload]["seed"] + 1000 * rank)
     tree, st, blk, cfg = wl["tree"], wl["states"], wl["model"], wl["cfg"]
@@ -116,7 +138,7 @@ def main():
             return t.Lk(None)
         # sharded evaluation: per-shard lnL stays on the device, ONE all-reduce over RCCL, then the host reads it
         t.Lk_Shard_Device(dev_lnl.data_ptr())
-        dist.all_reduce(dev_lnl)
+        shard.allreduce_sum(dev_lnl, dist)
         return float(dev_lnl[0].item())
 
     lnl = None
@@ -155,9 +177,22 @@ def main():
                        "parallelism": f"pattern-shard x{world}" if world > 1 else "single GPU"},
             "lnL": lnl,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "traverse_kernel", "kernel_avg_us": kdur * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": pmc_traffic(args.workload) if (world == 1 and args.patterns is None) else None,
+                         "kernel": "traverse_nt_kernel" if S == 4 else "traverse_aa_kernel", "kernel_avg_us": kdur * 1e6,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_site_update": alg_bytes / (float(P) * (n - 2))},
         }
+        if S == 20:
+            # 20-state path: FP64 MFMA work issued per launch (two 16-row tiles x five k-chunks per child and category)
+            mfma_flops = float((P + 15) // 16) * C * (n - 2) * 20 * 2048.0
+            out["mfma"] = {"achieved": mfma_flops / kdur / 1e12, "peak": 78.6, "unit": "TFLOP/s issued (f64 16x16x4)",
+                           "frac": mfma_flops / kdur / 1e12 / 78.6, "useful_frac_of_issued": 20.0 / 32.0}
+        if world == 1:
+            mr = measured_roofline()
+            if mr:
+                out["roofline"]["measured_read_GBps"] = mr["read_GBps"]
+                out["roofline"]["measured_write_GBps"] = mr["write_GBps"]
+                out["roofline"]["frac_of_measured_read"] = achieved / mr["read_GBps"]
         exp = workloads.manifest()["expected"].get(args.workload)
         if exp and world == 1 and P == exp["n_pattern"]:
             from phyml_amd import synth

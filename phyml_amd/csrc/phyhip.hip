@@ -304,10 +304,10 @@ int flush(Instance *I, const EdgeEval *ee)
     else
     {
       d_irec = reinterpret_cast<const IssueRec *>(dst);
-      d_xrec = reinterpret_cast<const ExecRec *>(dst + sizeof(IssueRec) * n_ops);
+      d_xrec = reinterpret_cast<const ExecRec *>(dst + sizeof(IssueRec) * (n_ops + (n_ops & 1)));
       q.last_dest = I->pending[n_ops - 1].dest;
     }
-    q.n_ops = n_ops;
+    q.n_ops = fat ? n_ops + (n_ops & 1) : n_ops;
   }
   else if (n_ops > 0)
   {
@@ -326,8 +326,11 @@ int flush(Instance *I, const EdgeEval *ee)
     }
     else
     {
-      // one record pair per operation, all address arithmetic done here once
-      const size_t ib = sizeof(IssueRec) * n_ops, xb = sizeof(ExecRec) * n_ops;
+      // one record pair per operation, all address arithmetic done here once.  The kernel alternates two
+      // register sets, so an odd list is padded with a re-execution of its last operation (idempotent: same
+      // inputs, same output, same address) whose forwarding flags are computed for its own position.
+      const int    n_rec = n_ops + (n_ops & 1);
+      const size_t ib = sizeof(IssueRec) * n_rec, xb = sizeof(ExecRec) * n_rec;
       rc = I->ring.alloc(ib + xb, I->stream, &st);
       if (rc) return rc;
       IssueRec *ir = reinterpret_cast<IssueRec *>(st);
@@ -339,11 +342,12 @@ int flush(Instance *I, const EdgeEval *ee)
         d.base = (unsigned long long)(uintptr_t)base; d.bytes = (unsigned)bytes; d.x = x;
         return d;
       };
-      for (int k = 0; k < n_ops; ++k)
+      auto at = [&](int k) -> const DevOp & { return I->pending[std::min(k, n_ops - 1)]; };
+      for (int k = 0; k < n_rec; ++k)
       {
-        const DevOp &o  = I->pending[k];
-        const int    e1 = k >= 1 ? I->pending[k - 1].dest : -1;
-        const int    e2 = (k >= 2 && I->prefetch_dist == 2) ? I->pending[k - 2].dest : -1;
+        const DevOp &o  = at(k);
+        const int    e1 = k >= 1 ? at(k - 1).dest : -1;
+        const int    e2 = (k >= 2 && I->prefetch_dist == 2) ? at(k - 2).dest : -1;
         unsigned     fl = 0;
         auto child = [&](int c, unsigned tipbit, unsigned f1bit, unsigned f2bit, Desc &data, Desc &scale, Desc &tip,
                          unsigned pmoff) {
@@ -369,7 +373,7 @@ int flush(Instance *I, const EdgeEval *ee)
       d_xrec = reinterpret_cast<const ExecRec *>(dst + ib);
       q.last_dest = I->pending[n_ops - 1].dest;
     }
-    q.n_ops = n_ops;
+    q.n_ops = fat ? n_ops + (n_ops & 1) : n_ops;
   }
   if (ee)
   {
@@ -580,7 +584,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
   I->ops_cap = 2 * I->nbuf + 8;
-  I->ops_slot_bytes = (size_t)(I->ops_cap + 1) * (sizeof(IssueRec) + sizeof(ExecRec));
+  I->ops_slot_bytes = (size_t)(I->ops_cap + 2) * (sizeof(IssueRec) + sizeof(ExecRec));
   HIPCHK(hipMalloc((void **)&I->d_ops, (size_t)I->ops_slots * I->ops_slot_bytes));
   size_t chunk = std::max<size_t>(64 * 1024, std::max(I->ops_slot_bytes,
                                                        (size_t)I->C * I->S * I->S * sizeof(double) * 4));

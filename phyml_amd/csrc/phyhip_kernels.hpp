@@ -105,6 +105,22 @@ template <int CP> __device__ __forceinline__ double group_max(double v)
   for (int off = 1; off < CP; off <<= 1) v = fmax(v, __shfl_xor(v, off, CP));
   return v;
 }
+// The rescaling test `max < 2^-256` (src/avx.c:498-506) on non-negative doubles only needs the HIGH 32 bits:
+// for x >= 0, x < 2^-256  <=>  hi32(x) < 0x2FF00000 (2^-256 has biased exponent 767 = 0x2FF and a zero
+// mantissa), and unsigned order of hi32 is the order of the values' magnitudes.  Partial likelihoods are
+// products of probabilities (never negative; a NaN has hi32 >= 0x7FF00000 and so never triggers a rescale, as
+// the reference's `>` scan never selects it).  One v_max3_u32 + two DPP quad permutes replace four FP64
+// compare/select pairs, two canonicalising v_max_f64 and two LDS ds_bpermute round trips.
+constexpr unsigned kHiInvTwoToLarge = 0x2FF00000u;
+__device__ __forceinline__ unsigned hi32(double x) { return (unsigned)(__double_as_longlong(x) >> 32); }
+template <int CP> __device__ __forceinline__ unsigned group_max_u32(unsigned v)
+{
+  if (CP >= 2) v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+  if (CP >= 4) v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int off = 4; off < CP; off <<= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, CP));
+  return v;
+}
 template <int CP> __device__ __forceinline__ int group_bcast0(int v) { return CP == 1 ? v : __shfl(v, 0, CP); }
 template <int CP> __device__ __forceinline__ int group_and(int v)
 {
@@ -520,11 +536,6 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
     // are extracted the same registers receive the loads of operation k+2.  The loop below alternates two
     // register sets, so no loaded value is ever copied (a copy would force a wait on loads still in flight).
     auto step = [&](const int k, const int parity, Raw &R, u32x4 (&PC)[NCH], Raw &Rn, u32x4 (&PCn)[NCH]) {
-      // scalar loads for the NEXT step (their latency hides behind this step's work): load-stage record of
-      // operation k+3, compute-stage record of operation k+1
-      const IssueRec nx3 = irec[(k + DIST + 1 < last) ? k + DIST + 1 : last];
-      const ExecRec  nx1 = xrec[(k + 1 < last) ? k + 1 : last];
-
       // stage this operation's matrices into the wave's LDS buffer (same-wave write -> read, in order);
       // lanes beyond the last piece rewrite piece 0 with the identical bytes they loaded for it
       double2 *buf = &lds_p[wid][parity][0];
@@ -562,9 +573,19 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
       if (DIST == 2) issue(nx2, R, PC);   // operation k+2 into the registers just freed
       else issue(nx2, Rn, PCn);           // operation k+1 into the other register set
 
-      bool ones = true; // all-ones shortcut, src/avx.c:575-587
+      // scalar loads for the NEXT step, issued only now (scalar loads return out of order, so any wait on an
+      // older one would also wait on these): load-stage record of operation k+DIST+1, compute-stage record of k+1
+      const IssueRec nx3 = irec[(k + DIST + 1 < last) ? k + DIST + 1 : last];
+      const ExecRec  nx1 = xrec[(k + 1 < last) ? k + 1 : last];
+
+      // all-ones shortcut, src/avx.c:575-587.  Exact 1.0 in all eight entries only happens under fully
+      // ambiguous subtrees; test two entries first and pay for the rest only when a lane of the wave passes
+      bool ones = (x1[0] == 1.0) && (x2[0] == 1.0);
+      if (__builtin_amdgcn_ballot_w64(ones))
+      {
 #pragma unroll
-      for (int j = 0; j < S; ++j) ones = ones && (x1[j] == 1.0) && (x2[j] == 1.0);
+        for (int j = 1; j < S; ++j) ones = ones && (x1[j] == 1.0) && (x2[j] == 1.0);
+      }
 
       // ---- this lane's two 4x4 blocks from LDS, then the AVX-ordered products (src/avx.c:593-616) ----
       double u1[S], u2[S];
@@ -595,16 +616,12 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
       __builtin_amdgcn_wave_barrier();
 
       double o_[S];
-      double mx = -__builtin_huge_val();
 #pragma unroll
-      for (int i = 0; i < S; ++i)
-      {
-        o_[i] = ones ? 1.0 : u1[i] * u2[i];
-        mx    = (o_[i] > mx) ? o_[i] : mx;
-      }
-      mx      = group_max<CP>(mx);   // clamped lanes hold a copy of a real lane's values: the max is unaffected
-      int osc = s1 + s2;             // src/avx.c:462-464
-      if (mx < kInvTwoToLarge && q.apply_scaling)
+      for (int i = 0; i < S; ++i) o_[i] = ones ? 1.0 : u1[i] * u2[i];
+      // clamped lanes hold a copy of a real lane's values: the maximum is unaffected
+      const unsigned mxh = group_max_u32<CP>(max(max(hi32(o_[0]), hi32(o_[1])), max(hi32(o_[2]), hi32(o_[3]))));
+      int            osc = s1 + s2; // src/avx.c:462-464
+      if (mxh < kHiInvTwoToLarge && q.apply_scaling)
       { // src/avx.c:504-510
 #pragma unroll
         for (int i = 0; i < S; ++i) o_[i] *= kTwoToLarge;
@@ -631,8 +648,7 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
       nx2 = nx3;
     };
 
-    // An odd operation count runs one extra step, which re-executes the last operation (descriptor
-    // indices are clamped): same inputs, same output, same address -- idempotent.
+    // the host pads the record list to an even length (see flush()), so the two-set alternation is exact
     for (int k = 0; k < q.n_ops; k += 2)
     {
       step(k, 0, RA, PA, RB, PB);
