@@ -120,7 +120,9 @@ struct Instance
   int      *d_fact     = nullptr;
   double   *d_block    = nullptr; // [2][grid]
   double   *d_result   = nullptr; // [2]
-  double   *h_result   = nullptr; // pinned, device-visible
+  double   *h_result   = nullptr; // pinned, device-visible: [0..1] results, [2] sequence number (as u64)
+  unsigned long long seq = 0;     // evaluations handed to the host so far
+  bool      spin_wait  = true;    // PHYHIP_SPIN=0: always hipStreamSynchronize
   int      *d_warn     = nullptr;
   int      *h_warn     = nullptr;
   void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
@@ -440,7 +442,8 @@ int flush(Instance *I, const EdgeEval *ee)
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
     const int nsum = fat ? I->grid_nt : (I->perm ? I->grid_aa : I->grid);
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, nsum, 1,
-                       nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn);
+                       nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn,
+                       ee->to_host ? ++I->seq : 0ull);
     HIPCHK(hipGetLastError());
   }
   I->pending.clear();
@@ -460,6 +463,27 @@ int check_partial_index(const Instance *I, int idx, bool allow_tip)
 {
   if (idx < 0 || idx >= I->nbuf || (!allow_tip && idx < I->tips))
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "partials buffer index %d out of range [%d,%d)", idx, allow_tip ? 0 : I->tips, I->nbuf);
+  return 0;
+}
+
+// Wait until the final reduction has published evaluation `seq` in host-mapped memory.  Spinning on the
+// sequence word avoids the stream-synchronise wake-up latency; after ~2 ms of spinning fall back to it.
+int wait_result(Instance *I)
+{
+  if (I->spin_wait)
+  {
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(I->h_result + 2);
+    for (long it = 0; it < 4000000; ++it)
+    {
+      if (*flag == I->seq)
+      {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return 0;
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  HIPCHK(hipStreamSynchronize(I->stream));
   return 0;
 }
 
@@ -575,7 +599,9 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   }
   HIPCHK(hipMalloc((void **)&I->d_block, (size_t)2 * std::max(std::max(I->grid, I->grid_nt), I->grid_aa) * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_result, 2 * sizeof(double)));
-  HIPCHK(hipHostMalloc((void **)&I->h_result, 2 * sizeof(double), hipHostMallocMapped));
+  HIPCHK(hipHostMalloc((void **)&I->h_result, 4 * sizeof(double), hipHostMallocMapped));
+  memset(I->h_result, 0, 4 * sizeof(double));
+  if (const char *e = getenv("PHYHIP_SPIN")) I->spin_wait = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_warn, sizeof(int)));
   HIPCHK(hipMemset(I->d_warn, 0, sizeof(int)));
   HIPCHK(hipHostMalloc((void **)&I->h_warn, sizeof(int), hipHostMallocMapped));
@@ -944,7 +970,7 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
   EdgeEval ee{parent[0], child[0], pm[0], nullptr, true};
   rc = flush(I, &ee);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(I->stream));
+  if ((rc = wait_result(I))) return rc;
   *outSum = I->h_result[0];
   return PHYHIP_SUCCESS;
 }
@@ -1095,9 +1121,9 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 2, I->grid,
-                     I->d_result, I->h_result, I->d_warn, I->h_warn);
+                     I->d_result, I->h_result, I->d_warn, I->h_warn, ++I->seq);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(I->stream));
+  if ((rc = wait_result(I))) return rc;
   *lnl = I->h_result[0];
   if (dlnl) *dlnl = I->h_result[1];
   return PHYHIP_SUCCESS;

@@ -763,18 +763,13 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
 }
 
 // Second stage: one block sums `n` per-block values of up to two interleaved streams in a fixed order.
-// out[k] = sum_i in[k*stride + i].
+// out[k] = sum_i in[k*stride + i].  Results, the numerical-warning flag and finally a sequence number go to
+// host-mapped memory: the host spins on the sequence number instead of paying a stream-synchronise wake-up
+// (SPR enters the surface ~10^5 times per search, each time waiting for one scalar).
 __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restrict__ in, int n, int nstreams, int stride,
                                                           double *__restrict__ out, double *__restrict__ out_host,
-                                                          int *warn, int *warn_host)
+                                                          int *warn, int *warn_host, unsigned long long seq)
 {
-  // hand the numerical-warning flag of this evaluation to the host and re-arm it for the next one
-  if (threadIdx.x == 0 && warn)
-  {
-    const int w = *warn;
-    if (warn_host) *warn_host = w;
-    *warn = 0;
-  }
   __shared__ double sh[256];
   for (int k = 0; k < nstreams; ++k)
   {
@@ -793,6 +788,22 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restr
       if (out_host) out_host[k] = sh[0];
     }
     __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    // hand the numerical-warning flag of this evaluation to the host and re-arm it for the next one
+    if (warn)
+    {
+      const int w = *warn;
+      if (warn_host) *warn_host = w;
+      *warn = 0;
+    }
+    if (out_host)
+    {
+      __threadfence_system(); // results before the sequence number, system scope (host reads over PCIe)
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(out_host + 2), seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
