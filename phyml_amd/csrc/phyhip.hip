@@ -244,24 +244,41 @@ int flush_pmats(Instance *I)
   const int count = (int)I->pm_idx.size();
   while (done < count)
   {
-    const int    n  = std::min(count - done, I->pm_scratch_cap);
-    void        *st = nullptr;
-    const size_t bi = (sizeof(int) * n + 15) & ~size_t(15), bl = sizeof(double) * n;
-    rc = I->ring.alloc(bi + bl, I->stream, &st);
-    if (rc) return rc;
-    memcpy(st, I->pm_idx.data() + done, sizeof(int) * n);
-    memcpy((char *)st + bi, I->pm_len.data() + done, bl);
-    HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
+    const int  n     = std::min(count - done, I->pm_scratch_cap);
+    const bool small = n <= kSmallPm; // short lists (SPR: 3 per candidate) ride in the kernel arguments
     PmatParams q;
-    q.indices = (const int *)I->d_pmscratch; q.lengths = (const double *)((char *)I->d_pmscratch + bi); q.count = n;
+    memset(&q, 0, sizeof q);
+    FragParams f;
+    memset(&f, 0, sizeof f);
+    if (small)
+    {
+      for (int k = 0; k < n; ++k)
+      {
+        q.small_idx[k] = f.small_idx[k] = I->pm_idx[done + k];
+        q.small_len[k] = I->pm_len[done + k];
+      }
+    }
+    else
+    {
+      void        *st = nullptr;
+      const size_t bi = (sizeof(int) * n + 15) & ~size_t(15), bl = sizeof(double) * n;
+      rc = I->ring.alloc(bi + bl, I->stream, &st);
+      if (rc) return rc;
+      memcpy(st, I->pm_idx.data() + done, sizeof(int) * n);
+      memcpy((char *)st + bi, I->pm_len.data() + done, bl);
+      HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
+      q.indices = f.indices = (const int *)I->d_pmscratch;
+      q.lengths = (const double *)((char *)I->d_pmscratch + bi);
+    }
+    q.count = n;
     q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
-    const int threads = std::min(256, ((I->C * I->S + 63) / 64) * 64);
-    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), sizeof(double) * I->C * I->S, I->stream, q);
+    const int threads = (I->S == 4) ? 64 : 256;
+    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), sizeof(double) * (I->C * I->S + I->C * I->S * I->S), I->stream, q);
     HIPCHK(hipGetLastError());
     if (I->perm)
     { // MFMA A-operand fragments of the matrices just built
-      FragParams f{q.indices, n, I->C, I->d_pmats, I->d_afrag};
+      f.count = n; f.C = I->C; f.pmats = I->d_pmats; f.afrag = I->d_afrag;
       hipLaunchKernelGGL(aa_frag_kernel, dim3(n), dim3(256), 0, I->stream, f);
       HIPCHK(hipGetLastError());
     }
@@ -901,12 +918,9 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
   HIPCHK(hipMemcpyAsync(I->d_pmats + (size_t)matrixIndex * I->C * I->S * I->S, st, bytes, hipMemcpyHostToDevice, I->stream));
   if (I->perm)
   {
-    void *si = nullptr;
-    rc = I->ring.alloc(16, I->stream, &si);
-    if (rc) return rc;
-    *(int *)si = matrixIndex;
-    HIPCHK(hipMemcpyAsync(I->d_pmscratch, si, sizeof(int), hipMemcpyHostToDevice, I->stream));
-    FragParams f{(const int *)I->d_pmscratch, 1, I->C, I->d_pmats, I->d_afrag};
+    FragParams f;
+    memset(&f, 0, sizeof f);
+    f.small_idx[0] = matrixIndex; f.count = 1; f.C = I->C; f.pmats = I->d_pmats; f.afrag = I->d_afrag;
     hipLaunchKernelGGL(aa_frag_kernel, dim3(1), dim3(256), 0, I->stream, f);
     HIPCHK(hipGetLastError());
   }

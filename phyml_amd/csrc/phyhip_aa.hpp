@@ -46,7 +46,8 @@ __host__ __device__ inline size_t aa_off(long long p, int C, int c, int s)
 // A-operand fragments of a set of transition matrices: afrag[m][c][tile][t][lane]
 struct FragParams
 {
-  const int    *indices;
+  const int    *indices; // nullptr: use small_idx
+  int           small_idx[kSmallPm];
   int           count;
   int           C;
   const double *pmats; // natural [m][c][i][j]
@@ -55,7 +56,15 @@ struct FragParams
 
 __global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
 {
-  const int     m   = q.indices[blockIdx.x];
+  int m;
+  if (q.indices) m = q.indices[blockIdx.x];
+  else
+  {
+    m = q.small_idx[0];
+#pragma unroll
+    for (int k = 1; k < kSmallPm; ++k)
+      if ((int)blockIdx.x == k) m = q.small_idx[k];
+  }
   const double *src = q.pmats + (size_t)m * q.C * 400;
   double       *dst = q.afrag + (size_t)m * q.C * (2 * kAaT * 64);
   for (int e = threadIdx.x; e < q.C * 2 * kAaT * 64; e += blockDim.x)

@@ -1020,10 +1020,13 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
 // K5: transition matrices on the device (src/models.c:257-326 behind src/lk.c:2280-2316)
 //     one block per matrix; thread (c,i) builds row i of category c
 // ---------------------------------------------------------------------------------------------
+constexpr int kSmallPm = 8; // up to this many (index, length) pairs travel inside the kernel arguments
 struct PmatParams
 {
-  const int    *indices; // [count]
+  const int    *indices; // [count]  (nullptr: use small_idx / small_len)
   const double *lengths; // [count] raw edge lengths b->l->v
+  int           small_idx[kSmallPm];
+  double        small_len[kSmallPm];
   int           count;
   int           S, C;
   const double *U, *V, *R;   // r_e_vect, l_e_vect, e_val
@@ -1037,7 +1040,17 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
   extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S]
   const int    m  = blockIdx.x;
   const int    S  = q.S, C = q.C;
-  const double l  = q.lengths[m];
+  // SPR refreshes three matrices per candidate: such short lists ride in the kernel arguments (no H2D copy)
+  double l;
+  int    mat;
+  if (q.indices) { l = q.lengths[m]; mat = q.indices[m]; }
+  else
+  {
+    l = q.small_len[0]; mat = q.small_idx[0];
+#pragma unroll
+    for (int k = 1; k < kSmallPm; ++k)
+      if (m == k) { l = q.small_len[k]; mat = q.small_idx[k]; }
+  }
   for (int t = threadIdx.x; t < C * S; t += blockDim.x)
   {
     const int c   = t / S, k = t % S;
@@ -1048,21 +1061,24 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
     expt[t] = exp(q.R[k] * len);                      // src/models.c:275
   }
   __syncthreads();
-  double *out = q.pmats + (size_t)q.indices[m] * C * S * S;
+  double *out = q.pmats + (size_t)mat * C * S * S;
+  double *tmp = expt + C * S; // [C][S][S] floored, un-normalised entries
+  // one thread per entry: acc = sum_k (U[i][k]*expt[c][k]) * V[k][j], ascending k with FMA (src/models.c:278-292)
+  for (int e = threadIdx.x; e < C * S * S; e += blockDim.x)
+  {
+    const int c = e / (S * S), i = (e / S) % S, j = e % S;
+    double    acc = 0.0;
+    for (int k = 0; k < S; ++k) acc = __builtin_fma(q.U[i * S + k] * expt[c * S + k], q.V[k * S + j], acc);
+    tmp[e] = (acc < kSmallPij) ? kSmallPij : acc; // :293
+  }
+  __syncthreads();
+  // row sums in ascending j, then the division (src/models.c:296-298)
   for (int t = threadIdx.x; t < C * S; t += blockDim.x)
   {
-    const int c = t / S, i = t % S;
-    double   *row = out + (size_t)c * S * S + (size_t)i * S;
-    double    sum = 0.0;
-    for (int j = 0; j < S; ++j)
-    {
-      double acc = 0.0;
-      for (int k = 0; k < S; ++k) acc = __builtin_fma(q.U[i * S + k] * expt[c * S + k], q.V[k * S + j], acc); // :278-292
-      if (acc < kSmallPij) acc = kSmallPij;                                                                  // :293
-      row[j] = acc;
-      sum += acc;                                                                                            // :296-297
-    }
-    for (int j = 0; j < S; ++j) row[j] /= sum;                                                               // :298
+    const double *row = tmp + (size_t)t * S;
+    double        sum = 0.0;
+    for (int j = 0; j < S; ++j) sum += row[j];
+    for (int j = 0; j < S; ++j) out[(size_t)t * S + j] = row[j] / sum;
   }
 }
 
