@@ -4,6 +4,7 @@
 #include "../../include/phyhip.h"
 #include "phyhip_kernels.hpp"
 #include "phyhip_aa.hpp"
+#include "phyhip_nt2.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -104,6 +105,8 @@ struct Instance
   int         tips = 0, nbuf = 0, S = 0, C = 0, CP = 0, nmat = 0;
   long long   P = 0, Ppad = 0; // Ppad: patterns per buffer as allocated (P, or P rounded up to 16 when perm)
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
+  bool        soa = false;     // 4-state buffers pattern-minor, lane-per-pattern kernel (phyhip_nt2.hpp)
+  int         grid_nt2 = 0;
   double     *d_afrag = nullptr;
   int         grid_aa = 0;
 
@@ -192,12 +195,19 @@ int next_pow2(int x)
 
 size_t buf_elems(const Instance *I) { return (size_t)I->Ppad * I->C * I->S; }
 
+// element offset of (pattern, category, state) inside a device partials buffer of a non-host layout
+size_t dev_off(const Instance *I, long long p, int c, int s)
+{
+  if (I->perm) return aa_off(p, I->C, c, s);
+  return (size_t)(c * I->S + s) * I->Ppad + (size_t)p; // pattern-minor
+}
+
 TreeParams base_params(Instance *I)
 {
   TreeParams q;
   memset(&q, 0, sizeof q);
   q.partials = I->d_partials; q.scales = I->d_scales;
-  q.wght = I->d_wght; q.P = I->P; q.Ppad = I->Ppad; q.perm = I->perm ? 1 : 0; q.C = I->C; q.tip_count = I->tips;
+  q.wght = I->d_wght; q.P = I->P; q.Ppad = I->Ppad; q.perm = I->perm ? 1 : (I->soa ? 2 : 0); q.C = I->C; q.tip_count = I->tips;
   q.apply_scaling = I->apply_scaling; q.pi = I->d_pi; q.cat_w = I->d_catw; q.invar_model = I->invar_model;
   q.pinvar = I->pinvar; q.invar = I->d_invar; q.block_sums = I->d_block; q.warn = I->d_warn; q.fact = I->d_fact;
   return q;
@@ -378,14 +388,14 @@ int flush(Instance *I, const EdgeEval *ee)
           if (f2) fl |= f2bit;
           const size_t b = ld ? (size_t)(c - I->tips) : 0;
           data  = desc(I->d_partials + b * buf_elems(I), ld ? bufbytes : 0, pmoff);
-          scale = desc(I->d_scales + b * I->P, ld ? (size_t)I->P * 4 : 0, 0);
-          tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->P, t ? (size_t)I->P : 0, 0);
+          scale = desc(I->d_scales + b * I->Ppad, ld ? (size_t)I->Ppad * 4 : 0, 0);
+          tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->Ppad, t ? (size_t)I->Ppad : 0, 0);
         };
         child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes);
         child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);
         const size_t b = (size_t)(o.dest - I->tips);
         xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), bufbytes, fl);
-        xr[k].dst_scale = desc(I->d_scales + b * I->P, (size_t)I->P * 4, 0);
+        xr[k].dst_scale = desc(I->d_scales + b * I->Ppad, (size_t)I->Ppad * 4, 0);
       }
       HIPCHK(hipMemcpyAsync(dst, st, ib + xb, hipMemcpyHostToDevice, I->stream));
       d_irec = reinterpret_cast<const IssueRec *>(dst);
@@ -408,6 +418,19 @@ int flush(Instance *I, const EdgeEval *ee)
   }
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    if constexpr (S_ == 4 && CP_ <= 4)
+    {
+      if (I->soa)
+      { // lane-per-pattern kernel, instantiated on the exact category count
+        switch (I->C)
+        {
+#define NT2CASE(c_) case c_: hipLaunchKernelGGL((traverse_nt2_kernel<c_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes); return 0;
+          NT2CASE(1) NT2CASE(2) NT2CASE(3) NT2CASE(4)
+#undef NT2CASE
+          default: break;
+        }
+      }
+    }
     if constexpr (S_ == 4)
     {
       if (!I->generic_nt)
@@ -457,7 +480,7 @@ int flush(Instance *I, const EdgeEval *ee)
   if (ee)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
-    const int nsum = fat ? I->grid_nt : (I->perm ? I->grid_aa : I->grid);
+    const int nsum = I->soa ? I->grid_nt2 : (fat ? I->grid_nt : (I->perm ? I->grid_aa : I->grid));
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, nsum, 1,
                        nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn,
                        ee->to_host ? ++I->seq : 0ull);
@@ -560,7 +583,10 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   HIPCHK(hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking));
 
   I->perm = (I->S == 20) && (I->C <= 4) && !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA")));
-  I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : I->P;
+  I->soa  = (I->S == 4) && (I->C <= 4) && !(getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
+            !(getenv("PHYHIP_GENERIC_NT") && atoi(getenv("PHYHIP_GENERIC_NT")));
+  I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
+  I->grid_nt2 = (int)(I->Ppad / 64);
   const size_t n_int = (size_t)(I->nbuf - I->tips);
   const size_t be    = buf_elems(I);
   HIPCHK(hipMalloc((void **)&I->d_partials, n_int * be * sizeof(double)));
@@ -574,8 +600,8 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
     HIPCHK(hipMemset(I->d_afrag, 0, fb));
     I->grid_aa = (int)(I->Ppad / 16); // one workgroup (C waves) per tile of 16 patterns
   }
-  HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->P));
-  HIPCHK(hipMemset(I->d_tipcodes, 0, (size_t)I->tips * I->P));
+  HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->Ppad));
+  HIPCHK(hipMemset(I->d_tipcodes, 0, (size_t)I->tips * I->Ppad));
   HIPCHK(hipMalloc((void **)&I->d_masks, 256 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void **)&I->d_pmats, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
   HIPCHK(hipMemset(I->d_pmats, 0, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
@@ -613,8 +639,10 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
     // pipeline unless that would leave a nearly empty second residency round
     const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
     if (!getenv("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
+    if (I->soa) I->prefetch_dist = 2;
   }
-  HIPCHK(hipMalloc((void **)&I->d_block, (size_t)2 * std::max(std::max(I->grid, I->grid_nt), I->grid_aa) * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_block,
+                   (size_t)2 * std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2)) * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_result, 2 * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&I->h_result, 4 * sizeof(double), hipHostMallocMapped));
   memset(I->h_result, 0, 4 * sizeof(double));
@@ -698,7 +726,7 @@ static int set_tip_codes(Instance *I, int tip, const std::vector<uint8_t> &codes
 {
   int rc = flush_sync(I);
   if (rc) return rc;
-  HIPCHK(hipMemcpy(I->d_tipcodes + (size_t)tip * I->P, codes.data(), (size_t)I->P, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(I->d_tipcodes + (size_t)tip * I->Ppad, codes.data(), (size_t)I->P, hipMemcpyHostToDevice));
   return upload_masks(I);
 }
 
@@ -773,7 +801,7 @@ int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials)
   if (rc) return rc;
   rc = flush_sync(I);
   if (rc) return rc;
-  if (!I->perm)
+  if (!I->perm && !I->soa)
   {
     HIPCHK(hipMemcpy(I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), inPartials, buf_elems(I) * sizeof(double),
                      hipMemcpyHostToDevice));
@@ -782,7 +810,8 @@ int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials)
   std::vector<double> tmp(buf_elems(I), 0.0);
   for (long long p = 0; p < I->P; ++p)
     for (int c = 0; c < I->C; ++c)
-      for (int s = 0; s < 20; ++s) tmp[aa_off(p, I->C, c, s)] = inPartials[((size_t)p * I->C + c) * 20 + s];
+      for (int s = 0; s < I->S; ++s)
+        tmp[dev_off(I, p, c, s)] = inPartials[((size_t)p * I->C + c) * I->S + s];
   HIPCHK(hipMemcpy(I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), tmp.data(), buf_elems(I) * sizeof(double),
                    hipMemcpyHostToDevice));
   return PHYHIP_SUCCESS;
@@ -1028,7 +1057,7 @@ int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *o
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
   if ((rc = flush_sync(I))) return rc;
-  if (!I->perm)
+  if (!I->perm && !I->soa)
   {
     HIPCHK(hipMemcpy(out, I->d_partials + (size_t)(bufferIndex - I->tips) * buf_elems(I), buf_elems(I) * sizeof(double),
                      hipMemcpyDeviceToHost));
@@ -1039,7 +1068,7 @@ int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *o
                    hipMemcpyDeviceToHost));
   for (long long p = 0; p < I->P; ++p)
     for (int c = 0; c < I->C; ++c)
-      for (int s = 0; s < 20; ++s) out[((size_t)p * I->C + c) * 20 + s] = tmp[aa_off(p, I->C, c, s)];
+      for (int s = 0; s < I->S; ++s) out[((size_t)p * I->C + c) * I->S + s] = tmp[dev_off(I, p, c, s)];
   return PHYHIP_SUCCESS;
 }
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * CP) void traverse_aa_kernel(const TreeParams q
   auto fetch = [&](int idx, double (&x)[T], int &sc) {
     if (idx < tips)
     {
-      const uint32_t m = code_masks[tip_codes[(size_t)idx * q.P + p]];
+      const uint32_t m = code_masks[tip_codes[(size_t)idx * q.Ppad + p]];
 #pragma unroll
       for (int t = 0; t < T; ++t) x[t] = ((m >> (4 * t + kk)) & 1u) ? 1.0 : 0.0;
       sc = 0;

@@ -74,7 +74,7 @@ struct TreeParams
   const double   *wght;       // [P]
   long long       P;
   long long       Ppad;       // patterns per scale vector (P, or P rounded up to 16 for the fragment-major layout)
-  int             perm;       // 1: 20-state partials are stored fragment-major (phyhip_aa.hpp)
+  int             perm;       // 0 host layout; 1: 20-state fragment-major (phyhip_aa.hpp); 2: 4-state pattern-minor (phyhip_nt2.hpp)
   int             C;
   int             tip_count;
   int             apply_scaling;
@@ -160,7 +160,19 @@ __device__ __forceinline__ void issue_side(const TreeParams &q, const RO &ro, in
   r.sc = 0;
   r.code = 0;
   if (r.tip)
-    r.code = ro.tip_codes[(size_t)idx * q.P + p];
+    r.code = ro.tip_codes[(size_t)idx * q.Ppad + p];
+  else if (S == 4 && q.perm == 2)
+  { // pattern-minor (SoA) layout of the lane-per-pattern nucleotide kernel: entry (c,s) of pattern p at (c*4+s)*Ppad + p
+    const size_t  b    = (size_t)(idx - q.tip_count);
+    const double *base = q.partials + b * (size_t)q.Ppad * (q.C * S) + (size_t)(c * S) * q.Ppad + p;
+#pragma unroll
+    for (int j = 0; j < S / 2; ++j)
+    {
+      r.v[j].x = base[(size_t)(2 * j) * q.Ppad];
+      r.v[j].y = base[(size_t)(2 * j + 1) * q.Ppad];
+    }
+    if (c == 0) r.sc = q.scales[b * q.Ppad + p];
+  }
   else if (S == 20 && q.perm)
   { // fragment-major layout: state s of (p,c) sits at ((tile*C + c)*5 + s/4)*64 + (s%4)*16 + p%16
     const size_t  b    = (size_t)(idx - q.tip_count);
@@ -669,7 +681,7 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
     auto side = [&](int idx, double (&v)[S], int &sc) {
       if (idx < tips)
       {
-        const unsigned m = tip_codes[(size_t)idx * q.P + p];
+        const unsigned m = tip_codes[(size_t)idx * q.Ppad + p];
 #pragma unroll
         for (int j = 0; j < S; ++j) v[j] = ((m >> j) & 1u) ? 1.0 : 0.0;
         sc = 0;

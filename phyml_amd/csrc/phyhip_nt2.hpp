@@ -1,0 +1,344 @@
+// phyhip_nt2.hpp -- nucleotide traversal, second generation: one lane = one PATTERN (all categories).
+//
+// Why: rocprofv3 showed the (pattern, category)-per-lane kernel to be bound by instruction issue, not by
+// memory (SQ_WAIT_INST_ANY ~45 % of wave-cycles, ~270 wave-instructions per operation for only 16 patterns:
+// every SIMD issues about one instruction per 4 cycles whatever its type, so 3125 waves x 98 operations x
+// 270 instructions is ~150 us of pure issue time on 1024 SIMDs).  Giving a lane the whole pattern
+//   * removes every cross-lane step (the max-scan of the rescaling rule, the category mixture and the scale
+//     exponent are lane-local), the replicated per-pattern work of the four category lanes and the LDS
+//     shuffles, and amortises the per-operation scalar work over 64 patterns instead of 16:
+//     ~270 instructions per operation per wave for 64 patterns (4x fewer per pattern);
+//   * lets tips use the reference's own shortcut: an unambiguous tip contributes the COLUMN P[.][s] of its
+//     matrix (Exex / Exin, src/avx.c:527-564) -- a 32-byte LDS lookup per category instead of a 4x4 product.
+//
+// Layout ("pattern-minor", SoA): buffer[c*4 + s][pattern], patterns padded to 64.  A wave's access to one
+// (category, state) row is one contiguous 512-byte transaction, so lane = pattern stays fully coalesced.
+// The host-facing layout ([pattern][category][state]) is restored by phyhip_get_partials.
+//
+// Everything else is the pipeline of traverse_nt_kernel: host-prepared buffer descriptors (size 0 = load
+// disabled, answered by the bounds check), loads of operation k+2 in flight while k is computed, results of
+// the last two operations forwarded in registers (two alternating register files, no copies), both
+// transition matrices of an operation staged once per wave into LDS and read back as broadcasts.
+#pragma once
+
+#include "phyhip_kernels.hpp"
+
+namespace phyhip
+{
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int C>
+__global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+                                                             const ExecRec *__restrict__ xrec,
+                                                             const double *__restrict__ pmats,
+                                                             const uint8_t *__restrict__ tip_codes)
+{
+  constexpr int S = 4, CS = C * S;
+  __shared__ __attribute__((aligned(16))) double lds_p[2][2 * C * 16]; // [buffer][matrix][c][i][j]
+
+  const int      lane = threadIdx.x;
+  const unsigned p    = blockIdx.x * 64u + lane;          // < Ppad by construction of the grid
+  const unsigned voff8 = p * 8u, voff4 = p * 4u;
+  const unsigned rowb = (unsigned)(q.Ppad * 8);           // bytes between consecutive (c,s) rows
+
+  struct Raw
+  {
+    u32x2    a[CS], b[CS]; // child 1 / child 2 entries
+    unsigned sa, sb;       // scale exponents
+    unsigned ca, cb;       // tip bytes (allowed-state masks)
+  };
+  const __amdgpu_buffer_rsrc_t pm_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pmats), 0, 0x7fffffff, 0x00020000);
+  auto rsrc = [](const Desc &d) {
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
+  };
+  auto as_d = [](const u32x2 &v) { double d; __builtin_memcpy(&d, &v, 8); return d; };
+
+  // issue every load an operation needs (which ones are live was decided by the host)
+  auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc) {
+    const __amdgpu_buffer_rsrc_t d1r = rsrc(o.c1_data), d2r = rsrc(o.c2_data), g1r = rsrc(o.c1_scale),
+                                 g2r = rsrc(o.c2_scale), y1r = rsrc(o.c1_tip), y2r = rsrc(o.c2_tip);
+#pragma unroll
+    for (int e = 0; e < CS; ++e) r.a[e] = __builtin_amdgcn_raw_buffer_load_b64(d1r, voff8, (unsigned)e * rowb, 0);
+#pragma unroll
+    for (int e = 0; e < CS; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b64(d2r, voff8, (unsigned)e * rowb, 0);
+    r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, voff4, 0, 0);
+    r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, voff4, 0, 0);
+    r.ca = __builtin_amdgcn_raw_buffer_load_b8(y1r, p, 0, 0);
+    r.cb = __builtin_amdgcn_raw_buffer_load_b8(y2r, p, 0, 0);
+    // this lane's 16-byte piece of [matrix 1 | matrix 2] (C*16 doubles each)
+    int ch = (lane < 16 * C) ? lane : 0;
+    const int      mat = ch / (8 * C), within = ch - mat * 8 * C;
+    const unsigned off = (mat ? o.c2_data.x : o.c1_data.x) + (unsigned)within * 16u;
+    pc = __builtin_amdgcn_raw_buffer_load_b128(pm_rsrc, off, 0, 0);
+  };
+
+  // u[c*4+i] = sum_j P[c][i][j] * x[c*4+j]: first product, then the FMA chain (src/avx.c:593-616);
+  // the matrix rows come from LDS as wave-wide broadcasts
+  auto matvec_x = [&](const double2 *M, const double (&x)[CS], double (&u)[CS]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+      {
+        const double2 lo = M[c * 8 + 2 * i], hi = M[c * 8 + 2 * i + 1];
+        double        a  = lo.x * x[c * 4];
+        a = __builtin_fma(lo.y, x[c * 4 + 1], a);
+        a = __builtin_fma(hi.x, x[c * 4 + 2], a);
+        a = __builtin_fma(hi.y, x[c * 4 + 3], a);
+        u[c * 4 + i] = a;
+      }
+  };
+  auto matvec_r = [&](const double2 *M, const u32x2 (&xr)[CS], double (&u)[CS]) {
+    double x[CS];
+#pragma unroll
+    for (int e = 0; e < CS; ++e) x[e] = as_d(xr[e]);
+    matvec_x(M, x, u);
+  };
+  // tip child with allowed-state mask m: u[c*4+i] = sum_{j in m} P[c][i][j] (ascending j).  An unambiguous tip
+  // (one state s) is the column lookup of the reference's Exex / Exin kernels (src/avx.c:527-564).
+  auto tip_u = [&](const double *Md, const double2 *M, unsigned m, double (&u)[CS]) {
+    const bool onehot = (m == 1u) || (m == 2u) || (m == 4u) || (m == 8u);
+    if (__builtin_amdgcn_ballot_w64(!onehot) == 0)
+    {
+      const int s = (m >> 1) - (m >> 3); // 1,2,4,8 -> 0,1,2,3
+#pragma unroll
+      for (int e = 0; e < CS; ++e) u[e] = Md[e * 4 + s];
+    }
+    else
+    {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+        {
+          const double2 lo = M[c * 8 + 2 * i], hi = M[c * 8 + 2 * i + 1];
+          double        a  = (m & 1u) ? lo.x : 0.0;
+          a = (m & 2u) ? a + lo.y : a;
+          a = (m & 4u) ? a + hi.x : a;
+          a = (m & 8u) ? a + hi.y : a;
+          u[c * 4 + i] = a;
+        }
+    }
+  };
+
+  double   FA[CS], FB[CS]; // results of the last two operations (alternating)
+  unsigned scA = 0, scB = 0;
+#pragma unroll
+  for (int e = 0; e < CS; ++e) FA[e] = FB[e] = 0.0;
+
+  if (q.n_ops > 0)
+  {
+    const int last = q.n_ops - 1; // host pads the list to an even length
+    Raw       RA, RB;
+    u32x4     PA, PB;
+    issue(irec[0], RA, PA);
+    issue(irec[(1 < last) ? 1 : last], RB, PB);
+    ExecRec  cur = xrec[0];
+    IssueRec nx2 = irec[(2 < last) ? 2 : last];
+
+    // One pipeline step: operation k; its loads are in (R, PC); Fprev = result of k-1, Fout = result of k-2
+    // on entry and the result of k on exit.
+    auto step = [&](const int k, const int parity, Raw &R, u32x4 &PC, double (&Fout)[CS], unsigned &scout,
+                    const double (&Fprev)[CS], const unsigned scprev) {
+      double2 *buf = reinterpret_cast<double2 *>(&lds_p[parity][0]);
+      {
+        double2 v;
+        __builtin_memcpy(&v, &PC, 16);
+        buf[(lane < 16 * C) ? lane : 0] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double *bufd = &lds_p[parity][0];
+
+      const unsigned fl = cur.dst_data.x;
+      double         u1[CS], u2[CS];
+      unsigned       s1, s2;
+      bool           one1, one2; // first-entry test of the all-ones shortcut
+      // ---- child 1 ----
+      if (fl & kOpTip1)
+      {
+        tip_u(bufd, buf, R.ca, u1);
+        s1 = 0; one1 = (R.ca == 15u);
+      }
+      else if (fl & kOpF11) { matvec_x(buf, Fprev, u1); s1 = scprev; one1 = (Fprev[0] == 1.0); }
+      else if (fl & kOpF12) { matvec_x(buf, Fout, u1); s1 = scout; one1 = (Fout[0] == 1.0); }
+      else { matvec_r(buf, R.a, u1); s1 = R.sa; one1 = (as_d(R.a[0]) == 1.0); }
+      // ---- child 2 ----
+      if (fl & kOpTip2)
+      {
+        tip_u(bufd + C * 16, buf + C * 8, R.cb, u2);
+        s2 = 0; one2 = (R.cb == 15u);
+      }
+      else if (fl & kOpF21) { matvec_x(buf + C * 8, Fprev, u2); s2 = scprev; one2 = (Fprev[0] == 1.0); }
+      else if (fl & kOpF22) { matvec_x(buf + C * 8, Fout, u2); s2 = scout; one2 = (Fout[0] == 1.0); }
+      else { matvec_r(buf + C * 8, R.b, u2); s2 = R.sb; one2 = (as_d(R.b[0]) == 1.0); }
+
+      // all-ones shortcut (src/avx.c:575-587): a category whose eight child entries are exactly 1.0 yields 1.0.
+      // Only fully ambiguous subtrees get here; the full test runs when some lane passes the first-entry test.
+      unsigned ones_mask = 0; // bit c: category c is all ones in both children
+      if (__builtin_amdgcn_ballot_w64(one1 && one2))
+      {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+        {
+          bool a1, a2;
+          if (fl & kOpTip1) a1 = (R.ca == 15u);
+          else
+          {
+            a1 = true;
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+              a1 = a1 && (((fl & kOpF11) ? Fprev[c * 4 + j] : (fl & kOpF12) ? Fout[c * 4 + j] : as_d(R.a[c * 4 + j])) == 1.0);
+          }
+          if (fl & kOpTip2) a2 = (R.cb == 15u);
+          else
+          {
+            a2 = true;
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+              a2 = a2 && (((fl & kOpF21) ? Fprev[c * 4 + j] : (fl & kOpF22) ? Fout[c * 4 + j] : as_d(R.b[c * 4 + j])) == 1.0);
+          }
+          ones_mask |= (a1 && a2) ? (1u << c) : 0u;
+        }
+      }
+
+      // prefetch operation k+2 into the registers just freed; then the scalar records of the next step
+      issue(nx2, R, PC);
+      const IssueRec nx3 = irec[(k + 3 < last) ? k + 3 : last];
+      const ExecRec  nx1 = xrec[(k + 1 < last) ? k + 1 : last];
+      __builtin_amdgcn_wave_barrier();
+
+      unsigned mxh = 0;
+#pragma unroll
+      for (int e = 0; e < CS; ++e)
+      {
+        const double v = ((ones_mask >> (e / 4)) & 1u) ? 1.0 : u1[e] * u2[e];
+        Fout[e] = v;
+        mxh     = max(mxh, hi32(v));
+      }
+      unsigned sc = s1 + s2; // src/avx.c:462-464
+      if (mxh < kHiInvTwoToLarge && q.apply_scaling)
+      { // src/avx.c:504-510
+#pragma unroll
+        for (int e = 0; e < CS; ++e) Fout[e] *= kTwoToLarge;
+        sc += kLarge;
+      }
+      scout = sc;
+      {
+        const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
+#pragma unroll
+        for (int e = 0; e < CS; ++e)
+        {
+          u32x2 w;
+          __builtin_memcpy(&w, &Fout[e], 8);
+          __builtin_amdgcn_raw_buffer_store_b64(w, dr, voff8, (unsigned)e * rowb, 0);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff4, 0, 0);
+      }
+      cur = nx1;
+      nx2 = nx3;
+    };
+
+    for (int k = 0; k < q.n_ops; k += 2)
+    {
+      step(k, 0, RA, PA, FA, scA, FB, scB);
+      step(k + 1, 1, RB, PB, FB, scB, FA, scA);
+    }
+  }
+
+  if (!q.edge_eval) return;
+
+  // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861), all lane-local ----------
+  double contrib = 0.0;
+  {
+    const int    tips = q.tip_count;
+    const size_t bufsz = (size_t)q.Ppad * CS;
+    double       x[CS], y[CS];
+    unsigned     sl, sr;
+    auto side = [&](int idx, double (&v)[CS], unsigned &sc) {
+      if (idx < tips)
+      {
+        const unsigned m = tip_codes[(size_t)idx * q.Ppad + p];
+#pragma unroll
+        for (int e = 0; e < CS; ++e) v[e] = ((m >> (e & 3)) & 1u) ? 1.0 : 0.0;
+        sc = 0;
+      }
+      else if (idx == q.last_dest)
+      { // the last queued operation's result is still in registers (FB: the list length is even)
+#pragma unroll
+        for (int e = 0; e < CS; ++e) v[e] = FB[e];
+        sc = scB;
+      }
+      else
+      {
+        const double *src = q.partials + (size_t)(idx - tips) * bufsz + p;
+#pragma unroll
+        for (int e = 0; e < CS; ++e) v[e] = src[(size_t)e * q.Ppad];
+        sc = (unsigned)q.scales[(size_t)(idx - tips) * q.Ppad + p];
+      }
+    };
+    side(q.e_parent, x, sl);
+    side(q.e_child, y, sr);
+    const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16); // rows: right-side state
+    double site = 0.0;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+    {
+      double t[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+      {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) a = __builtin_fma(M[c * 16 + kk * 4 + i], x[c * 4 + i], a);
+        t[kk] = a * (y[c * 4 + kk] * q.pi[kk]);
+      }
+      const double lkc = (t[0] + t[2]) + (t[1] + t[3]);
+      if (p < (unsigned)q.P && q.site_cat) q.site_cat[(size_t)p * C + c] = lkc;
+      site += lkc * q.cat_w[c]; // src/lk.c:816-818
+    }
+    if (p < (unsigned)q.P)
+    {
+      const double w = q.wght[p];
+      int          f = q.apply_scaling ? (int)(sl + sr) : 0;
+      if (w > kSmall)
+      {
+        if (q.invar_model)
+        {
+          const int iv = q.invar[p];
+          double    inv = 0.0;
+          bool      issue_ = false;
+          if (iv >= 0)
+          {
+            inv = q.pi[iv];
+            if (q.apply_scaling)
+            {
+              int e = f;
+              do
+              {
+                const int piece = e < 63 ? e : 63;
+                inv *= (double)(1ull << piece);
+                e -= piece;
+              } while (e != 0);
+            }
+            issue_ = isinf(inv);
+          }
+          if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
+          else site = site * (1. - q.pinvar) + inv * q.pinvar;
+        }
+        if (site < kSmall) { site = kSmall; *q.warn = 1; }
+        const double lsl = log(site) - kLog2 * (double)f;
+        if (q.site_lnl) q.site_lnl[p] = lsl;
+        if (q.site_lk) q.site_lk[p] = exp(lsl);
+        contrib = w * lsl;
+      }
+      q.fact[p] = f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+  if (lane == 0) q.block_sums[blockIdx.x] = contrib;
+}
+
+} // namespace phyhip
