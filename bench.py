@@ -178,7 +178,7 @@ def main():
             "lnL": lnl,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": pmc_traffic(args.workload) if (world == 1 and args.patterns is None) else None,
-                         "kernel": "traverse_nt_kernel" if S == 4 else "traverse_aa_kernel", "kernel_avg_us": kdur * 1e6,
+                         "kernel": ("traverse_nt2_kernel" if C <= 4 else "traverse_nt_kernel") if S == 4 else "traverse_aa_kernel", "kernel_avg_us": kdur * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_per_site_update": alg_bytes / (float(P) * (n - 2))},
         }
