@@ -109,10 +109,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("PHYHIP_BENCH_FORCE_DIST") == "1"   # exercise the sharded path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
@@ -134,7 +137,7 @@ def main():
     t.inst.set_stream(stream.cuda_stream)
 
     def step():
-        if world == 1:
+        if dist is None:
             return t.Lk(None)
         # sharded evaluation: per-shard lnL stays on the device, ONE all-reduce over RCCL, then the host reads it
         t.Lk_Shard_Device(dev_lnl.data_ptr())
@@ -161,6 +164,7 @@ def main():
         dt = float(tt.item())
     kern_ms, kern_n, kern_upd = t.inst.profile_read()
 
+    out = None
     if rank == 0:
         updates_per_step = float(P) * (n - 2) * world
         value = updates_per_step * args.steps / dt / 1e6
@@ -201,10 +205,18 @@ def main():
             out["input_checksum_ok"] = bool(synth.states_checksum(st) == exp["checksum"])
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample, args.cpu_reps)
-        print(json.dumps(out))
     t.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last, after RCCL has finished any chatter of its own on stdout
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    # RCCL prints a version banner on stdout while the interpreter shuts down; leave before that so the JSON
+    # line stays the last (and, single-GPU, the only) line on stdout
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":
