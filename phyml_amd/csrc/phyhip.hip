@@ -312,7 +312,7 @@ int flush(Instance *I, const EdgeEval *ee)
 
   TreeParams q = base_params(I);
   RO         ro = base_ro(I, nullptr);
-  const bool fat = (I->S == 4) && !I->generic_nt;
+  const bool fat = ((I->S == 4) && !I->generic_nt) || I->perm;
   const IssueRec *d_irec = nullptr;
   const ExecRec  *d_xrec = nullptr;
   q.last_dest = -1;
@@ -365,7 +365,10 @@ int flush(Instance *I, const EdgeEval *ee)
       IssueRec *ir = reinterpret_cast<IssueRec *>(st);
       ExecRec  *xr = reinterpret_cast<ExecRec *>((char *)st + ib);
       const size_t   bufbytes = buf_elems(I) * sizeof(double);
-      const unsigned matbytes = (unsigned)((size_t)I->C * I->S * I->S * sizeof(double));
+      // spare word of the data descriptors: byte offset of the child's matrix (natural table, or the MFMA
+      // A-fragment table for the 20-state kernel)
+      const unsigned matbytes = I->perm ? (unsigned)((size_t)I->C * 2 * kAaT * 64 * sizeof(double))
+                                        : (unsigned)((size_t)I->C * I->S * I->S * sizeof(double));
       auto desc = [](const void *base, size_t bytes, unsigned x) {
         Desc d;
         d.base = (unsigned long long)(uintptr_t)base; d.bytes = (unsigned)bytes; d.x = x;
@@ -460,8 +463,33 @@ int flush(Instance *I, const EdgeEval *ee)
     {
       if (I->perm)
       {
-        hipLaunchKernelGGL((traverse_aa_kernel<CP_>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, ro.ops,
-                           (const double *)I->d_afrag, ro.tip_codes, ro.code_masks);
+        if constexpr (CP_ == 4)
+          if (I->ablate & 8)
+          { // PHYHIP_ABLATE=8: cycle stamps of one wave, printed to stderr (diagnostics; costs a sync per launch)
+            static unsigned long long *d_dbg = nullptr;
+            if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
+            hipLaunchKernelGGL((traverse_aa_kernel<CP_, true>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
+                               (const double *)I->d_afrag, I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size(),
+                               I->ablate & 7, d_dbg);
+            static int printed = 0;
+            if (printed++ == 5)
+            {
+              unsigned long long h[64 * 8];
+              HIPCHK(hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, I->stream));
+              HIPCHK(hipStreamSynchronize(I->stream));
+              for (int k = 0; k < 64 && k < q.n_ops; ++k)
+              {
+                fprintf(stderr, "step %2d:", k);
+                for (int i = 1; i < 7; ++i) fprintf(stderr, " %6lld", (long long)(h[k * 8 + i] - h[k * 8 + i - 1]));
+                if (k + 1 < 64) fprintf(stderr, "  | next %6lld", (long long)(h[(k + 1) * 8] - h[k * 8 + 6]));
+                fprintf(stderr, "\n");
+              }
+            }
+            return 0;
+          }
+        hipLaunchKernelGGL((traverse_aa_kernel<CP_>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
+                           (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks,
+                           (int)I->masks.size(), I->ablate);
         return 0;
       }
     }
@@ -480,7 +508,7 @@ int flush(Instance *I, const EdgeEval *ee)
   if (ee)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
-    const int nsum = I->soa ? I->grid_nt2 : (fat ? I->grid_nt : (I->perm ? I->grid_aa : I->grid));
+    const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, nsum, 1,
                        nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn,
                        ee->to_host ? ++I->seq : 0ull);
@@ -640,6 +668,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
     const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
     if (!getenv("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
     if (I->soa) I->prefetch_dist = 2;
+    if (I->perm) I->prefetch_dist = 1; // the 20-state kernel forwards only the previous result
   }
   HIPCHK(hipMalloc((void **)&I->d_block,
                    (size_t)2 * std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2)) * sizeof(double)));

@@ -7,43 +7,55 @@
 // limits the VALU form (one LDS/SGPR operand fetch per fused multiply-add).  The 4-state path has a
 // 4x4 contraction per lane and stays on the VALU.
 //
-// MFMA shape and data layout
-//   D[16 x 16] += A[16 x 4] * B[4 x 16]          (one instruction, one wave)
-//   rows of D   = output states (two row tiles: states 0..15, and 16..19 padded with zero rows)
-//   columns     = 16 patterns (one wave owns one tile of 16 patterns)
+// MFMA shapes and data layout
+//   rows 0..15 of the result:  D[16 x 16] += A[16 x 4] * B[4 x 16]      v_mfma_f64_16x16x4_f64
+//   rows 16..19             :  4 blocks of D[4 x 4] += A[4 x 4] * B[4 x 4]   v_mfma_f64_4x4x4_4b_f64
+//   columns     = 16 patterns (one wave owns one tile of 16 patterns; block b of the 4x4x4 form = patterns 4b..4b+3)
 //   k           = 4 consecutive input states (five k-chunks cover the 20 states, ascending, so the
 //                 accumulation order over input states is the reference's: src/avx.c:593-616)
-//   lane l = (kk = l >> 4, pp = l & 15):  A operand  P[c][tile*16 + pp][4t + kk]
-//                                         B operand  x[pattern pp][c][4t + kk]
-//                                         D regs r   rows kk + 4r  -> output states kk + 4r (r = 0..3), 16 + kk
-// The D fragment of an update is therefore already the B fragment its parent needs: a lane owns states
+//   lane l = (kk = l >> 4, pp = l & 15):  B operand (both shapes)  x[pattern pp][c][4t + kk]
+//                                         A operand 16x16x4        P[c][pp][4t + kk]
+//                                         A operand 4x4x4_4b       P[c][16 + (l & 3)][4t + kk]   (same for every block)
+//                                         D 16x16x4 regs r         output states kk + 4r  (r = 0..3)
+//                                         D 4x4x4_4b               output state 16 + kk
+//   (4x4x4_4b lane maps measured with tools/probes/mfma4b.hip: A = 16k + 4b + i, B = 16k + 4b + j, D = 16i + 4b + j.)
+// The 4x4x4 form does the last four rows in a quarter of the matrix-core time of a zero-padded second
+// 16-row tile.  The D fragments of an update are already the B fragment its parent needs: a lane owns states
 // {kk, kk+4, kk+8, kk+12, kk+16} of pattern pp on input and on output, results are forwarded in
 // registers without any shuffle, and the elementwise product of the two children is lane-local.
 //
 // Device layout of an amino-acid partials buffer ("fragment-major"):
-//   [pattern tile of 16][category c][k-chunk t][lane]   one double each
-// so every fragment load/store is one fully coalesced 512-byte access.  The host-facing layout
-// ([pattern][category][state], t_edge::p_lk_*) is restored by phyhip_get_partials / accepted by
+//   [pattern tile of 16][category c][320 doubles: aa_slot(k-chunk t, lane)]
+// i.e. chunk pairs (0|1), (2|3) as 16 bytes per lane and chunk 4 as 8 bytes per lane: a lane's five values
+// move as 2 x dwordx4 + 1 x dwordx2, each instruction one contiguous 1 KiB / 512 B access.  The per-CU
+// vector-memory path issues ~1 wave-instruction per 12 cycles whatever its width (measured with the cycle
+// stamps of PHYHIP_ABLATE=8), so instruction count, not bytes, is what the layout minimises.  The host-facing
+// layout ([pattern][category][state], t_edge::p_lk_*) is restored by phyhip_get_partials / accepted by
 // phyhip_set_partials.
 #pragma once
 
 #include "phyhip_kernels.hpp"
+#include "phyhip_nt2.hpp"
 
 namespace phyhip
 {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int kAaT = 5; // k-chunks of 4 states
+typedef double       v4d __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef PHY_AA_EARLY
+#define PHY_AA_EARLY 0
+#endif
+constexpr int kAaT     = 5;   // k-chunks of 4 states
+constexpr int kAaBlock = 320; // doubles per (tile, category) block, and per half (rows 0..15 | 16..19) of an A table
 
 // element offset of (pattern p, category c, state s) inside a fragment-major buffer
 __host__ __device__ inline size_t aa_off(long long p, int C, int c, int s)
 {
   const long long tile = p >> 4;
-  const int       pp = (int)(p & 15), t = s >> 2, kk = s & 3;
-  return ((size_t)(tile * C + c) * kAaT + t) * 64 + (size_t)kk * 16 + pp;
+  return (size_t)(tile * C + c) * kAaBlock + (size_t)aa_slot(s >> 2, (s & 3) * 16 + (int)(p & 15));
 }
 
-// A-operand fragments of a set of transition matrices: afrag[m][c][tile][t][lane]
+// A-operand fragments of a set of transition matrices: afrag[m][c][half][aa_slot(t, lane)]
 struct FragParams
 {
   const int    *indices; // nullptr: use small_idx
@@ -66,12 +78,12 @@ __global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
       if ((int)blockIdx.x == k) m = q.small_idx[k];
   }
   const double *src = q.pmats + (size_t)m * q.C * 400;
-  double       *dst = q.afrag + (size_t)m * q.C * (2 * kAaT * 64);
+  double       *dst = q.afrag + (size_t)m * q.C * (2 * kAaBlock);
   for (int e = threadIdx.x; e < q.C * 2 * kAaT * 64; e += blockDim.x)
   {
-    const int lane = e & 63, t = (e >> 6) % kAaT, tile = ((e >> 6) / kAaT) & 1, c = (e >> 6) / (2 * kAaT);
-    const int i = tile * 16 + (lane & 15), j = 4 * t + (lane >> 4);
-    dst[e] = (i < 20) ? src[(size_t)c * 400 + i * 20 + j] : 0.0;
+    const int lane = e & 63, t = (e >> 6) % kAaT, half = ((e >> 6) / kAaT) & 1, c = (e >> 6) / (2 * kAaT);
+    const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
+    dst[(size_t)(c * 2 + half) * kAaBlock + aa_slot(t, lane)] = src[(size_t)c * 400 + i * 20 + j];
   }
 }
 
@@ -82,86 +94,127 @@ __global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
 // matrix core busy and to have other waves to switch to while one waits for memory.  The only
 // cross-category quantities, the per-pattern maximum of the rescaling rule (src/avx.c:498-510) and the
 // category mixture of Lk_Core (src/lk.c:816-818), go through a few bytes of LDS and one barrier per
-// operation.  The A fragments (transition matrices) of operation k+1 are fetched while operation k's
-// MFMAs run (two alternating register sets, as in the nucleotide kernel).
+// operation.
+// Pipeline: the host hands every operation over as ready-made buffer descriptors (size 0 = load disabled)
+// plus forwarding flags.  Within step k the children / scale words / tip bytes of operation k+1 are issued
+// before the matrix-core work into the second raw register set, and the A fragments of operation k+1 are
+// issued right after the MFMAs of operation k have consumed theirs, into the same registers (three waves per
+// SIMD need <= 168 VGPRs); the previous result is forwarded in registers.
 // ---------------------------------------------------------------------------------------------
-template <int CP>
-__global__ __launch_bounds__(64 * CP) void traverse_aa_kernel(const TreeParams q, const DevOp *__restrict__ ops,
-                                                              const double *__restrict__ afrag,
-                                                              const uint8_t *__restrict__ tip_codes,
-                                                              const uint32_t *__restrict__ code_masks)
+template <int CP, bool DBG = false>
+__global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+                                                                 const ExecRec *__restrict__ xrec,
+                                                                 const double *__restrict__ afrag, int n_frag_mats,
+                                                                 const uint8_t *__restrict__ tip_codes,
+                                                                 const uint32_t *__restrict__ code_masks, int n_masks,
+                                                                 int ablate, unsigned long long *dbg = nullptr)
 {
   constexpr int   T    = kAaT;
+  // DBG: cycle stamps of the first 64 steps of wave 0 of block 0 (PHYHIP_ABLATE=8), kept in LDS until the end
+  __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
+  const bool stamper = DBG && blockIdx.x == 0 && threadIdx.x == 0;
+#define PHY_STAMP(k_, i_)                                                                                              \
+  if (DBG)                                                                                                             \
+  {                                                                                                                    \
+    const unsigned long long t_ = __builtin_readcyclecounter();                                                        \
+    if (stamper && (k_) < 64) stamps[(k_) * 8 + (i_)] = t_;                                                            \
+  }
   const int       lane = threadIdx.x & 63;
   const int       c    = threadIdx.x >> 6;                 // this wave's rate category (blockDim = 64 * C)
   const long long tile = blockIdx.x;                       // grid = number of tiles: every wave is live
   const int       pp = lane & 15, kk = lane >> 4;
-  const long long p0   = tile * 16 + pp;
-  const bool      pact = p0 < q.P;                         // this lane's pattern exists
-  const long long p    = pact ? p0 : q.P - 1;              // clamp for tip / scale / weight reads
+  const long long p0   = tile * 16 + pp;                   // < Ppad
+  const bool      pact = p0 < q.P;
   const int       C    = q.C;
   const int       tips = q.tip_count;
   const size_t    ntiles     = (size_t)((q.P + 15) >> 4);
-  const size_t    tile_elems = (size_t)C * T * 64;
+  const size_t    tile_elems = (size_t)C * kAaBlock;
   const size_t    buf_elems  = ntiles * tile_elems;
-  const size_t    ppad       = ntiles * 16;                // scale vectors are padded to whole tiles
-  const size_t    lane_off   = (size_t)tile * tile_elems + (size_t)c * T * 64 + lane;
-  const size_t    frag_mat   = (size_t)C * 2 * T * 64;     // doubles per matrix in afrag
-  const size_t    frag_c     = (size_t)c * 2 * T * 64;
+  const size_t    frag_mat   = (size_t)C * 2 * kAaBlock;   // doubles per matrix in afrag
+  const unsigned  blk_bytes  = (unsigned)(((size_t)tile * tile_elems + (size_t)c * kAaBlock) * 8);
+  const unsigned  voff_d16 = blk_bytes + lane * 16, voff_d8 = blk_bytes + 2048 + lane * 8; // chunk pairs | chunk 4
+  const unsigned  voff_s = (unsigned)p0 * 4u, voff_t = (unsigned)p0;
+  const unsigned  voff_a16 = (unsigned)c * 2 * kAaBlock * 8 + lane * 16, voff_a8 = (unsigned)c * 2 * kAaBlock * 8 + 2048 + lane * 8;
 
-  __shared__ double xch[2][CP][16]; // per-pattern maxima / category likelihoods, double-buffered by parity
+  __shared__ unsigned xchm[2][CP][16]; // per-pattern maxima (high words), double-buffered by step parity
+  __shared__ double   xchl[CP][16];    // category likelihoods of the edge evaluation
+  __shared__ unsigned lmask[256];      // allowed-state masks of the tip codes
+  for (int i = threadIdx.x; i < n_masks && i < 256; i += blockDim.x) lmask[i] = code_masks[i];
+  __syncthreads();
 
-  double prev[T] = {0., 0., 0., 0., 0.};
-  int    prev_sc = 0, prev_dest = -1;
-
-  // B-operand fragment of one child: tip -> 0/1 from its state set, forwarded -> registers, else memory
-  auto fetch = [&](int idx, double (&x)[T], int &sc) {
-    if (idx < tips)
-    {
-      const uint32_t m = code_masks[tip_codes[(size_t)idx * q.Ppad + p]];
-#pragma unroll
-      for (int t = 0; t < T; ++t) x[t] = ((m >> (4 * t + kk)) & 1u) ? 1.0 : 0.0;
-      sc = 0;
-    }
-    else if (idx == prev_dest)
-    {
-#pragma unroll
-      for (int t = 0; t < T; ++t) x[t] = prev[t];
-      sc = prev_sc;
-    }
-    else
-    {
-      const double *src = q.partials + (size_t)(idx - tips) * buf_elems + lane_off;
-#pragma unroll
-      for (int t = 0; t < T; ++t) x[t] = src[(size_t)t * 64];
-      sc = q.scales[(size_t)(idx - tips) * ppad + (size_t)tile * 16 + pp];
-    }
+  struct Frag
+  { // a lane's five k-chunk values as they come from memory
+    u32x4 p01, p23;
+    u32x2 p4;
   };
-  // A-operand fragments of one matrix for this category: [row tile][k-chunk]
-  auto load_a = [&](int pm, double (&a)[2 * T]) {
-    const double *A = afrag + (size_t)pm * frag_mat + frag_c + lane;
-#pragma unroll
-    for (int t = 0; t < 2 * T; ++t) a[t] = A[(size_t)t * 64];
+  struct Raw
+  {
+    Frag     a, b;
+    unsigned sa, sb, ca, cb;
   };
-  // u[t] = sum over input states of P[c][state kk+4t][.] * x[.]   (two row tiles, five k-chunks)
-  auto matvec = [&](const double (&a)[2 * T], const double (&x)[T], double (&u)[T]) {
-    v4d lo = {0., 0., 0., 0.}, hi = {0., 0., 0., 0.};
+  struct AFrag
+  {
+    Frag lo, hi; // rows 0..15 | rows 16..19 of one child's matrix
+  };
+  const __amdgpu_buffer_rsrc_t af_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double *>(afrag), 0, (int)((size_t)n_frag_mats * frag_mat * 8), 0x00020000);
+  auto rsrc = [](const Desc &d) {
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
+  };
+  auto load_frag = [](Frag &f, const __amdgpu_buffer_rsrc_t r, unsigned v16, unsigned v8, unsigned soff) {
+    f.p01 = __builtin_amdgcn_raw_buffer_load_b128(r, v16, soff, 0);
+    f.p23 = __builtin_amdgcn_raw_buffer_load_b128(r, v16 + 1024, soff, 0);
+    f.p4  = __builtin_amdgcn_raw_buffer_load_b64(r, v8, soff, 0);
+  };
+  auto unpack = [](const Frag &f, double (&x)[T]) {
+    __builtin_memcpy(&x[0], &f.p01, 16);
+    __builtin_memcpy(&x[2], &f.p23, 16);
+    __builtin_memcpy(&x[4], &f.p4, 8);
+  };
+  auto pack = [](const double (&x)[T], Frag &f) {
+    __builtin_memcpy(&f.p01, &x[0], 16);
+    __builtin_memcpy(&f.p23, &x[2], 16);
+    __builtin_memcpy(&f.p4, &x[4], 8);
+  };
+
+  auto issue_children = [&](const IssueRec &o, Raw &r) {
+    load_frag(r.a, rsrc(o.c1_data), voff_d16, voff_d8, 0);
+    load_frag(r.b, rsrc(o.c2_data), voff_d16, voff_d8, 0);
+    r.sa = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c1_scale), voff_s, 0, 0);
+    r.sb = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_scale), voff_s, 0, 0);
+    r.ca = __builtin_amdgcn_raw_buffer_load_b8(rsrc(o.c1_tip), voff_t, 0, 0);
+    r.cb = __builtin_amdgcn_raw_buffer_load_b8(rsrc(o.c2_tip), voff_t, 0, 0);
+  };
+  auto issue_matrices = [&](unsigned off1, unsigned off2, AFrag &A1, AFrag &A2) {
+    load_frag(A1.lo, af_rsrc, voff_a16, voff_a8, off1);
+    load_frag(A2.lo, af_rsrc, voff_a16, voff_a8, off2);
+    load_frag(A1.hi, af_rsrc, voff_a16 + kAaBlock * 8, voff_a8 + kAaBlock * 8, off1);
+    load_frag(A2.hi, af_rsrc, voff_a16 + kAaBlock * 8, voff_a8 + kAaBlock * 8, off2);
+  };
+  // u[t] = sum over input states of P[c][state kk + 4t][.] * x[.]: rows 0..15 on the 16x16x4 shape, rows 16..19 on
+  // the four-block 4x4x4 shape, five k-chunks each, ascending
+  auto matvec = [&](const AFrag &A, const double (&x)[T], double (&u)[T]) {
+    double alo[T], ahi[T];
+    unpack(A.lo, alo);
+    unpack(A.hi, ahi);
+    v4d    lo = {0., 0., 0., 0.};
+    double hi = 0.;
 #pragma unroll
     for (int t = 0; t < T; ++t)
     {
-      lo = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], x[t], lo, 0, 0, 0);
-      hi = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T + t], x[t], hi, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_f64_16x16x4f64(alo[t], x[t], lo, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_f64_4x4x4f64(ahi[t], x[t], hi, 0, 0, 0);
     }
-    u[0] = lo[0]; u[1] = lo[1]; u[2] = lo[2]; u[3] = lo[3]; u[4] = hi[0];
+    u[0] = lo[0]; u[1] = lo[1]; u[2] = lo[2]; u[3] = lo[3]; u[4] = hi;
   };
   auto and4 = [&](int v) { // AND over the four lanes (kk = 0..3) that share a pattern
     v &= __shfl_xor(v, 16, 64);
     v &= __shfl_xor(v, 32, 64);
     return v;
   };
-  auto max4 = [&](double v) {
-    v = fmax(v, __shfl_xor(v, 16, 64));
-    v = fmax(v, __shfl_xor(v, 32, 64));
+  auto maxu4 = [&](unsigned v) {
+    v = max(v, (unsigned)__shfl_xor((int)v, 16, 64));
+    v = max(v, (unsigned)__shfl_xor((int)v, 32, 64));
     return v;
   };
   auto sum4 = [&](double v) {
@@ -169,101 +222,220 @@ __global__ __launch_bounds__(64 * CP) void traverse_aa_kernel(const TreeParams q
     v += __shfl_xor(v, 32, 64);
     return v;
   };
+  auto tip_vec = [&](unsigned code, double (&x)[T]) {
+    const unsigned m = lmask[code & 255u] >> kk;
+#pragma unroll
+    for (int t = 0; t < T; ++t) x[t] = ((m >> (4 * t)) & 1u) ? 1.0 : 0.0;
+  };
+
+  double   prev[T] = {0., 0., 0., 0., 0.}; // result of the previous operation (this lane's D fragments)
+  unsigned prev_sc = 0;
 
   if (q.n_ops > 0)
   {
-    const int last = q.n_ops - 1;
-    double    A1a[2 * T], A2a[2 * T], A1b[2 * T], A2b[2 * T];
-    load_a(ops[0].pm1, A1a);
-    load_a(ops[0].pm2, A2a);
+    const int last = q.n_ops - 1; // host pads the list to an even length
+    Raw       RA, RB;
+    AFrag     A1, A2;
+    ExecRec   cur = xrec[0];
+    IssueRec  nx1 = irec[(1 < last) ? 1 : last];
+    {
+      const IssueRec first = irec[0];
+      issue_children(first, RA);
+      issue_matrices(first.c1_data.x, first.c2_data.x, A1, A2);
+      // The loop body sees [A loads][4 result stores][children loads] between an A load and its use.  Four
+      // stores through a zero-sized descriptor (dropped by the hardware, but counted) give the loop entry the
+      // same in-flight shape, so the compiler's merged s_waitcnt counts never include the previous step's stores.
+      const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+      const u32x4                  z4   = {0u, 0u, 0u, 0u};
+      const u32x2                  z2   = {0u, 0u};
+      __builtin_amdgcn_raw_buffer_store_b128(z4, none, 0, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(z4, none, 1024, 0, 0); // distinct offsets: identical stores would be merged
+      __builtin_amdgcn_raw_buffer_store_b64(z2, none, 2048, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(0u, none, 4096, 0, 0);
+    }
 
-    auto step = [&](const int k, const int parity, double (&A1)[2 * T], double (&A2)[2 * T], double (&A1n)[2 * T],
-                    double (&A2n)[2 * T]) {
-      const DevOp op = ops[(k < last) ? k : last];
-      const DevOp nx = ops[(k + 1 < last) ? k + 1 : last];
-      double      x1[T], x2[T], u1[T], u2[T], o[T];
-      int         s1, s2;
-      fetch(op.c1, x1, s1);
-      fetch(op.c2, x2, s2);
-      load_a(nx.pm1, A1n); // next operation's matrices: in flight during this operation's MFMAs
-      load_a(nx.pm2, A2n);
-      // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587
+    auto step = [&](const int k, const int parity, Raw &R, Raw &Rn) {
+      const unsigned fl = cur.dst_data.x;
+      double         x1[T], x2[T], u1[T], u2[T], o[T];
+      unsigned       s1, s2;
+      PHY_STAMP(k, 0)
+#if PHY_AA_EARLY
+      issue_children(nx1, Rn);
+#endif
+      if (fl & kOpTip1) { tip_vec(R.ca, x1); s1 = 0; }
+      else if (fl & kOpF11)
+      {
+#pragma unroll
+        for (int t = 0; t < T; ++t) x1[t] = prev[t];
+        s1 = prev_sc;
+      }
+      else { unpack(R.a, x1); s1 = R.sa; }
+      if (fl & kOpTip2) { tip_vec(R.cb, x2); s2 = 0; }
+      else if (fl & kOpF21)
+      {
+#pragma unroll
+        for (int t = 0; t < T; ++t) x2[t] = prev[t];
+        s2 = prev_sc;
+      }
+      else { unpack(R.b, x2); s2 = R.sb; }
+
+      PHY_STAMP(k, 1)
+      // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587.  Evaluated without a
+      // branch and before the matrix-core phase so that x1 / x2 die with the last MFMA that reads them.
       int ones = 1;
 #pragma unroll
       for (int t = 0; t < T; ++t) ones &= (x1[t] == 1.0) & (x2[t] == 1.0);
       ones = and4(ones);
-      matvec(A1, x1, u1);
-      matvec(A2, x2, u2);
-      double mx = -__builtin_huge_val();
+      PHY_STAMP(k, 2)
+      const unsigned nx_off1 = nx1.c1_data.x, nx_off2 = nx1.c2_data.x;
+      {
+        // Matrix-core phase.  The ten 16x16x4 MFMAs occupy the pipe for 64 cycles each; the ten vector-memory
+        // instructions of operation k+1 (children, scale words, tip bytes -> the other raw set) are slotted one
+        // per MFMA so that their issue cost disappears behind the matrix cores (sched_group_barrier pins the
+        // interleave).  The A fragments of operation k+1 follow the last MFMA that reads this operation's, into
+        // the same registers.
+        double a1lo[T], a1hi[T], a2lo[T], a2hi[T];
+        unpack(A1.lo, a1lo);
+        unpack(A1.hi, a1hi);
+        unpack(A2.lo, a2lo);
+        unpack(A2.hi, a2hi);
+        v4d    lo1 = {0., 0., 0., 0.}, lo2 = {0., 0., 0., 0.};
+        double hi1 = 0., hi2 = 0.;
+#if !PHY_AA_EARLY
+        issue_children(nx1, Rn);
+#endif
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+        {
+          lo1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1lo[t], x1[t], lo1, 0, 0, 0);
+          lo2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2lo[t], x2[t], lo2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+        {
+          hi1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1hi[t], x1[t], hi1, 0, 0, 0);
+          hi2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2hi[t], x2[t], hi2, 0, 0, 0);
+        }
+        issue_matrices(nx_off1, nx_off2, A1, A2);
+#if !PHY_AA_EARLY
+#pragma unroll
+        for (int i = 0; i < 2 * T; ++i)
+        {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // one vector-memory read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * T, 0);  // the 4x4x4 chain
+        __builtin_amdgcn_sched_group_barrier(0x020, 12, 0);     // A fragments of operation k+1
+#endif
+        u1[0] = lo1[0]; u1[1] = lo1[1]; u1[2] = lo1[2]; u1[3] = lo1[3]; u1[4] = hi1;
+        u2[0] = lo2[0]; u2[1] = lo2[1]; u2[2] = lo2[2]; u2[3] = lo2[3]; u2[4] = hi2;
+      }
+      const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
+      const ExecRec  nxe = xrec[(k + 1 < last) ? k + 1 : last];
+
+      PHY_STAMP(k, 3)
+      unsigned mxh = 0;
 #pragma unroll
       for (int t = 0; t < T; ++t)
       {
         o[t] = ones ? 1.0 : u1[t] * u2[t];
-        mx   = (o[t] > mx) ? o[t] : mx;
+        mxh  = max(mxh, hi32(o[t]));
       }
-      mx = max4(mx);
-      if (CP > 1)
+      mxh = maxu4(mxh);
+      PHY_STAMP(k, 4)
+      if (CP > 1 && !(ablate & 2))
       { // maximum over the categories of the pattern: one LDS round trip, one barrier
-        if (kk == 0) xch[parity][c][pp] = mx;
+        if (kk == 0) xchm[parity][c][pp] = mxh;
         __syncthreads();
 #pragma unroll
         for (int cc = 0; cc < CP; ++cc)
-          if (cc < C) mx = fmax(mx, xch[parity][cc][pp]);
+          if (cc < C) mxh = max(mxh, xchm[parity][cc][pp]);
       }
-      int sc = s1 + s2; // src/avx.c:462-464
-      if (mx < kInvTwoToLarge && q.apply_scaling)
+      PHY_STAMP(k, 5)
+      unsigned sc = s1 + s2; // src/avx.c:462-464
+      if (mxh < kHiInvTwoToLarge && q.apply_scaling)
       { // src/avx.c:504-510
 #pragma unroll
         for (int t = 0; t < T; ++t) o[t] *= kTwoToLarge;
         sc += kLarge;
       }
       {
-        double *dst = q.partials + (size_t)(op.dest - tips) * buf_elems + lane_off;
-#pragma unroll
-        for (int t = 0; t < T; ++t) dst[(size_t)t * 64] = o[t];
-        if (kk == 0 && c == 0) q.scales[(size_t)(op.dest - tips) * ppad + (size_t)tile * 16 + pp] = sc;
+        const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
+        Frag w;
+        pack(o, w);
+        __builtin_amdgcn_raw_buffer_store_b128(w.p01, dr, voff_d16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(w.p23, dr, voff_d16 + 1024, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(w.p4, dr, voff_d8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_s, 0, 0); // every lane of the pattern stores the same word
       }
+      PHY_STAMP(k, 6)
 #pragma unroll
       for (int t = 0; t < T; ++t) prev[t] = o[t];
-      prev_sc   = sc;
-      prev_dest = op.dest;
+      prev_sc = sc;
+      cur     = nxe;
+      nx1     = nx2;
     };
-    // an odd operation count re-executes the last operation once more (idempotent; keeps the two-set
-    // alternation and the barrier count uniform across the workgroup)
     for (int k = 0; k < q.n_ops; k += 2)
     {
-      step(k, 0, A1a, A2a, A1b, A2b);
-      step(k + 1, 1, A1b, A2b, A1a, A2a);
+      step(k, 0, RA, RB);
+      step(k + 1, 1, RB, RA);
     }
   }
 
+  if (DBG && stamper && dbg)
+    for (int i = 0; i < 64 * 8; ++i) dbg[i] = stamps[i];
+#undef PHY_STAMP
   if (!q.edge_eval) return;
 
   // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861) ---------------------
   double contrib = 0.0;
   {
-    double x[T], y[T], u[T], a[2 * T];
-    int    sl, sr;
+    double   x[T], y[T], u[T];
+    unsigned sl, sr;
+    auto side = [&](int idx, double (&v)[T], unsigned &sc) {
+      if (idx < tips)
+      {
+        tip_vec(tip_codes[(size_t)idx * q.Ppad + p0], v);
+        sc = 0;
+      }
+      else if (idx == q.last_dest)
+      {
+#pragma unroll
+        for (int t = 0; t < T; ++t) v[t] = prev[t];
+        sc = prev_sc;
+      }
+      else
+      {
+        const double *src = q.partials + (size_t)(idx - tips) * buf_elems + (size_t)tile * tile_elems + (size_t)c * kAaBlock;
+#pragma unroll
+        for (int t = 0; t < T; ++t) v[t] = src[aa_slot(t, lane)];
+        sc = (unsigned)q.scales[(size_t)(idx - tips) * q.Ppad + p0];
+      }
+    };
     __syncthreads();
-    fetch(q.e_parent, x, sl);
-    fetch(q.e_child, y, sr);
-    load_a(q.e_pm, a);
-    matvec(a, x, u); // rows: right-side state
+    side(q.e_parent, x, sl);
+    side(q.e_child, y, sr);
+    {
+      AFrag A;
+      load_frag(A.lo, af_rsrc, voff_a16, voff_a8, (unsigned)((size_t)q.e_pm * frag_mat * 8));
+      load_frag(A.hi, af_rsrc, voff_a16 + kAaBlock * 8, voff_a8 + kAaBlock * 8, (unsigned)((size_t)q.e_pm * frag_mat * 8));
+      matvec(A, x, u); // rows: right-side state
+    }
     double part = 0.0;
 #pragma unroll
     for (int t = 0; t < T; ++t) part += u[t] * (y[t] * q.pi[4 * t + kk]);
     const double lkc = sum4(part);
     if (pact && kk == 0 && q.site_cat) q.site_cat[(size_t)p0 * C + c] = lkc;
-    if (kk == 0) xch[0][c][pp] = lkc;
+    if (kk == 0) xchl[c][pp] = lkc;
     __syncthreads();
     if (c == 0 && kk == 0 && pact)
     {
       double site = 0.0;
 #pragma unroll
       for (int cc = 0; cc < CP; ++cc)
-        if (cc < C) site += xch[0][cc][pp] * q.cat_w[cc]; // src/lk.c:816-818
+        if (cc < C) site += xchl[cc][pp] * q.cat_w[cc]; // src/lk.c:816-818
       const double w = q.wght[p0];
-      int          f = q.apply_scaling ? (sl + sr) : 0;
+      int          f = q.apply_scaling ? (int)(sl + sr) : 0;
       if (w > kSmall)
       {
         if (q.invar_model)

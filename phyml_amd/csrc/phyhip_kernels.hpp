@@ -142,6 +142,11 @@ struct RO
   const uint32_t *__restrict__ code_masks; // allowed-state bit mask per code
 };
 
+// 20-state fragment-major layout (phyhip_aa.hpp): one (tile of 16 patterns, category) block is 320 doubles --
+// the five k-chunk values a lane owns are stored as two 16-byte pairs (chunks 0|1 and 2|3) and one single
+// (chunk 4), each group contiguous over the 64 lanes, so a fragment set moves as 2 x dwordx4 + 1 x dwordx2.
+__host__ __device__ inline int aa_slot(int t, int lane) { return t < 4 ? (t >> 1) * 128 + lane * 2 + (t & 1) : 256 + lane; }
+
 // child fetch in two phases so that ALL loads of an operation are in flight before the first wait:
 //   issue_side  -- only issues the loads (tip: one code byte; internal: S doubles + the scale word)
 //   finish_side -- turns the raw values into the S-vector and the pattern's scale exponent
@@ -174,16 +179,17 @@ __device__ __forceinline__ void issue_side(const TreeParams &q, const RO &ro, in
     if (c == 0) r.sc = q.scales[b * q.Ppad + p];
   }
   else if (S == 20 && q.perm)
-  { // fragment-major layout: state s of (p,c) sits at ((tile*C + c)*5 + s/4)*64 + (s%4)*16 + p%16
+  { // fragment-major layout (phyhip_aa.hpp): 320 doubles per (tile, category), slot aa_slot(s / 4, lane)
     const size_t  b    = (size_t)(idx - q.tip_count);
     const size_t  nt   = (size_t)((q.P + 15) >> 4);
-    const double *base = q.partials + b * nt * (size_t)q.C * 5 * 64 + ((size_t)(p >> 4) * q.C + c) * 5 * 64 + (size_t)(p & 15);
+    const double *base = q.partials + b * nt * (size_t)q.C * 320 + ((size_t)(p >> 4) * q.C + c) * 320;
+    const int     pp   = (int)(p & 15);
 #pragma unroll
     for (int j = 0; j < S / 2; ++j)
     {
       const int s0 = 2 * j, s1 = 2 * j + 1;
-      r.v[j].x = base[(size_t)(s0 >> 2) * 64 + (s0 & 3) * 16];
-      r.v[j].y = base[(size_t)(s1 >> 2) * 64 + (s1 & 3) * 16];
+      r.v[j].x = base[aa_slot(s0 >> 2, (s0 & 3) * 16 + pp)];
+      r.v[j].y = base[aa_slot(s1 >> 2, (s1 & 3) * 16 + pp)];
     }
     if (c == 0) r.sc = q.scales[b * q.Ppad + p];
   }
