@@ -216,7 +216,8 @@ def main():
     # RCCL prints a version banner on stdout while the interpreter shuts down; leave before that so the JSON
     # line stays the last (and, single-GPU, the only) line on stdout
     sys.stdout.flush(); sys.stderr.flush()
-    os._exit(0)
+    if dist is not None:
+        os._exit(0)  # (not when single-process: profilers such as rocprofv3 flush their traces at normal exit)
 
 
 if __name__ == "__main__":

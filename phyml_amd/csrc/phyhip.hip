@@ -107,6 +107,7 @@ struct Instance
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
   bool        soa = false;     // 4-state buffers pattern-minor, lane-per-pattern kernel (phyhip_nt2.hpp)
   int         grid_nt2 = 0;
+  int         nt_groups = 1; // lanes per pattern in the lane-per-pattern nucleotide kernel
   double     *d_afrag = nullptr;
   int         grid_aa = 0;
 
@@ -152,6 +153,9 @@ struct Instance
   int    apply_scaling = 1, invar_model = 0;
   bool   want_site_outputs = true;
   int    prefetch_dist = 2;  // PHYHIP_DIST: load-stage distance of the nt pipeline (1 or 2)
+  bool   pm_copy = true;       // PHYHIP_PM_COPY=0: kernels read the P-matrix work list from pinned host memory (slower for 20 states)
+  bool   split_reduce = false; // PHYHIP_SPLIT_REDUCE: separate final_reduce_kernel instead of the fused last-workgroup sum
+  unsigned *d_tickets = nullptr;
   int    ablate = 0;         // PHYHIP_ABLATE: timing-only kernel variants (results invalid)
   bool   no_loads = false;   // PHYHIP_NOLOADS: zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
@@ -276,9 +280,18 @@ int flush_pmats(Instance *I)
       if (rc) return rc;
       memcpy(st, I->pm_idx.data() + done, sizeof(int) * n);
       memcpy((char *)st + bi, I->pm_len.data() + done, bl);
-      HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
-      q.indices = f.indices = (const int *)I->d_pmscratch;
-      q.lengths = (const double *)((char *)I->d_pmscratch + bi);
+      if (I->pm_copy)
+      {
+        HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
+        q.indices = f.indices = (const int *)I->d_pmscratch;
+        q.lengths = (const double *)((char *)I->d_pmscratch + bi);
+      }
+      else
+      { // the kernels read the (index, length) pairs straight from the pinned staging chunk: a few hundred bytes over
+        // the host link cost less than a copy command ahead of the launch
+        q.indices = f.indices = (const int *)st;
+        q.lengths = (const double *)((char *)st + bi);
+      }
     }
     q.count = n;
     q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
@@ -410,6 +423,12 @@ int flush(Instance *I, const EdgeEval *ee)
   if (ee)
   {
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
+    if (!I->split_reduce)
+    { // the traversal kernel's last workgroup finishes the sum and reports to the host
+      q.tickets = I->d_tickets; q.result = ee->dev_out ? ee->dev_out : I->d_result;
+      q.result_host = ee->to_host ? I->h_result : nullptr; q.warn_host = I->h_warn;
+      q.seq = ee->to_host ? ++I->seq : 0ull;
+    }
     if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -425,13 +444,19 @@ int flush(Instance *I, const EdgeEval *ee)
     {
       if (I->soa)
       { // lane-per-pattern kernel, instantiated on the exact category count
-        switch (I->C)
+#define NT2CASE(c_, g_) hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes); return 0;
+        switch (I->C * 8 + I->nt_groups)
         {
-#define NT2CASE(c_) case c_: hipLaunchKernelGGL((traverse_nt2_kernel<c_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes); return 0;
-          NT2CASE(1) NT2CASE(2) NT2CASE(3) NT2CASE(4)
-#undef NT2CASE
+          case 1 * 8 + 1: NT2CASE(1, 1)
+          case 2 * 8 + 1: NT2CASE(2, 1)
+          case 2 * 8 + 2: NT2CASE(2, 2)
+          case 3 * 8 + 1: NT2CASE(3, 1)
+          case 4 * 8 + 1: NT2CASE(4, 1)
+          case 4 * 8 + 2: NT2CASE(4, 2)
+          case 4 * 8 + 4: NT2CASE(4, 4)
           default: break;
         }
+#undef NT2CASE
       }
     }
     if constexpr (S_ == 4)
@@ -505,7 +530,7 @@ int flush(Instance *I, const EdgeEval *ee)
     I->prof_updates += (double)n_ops * (double)I->P;
   }
   HIPCHK(hipGetLastError());
-  if (ee)
+  if (ee && I->split_reduce)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
     const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
@@ -614,7 +639,16 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->soa  = (I->S == 4) && (I->C <= 4) && !(getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
             !(getenv("PHYHIP_GENERIC_NT") && atoi(getenv("PHYHIP_GENERIC_NT")));
   I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
-  I->grid_nt2 = (int)(I->Ppad / 64);
+  // category groups of the lane-per-pattern kernel (phyhip_nt2.hpp): split a pattern over 2 lanes while the
+  // alignment is too short to give every SIMD two waves of 64 patterns
+  I->nt_groups = 1;
+  if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 1280) I->nt_groups = 2; // measured: G=2 wins at 50k (223 vs 247 us), G=1 from 125k
+  if (const char *e = getenv("PHYHIP_NT_GROUPS"))
+  {
+    const int g = atoi(e);
+    if (g >= 1 && g <= 4 && I->C % g == 0 && 64 % g == 0 && !(I->C == 2 && g == 4)) I->nt_groups = g;
+  }
+  I->grid_nt2 = (int)(I->Ppad / (64 / I->nt_groups));
   const size_t n_int = (size_t)(I->nbuf - I->tips);
   const size_t be    = buf_elems(I);
   HIPCHK(hipMalloc((void **)&I->d_partials, n_int * be * sizeof(double)));
@@ -696,6 +730,10 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
+  if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) I->split_reduce = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
+  HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
+  HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned)));
   if (const char *e = getenv("PHYHIP_DIST")) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
   if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
 
@@ -734,7 +772,7 @@ int phyhip_finalize_instance(int instance)
   collect_profile(I);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag};
+                  I->d_pmscratch, I->d_afrag, I->d_tickets};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
           if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
           else site = site * (1. - q.pinvar) + inv * q.pinvar;
         }
-        if (site < kSmall) { site = kSmall; *q.warn = 1; }
+        if (site < kSmall) { site = kSmall; raise_warn(q); }
         const double lsl = log(site) - kLog2 * (double)f;
         if (q.site_lnl) q.site_lnl[p0] = lsl;
         if (q.site_lk) q.site_lk[p0] = exp(lsl);
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
   {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
-    if (lane == 0) q.block_sums[blockIdx.x] = contrib;
+    publish_block_sum(q, contrib, lane);
   }
 }
 

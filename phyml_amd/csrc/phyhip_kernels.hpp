@@ -93,6 +93,13 @@ struct TreeParams
   double         *site_cat;   // unscaled_site_lk_cat [P][C] (may be null)
   int            *fact;       // fact_sum_scale [P] (always written: dLk needs it)
   double         *block_sums; // [gridDim.x]
+  // fused final reduction (result != nullptr): the last workgroup to finish adds the block sums in the fixed order
+  // of final_reduce_kernel and hands lnL, the warning flag and the sequence number to the host
+  unsigned           *tickets;     // one counter, zero between launches
+  double             *result;      // device lnL (or the caller's device pointer)
+  double             *result_host; // host-mapped {lnL, -, seq} or nullptr
+  int                *warn_host;
+  unsigned long long  seq;
   int            *warn;
 };
 
@@ -255,6 +262,66 @@ __device__ __forceinline__ void matvec_rows(const double *__restrict__ M, const 
 // ---------------------------------------------------------------------------------------------
 // K1 + K2: traversal kernel
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void raise_warn(const TreeParams &q)
+{ // visible to whichever workgroup ends up doing the final reduction (other XCD, other L2)
+  __hip_atomic_store(q.warn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// End of an edge evaluation.  Called by every lane of ONE wave per workgroup with the workgroup's weighted
+// log-likelihood sum in lane 0.  Without q.result the sum is only recorded (final_reduce_kernel follows).  With it,
+// the sum is stored through to memory (agent scope), a ticket is drawn, and the workgroup that draws the last ticket
+// adds all block sums -- same grouping and order as final_reduce_kernel, so lnL does not depend on which workgroup
+// finishes last -- and publishes the result.  One kernel launch and one inter-kernel gap less per Lk() call.
+__device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s, int lane)
+{
+  if (!q.result)
+  {
+    if (lane == 0) q.block_sums[blockIdx.x] = s;
+    return;
+  }
+  unsigned ticket = 0;
+  if (lane == 0)
+  {
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &s, 8);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(q.block_sums) + blockIdx.x, bits, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0); // the write-through store is acknowledged before the ticket is drawn
+    ticket = __hip_atomic_fetch_add(q.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  ticket = __shfl(ticket, 0, 64);
+  if (ticket != gridDim.x - 1) return;
+  const int n = (int)gridDim.x;
+  // every block sum was written through to memory before its ticket was drawn; drop whatever stale copies this
+  // CU's L1 / this XCD's L2 may hold, then read them with ordinary (pipelined) loads
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  double acc[4]; // the four "threads" lane, lane+64, lane+128, lane+192 of the 256-thread reduction
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+  {
+    acc[j] = 0.0;
+    for (int i = lane + 64 * j; i < n; i += 256) acc[j] += q.block_sums[i];
+  }
+  double t = (acc[0] + acc[2]) + (acc[1] + acc[3]); // tree levels 128 and 64
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (lane == 0)
+  {
+    *q.result = t;
+    const int w = __hip_atomic_load(q.warn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q.warn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (q.warn_host) *q.warn_host = w;
+    if (q.result_host)
+    {
+      q.result_host[0] = t;
+      __threadfence_system(); // results before the sequence number, system scope (host reads over PCIe)
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(q.result_host + 2), q.seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 template <int S, int CP>
 __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const DevOp *__restrict__ ops_,
                                                        const double *__restrict__ pmats_,
@@ -424,7 +491,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
         if (site < kSmall)
         { // src/lk.c:847-851
           site = kSmall;
-          *q.warn = 1;
+          raise_warn(q);
         }
         const double lsl = log(site) - kLog2 * (double)f; // src/lk.c:854
         if (q.site_lnl) q.site_lnl[p] = lsl;
@@ -442,11 +509,11 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) wsum[wid] = contrib;
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (wid == 0)
   {
     double s = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += wsum[w];
-    q.block_sums[blockIdx.x] = s;
+    publish_block_sum(q, s, lane);
   }
 }
 
@@ -758,7 +825,7 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
           if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
           else site = site * (1. - q.pinvar) + inv * q.pinvar;
         }
-        if (site < kSmall) { site = kSmall; *q.warn = 1; }
+        if (site < kSmall) { site = kSmall; raise_warn(q); }
         const double lsl = log(site) - kLog2 * (double)f;
         if (q.site_lnl) q.site_lnl[p] = lsl;
         if (q.site_lk) q.site_lk[p] = exp(lsl);
@@ -772,11 +839,11 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
   for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
   if (lane == 0) wsum[wid] = contrib;
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (wid == 0)
   {
     double s = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += wsum[w];
-    q.block_sums[blockIdx.x] = s;
+    publish_block_sum(q, s, lane);
   }
 }
 

@@ -28,19 +28,29 @@ namespace phyhip
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int C>
-__global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+// G > 1 ("category groups"): a pattern is spread over G lanes, lane (g, pl) = g * (64/G) + pl owning the C/G
+// categories g*C/G ... of pattern pl.  Mid-sized alignments (50 000 patterns = 782 waves of 64 patterns on 1024
+// SIMDs) leave every SIMD with at most one wave, so nothing overlaps a wave's FMA chain (256 FP64 FMAs per
+// operation = ~1300 cycles) with its own memory waits; with G = 2 there are twice as many waves of half the
+// arithmetic and half the registers, two or three per SIMD.  The only cross-lane traffic is one 32-bit exchange per
+// operation (the rescaling maximum) and the category mixture of the edge evaluation.  G = 1 stays the choice for
+// large alignments, where the kernel is HBM-bound and fewer, fatter waves issue fewer instructions per pattern.
+template <int C, int G = 1>
+__global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec,
                                                              const double *__restrict__ pmats,
                                                              const uint8_t *__restrict__ tip_codes)
 {
-  constexpr int S = 4, CS = C * S;
+  static_assert(C % G == 0 && 64 % G == 0, "category groups must divide the categories and the wave");
+  constexpr int S = 4, CL = C / G, CS = CL * S, PW = 64 / G; // categories per lane, entries per lane, patterns per wave
   __shared__ __attribute__((aligned(16))) double lds_p[2][2 * C * 16]; // [buffer][matrix][c][i][j]
 
   const int      lane = threadIdx.x;
-  const unsigned p    = blockIdx.x * 64u + lane;          // < Ppad by construction of the grid
-  const unsigned voff8 = p * 8u, voff4 = p * 4u;
+  const int      grp  = lane / PW, pl = lane % PW;        // category group, pattern within the wave
+  const int      c0   = grp * CL;                         // first category of this lane
+  const unsigned p    = blockIdx.x * (unsigned)PW + pl;   // < Ppad by construction of the grid
   const unsigned rowb = (unsigned)(q.Ppad * 8);           // bytes between consecutive (c,s) rows
+  const unsigned voff8 = p * 8u + (unsigned)(c0 * S) * rowb, voff4 = p * 4u;
 
   struct Raw
   {
@@ -78,11 +88,11 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
   // the matrix rows come from LDS as wave-wide broadcasts
   auto matvec_x = [&](const double2 *M, const double (&x)[CS], double (&u)[CS]) {
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+    for (int c = 0; c < CL; ++c)
 #pragma unroll
       for (int i = 0; i < S; ++i)
       {
-        const double2 lo = M[c * 8 + 2 * i], hi = M[c * 8 + 2 * i + 1];
+        const double2 lo = M[(c0 + c) * 8 + 2 * i], hi = M[(c0 + c) * 8 + 2 * i + 1];
         double        a  = lo.x * x[c * 4];
         a = __builtin_fma(lo.y, x[c * 4 + 1], a);
         a = __builtin_fma(hi.x, x[c * 4 + 2], a);
@@ -104,16 +114,16 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
     {
       const int s = (m >> 1) - (m >> 3); // 1,2,4,8 -> 0,1,2,3
 #pragma unroll
-      for (int e = 0; e < CS; ++e) u[e] = Md[e * 4 + s];
+      for (int e = 0; e < CS; ++e) u[e] = Md[(c0 * S + e) * 4 + s];
     }
     else
     {
 #pragma unroll
-      for (int c = 0; c < C; ++c)
+      for (int c = 0; c < CL; ++c)
 #pragma unroll
         for (int i = 0; i < S; ++i)
         {
-          const double2 lo = M[c * 8 + 2 * i], hi = M[c * 8 + 2 * i + 1];
+          const double2 lo = M[(c0 + c) * 8 + 2 * i], hi = M[(c0 + c) * 8 + 2 * i + 1];
           double        a  = (m & 1u) ? lo.x : 0.0;
           a = (m & 2u) ? a + lo.y : a;
           a = (m & 4u) ? a + hi.x : a;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
       if (__builtin_amdgcn_ballot_w64(one1 && one2))
       {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+        for (int c = 0; c < CL; ++c)
         {
           bool a1, a2;
           if (fl & kOpTip1) a1 = (R.ca == 15u);
@@ -216,6 +226,11 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
         const double v = ((ones_mask >> (e / 4)) & 1u) ? 1.0 : u1[e] * u2[e];
         Fout[e] = v;
         mxh     = max(mxh, hi32(v));
+      }
+      if constexpr (G > 1)
+      { // the maximum runs over all categories of the pattern (src/avx.c:498-503): combine the category groups
+#pragma unroll
+        for (int d = PW; d < 64; d <<= 1) mxh = max(mxh, (unsigned)__shfl_xor((int)mxh, d, 64));
       }
       unsigned sc = s1 + s2; // src/avx.c:462-464
       if (mxh < kHiInvTwoToLarge && q.apply_scaling)
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
   double contrib = 0.0;
   {
     const int    tips = q.tip_count;
-    const size_t bufsz = (size_t)q.Ppad * CS;
+    const size_t bufsz = (size_t)q.Ppad * C * S;
     double       x[CS], y[CS];
     unsigned     sl, sr;
     auto side = [&](int idx, double (&v)[CS], unsigned &sc) {
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
       }
       else
       {
-        const double *src = q.partials + (size_t)(idx - tips) * bufsz + p;
+        const double *src = q.partials + (size_t)(idx - tips) * bufsz + (size_t)(c0 * S) * q.Ppad + p;
 #pragma unroll
         for (int e = 0; e < CS; ++e) v[e] = src[(size_t)e * q.Ppad];
         sc = (unsigned)q.scales[(size_t)(idx - tips) * q.Ppad + p];
@@ -280,10 +295,10 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
     };
     side(q.e_parent, x, sl);
     side(q.e_child, y, sr);
-    const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16); // rows: right-side state
-    double site = 0.0;
+    const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16) + c0 * 16; // rows: right-side state
+    double prod[CL];
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+    for (int c = 0; c < CL; ++c)
     {
       double t[4];
 #pragma unroll
@@ -295,10 +310,18 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
         t[kk] = a * (y[c * 4 + kk] * q.pi[kk]);
       }
       const double lkc = (t[0] + t[2]) + (t[1] + t[3]);
-      if (p < (unsigned)q.P && q.site_cat) q.site_cat[(size_t)p * C + c] = lkc;
-      site += lkc * q.cat_w[c]; // src/lk.c:816-818
+      if (p < (unsigned)q.P && q.site_cat) q.site_cat[(size_t)p * C + c0 + c] = lkc;
+      prod[c] = lkc * q.cat_w[c0 + c];
     }
-    if (p < (unsigned)q.P)
+    double site = 0.0; // src/lk.c:816-818: categories in ascending order, whichever lane holds them
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+    {
+      double t = prod[c % CL];
+      if constexpr (G > 1) t = __shfl(t, (c / CL) * PW + pl, 64);
+      site += t;
+    }
+    if ((G == 1 || grp == 0) && p < (unsigned)q.P) // the group-0 lane of a pattern reports
     {
       const double w = q.wght[p];
       int          f = q.apply_scaling ? (int)(sl + sr) : 0;
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
           if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
           else site = site * (1. - q.pinvar) + inv * q.pinvar;
         }
-        if (site < kSmall) { site = kSmall; *q.warn = 1; }
+        if (site < kSmall) { site = kSmall; raise_warn(q); }
         const double lsl = log(site) - kLog2 * (double)f;
         if (q.site_lnl) q.site_lnl[p] = lsl;
         if (q.site_lk) q.site_lk[p] = exp(lsl);
@@ -338,7 +361,7 @@ __global__ __launch_bounds__(64, 1) void traverse_nt2_kernel(const TreeParams q,
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
-  if (lane == 0) q.block_sums[blockIdx.x] = contrib;
+  publish_block_sum(q, contrib, lane);
 }
 
 } // namespace phyhip
