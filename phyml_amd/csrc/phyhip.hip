@@ -730,6 +730,9 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
+  // measured (MI355X): fusing the final sum into the traversal saves ~10 us per call for 20 states; for 4 states the
+  // ticket draw and the last workgroup's pass cost the kernel what the extra launch cost the stream
+  I->split_reduce = !I->perm;
   if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) I->split_reduce = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
