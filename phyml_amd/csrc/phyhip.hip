@@ -262,13 +262,11 @@ int flush_pmats(Instance *I)
     const bool small = n <= kSmallPm; // short lists (SPR: 3 per candidate) ride in the kernel arguments
     PmatParams q;
     memset(&q, 0, sizeof q);
-    FragParams f;
-    memset(&f, 0, sizeof f);
     if (small)
     {
       for (int k = 0; k < n; ++k)
       {
-        q.small_idx[k] = f.small_idx[k] = I->pm_idx[done + k];
+        q.small_idx[k] = I->pm_idx[done + k];
         q.small_len[k] = I->pm_len[done + k];
       }
     }
@@ -283,13 +281,13 @@ int flush_pmats(Instance *I)
       if (I->pm_copy)
       {
         HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
-        q.indices = f.indices = (const int *)I->d_pmscratch;
+        q.indices = (const int *)I->d_pmscratch;
         q.lengths = (const double *)((char *)I->d_pmscratch + bi);
       }
       else
       { // the kernels read the (index, length) pairs straight from the pinned staging chunk: a few hundred bytes over
         // the host link cost less than a copy command ahead of the launch
-        q.indices = f.indices = (const int *)st;
+        q.indices = (const int *)st;
         q.lengths = (const double *)((char *)st + bi);
       }
     }
@@ -297,14 +295,10 @@ int flush_pmats(Instance *I)
     q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
     const int threads = (I->S == 4) ? 64 : 256;
-    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), sizeof(double) * (I->C * I->S + I->C * I->S * I->S), I->stream, q);
+    q.afrag = I->perm ? I->d_afrag : nullptr; // 20 states: the MFMA A-operand fragments come out of the same kernel
+    const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)I->C * I->S * I->S + (size_t)2 * I->S * I->S);
+    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), lds, I->stream, q);
     HIPCHK(hipGetLastError());
-    if (I->perm)
-    { // MFMA A-operand fragments of the matrices just built
-      f.count = n; f.C = I->C; f.pmats = I->d_pmats; f.afrag = I->d_afrag;
-      hipLaunchKernelGGL(aa_frag_kernel, dim3(n), dim3(256), 0, I->stream, f);
-      HIPCHK(hipGetLastError());
-    }
     done += n;
   }
   for (int m : I->pm_idx) I->pm_slot[m] = -1;

@@ -1118,11 +1118,12 @@ struct PmatParams
   const double *rates;       // gamma_rr
   double        br_len_mult, l_min, l_max;
   double       *pmats;
+  double       *afrag;       // 20-state MFMA A-operand copy (nullptr otherwise)
 };
 
 __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
 {
-  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S]
+  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S] | tmp [C][S][S] | row sums [C][S] | U [S][S] | V [S][S]
   const int    m  = blockIdx.x;
   const int    S  = q.S, C = q.C;
   // SPR refreshes three matrices per candidate: such short lists ride in the kernel arguments (no H2D copy)
@@ -1136,6 +1137,15 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
     for (int k = 1; k < kSmallPm; ++k)
       if (m == k) { l = q.small_len[k]; mat = q.small_idx[k]; }
   }
+  double *tmp  = expt + C * S;         // [C][S][S] floored, un-normalised entries
+  double *rsum = tmp + C * S * S;      // [C][S]
+  double *Us   = rsum + C * S;         // eigenvectors staged once per block
+  double *Vs   = Us + S * S;
+  for (int t = threadIdx.x; t < S * S; t += blockDim.x)
+  {
+    Us[t] = q.U[t];
+    Vs[t] = q.V[t];
+  }
   for (int t = threadIdx.x; t < C * S; t += blockDim.x)
   {
     const int c   = t / S, k = t % S;
@@ -1146,24 +1156,36 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
     expt[t] = exp(q.R[k] * len);                      // src/models.c:275
   }
   __syncthreads();
-  double *out = q.pmats + (size_t)mat * C * S * S;
-  double *tmp = expt + C * S; // [C][S][S] floored, un-normalised entries
   // one thread per entry: acc = sum_k (U[i][k]*expt[c][k]) * V[k][j], ascending k with FMA (src/models.c:278-292)
   for (int e = threadIdx.x; e < C * S * S; e += blockDim.x)
   {
     const int c = e / (S * S), i = (e / S) % S, j = e % S;
     double    acc = 0.0;
-    for (int k = 0; k < S; ++k) acc = __builtin_fma(q.U[i * S + k] * expt[c * S + k], q.V[k * S + j], acc);
+    for (int k = 0; k < S; ++k) acc = __builtin_fma(Us[i * S + k] * expt[c * S + k], Vs[k * S + j], acc);
     tmp[e] = (acc < kSmallPij) ? kSmallPij : acc; // :293
   }
   __syncthreads();
-  // row sums in ascending j, then the division (src/models.c:296-298)
+  // row sums in ascending j (src/models.c:296-297)
   for (int t = threadIdx.x; t < C * S; t += blockDim.x)
   {
     const double *row = tmp + (size_t)t * S;
     double        sum = 0.0;
     for (int j = 0; j < S; ++j) sum += row[j];
-    for (int j = 0; j < S; ++j) out[(size_t)t * S + j] = row[j] / sum;
+    rsum[t] = sum;
+  }
+  __syncthreads();
+  // the division (src/models.c:298), one coalesced pass over the matrix
+  double *out = q.pmats + (size_t)mat * C * S * S;
+  for (int e = threadIdx.x; e < C * S * S; e += blockDim.x) out[e] = tmp[e] / rsum[e / S];
+  if (q.afrag)
+  { // 20 states: the same entries once more in MFMA A-operand order (phyhip_aa.hpp: afrag[m][c][half][aa_slot(t, lane)])
+    double *dst = q.afrag + (size_t)mat * C * 640;
+    for (int e = threadIdx.x; e < C * 640; e += blockDim.x)
+    {
+      const int lane = e & 63, t = (e >> 6) % 5, half = ((e >> 6) / 5) & 1, c = (e >> 6) / 10;
+      const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
+      dst[(size_t)(c * 2 + half) * 320 + aa_slot(t, lane)] = tmp[(c * S + i) * S + j] / rsum[c * S + i];
+    }
   }
 }
 
