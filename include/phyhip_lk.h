@@ -130,12 +130,14 @@ void   Lk_Shard_Device(t_tree *tree, double *device_out);
 /* Caller-side counterpart for tree search: replays a recorded stream of surface calls
    -- the calls spr.c / optimiz.c make through Update_PMat_At_Given_Edge, Update_Partial_Lk, Lk(b), Update_Eigen_Lr
    and dLk (src/spr.c:543,643-646; src/optimiz.c:622-632) -- at buffer-index level, in one C loop, and records the
-   scalar every call returned.  kind[i]: */
+   scalar every call returned.  Streams recorded from real PhyML searches (oracle/trace_driver.c) use the same
+   records with buffer ids in order of first appearance.  kind[i]: */
 #define PHL_REC_SET_PMAT 0 /* a = matrix index, x = edge length                               */
 #define PHL_REC_UPDATE   1 /* a = dest, b = child1, c = matrix1, d = child2, e = matrix2       */
 #define PHL_REC_EDGE_LNL 2 /* a = left buffer, b = right buffer or tip, c = matrix -> out = lnL */
 #define PHL_REC_EIGEN_LR 3 /* a = left, b = right                                              */
 #define PHL_REC_DLK      4 /* x = length -> out = lnL, out2 = dlnL                             */
+#define PHL_REC_EIGEN_LNL 5 /* x = length -> out = lnL: Lk(b) in the eigen basis (src/lk.c:592-603) */
 void Replay_Surface_Trace(t_tree *tree, int n_rec, const int *kind, const int *a, const int *b, const int *c, const int *d,
                           const int *e, const phydbl *x, phydbl *out, phydbl *out2);
 

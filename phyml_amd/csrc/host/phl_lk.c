@@ -585,12 +585,19 @@ void Replay_Surface_Trace(t_tree *tree, int n_rec, const int *kind, const int *a
       out2[i] = tree->c_dlnL = dlnl;
       break;
     }
+    case PHL_REC_EIGEN_LNL:
+    {
+      double lnl = 0.0;
+      rc = phyhip_calculate_eigen_lnl(tree->b_inst, x[i], &lnl);
+      out[i] = tree->c_lnL = lnl;
+      break;
+    }
     default: rc = -1; break;
     }
     if (rc < 0)
     {
       free(scratch);
-      Lk_Exit("Replay_Surface_Trace", rc == -1 && kind[i] > PHL_REC_DLK ? "unknown record kind" : phyhip_get_last_error());
+      Lk_Exit("Replay_Surface_Trace", rc == -1 && kind[i] > PHL_REC_EIGEN_LNL ? "unknown record kind" : phyhip_get_last_error());
       return;
     }
   }

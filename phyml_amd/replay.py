@@ -19,7 +19,7 @@ import numpy as np
 
 from . import synth
 
-SET_PMAT, UPDATE, EDGE_LNL, EIGEN_LR, DLK = 0, 1, 2, 3, 4
+SET_PMAT, UPDATE, EDGE_LNL, EIGEN_LR, DLK, EIGEN_LNL = 0, 1, 2, 3, 4, 5
 
 
 def side_buffer_map(n_otu, edge_left, edge_rght):
@@ -83,3 +83,27 @@ def make_trace(n_otu, edge_left, edge_rght, edge_len, n_candidates, seed, walk_e
                 push(DLK, x=pend * (0.25 + 0.25 * j))
     out = {k: np.array(v, dtype=np.float64 if k == "x" else np.int32) for k, v in rec.items()}
     return out
+
+
+def recorded_trace(d):
+    """The op stream of a trace recorded from a real PhyML run (oracle/trace_driver.c, tests/golden/trace_*.phyg) as the
+    dict Replay_Surface_Trace takes, plus the scalars the reference returned: (trace, out, out2)."""
+    tr = {k: np.ascontiguousarray(d["trace_" + k], dtype=np.int32) for k in ("kind", "a", "b", "c", "d", "e")}
+    tr["x"] = np.ascontiguousarray(d["trace_x"], dtype=np.float64)
+    return tr, np.asarray(d["trace_out"], dtype=np.float64), np.asarray(d["trace_out2"], dtype=np.float64)
+
+
+def tips_from_masks(tip_mask, ns):
+    """0/1 tip vectors [P][ns], digit states and ambiguity flags from allowed-state bit masks (one bit = unambiguous,
+    src/lk.c:26-161)."""
+    tip_mask = np.asarray(tip_mask)
+    vecs, states, amb = [], [], []
+    bits = (1 << np.arange(ns, dtype=np.int64))
+    for t in range(tip_mask.shape[0]):
+        m = tip_mask[t].astype(np.int64)
+        v = ((m[:, None] & bits[None, :]) != 0).astype(np.float64)
+        cnt = v.sum(axis=1)
+        vecs.append(np.ascontiguousarray(v))
+        amb.append((cnt != 1).astype(np.int16))
+        states.append(np.where(cnt == 1, v.argmax(axis=1), 0).astype(np.int16))
+    return vecs, states, amb

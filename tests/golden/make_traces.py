@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Record surface-call traces from REAL PhyML tree searches (tests/golden/trace_*.phyg).
+
+Runs only in the build container (needs /root/reference and `make -C oracle ref`):
+    python tests/golden/make_traces.py
+oracle/_ref/phyml_trace_driver runs the unmodified reference (SPR search + branch-length optimisation on the
+reference's own example alignments) with the likelihood surface interposed, and writes the first N records of
+the call stream -- buffer-level operations plus the scalar every call returned -- together with the inputs a
+replay needs (model block, tip state sets, pattern weights).  The outputs are data only.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "phyml_trace_driver")
+REF = os.environ.get("PHYML_REF", "/root/reference")
+
+TRACES = {
+    # name: (example file, max records, driver opts, phyml args)
+    "trace_nucleic_spr": ("nucleic", 12000, ["--gtr-rr", "1,2.5,0.8,1.2,3.0,1"],
+                          ["-d", "nt", "-m", "GTR", "-f", "0.3,0.2,0.2,0.3", "-c", "4", "-a", "0.8", "-s", "SPR", "-o", "tl", "-b", "0",
+                           "--r_seed", "1"]),
+    "trace_proteic_spr": ("proteic", 9000, [],
+                          ["-d", "aa", "-m", "LG", "-f", "m", "-c", "4", "-a", "1.0", "-s", "SPR", "-o", "tl", "-b", "0", "--r_seed", "1"]),
+}
+
+
+def main():
+    if not os.path.exists(DRIVER):
+        raise SystemExit("build oracle/_ref first: make -C oracle ref")
+    tmp = tempfile.mkdtemp(prefix="traces_")
+    for name, (example, nrec, dopts, pargs) in TRACES.items():
+        shutil.copy(os.path.join(REF, "examples", example), tmp)
+        os.chmod(os.path.join(tmp, example), 0o644)
+        out = os.path.join(HERE, name + ".phyg")
+        r = subprocess.run([DRIVER, out, str(nrec)] + dopts + ["--", "-i", example] + pargs, cwd=tmp,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        m = re.search(r"TRACE_DRIVER records=.*", r.stdout)
+        if r.returncode != 0 or not m:
+            print(r.stdout[-3000:])
+            raise SystemExit(f"trace driver failed for {name}")
+        print(f"{name:22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -68,4 +68,37 @@ class OracleReplayer:
                                       orc._p(m.r_e_vect), orc._p(m.l_e_vect), orc._p(m.pi), orc._p(ot.dot_prod), C.c_int(ot.arith))
             elif k == replay.DLK:
                 _, out[i], out2[i] = ot.dlk(x)
+            elif k == replay.EIGEN_LNL:
+                out[i] = ot.lk_eigen(x)
         return out, out2
+
+
+class RecordedReplayer(OracleReplayer):
+    """Replays a stream recorded from a real PhyML run (oracle/trace_driver.c): buffer and matrix ids are whatever the
+    recorder assigned (order of first appearance), so storage is allocated per id on first use."""
+
+    def __init__(self, ot: orc.OracleTree):
+        self.ot = ot
+        self.bufs, self.pms = {}, {}
+
+    def _pm(self, idx):
+        m = self.ot.m
+        if idx not in self.pms:
+            self.pms[idx] = np.zeros((m.ncatg, m.ns, m.ns))
+        return self.pms[idx]
+
+    def _arrays(self, idx):
+        m = self.ot.m
+        if idx not in self.bufs:
+            self.bufs[idx] = (np.zeros((self.ot.P, m.ncatg * m.ns)), np.zeros(self.ot.P, np.int32))
+        return self.bufs[idx]
+
+
+def tree_from_recorded(d, arith=1):
+    """OracleTree carrying the model, weights and tips of a recorded trace (its own edge arrays are only used for
+    sizing: the replay works at buffer level)."""
+    m = orc.Model(d)
+    n = int(d["n_otu"][0])
+    tv, ds, amb = replay.tips_from_masks(d["tip_mask"], m.ns)
+    return orc.OracleTree(m, n, d["edge_left"], d["edge_rght"], d["edge_len"], d["wght"], tv, ds, amb, invar=d["invar"],
+                          apply_scaling=int(d["apply_lk_scaling"][0]), arith=arith)
