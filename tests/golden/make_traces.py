@@ -30,6 +30,17 @@ TRACES = {
 }
 
 
+GLUE = os.path.join(ROOT, "oracle", "_ref", "phyml_glue_driver")
+SEARCHES = {
+    # name: (example file, driver opts, phyml args) -- SPR topology search + branch lengths, model fixed
+    "search_nucleic_spr": ("nucleic", ["--gtr-rr", "1,2.5,0.8,1.2,3.0,1"],
+                           ["-d", "nt", "-m", "GTR", "-f", "0.3,0.2,0.2,0.3", "-c", "4", "-a", "0.8", "-s", "SPR", "-o", "tl", "-b", "0",
+                            "--r_seed", "1"]),
+    "search_proteic_spr": ("proteic", [],
+                           ["-d", "aa", "-m", "LG", "-f", "m", "-c", "4", "-a", "1.0", "-s", "SPR", "-o", "tl", "-b", "0", "--r_seed", "1"]),
+}
+
+
 def main():
     if not os.path.exists(DRIVER):
         raise SystemExit("build oracle/_ref first: make -C oracle ref")
@@ -45,6 +56,26 @@ def main():
             print(r.stdout[-3000:])
             raise SystemExit(f"trace driver failed for {name}")
         print(f"{name:22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
+
+    # --- whole searches: the CPU-only run of the command lines tests/test_gpu_search.py repeats on the GPU ----------
+    import json
+    expected = {}
+    for name, (example, dopts, pargs) in SEARCHES.items():
+        # the example alignments travel as data files (the GPU box has no /root/reference)
+        shutil.copy(os.path.join(REF, "examples", example), os.path.join(HERE, "examples_" + example + ".phy"))
+        os.chmod(os.path.join(HERE, "examples_" + example + ".phy"), 0o644)
+        env = dict(os.environ, GLUE_MODE="host")
+        r = subprocess.run([GLUE] + dopts + ["--", "-i", example] + pargs, cwd=tmp, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+        if r.returncode != 0 or not m:
+            print(r.stdout[-3000:])
+            raise SystemExit(f"glue driver (host mode) failed for {name}")
+        info = json.loads(m.group(1))
+        expected[name] = dict(example=example, driver_opts=dopts, phyml_args=pargs, lnL_init=info["lnL_init"],
+                              lnL_final=info["lnL_final"], tree=info["tree"], calls=info["calls"], cpu_seconds=info["seconds"])
+        print(f"{name:22s} lnL {info['lnL_init']:.6f} -> {info['lnL_final']:.6f}  {info['calls']}  {info['seconds']:.1f} s (1 core, this container)")
+    json.dump(expected, open(os.path.join(HERE, "search_expected.json"), "w"), indent=1, sort_keys=True)
     shutil.rmtree(tmp, ignore_errors=True)
 
 
