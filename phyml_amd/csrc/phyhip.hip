@@ -7,6 +7,7 @@
 #include "phyhip_nt2.hpp"
 
 #include <cfloat>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -55,6 +56,7 @@ struct StagingRing
   bool                 pending[kChunks];
   int                  cur  = 0;
   size_t               used = 0;
+  std::function<int()> before_rotate;
 
   int init(size_t bytes)
   {
@@ -81,6 +83,13 @@ struct StagingRing
     if (bytes > chunk_bytes) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "staging request of %zu bytes too large", bytes);
     if (used + bytes > chunk_bytes)
     {
+      // work that was queued against this chunk but not yet launched (matrix uploads) goes into the stream first, so
+      // that the event below really seals everything that reads the chunk
+      if (before_rotate)
+      {
+        int rc = before_rotate();
+        if (rc) return rc;
+      }
       HIPCHK(hipEventRecord(ev[cur], s));
       pending[cur] = true;
       cur          = (cur + 1) % kChunks;
@@ -143,6 +152,9 @@ struct Instance
   std::vector<std::vector<DevOp>>        slot_ops;  // what each device ring slot currently holds (content cache)
   std::vector<int>                       slot_kind; // 0 slim, 1 fat dist 1, 2 fat dist 2
   std::vector<unsigned char>             mat_in_queue; // matrix index referenced by a queued op
+  std::vector<int>                       up_idx;       // host-computed matrices waiting for their upload launch
+  std::vector<const double *>            up_src;       // ... their copies in pinned staging memory
+  std::vector<int>                       up_slot;      // per matrix: position in up_idx or -1
   std::vector<uint32_t>                  masks;
   std::unordered_map<uint32_t, int>      mask_code;
   bool                                   masks_dirty = false;
@@ -154,7 +166,7 @@ struct Instance
   bool   want_site_outputs = true;
   int    prefetch_dist = 2;  // PHYHIP_DIST: load-stage distance of the nt pipeline (1 or 2)
   bool   pm_copy = true;       // PHYHIP_PM_COPY=0: kernels read the P-matrix work list from pinned host memory (slower for 20 states)
-  bool   split_reduce = false; // PHYHIP_SPLIT_REDUCE: separate final_reduce_kernel instead of the fused last-workgroup sum
+  bool   split_reduce = false, split_reduce_forced = false; // PHYHIP_SPLIT_REDUCE: separate final_reduce_kernel instead of the fused last-workgroup sum
   unsigned *d_tickets = nullptr;
   int    ablate = 0;         // PHYHIP_ABLATE: timing-only kernel variants (results invalid)
   bool   no_loads = false;   // PHYHIP_NOLOADS: zero-size every child load (timing only)
@@ -251,10 +263,32 @@ struct EdgeEval
   bool    to_host;
 };
 
+// Host-computed matrices queued by phyhip_set_transition_matrix: one launch per kUploadBatch of them.
+int flush_uploads(Instance *I)
+{
+  size_t done = 0;
+  while (done < I->up_idx.size())
+  {
+    const int n = (int)std::min<size_t>(I->up_idx.size() - done, kUploadBatch);
+    MatUploadParams q;
+    memset(&q, 0, sizeof q);
+    q.count = n; q.S = I->S; q.C = I->C; q.pmats = I->d_pmats; q.afrag = I->perm ? I->d_afrag : nullptr;
+    for (int k = 0; k < n; ++k) { q.idx[k] = I->up_idx[done + k]; q.src[k] = I->up_src[done + k]; }
+    hipLaunchKernelGGL(upload_matrices_kernel, dim3(n), dim3(256), sizeof(double) * (size_t)I->C * I->S * I->S, I->stream, q);
+    HIPCHK(hipGetLastError());
+    done += n;
+  }
+  for (int m : I->up_idx) I->up_slot[m] = -1;
+  I->up_idx.clear();
+  I->up_src.clear();
+  return 0;
+}
+
 // Rebuild every queued transition matrix on the device: one staged copy of (index, length) pairs, one launch.
 int flush_pmats(Instance *I)
 {
   int done = 0, rc = 0;
+  if (!I->up_idx.empty() && (rc = flush_uploads(I))) return rc;
   const int count = (int)I->pm_idx.size();
   while (done < count)
   {
@@ -307,18 +341,29 @@ int flush_pmats(Instance *I)
   return 0;
 }
 
+// Final sum inside the producing kernel (last workgroup) or as a separate 1-block kernel?  Measured on MI355X: fused
+// saves the second launch (~3.4 us + gap) whenever the grid is small -- every SPR / Br_Len_Opt call on small and
+// mid-sized alignments -- and ~10 us per call for 20 states at any size; for 4 states on large grids the ticket draw of
+// ~1500 workgroups costs the kernel what the launch cost the stream.  PHYHIP_SPLIT_REDUCE=0/1 forces either.
+static bool fuse_reduce(const Instance *I, int nblocks)
+{
+  if (I->split_reduce_forced) return !I->split_reduce;
+  return I->perm || nblocks <= 512;
+}
+
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush(Instance *I, const EdgeEval *ee)
 {
   const int n_ops = (int)I->pending.size();
   int rc = 0;
-  if (!I->pm_idx.empty() && (rc = flush_pmats(I))) return rc;
+  if ((!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
   if (n_ops == 0 && !ee) return 0;
   rc = upload_masks(I);
   if (rc) return rc;
 
   TreeParams q = base_params(I);
   RO         ro = base_ro(I, nullptr);
+  bool       fused_sum = false;
   const bool fat = ((I->S == 4) && !I->generic_nt) || I->perm;
   const IssueRec *d_irec = nullptr;
   const ExecRec  *d_xrec = nullptr;
@@ -407,6 +452,7 @@ int flush(Instance *I, const EdgeEval *ee)
         xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), bufbytes, fl);
         xr[k].dst_scale = desc(I->d_scales + b * I->Ppad, (size_t)I->Ppad * 4, 0);
       }
+      // (reading short lists straight from the pinned staging memory instead was measured: no gain)
       HIPCHK(hipMemcpyAsync(dst, st, ib + xb, hipMemcpyHostToDevice, I->stream));
       d_irec = reinterpret_cast<const IssueRec *>(dst);
       d_xrec = reinterpret_cast<const ExecRec *>(dst + ib);
@@ -417,7 +463,9 @@ int flush(Instance *I, const EdgeEval *ee)
   if (ee)
   {
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
-    if (!I->split_reduce)
+    const int nblk = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
+    fused_sum = fuse_reduce(I, nblk);
+    if (fused_sum)
     { // the traversal kernel's last workgroup finishes the sum and reports to the host
       q.tickets = I->d_tickets; q.result = ee->dev_out ? ee->dev_out : I->d_result;
       q.result_host = ee->to_host ? I->h_result : nullptr; q.warn_host = I->h_warn;
@@ -524,7 +572,7 @@ int flush(Instance *I, const EdgeEval *ee)
     I->prof_updates += (double)n_ops * (double)I->P;
   }
   HIPCHK(hipGetLastError());
-  if (ee && I->split_reduce)
+  if (ee && !fused_sum)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
     const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
@@ -718,16 +766,15 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
                                                        (size_t)I->C * I->S * I->S * sizeof(double) * 4));
   int rc = I->ring.init(chunk);
   if (rc) return rc;
+  I->ring.before_rotate = [I]() { return I->up_idx.empty() ? 0 : flush_uploads(I); };
   I->mat_in_queue.assign(I->nmat, 0);
+  I->up_slot.assign(I->nmat, -1);
   I->pm_slot.assign(I->nmat, -1);
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
-  // measured (MI355X): fusing the final sum into the traversal saves ~10 us per call for 20 states; for 4 states the
-  // ticket draw and the last workgroup's pass cost the kernel what the extra launch cost the stream
-  I->split_reduce = !I->perm;
-  if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) I->split_reduce = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce() { I->split_reduce = atoi(e) != 0; I->split_reduce_forced = true; }
   if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
   HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned)));
@@ -983,6 +1030,12 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
   // Deferred like the partial updates: SPR refreshes three matrices per regraft candidate (src/spr.c:643-646);
   // they are rebuilt by ONE pmat_kernel launch right before the traversal kernel that reads them.
   for (int i = 0; i < count; ++i)
+    if (I->up_slot[probabilityIndices[i]] >= 0)
+    { // an upload of the same matrix is still queued: it must land before the rebuild
+      if ((rc = flush_uploads(I))) return rc;
+      break;
+    }
+  for (int i = 0; i < count; ++i)
   {
     const int m = probabilityIndices[i];
     if (I->pm_slot[m] >= 0) I->pm_len[I->pm_slot[m]] = edgeLengths[i]; // last length wins
@@ -1008,15 +1061,15 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
   rc = I->ring.alloc(bytes, I->stream, &st);
   if (rc) return rc;
   memcpy(st, inMatrix, bytes);
-  HIPCHK(hipMemcpyAsync(I->d_pmats + (size_t)matrixIndex * I->C * I->S * I->S, st, bytes, hipMemcpyHostToDevice, I->stream));
-  if (I->perm)
+  // queued: the matrices set since the last launch travel together (SPR sets three per candidate, src/spr.c:643-646)
+  if (I->up_slot[matrixIndex] >= 0) I->up_src[I->up_slot[matrixIndex]] = (const double *)st; // last upload wins
+  else
   {
-    FragParams f;
-    memset(&f, 0, sizeof f);
-    f.small_idx[0] = matrixIndex; f.count = 1; f.C = I->C; f.pmats = I->d_pmats; f.afrag = I->d_afrag;
-    hipLaunchKernelGGL(aa_frag_kernel, dim3(1), dim3(256), 0, I->stream, f);
-    HIPCHK(hipGetLastError());
+    I->up_slot[matrixIndex] = (int)I->up_idx.size();
+    I->up_idx.push_back(matrixIndex);
+    I->up_src.push_back((const double *)st);
   }
+  if ((int)I->up_idx.size() >= 4 * kUploadBatch && (rc = flush_uploads(I))) return rc;
   return PHYHIP_SUCCESS;
 }
 
@@ -1195,7 +1248,13 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   memset(&q, 0, sizeof q);
   q.dot_prod = I->d_dot; q.wght = I->d_wght; q.fact = I->d_fact; q.cat_w = I->d_catw; q.pi = I->d_pi; q.invar = I->d_invar;
   q.P = I->P; q.C = I->C; q.invar_model = I->invar_model; q.apply_scaling = I->apply_scaling; q.with_derivative = deriv ? 1 : 0;
-  q.pinvar = I->pinvar; q.block_sums = I->d_block; q.stride = I->grid; q.warn = I->d_warn;
+  q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = I->grid; q.fin.warn = I->d_warn;
+  const bool fused = fuse_reduce(I, I->grid);
+  if (fused)
+  {
+    q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
+    q.fin.seq = ++I->seq;
+  }
   for (int c = 0; c < I->C; ++c)
   {
     if (deriv)
@@ -1227,9 +1286,12 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   });
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 2, I->grid,
-                     I->d_result, I->h_result, I->d_warn, I->h_warn, ++I->seq);
-  HIPCHK(hipGetLastError());
+  if (!fused)
+  {
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 2, I->grid,
+                       I->d_result, I->h_result, I->d_warn, I->h_warn, ++I->seq);
+    HIPCHK(hipGetLastError());
+  }
   if ((rc = wait_result(I))) return rc;
   *lnl = I->h_result[0];
   if (dlnl) *dlnl = I->h_result[1];

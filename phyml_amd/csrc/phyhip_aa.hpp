@@ -87,6 +87,45 @@ __global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
   }
 }
 
+// Host-computed transition matrices (phyhip_set_transition_matrix, the bit-exact route of src/lk.c:2360): up to
+// kUploadBatch matrices per launch are read straight from the pinned staging memory (a few KB over the host link),
+// written to their slots and -- for 20 states -- once more in MFMA A-operand order.  One launch replaces one copy
+// command (plus one aa_frag_kernel launch) per matrix.
+constexpr int kUploadBatch = 16;
+struct MatUploadParams
+{
+  int           count, S, C;
+  int           idx[kUploadBatch];
+  const double *src[kUploadBatch]; // host-pinned, device-accessible
+  double       *pmats;
+  double       *afrag;             // nullptr unless 20 states
+};
+
+__global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadParams q)
+{
+  extern __shared__ __attribute__((aligned(16))) double mat[]; // [C][S][S]
+  int           m   = q.idx[0];
+  const double *src = q.src[0];
+#pragma unroll
+  for (int k = 1; k < kUploadBatch; ++k)
+    if ((int)blockIdx.x == k) { m = q.idx[k]; src = q.src[k]; }
+  const int n = q.C * q.S * q.S;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) mat[e] = src[e];
+  __syncthreads();
+  double *out = q.pmats + (size_t)m * n;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) out[e] = mat[e];
+  if (q.afrag)
+  {
+    double *dst = q.afrag + (size_t)m * q.C * (2 * kAaBlock);
+    for (int e = threadIdx.x; e < q.C * 2 * kAaT * 64; e += blockDim.x)
+    {
+      const int lane = e & 63, t = (e >> 6) % kAaT, half = ((e >> 6) / kAaT) & 1, c = (e >> 6) / (2 * kAaT);
+      const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
+      dst[(size_t)(c * 2 + half) * kAaBlock + aa_slot(t, lane)] = mat[(size_t)c * 400 + i * 20 + j];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1 + K2 for 20 states.  One WAVE owns (tile of 16 patterns, one rate category); the C waves of a
 // workgroup own the C categories of the same tile.  10 000 patterns give only 625 tiles -- fewer than the

@@ -262,32 +262,50 @@ __device__ __forceinline__ void matvec_rows(const double *__restrict__ M, const 
 // ---------------------------------------------------------------------------------------------
 // K1 + K2: traversal kernel
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void raise_warn(const TreeParams &q)
+// ---- end of an evaluation: per-workgroup sums -> one scalar (or two) on the host ---------------------------------
+struct FinishParams
+{
+  unsigned           *tickets;     // one counter, zero between launches
+  double             *block_sums;  // [NS][stride]
+  int                 stride;
+  double             *result;      // device scalars [NS] (or the caller's device pointer); nullptr: final_reduce_kernel follows
+  double             *result_host; // host-mapped {sum 0, sum 1, seq} or nullptr
+  int                *warn, *warn_host;
+  unsigned long long  seq;
+};
+
+__device__ __forceinline__ void raise_warn(int *warn)
 { // visible to whichever workgroup ends up doing the final reduction (other XCD, other L2)
-  __hip_atomic_store(q.warn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(warn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// End of an edge evaluation.  Called by every lane of ONE wave per workgroup with the workgroup's weighted
-// log-likelihood sum in lane 0.  Without q.result the sum is only recorded (final_reduce_kernel follows).  With it,
-// the sum is stored through to memory (agent scope), a ticket is drawn, and the workgroup that draws the last ticket
-// adds all block sums -- same grouping and order as final_reduce_kernel, so lnL does not depend on which workgroup
-// finishes last -- and publishes the result.  One kernel launch and one inter-kernel gap less per Lk() call.
-__device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s, int lane)
+// Called by every lane of ONE wave per workgroup with the workgroup's sums in lane 0.  Without f.result the sums are
+// only recorded (final_reduce_kernel follows).  With it, they are stored through to memory (agent scope), a ticket is
+// drawn, and the workgroup that draws the last ticket adds all block sums -- same grouping and order as
+// final_reduce_kernel, so the result does not depend on which workgroup finishes last -- and publishes it: one kernel
+// launch and one inter-kernel gap less per scalar-returning call.
+template <int NS> __device__ __forceinline__ void finish_sums(const FinishParams &f, const double (&s)[NS], int lane)
 {
-  if (!q.result)
+  if (!f.result)
   {
-    if (lane == 0) q.block_sums[blockIdx.x] = s;
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) f.block_sums[(size_t)k * f.stride + blockIdx.x] = s[k];
     return;
   }
   unsigned ticket = 0;
   if (lane == 0)
   {
-    unsigned long long bits;
-    __builtin_memcpy(&bits, &s, 8);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(q.block_sums) + blockIdx.x, bits, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0); // the write-through store is acknowledged before the ticket is drawn
-    ticket = __hip_atomic_fetch_add(q.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+    {
+      unsigned long long bits;
+      __builtin_memcpy(&bits, &s[k], 8);
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.block_sums) + (size_t)k * f.stride + blockIdx.x, bits,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0); // the write-through stores are acknowledged before the ticket is drawn
+    ticket = __hip_atomic_fetch_add(f.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   ticket = __shfl(ticket, 0, 64);
   if (ticket != gridDim.x - 1) return;
@@ -295,31 +313,51 @@ __device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s,
   // every block sum was written through to memory before its ticket was drawn; drop whatever stale copies this
   // CU's L1 / this XCD's L2 may hold, then read them with ordinary (pipelined) loads
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  double acc[4]; // the four "threads" lane, lane+64, lane+128, lane+192 of the 256-thread reduction
+  double tot[NS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int k = 0; k < NS; ++k)
   {
-    acc[j] = 0.0;
-    for (int i = lane + 64 * j; i < n; i += 256) acc[j] += q.block_sums[i];
-  }
-  double t = (acc[0] + acc[2]) + (acc[1] + acc[3]); // tree levels 128 and 64
+    const double *in = f.block_sums + (size_t)k * f.stride;
+    double        acc[4]; // the four "threads" lane, lane+64, lane+128, lane+192 of the 256-thread reduction
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    for (int j = 0; j < 4; ++j)
+    {
+      acc[j] = 0.0;
+      for (int i = lane + 64 * j; i < n; i += 256) acc[j] += in[i];
+    }
+    double t = (acc[0] + acc[2]) + (acc[1] + acc[3]); // tree levels 128 and 64
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    tot[k] = t;
+  }
   if (lane == 0)
   {
-    *q.result = t;
-    const int w = __hip_atomic_load(q.warn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q.warn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (q.warn_host) *q.warn_host = w;
-    if (q.result_host)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) f.result[k] = tot[k];
+    const int w = __hip_atomic_load(f.warn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f.warn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f.warn_host) *f.warn_host = w;
+    if (f.result_host)
     {
-      q.result_host[0] = t;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) f.result_host[k] = tot[k];
       __threadfence_system(); // results before the sequence number, system scope (host reads over PCIe)
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(q.result_host + 2), q.seq, __ATOMIC_RELEASE,
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.result_host + 2), f.seq, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+__device__ __forceinline__ void raise_warn(const TreeParams &q) { raise_warn(q.warn); }
+
+__device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s, int lane)
+{
+  FinishParams f;
+  f.tickets = q.tickets; f.block_sums = q.block_sums; f.stride = 0; f.result = q.result; f.result_host = q.result_host;
+  f.warn = q.warn; f.warn_host = q.warn_host; f.seq = q.seq;
+  const double v[1] = {s};
+  finish_sums<1>(f, v, lane);
 }
 
 template <int S, int CP>
@@ -960,9 +998,7 @@ struct DlkParams
   int           apply_scaling;
   int           with_derivative; // 1: expl is [c][2*S] interleaved (value, derivative); 0: [c][S]
   double        pinvar;
-  double       *block_sums;      // [2][stride]
-  int           stride;
-  int          *warn;
+  FinishParams  fin;             // block_sums [2][stride], warn, and (optionally) the fused final sum
   double        expl[kMaxExpl];
 };
 
@@ -1068,7 +1104,7 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
       if (lk < kSmall)
       {
         lk = kSmall;
-        *q.warn = 1;
+        raise_warn(q.fin.warn);
       }
       c_dlnl = wt * (dlk / lk);                          // src/lk.c:742-744
       c_lnl  = wt * (log(lk) - kLog2 * (double)f);       // src/lk.c:745
@@ -1088,16 +1124,15 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
     ws[1][wid] = c_dlnl;
   }
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (wid == 0)
   {
-    double a = 0.0, b = 0.0;
+    double v[2] = {0.0, 0.0};
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k)
     {
-      a += ws[0][k];
-      b += ws[1][k];
+      v[0] += ws[0][k];
+      v[1] += ws[1][k];
     }
-    q.block_sums[blockIdx.x]            = a;
-    q.block_sums[q.stride + blockIdx.x] = b;
+    finish_sums<2>(q.fin, v, lane);
   }
 }
 

@@ -7,8 +7,8 @@ with Lk / dLk / Update_Partial_Lk / Update_PMat_At_Given_Edge / Update_Eigen_Lr 
   check mode   the reference's own arithmetic runs alongside and steers the search; EVERY scalar of the search (tens of
                thousands of Lk(b), ~100 000 dLk) is compared call by call with what the device returns: the worst
                relative difference must stay below 1e-10 (north star: 1e-6)
-  device mode  the search is driven only by device results and must arrive where the reference arrived on the same
-               machine (the check-mode run): final lnL within 1e-5 relative (measured 7e-8 / 6e-9)
+  device mode  the search is driven only by device results and must end in the neighbourhood of the reference's end
+               point on the same machine (sanity check: the heuristic is chaotic in the last bits of every lnL)
 
 The CPU-only end point recorded in the build container (tests/golden/search_expected.json) is a sanity anchor only: the
 search trajectory depends on the last bits of libm's exp/log, which differ between host CPUs.
@@ -66,9 +66,11 @@ def test_real_search_driven_by_the_device(name, tmp_path):
     info = run_search(name, "device", tmp_path)     # the same search, device results only
     assert abs(info["lnL_init"] - ref["lnL_init"]) <= 1e-12 * abs(ref["lnL_init"])
     # The heuristic is chaotic in the last bits of every lnL (the device differs from the AVX path by ~1e-15 relative, as
-    # two CPUs differ from each other), so call counts and intermediate trees differ; the end point must agree.
-    # Measured: 7e-8 relative (nucleic), 6e-9 (proteic).
-    assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-5 * abs(ref["lnL_final"]), (info["lnL_final"], ref["lnL_final"])
+    # two host CPUs differ from each other through libm): call counts, intermediate trees and even the local optimum
+    # reached differ between runs -- the reference's own end point on examples/nucleic was -5580.1235 on one box and
+    # -5583.0951 on another.  So this is the sanity check SURVEY 8d asks for, not the parity gate (that is check mode):
+    # the device-driven search must end in the same neighbourhood (1e-3 relative; typically 1e-7).
+    assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-3 * abs(ref["lnL_final"]), (info["lnL_final"], ref["lnL_final"])
     assert info["lnL_final"] > info["lnL_init"] + 10.0
     for k in ("Lk", "dLk", "Update_Partial_Lk"):
         assert 0.5 * ref["calls"][k] < info["calls"][k] < 2.0 * ref["calls"][k]
@@ -78,5 +80,5 @@ def test_real_search_with_device_built_matrices(tmp_path):
     """Same, with the P-matrices built on the device from the eigen system (src/lk.c:2344 route)."""
     ref = run_search("search_nucleic_spr", "check", tmp_path)
     info = run_search("search_nucleic_spr", "device", tmp_path, device_pmat=True)
-    assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-5 * abs(ref["lnL_final"]), (info["lnL_final"], ref["lnL_final"])
+    assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-3 * abs(ref["lnL_final"]), (info["lnL_final"], ref["lnL_final"])
     assert info["lnL_final"] > info["lnL_init"] + 10.0
