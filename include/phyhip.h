@@ -191,6 +191,22 @@ int phyhip_set_scale_factors(int instance, int bufferIndex, const int *inScaleFa
 /* tree->numerical_warning of the last edge evaluation (src/lk.c:847-851) */
 int phyhip_get_numerical_warning(int instance, int *outWarning);
 
+/* ---- mixtures of class models ---------------------------------------------- */
+
+/* MIXT_Lk(b, mixt_tree), src/mixt.c:730-1160, for one partition element without +I: every class tree of the mixture
+   (n_catg = 1, its own rate matrix / frequencies; src/mixt.c:2603-2640) is one instance whose single category rate is
+   the class rate (mixt_tree->mod->ras->gamma_rr[parent_class_number], src/lk.c:2298).  Flushes the queued operations
+   of every class instance, evaluates the given edge in each (the Lk_Core calls of src/mixt.c:997-1010) and combines
+   the classes per pattern: 2^-sum rescaling, proba * r_mat_weight / rMatWeightSum * e_frq_weight / eFrqWeightSum /
+   sumProbas (src/mixt.c:1048-1053), DBL_MIN floor, log, pattern weights of the FIRST instance.  All instances must sit
+   on the same device with the same pattern count and one category.  The per-pattern log-likelihoods
+   (mixt_tree->c_lnL_sorted) are left in the first instance (phyhip_get_site_log_likelihoods). */
+int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, const int *parentBufferIndices,
+                                            const int *childBufferIndices, const int *probabilityIndices,
+                                            const double *classProba, const double *rMatWeight, const double *eFrqWeight,
+                                            double rMatWeightSum, double eFrqWeightSum, double sumProbas,
+                                            double *outSumLogLikelihood);
+
 /* ---- eigen-basis branch-length derivative (no BEAGLE counterpart in the seam) ---------------- */
 
 /* Update_Eigen_Lr(b,tree), src/lk.c:1038-1114 / src/avx.c:21-105: fills the instance's dot_prod

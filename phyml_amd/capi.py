@@ -41,7 +41,7 @@ SYMBOLS = [
     "phyhip_get_site_log_likelihoods", "phyhip_get_site_outputs", "phyhip_get_partials", "phyhip_get_scale_factors",
     "phyhip_set_scale_factors", "phyhip_get_numerical_warning", "phyhip_update_eigen_lr",
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
-    "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read",
+    "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
 ]
 
 _lib = None
@@ -231,3 +231,16 @@ class Instance:
         ms = C.c_double(0); n = C.c_int(0); u = C.c_double(0)
         _chk(self.L.phyhip_profile_read(self.id, C.byref(ms), C.byref(n), C.byref(u)))
         return ms.value, n.value, u.value
+
+
+def mixture_log_likelihood(instance_ids, parents, children, matrices, proba, r_mat_weight, e_frq_weight, r_sum, e_sum, sum_probas):
+    """phyhip_calculate_mixture_log_likelihood: MIXT_Lk over class instances (one category each)."""
+    L = load()
+    n = len(instance_ids)
+    ia = lambda v: (C.c_int * n)(*[int(x) for x in v])
+    da = lambda v: (C.c_double * n)(*[float(x) for x in v])
+    out = C.c_double(0.0)
+    _chk(L.phyhip_calculate_mixture_log_likelihood(ia(instance_ids), n, ia(parents), ia(children), ia(matrices), da(proba),
+                                                   da(r_mat_weight), da(e_frq_weight), C.c_double(r_sum), C.c_double(e_sum),
+                                                   C.c_double(sum_probas), C.byref(out)))
+    return out.value

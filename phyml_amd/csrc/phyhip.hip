@@ -1146,6 +1146,52 @@ int phyhip_calculate_edge_log_likelihoods_device(int instance, int parent, int c
   return flush(I, &ee);
 }
 
+int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, const int *parent, const int *child, const int *pm,
+                                            const double *classProba, const double *rMatWeight, const double *eFrqWeight,
+                                            double rMatWeightSum, double eFrqWeightSum, double sumProbas, double *outLnL)
+{
+  if (count < 1 || count > kMaxMixClasses) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "1..%d mixture classes", kMaxMixClasses);
+  Instance *I0 = nullptr;
+  MixParams q;
+  memset(&q, 0, sizeof q);
+  for (int k = 0; k < count; ++k)
+  {
+    GET_INST(I, instances[k]);
+    if (k == 0) I0 = I;
+    if (I->C != 1 || I->P != I0->P || I->dev != I0->dev)
+      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture class %d: needs one category, the same pattern count and the same device", k);
+    int rc = check_partial_index(I, parent[k], true);
+    if (rc) return rc;
+    if ((rc = check_partial_index(I, child[k], true))) return rc;
+    if (pm[k] < 0 || pm[k] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm[k]);
+    // the class's own edge evaluation: leaves unscaled_site_lk_cat and fact_sum_scale in its device arrays, no host sync
+    EdgeEval ee{parent[k], child[k], pm[k], I->d_result, false};
+    if ((rc = flush(I, &ee))) return rc;
+    if (I != I0)
+    { // the combination runs on the first instance's stream, after every class stream
+      hipEvent_t ev;
+      HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(ev, I->stream));
+      HIPCHK(hipStreamWaitEvent(I0->stream, ev, 0));
+      HIPCHK(hipEventDestroy(ev));
+    }
+    q.site_cat[k] = I->d_site_cat; q.fact[k] = I->d_fact;
+    q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
+  }
+  q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
+  q.wght = I0->d_wght; q.site_lnl = I0->d_site_lnl;
+  const int grid = (int)((I0->P + 255) / 256);
+  q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
+  q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
+  q.fin.seq = ++I0->seq;
+  hipLaunchKernelGGL(mixture_combine_kernel, dim3(grid), dim3(256), 0, I0->stream, q);
+  HIPCHK(hipGetLastError());
+  int rc = wait_result(I0);
+  if (rc) return rc;
+  *outLnL = I0->h_result[0];
+  return PHYHIP_SUCCESS;
+}
+
 int phyhip_get_site_log_likelihoods(int instance, double *out)
 {
   GET_INST(I, instance);

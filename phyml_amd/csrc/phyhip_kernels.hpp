@@ -1137,6 +1137,60 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mixture of class models: the site loop of MIXT_Lk after the per-class Lk_Core calls (src/mixt.c:1027-1135).
+// Every class is its own instance (one rate category, own rate matrix / frequencies, the class rate as category rate);
+// their edge evaluations left the per-site class likelihood (unscaled_site_lk_cat) and the scale exponent
+// (fact_sum_scale) in device memory.  Here: common scale 2^-sum (sum capped at 1023 above 1024 with a warning, :1027-1034),
+// weights in the reference's operation order (:1048-1053), DBL_MIN floor (:1114-1117), log, weighted sum.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxMixClasses = 16;
+struct MixParams
+{
+  int           count;
+  long long     P;
+  const double *site_cat[kMaxMixClasses]; // per class: [P] (C = 1)
+  const int    *fact[kMaxMixClasses];
+  double        proba[kMaxMixClasses], r_w[kMaxMixClasses], e_w[kMaxMixClasses];
+  double        r_sum, e_sum, sum_probas;
+  const double *wght;
+  double       *site_lnl; // mixture c_lnL_sorted (optional)
+  FinishParams  fin;
+};
+
+__global__ __launch_bounds__(256) void mixture_combine_kernel(const MixParams q)
+{
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double          contrib = 0.0;
+  if (p < q.P)
+  {
+    double site_lk = 0.0;
+    for (int k = 0; k < q.count; ++k)
+    {
+      int s = q.fact[k][p];
+      if (s > 1024) { s = 1023; raise_warn(q.fin.warn); }
+      const double x = ldexp(q.site_cat[k][p], -s); // == site_lk_cat / pow(2, sum): exact power-of-two scaling
+      site_lk += x * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
+    }
+    if (site_lk < kSmall) { site_lk = kSmall; raise_warn(q.fin.warn); }
+    const double lsl = log(site_lk);
+    if (q.site_lnl) q.site_lnl[p] = lsl;
+    contrib = q.wght[p] * lsl; // src/mixt.c:1133 (zero-weight patterns contribute 0)
+  }
+  __shared__ double ws[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) ws[wid] = contrib;
+  __syncthreads();
+  if (wid == 0)
+  {
+    double v[1] = {0.0};
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) v[0] += ws[k];
+    finish_sums<1>(q.fin, v, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K5: transition matrices on the device (src/models.c:257-326 behind src/lk.c:2280-2316)
 //     one block per matrix; thread (c,i) builds row i of category c
 // ---------------------------------------------------------------------------------------------

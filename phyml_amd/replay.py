@@ -107,3 +107,40 @@ def tips_from_masks(tip_mask, ns):
         amb.append((cnt != 1).astype(np.int16))
         states.append(np.where(cnt == 1, v.argmax(axis=1), 0).astype(np.int16))
     return vecs, states, amb
+
+
+# ---- mixture models (class trees, src/mixt.c) -------------------------------------------------------------------------
+
+def mixture_classes(d):
+    """Per-class model blocks of a mixture dump (oracle/mixt_driver.c): each class tree is a plain single-category
+    model whose branch lengths are multiplied by the class rate (src/lk.c:2298); returns (list of model dicts, list of
+    coefficient factor tuples (proba, r_mat_weight, e_frq_weight))."""
+    K = int(d["n_classes"][0])
+    models, factors = [], []
+    for k in range(K):
+        g = lambda name: d[f"class{k}_{name}"]
+        rate = float(g("rate")[0]) * float(g("own_gamma_rr")[0])
+        models.append(dict(ns=d["ns"], ncatg=np.array([1.0]), pi=g("pi"), gamma_rr=np.array([rate]), gamma_r_proba=np.array([1.0]),
+                           e_val=g("e_val"), r_e_vect=g("r_e_vect"), l_e_vect=g("l_e_vect"), l_min=g("l_min"), l_max=g("l_max"),
+                           br_len_mult=g("br_len_mult"), invar_model=np.array([0.0]), pinvar=np.array([0.0]), datatype=d["datatype"]))
+        factors.append((float(g("proba")[0]), float(g("r_mat_weight")[0]), float(g("e_frq_weight")[0])))
+    return models, factors
+
+
+def mixture_combine(unscaled, fact, factors, r_sum, e_sum, sum_probas, wght):
+    """The site loop of MIXT_Lk after the per-class Lk_Core calls (src/mixt.c:1027-1135), no +I: class likelihoods are
+    brought to a common scale with 2^-sum (sum capped at 1023, :1027-1034), weighted (:1048-1053, same operation order),
+    floored at DBL_MIN (:1114-1117), logged and accumulated in site order (:1133).  Returns (lnL, per-site log-lk)."""
+    P = len(wght)
+    site_lk = np.zeros(P)
+    for u, f, (proba, rw, ew) in zip(unscaled, fact, factors):
+        s = np.minimum(np.asarray(f, dtype=np.float64), 1024.0)
+        s = np.where(np.asarray(f) > 1024, 1023.0, s)
+        x = np.asarray(u, dtype=np.float64) / np.power(2.0, s)
+        site_lk = site_lk + x * proba * rw / r_sum * ew / e_sum / sum_probas
+    site_lk = np.maximum(site_lk, np.finfo(np.float64).tiny)
+    logs = np.log(site_lk)
+    lnl = 0.0
+    for p in range(P):
+        lnl += wght[p] * logs[p]
+    return lnl, logs

@@ -1,0 +1,51 @@
+"""GPU: the LG4X mixture (src/mixt.c) through the C ABI: four class instances (one category each, own
+rate matrix / frequencies / class rate) + phyhip_calculate_mixture_log_likelihood, against the dump of the REAL
+reference in XML mode (tests/golden/mixture_lg4x.phyg, oracle/mixt_driver.c)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from phyml_amd import capi, lktree, phyg, replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("host_pmat", [True, False])
+def test_lg4x_mixture_on_device(host_pmat):
+    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x.phyg"))
+    models, factors = replay.mixture_classes(d)
+    n, P, S = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0])
+    tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
+    trees = []
+    try:
+        for md in models:
+            t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, 1, host_pmat=host_pmat)
+            t.tip_root = 0  # src/mixt.c:889
+            t.set_model(md["pi"], md["gamma_rr"], md["gamma_r_proba"], md["e_val"], md["r_e_vect"], md["l_e_vect"],
+                        float(md["l_min"][0]), float(md["l_max"][0]), float(md["br_len_mult"][0]), 1, 0, 0.0)
+            t.Make_Tree_For_Lk(d["wght"], None)
+            t.set_tips(tip_partials=tv)
+            t.Lk()  # the class tree's own traversal (MIXT_Post_Order_Lk -> Update_Partial_Lk per class, src/mixt.c:1191-1250)
+            trees.append(t)
+        e = int(d["eval_edge"][0])
+        ids = [t.tree.contents.b_inst for t in trees]
+        parents = [t.side_buffer(e, 0) for t in trees]
+        children = [t.side_buffer(e, 1) for t in trees]
+        mats = [t.edge(e).contents.Pij_rr_idx for t in trees]
+        lnl = capi.mixture_log_likelihood(ids, parents, children, mats, [f[0] for f in factors], [f[1] for f in factors],
+                                          [f[2] for f in factors], float(d["r_mat_weight_sum"][0]),
+                                          float(d["e_frq_weight_sum"][0]), float(d["sum_probas"][0]))
+        ref = float(d["lnL"][0])
+        assert abs(lnl - ref) <= (1e-13 if host_pmat else 1e-11) * abs(ref), (lnl, ref)
+        logs = trees[0].inst.site_log_likelihoods()
+        assert np.max(np.abs(logs - d["c_lnL_sorted"])) < (1e-11 if host_pmat else 1e-9)
+        for k, t in enumerate(trees):  # per-class pieces the combination used
+            _, _, u, f = t.inst.site_outputs()
+            assert np.array_equal(np.asarray(f), d[f"class{k}_fact"])
+            ref_u = d[f"class{k}_unscaled_site_lk_cat"]
+            assert np.max(np.abs(np.asarray(u).reshape(-1) - ref_u) / ref_u) < (1e-13 if host_pmat else 1e-10)
+    finally:
+        for t in trees:
+            t.close()
