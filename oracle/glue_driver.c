@@ -27,7 +27,12 @@
  *   host              every call is forwarded to the reference untouched (no device): the CPU-only run of the same
  *                     command, same output format -- how the expected values of tests/golden/search_expected.json are made
  *
- * usage: phyml_glue_driver [--gtr-rr a,..,f] -- <phyml command line>
+ * Mixtures (XML mode, e.g. examples/lg4x): check mode only.  Every class tree of the mixture (src/mixt.c:2603-2640) gets
+ * its own instance; MIXT_Update_Partial_Lk / MIXT_Update_PMat_At_Given_Edge loop over the class trees and come back
+ * through the wrappers; MIXT_Lk is interposed too and, after the original, repeats the evaluation with
+ * phyhip_calculate_mixture_log_likelihood over the class instances (GLUE_MAX_MIXT=n stops after n comparisons).
+ *
+ * usage: phyml_glue_driver [--gtr-rr a,..,f] -- <phyml command line>      (or: -- --xml=<file>)
  * prints: GLUE_DRIVER {json}   (final lnL, tree, call counts, worst per-call differences in check mode)
  */
 #define _GNU_SOURCE
@@ -37,12 +42,13 @@
 #include "ref_driver.c"
 #undef main
 
+#include "mixt.h"
 #include "../include/phyhip.h"
+#define kMaxClasses 16
 
-static int g_inst = -1, g_check = 0, g_device_pmat = 0, g_host = 0;
-static t_tree *g_tree = NULL;
-static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat = 0, g_n_eig = 0;
-static double  g_worst_lnl = 0.0, g_worst_dlnl = 0.0;
+static int g_check = 0, g_device_pmat = 0, g_host = 0;
+static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat = 0, g_n_eig = 0, g_n_mixt = 0, g_n_mixt_skipped = 0;
+static double  g_worst_lnl = 0.0, g_worst_dlnl = 0.0, g_worst_mixt = 0.0;
 
 static void die(const char *what)
 {
@@ -51,60 +57,84 @@ static void die(const char *what)
 }
 #define OK(call) do { if ((call) < 0) die(#call); } while (0)
 
-/* pointer -> device index tables */
-#define MAXID 8192
-static const void *g_bufptr[MAXID]; static int g_nbuf = 0, g_bufcap = 0;
-static const void *g_matptr[MAXID]; static int g_nmat = 0, g_matcap = 0;
+/* one device instance per tree object that reaches the surface: the tree of an ordinary run, or every class tree of a
+   mixture (src/mixt.c:2603-2640); pointer -> device index tables per instance */
+#define MAXID 2048
+#define MAXCTX 32
+typedef struct
+{
+  t_tree     *tree;
+  int         inst;
+  const void *bufptr[MAXID]; int nbuf, bufcap;
+  const void *matptr[MAXID]; int nmat, matcap;
+} ctx_t;
+static ctx_t g_ctx[MAXCTX];
+static int   g_nctx = 0;
+#define g_inst (g_ctx[0].inst)
+#define g_nbuf (g_ctx[0].nbuf)
+#define g_nmat (g_ctx[0].nmat)
 
-static int buf_id(const t_tree *tree, const void *p_lk)
+static int buf_id(ctx_t *c, const void *p_lk)
 {
-  for (int i = 0; i < g_nbuf; ++i) if (g_bufptr[i] == p_lk) return tree->n_otu + i;
-  if (g_nbuf == g_bufcap) { fprintf(stderr, "glue_driver: more partial buffers than the instance holds\n"); exit(5); }
-  g_bufptr[g_nbuf] = p_lk;
-  return tree->n_otu + g_nbuf++;
+  for (int i = 0; i < c->nbuf; ++i) if (c->bufptr[i] == p_lk) return c->tree->n_otu + i;
+  if (c->nbuf == c->bufcap) { fprintf(stderr, "glue_driver: more partial buffers than the instance holds\n"); exit(5); }
+  c->bufptr[c->nbuf] = p_lk;
+  return c->tree->n_otu + c->nbuf++;
 }
-static int mat_id(const void *pij)
+static int mat_id(ctx_t *c, const void *pij)
 {
-  for (int i = 0; i < g_nmat; ++i) if (g_matptr[i] == pij) return i;
-  if (g_nmat == g_matcap) { fprintf(stderr, "glue_driver: more matrices than the instance holds\n"); exit(5); }
-  g_matptr[g_nmat] = pij;
-  return g_nmat++;
+  for (int i = 0; i < c->nmat; ++i) if (c->matptr[i] == pij) return i;
+  if (c->nmat == c->matcap) { fprintf(stderr, "glue_driver: more matrices than the instance holds\n"); exit(5); }
+  c->matptr[c->nmat] = pij;
+  return c->nmat++;
 }
-static void edge_sides(const t_tree *tree, const t_edge *b, int *left, int *right)
+static void edge_sides(ctx_t *c, const t_edge *b, int *left, int *right)
 { /* src/lk.c:605-606 */
-  *left  = buf_id(tree, b->p_lk_left);
-  *right = b->rght->tax ? b->rght->num : buf_id(tree, b->p_lk_rght);
+  *left  = buf_id(c, b->p_lk_left);
+  *right = b->rght->tax ? b->rght->num : buf_id(c, b->p_lk_rght);
 }
 
-static void push_model(t_tree *tree)
+static void push_model(ctx_t *c)
 { /* update_beagle_ras / _efrqs / _eigen, src/beagle_utils.c:273-395 */
-  t_mod *m = tree->mod;
-  OK(phyhip_set_category_rates(g_inst, m->ras->gamma_rr->v));
-  OK(phyhip_set_category_weights(g_inst, 0, m->ras->gamma_r_proba->v));
-  OK(phyhip_set_state_frequencies(g_inst, 0, m->e_frq->pi->v));
-  OK(phyhip_set_eigen_decomposition(g_inst, 0, m->eigen->r_e_vect, m->eigen->l_e_vect, m->eigen->e_val));
-  OK(phyhip_set_phyml_options(g_inst, m->l_min, m->l_max, m->br_len_mult->v, tree->apply_lk_scaling));
-  OK(phyhip_set_invariant_sites(g_inst, m->ras->invar, m->ras->pinvar->v, tree->data->invar));
+  t_tree *tree = c->tree;
+  t_mod  *m = tree->mod;
+  if (tree->mixt_tree)
+  { /* class tree: one category whose rate is the class rate of the mixture (src/lk.c:2298) */
+    const double rate = m->ras->gamma_rr->v[0] * tree->mixt_tree->mod->ras->gamma_rr->v[m->ras->parent_class_number], one = 1.0;
+    OK(phyhip_set_category_rates(c->inst, &rate));
+    OK(phyhip_set_category_weights(c->inst, 0, &one));
+  }
+  else
+  {
+    OK(phyhip_set_category_rates(c->inst, m->ras->gamma_rr->v));
+    OK(phyhip_set_category_weights(c->inst, 0, m->ras->gamma_r_proba->v));
+  }
+  OK(phyhip_set_state_frequencies(c->inst, 0, m->e_frq->pi->v));
+  OK(phyhip_set_eigen_decomposition(c->inst, 0, m->eigen->r_e_vect, m->eigen->l_e_vect, m->eigen->e_val));
+  OK(phyhip_set_phyml_options(c->inst, m->l_min, m->l_max, m->br_len_mult->v, tree->apply_lk_scaling));
+  OK(phyhip_set_invariant_sites(c->inst, m->ras->invar, m->ras->pinvar->v, tree->data->invar));
 }
 
-static void ensure_instance(t_tree *tree)
+static ctx_t *ensure_instance(t_tree *tree)
 { /* create_beagle_instance, src/beagle_utils.c:97-190: after Make_Tree_For_Lk (src/main.c:235) */
-  if (g_inst >= 0)
-  {
-    if (tree != g_tree) { fprintf(stderr, "glue_driver: a second tree object reached the likelihood surface\n"); exit(5); }
-    return;
-  }
+  for (int i = 0; i < g_nctx; ++i) if (g_ctx[i].tree == tree) return &g_ctx[i];
   if (tree->is_mixt_tree || tree->n_root || tree->mod->gamma_mgf_bl == YES || tree->mod->log_l == YES || tree->mod->use_m4mod)
-  { fprintf(stderr, "glue_driver: unsupported tree kind (mixture / rooted / mgf / log_l / m4)\n"); exit(5); }
+  { fprintf(stderr, "glue_driver: unsupported tree kind (rooted / mgf / log_l / m4, or the mixture tree itself)\n"); exit(5); }
+  if (!tree->mixt_tree && g_nctx > 0) { fprintf(stderr, "glue_driver: a second ordinary tree object reached the likelihood surface\n"); exit(5); }
+  if (g_nctx == MAXCTX) { fprintf(stderr, "glue_driver: too many class trees\n"); exit(5); }
+  ctx_t *c = &g_ctx[g_nctx++];
+  memset(c, 0, sizeof *c);
   const int n = tree->n_otu, P = tree->data->n_pattern, S = tree->mod->ns, C = tree->mod->ras->n_catg;
-  g_bufcap = 3 * n - 2;  /* internal edge sides + both sides of the two spare SPR edges (src/make.c:96-104) */
-  g_matcap = 2 * n - 1;
-  g_inst = phyhip_create_instance(n, n + g_bufcap, 0, S, P, 1, g_matcap, C, 0, NULL, 0, 0, 0, NULL);
-  if (g_inst < 0) die("phyhip_create_instance");
-  g_tree = tree;
-  OK(phyhip_set_pattern_weights(g_inst, tree->data->wght));
-  for (int t = 0; t < n; ++t) OK(phyhip_set_tip_partials(g_inst, tree->a_nodes[t]->num, tree->a_nodes[t]->b[0]->p_lk_tip_r));
-  push_model(tree);
+  c->tree = tree;
+  c->bufcap = 3 * n - 2;  /* internal edge sides + both sides of the two spare SPR edges (src/make.c:96-104) */
+  c->matcap = 2 * n - 1;
+  if (c->bufcap > MAXID || c->matcap > MAXID) { fprintf(stderr, "glue_driver: tree too large for the index tables\n"); exit(5); }
+  c->inst = phyhip_create_instance(n, n + c->bufcap, 0, S, P, 1, c->matcap, C, 0, NULL, 0, 0, 0, NULL);
+  if (c->inst < 0) die("phyhip_create_instance");
+  OK(phyhip_set_pattern_weights(c->inst, tree->data->wght));
+  for (int t = 0; t < n; ++t) OK(phyhip_set_tip_partials(c->inst, tree->a_nodes[t]->num, tree->a_nodes[t]->b[0]->p_lk_tip_r));
+  push_model(c);
+  return c;
 }
 
 static void track(double *worst, double dev, double ref, double floor_)
@@ -120,18 +150,18 @@ void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
   static void (*real)(t_edge *, t_tree *) = NULL;
   if (!real) real = (void (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "Update_PMat_At_Given_Edge");
   ++g_n_pmat;
-  if (g_host) { real(b_fcus, tree); return; }
-  ensure_instance(tree);
+  if (g_host || tree->is_mixt_tree) { real(b_fcus, tree); return; } /* mixture tree: the original loops over the class trees */
+  ctx_t *c = ensure_instance(tree);
   if (b_fcus->has_zero_br_len == YES) { fprintf(stderr, "glue_driver: zero-length edge flag not supported\n"); exit(5); }
-  const int m = mat_id(b_fcus->Pij_rr);
+  const int m = mat_id(c, b_fcus->Pij_rr);
   if (g_device_pmat && !g_check)
   { /* src/lk.c:2344: matrices built on the device from (U, lambda, U^-1, length) */
     const double len = b_fcus->l->v;
-    OK(phyhip_update_transition_matrices(g_inst, 0, &m, NULL, NULL, &len, 1));
+    OK(phyhip_update_transition_matrices(c->inst, 0, &m, NULL, NULL, &len, 1));
     return;
   }
   real(b_fcus, tree); /* host PMat (src/models.c:257-373) into b->Pij_rr ... */
-  OK(phyhip_set_transition_matrix(g_inst, m, b_fcus->Pij_rr, -1.0)); /* ... and the upload of src/lk.c:2360 */
+  OK(phyhip_set_transition_matrix(c->inst, m, b_fcus->Pij_rr, -1.0)); /* ... and the upload of src/lk.c:2360 */
 }
 
 void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
@@ -141,23 +171,24 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   /* src/lk.c:1285-1297 */
   if (b->left == d && b->update_partial_lk_left == NO) return;
   if (b->rght == d && b->update_partial_lk_rght == NO) return;
+  if (tree->is_mixt_tree) { real(tree, b, d); return; } /* MIXT_Update_Partial_Lk: per class tree, back through this wrapper */
   if (d->tax) return;
   ++g_n_upd;
   if (g_host) { real(tree, b, d); return; }
-  ensure_instance(tree);
+  ctx_t *c = ensure_instance(tree);
   t_node *n_v1 = NULL, *n_v2 = NULL;
   phydbl *p_lk = NULL, *p_lk_v1 = NULL, *p_lk_v2 = NULL, *Pij1 = NULL, *Pij2 = NULL, *tPij1 = NULL, *tPij2 = NULL;
   int    *sum_scale = NULL, *sum_scale_v1 = NULL, *sum_scale_v2 = NULL, *p_lk_loc = NULL;
   Set_All_Partial_Lk(&n_v1, &n_v2, &p_lk, &sum_scale, &p_lk_loc, &Pij1, &tPij1, &p_lk_v1, &sum_scale_v1, &Pij2, &tPij2,
                      &p_lk_v2, &sum_scale_v2, d, b, tree);
   phyhip_operation op;
-  op.destinationPartials = buf_id(tree, p_lk);
+  op.destinationPartials = buf_id(c, p_lk);
   op.destinationScaleWrite = op.destinationScaleRead = PHYHIP_OP_NONE;
-  op.child1Partials = n_v1->tax ? n_v1->num : buf_id(tree, p_lk_v1);
-  op.child1TransitionMatrix = mat_id(Pij1);
-  op.child2Partials = n_v2->tax ? n_v2->num : buf_id(tree, p_lk_v2);
-  op.child2TransitionMatrix = mat_id(Pij2);
-  OK(phyhip_update_partials(g_inst, &op, 1, PHYHIP_OP_NONE));
+  op.child1Partials = n_v1->tax ? n_v1->num : buf_id(c, p_lk_v1);
+  op.child1TransitionMatrix = mat_id(c, Pij1);
+  op.child2Partials = n_v2->tax ? n_v2->num : buf_id(c, p_lk_v2);
+  op.child2TransitionMatrix = mat_id(c, Pij2);
+  OK(phyhip_update_partials(c->inst, &op, 1, PHYHIP_OP_NONE));
   if (g_check) real(tree, b, d);
 }
 
@@ -166,25 +197,78 @@ void Update_Eigen_Lr(t_edge *b, t_tree *tree)
   static void (*real)(t_edge *, t_tree *) = NULL;
   if (!real) real = (void (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "Update_Eigen_Lr");
   ++g_n_eig;
-  if (g_host) { real(b, tree); return; }
-  ensure_instance(tree);
+  if (g_host || tree->is_mixt_tree) { real(b, tree); return; }
+  ctx_t *c = ensure_instance(tree);
   int l, r;
-  edge_sides(tree, b, &l, &r);
-  OK(phyhip_update_eigen_lr(g_inst, l, r));
+  edge_sides(c, b, &l, &r);
+  OK(phyhip_update_eigen_lr(c->inst, l, r));
   if (g_check) real(b, tree);
 }
 
 static double device_edge_value(t_tree *tree, const t_edge *b)
 {
+  ctx_t *c = ensure_instance(tree);
   double lnl = 0.0;
-  if (tree->use_eigen_lr == YES) OK(phyhip_calculate_eigen_lnl(g_inst, b->l->v, &lnl)); /* src/lk.c:592-603 */
+  if (tree->use_eigen_lr == YES) OK(phyhip_calculate_eigen_lnl(c->inst, b->l->v, &lnl)); /* src/lk.c:592-603 */
   else
   {
-    int l, r, pm = mat_id(b->Pij_rr), zero = 0;
-    edge_sides(tree, b, &l, &r);
-    OK(phyhip_calculate_edge_log_likelihoods(g_inst, &l, &r, &pm, NULL, NULL, &zero, &zero, NULL, 1, &lnl, NULL, NULL));
+    int l, r, pm = mat_id(c, b->Pij_rr), zero = 0;
+    edge_sides(c, b, &l, &r);
+    OK(phyhip_calculate_edge_log_likelihoods(c->inst, &l, &r, &pm, NULL, NULL, &zero, &zero, NULL, 1, &lnl, NULL, NULL));
   }
   return lnl;
+}
+
+static double g_t0 = 0.0;
+static long   g_max_mixt = 0; /* GLUE_MAX_MIXT: stop after this many compared MIXT_Lk calls (bounded test runs) */
+static void report_xml_and_exit(void)
+{
+  printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"xml\": 1, \"seconds\": %.3f, \"calls\": {\"Lk\": %ld, \"MIXT_Lk\": %ld, \"MIXT_Lk_skipped\": %ld, "
+         "\"Update_Partial_Lk\": %ld, \"Update_PMat\": %ld, \"Update_Eigen_Lr\": %ld, \"dLk\": %ld}, \"class_instances\": %d, "
+         "\"worst_rel_mixture_lnL\": %.3g}\n",
+         g_host ? "host" : "check", now_s() - g_t0, g_n_lk, g_n_mixt, g_n_mixt_skipped, g_n_upd, g_n_pmat, g_n_eig, g_n_dlk, g_nctx,
+         g_worst_mixt);
+  fflush(stdout);
+  _exit(0);
+}
+
+/* MIXT_Lk (src/mixt.c:730-1160), check mode: the original runs (its per-class matrix refreshes and partial updates reach
+   the class instances through the wrappers above), then the device repeats the evaluation of the same edge over the
+   class instances and the two results are compared. */
+phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
+{
+  static phydbl (*real)(t_edge *, t_tree *) = NULL;
+  if (!real) real = (phydbl (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "MIXT_Lk");
+  const phydbl ref = real(mixt_b, mixt_tree);
+  if (g_host) return ref;
+  if (!g_check) { fprintf(stderr, "glue_driver: mixtures run in check mode only (GLUE_MODE=check)\n"); exit(5); }
+  ++g_n_mixt;
+  if (mixt_tree->n_root || mixt_tree->next_mixt || mixt_tree->mod->ras->invar == YES || mixt_tree->next->use_eigen_lr == YES)
+  { ++g_n_mixt_skipped; return ref; } /* eigen-basis evaluations, partitions and +I mixtures: not on the device yet */
+  t_edge *e = mixt_b ? mixt_b : mixt_tree->a_nodes[0]->b[0]; /* src/mixt.c:889 */
+  int    ids[kMaxClasses], par[kMaxClasses], chi[kMaxClasses], pms[kMaxClasses], K = 0;
+  double proba[kMaxClasses], rw[kMaxClasses], ew[kMaxClasses];
+  t_edge *b = e->next;
+  for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
+  {
+    if (K == kMaxClasses || t->mod->ras->invar == YES) { ++g_n_mixt_skipped; return ref; }
+    ctx_t *c = ensure_instance(t);
+    push_model(c);
+    ids[K] = c->inst;
+    edge_sides(c, b, &par[K], &chi[K]);
+    pms[K] = mat_id(c, b->Pij_rr);
+    proba[K] = mixt_tree->mod->ras->gamma_r_proba->v[t->mod->ras->parent_class_number];
+    rw[K] = t->mod->r_mat_weight->v; ew[K] = t->mod->e_frq_weight->v;
+    ++K;
+  }
+  const double r_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->r_mat_weight);
+  const double e_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->e_frq_weight);
+  const double sum_p = MIXT_Get_Sum_Of_Probas_Across_Mixtures(r_sum, e_sum, mixt_tree);
+  double lnl = 0.0;
+  OK(phyhip_calculate_mixture_log_likelihood(ids, K, par, chi, pms, proba, rw, ew, r_sum, e_sum, sum_p, &lnl));
+  track(&g_worst_mixt, lnl, ref, 1.0);
+  if (g_max_mixt && g_n_mixt - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
+  return ref;
 }
 
 phydbl Lk(t_edge *b, t_tree *tree)
@@ -193,12 +277,12 @@ phydbl Lk(t_edge *b, t_tree *tree)
   if (!real) real = (phydbl (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "Lk");
   ++g_n_lk;
   if (!b) ++g_n_lk_full;
-  if (g_host) return real(b, tree);
+  if (g_host || tree->is_mixt_tree) return real(b, tree); /* mixture: src/lk.c:465-472 diverts to MIXT_Lk (above) */
+  if (tree->mixt_tree && !g_check) { fprintf(stderr, "glue_driver: mixtures run in check mode only\n"); exit(5); }
   if (g_check)
   {
     const phydbl ref = real(b, tree); /* drives the device through the nested surface calls as well */
-    ensure_instance(tree);
-    if (!b) push_model(tree);
+    if (!b) push_model(ensure_instance(tree));
     const t_edge *e = b ? b : tree->a_nodes[tree->tip_root]->b[0];
     track(&g_worst_lnl, device_edge_value(tree, e), ref, 1.0);
     return ref;
@@ -212,8 +296,7 @@ phydbl Lk(t_edge *b, t_tree *tree)
     Update_Efrq(tree->mod);
     Update_Eigen(tree->mod);
   }
-  ensure_instance(tree);
-  if (!b) push_model(tree);
+  if (!b) push_model(ensure_instance(tree));
   if (tree->mod->s_opt->skip_tree_traversal == NO)
   {
     if (!b)
@@ -231,7 +314,7 @@ phydbl Lk(t_edge *b, t_tree *tree)
   tree->c_lnL = device_edge_value(tree, b);
   {
     int w = 0;
-    OK(phyhip_get_numerical_warning(g_inst, &w));
+    OK(phyhip_get_numerical_warning(ensure_instance(tree)->inst, &w));
     if (w) tree->numerical_warning = YES;
   }
   return tree->c_lnL;
@@ -242,13 +325,13 @@ phydbl dLk(phydbl *l, t_edge *b, t_tree *tree)
   static phydbl (*real)(phydbl *, t_edge *, t_tree *) = NULL;
   if (!real) real = (phydbl (*)(phydbl *, t_edge *, t_tree *))dlsym(RTLD_NEXT, "dLk");
   ++g_n_dlk;
-  if (g_host) return real(l, b, tree);
-  ensure_instance(tree);
+  if (g_host || tree->is_mixt_tree || tree->mixt_tree) return real(l, b, tree); /* MIXT_dLk stays on the host (check mode) */
+  ctx_t *c = ensure_instance(tree);
   if (g_check)
   {
     double x = *l, lnl = 0.0, dlnl = 0.0;
     const phydbl ref = real(l, b, tree); /* its Update_Eigen_Lr (if any) reaches the device through the wrapper */
-    OK(phyhip_calculate_eigen_lnl_dlnl(g_inst, &x, &lnl, &dlnl));
+    OK(phyhip_calculate_eigen_lnl_dlnl(c->inst, &x, &lnl, &dlnl));
     track(&g_worst_lnl, lnl, ref, 1.0);
     track(&g_worst_dlnl, dlnl, tree->c_dlnL, 1.0);
     return ref;
@@ -257,7 +340,7 @@ phydbl dLk(phydbl *l, t_edge *b, t_tree *tree)
   tree->numerical_warning = NO;
   if (tree->update_eigen_lr == YES) Update_Eigen_Lr(b, tree);
   double lnl = 0.0, dlnl = 0.0;
-  OK(phyhip_calculate_eigen_lnl_dlnl(g_inst, l, &lnl, &dlnl)); /* clamps *l like src/lk.c:672-673 */
+  OK(phyhip_calculate_eigen_lnl_dlnl(c->inst, l, &lnl, &dlnl)); /* clamps *l like src/lk.c:672-673 */
   tree->c_dlnL = dlnl;
   tree->c_lnL  = lnl;
   return tree->c_lnL;
@@ -292,6 +375,14 @@ int main(int argc, char **argv)
   g_device_pmat = getenv("GLUE_DEVICE_PMAT") && atoi(getenv("GLUE_DEVICE_PMAT"));
 
   const double t0 = now_s();
+  g_t0 = t0;
+  if (getenv("GLUE_MAX_MIXT")) g_max_mixt = atol(getenv("GLUE_MAX_MIXT"));
+  for (int k = 1; k < pargc; ++k)
+    if (!strncmp(pargv[k], "--xml", 5))
+    { /* XML mode (mixtures): the whole analysis runs inside Get_Input (src/cl.c:335, src/io.c:5033) */
+      Get_Input(pargc, pargv);
+      report_xml_and_exit();
+    }
   t_tree *tree = setup_tree(pargc, pargv, &o); /* src/main.c:73-258, first Lk(NULL) included */
   const double lnl_init = tree->c_lnL;
   /* src/main.c:262-275 */
@@ -309,6 +400,6 @@ int main(int argc, char **argv)
          g_host ? "host" : (g_check ? "check" : "device"), g_device_pmat, lnl_init, tree->c_lnL, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
          g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, nwk ? nwk : "");
   fflush(stdout);
-  if (g_inst >= 0) OK(phyhip_finalize_instance(g_inst));
+  for (int k = 0; k < g_nctx; ++k) OK(phyhip_finalize_instance(g_ctx[k].inst));
   _exit(0);
 }
