@@ -486,7 +486,31 @@ int flush(Instance *I, const EdgeEval *ee)
     {
       if (I->soa)
       { // lane-per-pattern kernel, instantiated on the exact category count
-#define NT2CASE(c_, g_) hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes); return 0;
+        if ((I->ablate & 8) && I->C == 4 && I->nt_groups <= 2)
+        { // PHYHIP_ABLATE=8: cycle stamps of one wave, printed to stderr (diagnostics; costs a sync)
+          static unsigned long long *d_dbg = nullptr;
+          if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
+          if (I->nt_groups == 2)
+            hipLaunchKernelGGL((traverse_nt2_kernel<4, 2, true>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes, d_dbg);
+          else
+            hipLaunchKernelGGL((traverse_nt2_kernel<4, 1, true>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes, d_dbg);
+          static int printed = 0;
+          if (printed++ == 5)
+          {
+            unsigned long long h[64 * 8];
+            HIPCHK(hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, I->stream));
+            HIPCHK(hipStreamSynchronize(I->stream));
+            for (int k = 0; k < 64 && k < q.n_ops; ++k)
+            {
+              fprintf(stderr, "step %2d:", k);
+              for (int i = 1; i < 7; ++i) fprintf(stderr, " %6lld", (long long)(h[k * 8 + i] - h[k * 8 + i - 1]));
+              if (k + 1 < 64) fprintf(stderr, "  | next %6lld", (long long)(h[(k + 1) * 8] - h[k * 8 + 6]));
+              fprintf(stderr, "\n");
+            }
+          }
+          return 0;
+        }
+#define NT2CASE(c_, g_) hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes, (unsigned long long *)nullptr); return 0;
         switch (I->C * 8 + I->nt_groups)
         {
           case 1 * 8 + 1: NT2CASE(1, 1)

@@ -35,12 +35,22 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // arithmetic and half the registers, two or three per SIMD.  The only cross-lane traffic is one 32-bit exchange per
 // operation (the rescaling maximum) and the category mixture of the edge evaluation.  G = 1 stays the choice for
 // large alignments, where the kernel is HBM-bound and fewer, fatter waves issue fewer instructions per pattern.
-template <int C, int G = 1>
+template <int C, int G = 1, bool DBG = false>
 __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec,
                                                              const double *__restrict__ pmats,
-                                                             const uint8_t *__restrict__ tip_codes)
+                                                             const uint8_t *__restrict__ tip_codes,
+                                                             unsigned long long *dbg = nullptr)
 {
+  // DBG: cycle stamps of the first 64 steps of one wave (PHYHIP_ABLATE=8), kept in LDS until the end
+  __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
+  const bool stamper = DBG && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+#define PHY_STAMP(k_, i_)                                                                                              \
+  if (DBG)                                                                                                             \
+  {                                                                                                                    \
+    const unsigned long long t_ = __builtin_readcyclecounter();                                                        \
+    if (stamper && (k_) < 64) stamps[(k_) * 8 + (i_)] = t_;                                                            \
+  }
   static_assert(C % G == 0 && 64 % G == 0, "category groups must divide the categories and the wave");
   constexpr int S = 4, CL = C / G, CS = CL * S, PW = 64 / G; // categories per lane, entries per lane, patterns per wave
   __shared__ __attribute__((aligned(16))) double lds_p[2][2 * C * 16]; // [buffer][matrix][c][i][j]
@@ -152,6 +162,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     // on entry and the result of k on exit.
     auto step = [&](const int k, const int parity, Raw &R, u32x4 &PC, double (&Fout)[CS], unsigned &scout,
                     const double (&Fprev)[CS], const unsigned scprev) {
+      PHY_STAMP(k, 0)
       double2 *buf = reinterpret_cast<double2 *>(&lds_p[parity][0]);
       {
         double2 v;
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       else if (fl & kOpF11) { matvec_x(buf, Fprev, u1); s1 = scprev; one1 = (Fprev[0] == 1.0); }
       else if (fl & kOpF12) { matvec_x(buf, Fout, u1); s1 = scout; one1 = (Fout[0] == 1.0); }
       else { matvec_r(buf, R.a, u1); s1 = R.sa; one1 = (as_d(R.a[0]) == 1.0); }
+      PHY_STAMP(k, 1)
       // ---- child 2 ----
       if (fl & kOpTip2)
       {
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       else if (fl & kOpF22) { matvec_x(buf + C * 8, Fout, u2); s2 = scout; one2 = (Fout[0] == 1.0); }
       else { matvec_r(buf + C * 8, R.b, u2); s2 = R.sb; one2 = (as_d(R.b[0]) == 1.0); }
 
+      PHY_STAMP(k, 2)
       // all-ones shortcut (src/avx.c:575-587): a category whose eight child entries are exactly 1.0 yields 1.0.
       // Only fully ambiguous subtrees get here; the full test runs when some lane passes the first-entry test.
       unsigned ones_mask = 0; // bit c: category c is all ones in both children
@@ -213,11 +226,13 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
         }
       }
 
+      PHY_STAMP(k, 3)
       // prefetch operation k+2 into the registers just freed; then the scalar records of the next step
       issue(nx2, R, PC);
       const IssueRec nx3 = irec[(k + 3 < last) ? k + 3 : last];
       const ExecRec  nx1 = xrec[(k + 1 < last) ? k + 1 : last];
       __builtin_amdgcn_wave_barrier();
+      PHY_STAMP(k, 4)
 
       unsigned mxh = 0;
 #pragma unroll
@@ -240,6 +255,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
         sc += kLarge;
       }
       scout = sc;
+      PHY_STAMP(k, 5)
       {
         const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
 #pragma unroll
@@ -251,6 +267,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
         }
         __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff4, 0, 0);
       }
+      PHY_STAMP(k, 6)
       cur = nx1;
       nx2 = nx3;
     };
@@ -262,6 +279,9 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     }
   }
 
+  if (DBG && stamper && dbg)
+    for (int i = 0; i < 64 * 8; ++i) dbg[i] = stamps[i];
+#undef PHY_STAMP
   if (!q.edge_eval) return;
 
   // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861), all lane-local ----------
