@@ -76,6 +76,26 @@ def main():
                               lnL_final=info["lnL_final"], tree=info["tree"], calls=info["calls"], cpu_seconds=info["seconds"])
         print(f"{name:22s} lnL {info['lnL_init']:.6f} -> {info['lnL_final']:.6f}  {info['calls']}  {info['seconds']:.1f} s (1 core, this container)")
     json.dump(expected, open(os.path.join(HERE, "search_expected.json"), "w"), indent=1, sort_keys=True)
+
+    # --- mixture golden vector: the first MIXT_Lk of the LG4X example with every optimisation switched off ----------
+    mixt = os.path.join(ROOT, "oracle", "_ref", "phyml_mixt_driver")
+    os.makedirs(os.path.join(tmp, "examples", "lg4x"), exist_ok=True); os.makedirs(os.path.join(tmp, "run"), exist_ok=True)
+    for f in ("X1.mat", "X2.mat", "X3.mat", "X4.mat"):
+        shutil.copy(os.path.join(REF, "examples", "lg4x", f), os.path.join(HERE, "lg4x", f))
+        os.chmod(os.path.join(HERE, "lg4x", f), 0o644)
+        shutil.copy(os.path.join(HERE, "lg4x", f), os.path.join(tmp, "examples", "lg4x", f))
+    shutil.copy(os.path.join(REF, "examples", "proteic"), os.path.join(tmp, "examples", "proteic"))
+    xml = open(os.path.join(HERE, "lg4x", "lg4x_check.xml")).read()
+    xml = xml.replace('optimise.freerates="yes"', 'optimise.freerates="no"').replace('optimise.lens="yes"', 'optimise.lens="no"')
+    open(os.path.join(tmp, "examples", "lg4x", "fixed.xml"), "w").write(xml)
+    out = os.path.join(HERE, "mixture_lg4x.phyg")
+    r = subprocess.run([mixt, out, "0", "--", "--xml=../examples/lg4x/fixed.xml"], cwd=os.path.join(tmp, "run"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    m = re.search(r"MIXT_DRIVER .*", r.stdout)
+    if r.returncode != 0 or not m:
+        print(r.stdout[-3000:])
+        raise SystemExit("mixture driver failed")
+    print(f"{'mixture_lg4x':22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
     shutil.rmtree(tmp, ignore_errors=True)
 
 
