@@ -104,6 +104,11 @@ void Free_Tree_Lk(t_tree *tree);
 /* tip data: 0/1 tip vector [pattern][state] (a_nodes[i]->b[0]->p_lk_tip_r) or compact states */
 void Init_Partial_Lk_Tips_Double_One_Tip(t_tree *tree, int tax_id, const phydbl *p_lk_tip);
 void Init_Partial_Lk_Tips_States_One_Tip(t_tree *tree, int tax_id, const int *states);
+/* character encoders (src/lk.c:26-69, 122-161): one alignment character -> ns 0/1 entries at p_lk[pos..]; and a whole
+   compressed sequence (n_pattern characters) of one taxon, encoded and uploaded (src/lk.c:2060-2118) */
+void Init_Tips_At_One_Site_Nucleotides_Float(char state, int pos, phydbl *p_lk);
+void Init_Tips_At_One_Site_AA_Float(char aa, int pos, phydbl *p_lk);
+void Init_Partial_Lk_Tips_Chars_One_Tip(t_tree *tree, int tax_id, const char *seq);
 /* push model changes: update_beagle_ras / _efrqs / _eigen of the seam (src/beagle_utils.c:273-395) */
 void Update_Model_On_Device(t_tree *tree);
 

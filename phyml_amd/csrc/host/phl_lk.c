@@ -225,6 +225,62 @@ void Init_Partial_Lk_Tips_States_One_Tip(t_tree *tree, int tax_id, const int *st
   CHK(phyhip_set_tip_states(tree->b_inst, tax_id, states));
 }
 
+/* ---- a14: character -> 0/1 tip vector (src/lk.c:26-69 nucleotides, :122-161 amino acids) ---------------------- */
+/* Allowed-state sets as bit masks, one table per alphabet, built on first use.  Nucleotides: IUPAC codes, U = T,
+   N X ? O - = any state.  Amino acids: the 20 letters in PhyML's order ARNDCQEGHILKMFPSTWYV; the reference resolves
+   B to asparagine and Z to glutamine (src/lk.c:149-150) rather than to two-state sets; X ? - = any state. */
+static unsigned g_nt_mask[256], g_aa_mask[256];
+static int      g_tip_tables_ready = 0;
+static void build_tip_tables(void)
+{
+  static const struct { char c; unsigned m; } nt[] = {
+      {'A', 1}, {'C', 2}, {'G', 4}, {'T', 8}, {'U', 8}, {'M', 1 | 2}, {'R', 1 | 4}, {'W', 1 | 8}, {'S', 2 | 4}, {'Y', 2 | 8},
+      {'K', 4 | 8}, {'B', 2 | 4 | 8}, {'D', 1 | 4 | 8}, {'H', 1 | 2 | 8}, {'V', 1 | 2 | 4}, {'N', 15}, {'X', 15}, {'?', 15},
+      {'O', 15}, {'-', 15}};
+  static const char aa_order[] = "ARNDCQEGHILKMFPSTWYV";
+  for (int i = 0; i < 256; ++i) g_nt_mask[i] = g_aa_mask[i] = 0u;
+  for (unsigned i = 0; i < sizeof nt / sizeof nt[0]; ++i) g_nt_mask[(unsigned char)nt[i].c] = nt[i].m;
+  for (int i = 0; i < 20; ++i) g_aa_mask[(unsigned char)aa_order[i]] = 1u << i;
+  g_aa_mask[(unsigned char)'B'] = 1u << 2;
+  g_aa_mask[(unsigned char)'Z'] = 1u << 5;
+  g_aa_mask[(unsigned char)'X'] = g_aa_mask[(unsigned char)'?'] = g_aa_mask[(unsigned char)'-'] = (1u << 20) - 1u;
+  g_tip_tables_ready = 1;
+}
+static void tip_vector(const unsigned *table, int ns, char state, int pos, phydbl *p_lk, const char *who)
+{
+  if (!g_tip_tables_ready) build_tip_tables();
+  const unsigned m = table[(unsigned char)state];
+  if (!m)
+  {
+    char msg[96];
+    snprintf(msg, sizeof msg, "unknown character state '%c' at position %d", state, pos);
+    Lk_Exit(who, msg);
+    return;
+  }
+  for (int s = 0; s < ns; ++s) p_lk[pos + s] = ((m >> s) & 1u) ? 1.0 : 0.0;
+}
+void Init_Tips_At_One_Site_Nucleotides_Float(char state, int pos, phydbl *p_lk)
+{
+  tip_vector(g_nt_mask, 4, state, pos, p_lk, "Init_Tips_At_One_Site_Nucleotides_Float");
+}
+void Init_Tips_At_One_Site_AA_Float(char aa, int pos, phydbl *p_lk)
+{
+  tip_vector(g_aa_mask, 20, aa, pos, p_lk, "Init_Tips_At_One_Site_AA_Float");
+}
+void Init_Partial_Lk_Tips_Chars_One_Tip(t_tree *tree, int tax_id, const char *seq)
+{ /* the per-tip loop of Init_Partial_Lk_Tips_Double (src/lk.c:2060-2118) + the upload */
+  const int ns = tree->mod->ns, P = tree->n_pattern;
+  if (ns != 4 && ns != 20) { Lk_Exit("Init_Partial_Lk_Tips_Chars_One_Tip", "4 or 20 states"); return; }
+  phydbl *v = (phydbl *)malloc(sizeof(phydbl) * (size_t)P * ns);
+  for (int p = 0; p < P; ++p)
+  {
+    if (ns == 4) Init_Tips_At_One_Site_Nucleotides_Float(seq[p], p * ns, v);
+    else Init_Tips_At_One_Site_AA_Float(seq[p], p * ns, v);
+  }
+  Init_Partial_Lk_Tips_Double_One_Tip(tree, tax_id, v);
+  free(v);
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* a12: transition matrices                                                                           */
 /* ------------------------------------------------------------------------------------------------ */

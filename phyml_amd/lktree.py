@@ -137,9 +137,12 @@ class LkTree:
         self._made = True
         self.inst = _InstanceView(self.tree.contents.b_inst, self)
 
-    def set_tips(self, tip_partials=None, tip_states=None):
+    def set_tips(self, tip_partials=None, tip_states=None, tip_chars=None):
         for t in range(self.n):
-            if tip_partials is not None:
+            if tip_chars is not None:  # compressed sequences as characters: the host layer's own encoders (src/lk.c:26-161)
+                seq = bytes(np.ascontiguousarray(tip_chars[t], dtype=np.uint8)); assert len(seq) == self.P
+                self.L.Init_Partial_Lk_Tips_Chars_One_Tip(self.tree, t, C.c_char_p(seq))
+            elif tip_partials is not None:
                 a = np.ascontiguousarray(tip_partials[t], dtype=np.float64); assert a.size == self.P * self.S
                 self.L.Init_Partial_Lk_Tips_Double_One_Tip(self.tree, t, _dp(a))
             else:

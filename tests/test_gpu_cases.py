@@ -7,6 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import orc
+import gpu_common
 from gpu_common import synthetic_pair
 from phyml_amd import capi, lktree, synth, workloads
 
@@ -168,3 +169,17 @@ def test_baseline_configs_full_size(name, tol):
         assert abs((a.Lk(None) + b.Lk(None)) - lnl) / abs(lnl) < 1e-12     # what the multi-GPU all-reduce relies on
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", ["nucleic_gtr_g4", "proteic_lg_g4"])
+def test_tips_from_characters(name, golden):
+    """Tips encoded by the host layer's character encoders (a14) give the reference's lnL on its own example alignments
+    (IUPAC ambiguity, gaps)."""
+    d = golden(name)
+    t, ot = gpu_common.device_tree_from_golden(d)
+    try:
+        t.set_tips(tip_chars=d["tip_chars"])
+        lnl = t.Lk()
+        assert abs(lnl - float(d["lnL"][0])) <= 1e-12 * abs(lnl)
+    finally:
+        t.close()
