@@ -42,9 +42,6 @@ namespace phyhip
 
 typedef double       v4d __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#ifndef PHY_AA_EARLY
-#define PHY_AA_EARLY 0
-#endif
 constexpr int kAaT     = 5;   // k-chunks of 4 states
 constexpr int kAaBlock = 320; // doubles per (tile, category) block, and per half (rows 0..15 | 16..19) of an A table
 
@@ -298,9 +295,6 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
       double         x1[T], x2[T], u1[T], u2[T], o[T];
       unsigned       s1, s2;
       PHY_STAMP(k, 0)
-#if PHY_AA_EARLY
-      issue_children(nx1, Rn);
-#endif
       if (fl & kOpTip1) { tip_vec(R.ca, x1); s1 = 0; }
       else if (fl & kOpF11)
       {
@@ -331,7 +325,8 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
         // Matrix-core phase.  The ten 16x16x4 MFMAs occupy the pipe for 64 cycles each; the ten vector-memory
         // instructions of operation k+1 (children, scale words, tip bytes -> the other raw set) are slotted one
         // per MFMA so that their issue cost disappears behind the matrix cores (sched_group_barrier pins the
-        // interleave).  The A fragments of operation k+1 follow the last MFMA that reads this operation's, into
+        // interleave).  Measured alternatives, both slower at 10 000 patterns: all of them before the operand
+        // select (628 vs 589 us), all of them after the MFMA chain (627 vs 576 us).  The A fragments of operation k+1 follow the last MFMA that reads this operation's, into
         // the same registers.
         double a1lo[T], a1hi[T], a2lo[T], a2hi[T];
         unpack(A1.lo, a1lo);
@@ -340,9 +335,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
         unpack(A2.hi, a2hi);
         v4d    lo1 = {0., 0., 0., 0.}, lo2 = {0., 0., 0., 0.};
         double hi1 = 0., hi2 = 0.;
-#if !PHY_AA_EARLY
         issue_children(nx1, Rn);
-#endif
 #pragma unroll
         for (int t = 0; t < T; ++t)
         {
@@ -356,7 +349,6 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
           hi2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2hi[t], x2[t], hi2, 0, 0, 0);
         }
         issue_matrices(nx_off1, nx_off2, A1, A2);
-#if !PHY_AA_EARLY
 #pragma unroll
         for (int i = 0; i < 2 * T; ++i)
         {
@@ -365,7 +357,6 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * T, 0);  // the 4x4x4 chain
         __builtin_amdgcn_sched_group_barrier(0x020, 12, 0);     // A fragments of operation k+1
-#endif
         u1[0] = lo1[0]; u1[1] = lo1[1]; u1[2] = lo1[2]; u1[3] = lo1[3]; u1[4] = hi1;
         u2[0] = lo2[0]; u2[1] = lo2[1]; u2[2] = lo2[2]; u2[3] = lo2[3]; u2[4] = hi2;
       }
