@@ -207,6 +207,16 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
                                             double rMatWeightSum, double eFrqWeightSum, double sumProbas,
                                             double *outSumLogLikelihood);
 
+/* MIXT_dLk(&l, b, mixt_tree), src/mixt.c:2962-3340 (same restrictions): lnL and dlnL/dl of the mixture at length *l of
+   the edge whose eigen-basis products every class instance holds (phyhip_update_eigen_lr on each class first, as
+   MIXT_Update_Eigen_Lr does).  *l is clamped with the FIRST instance's [l_min,l_max] like src/lk.c:672-673; per class
+   the length is scaled by its category rate and br_len_mult and clamped again (src/mixt.c:3056-3083).
+   left/rightBufferIndices: the two sides of the class edges (their scale exponents enter the 2^-sum rescaling). */
+int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, const int *leftBufferIndices,
+                                            const int *rightBufferIndices, double *l, const double *classProba,
+                                            const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
+                                            double eFrqWeightSum, double sumProbas, double *outLnL, double *outDLnL);
+
 /* ---- eigen-basis branch-length derivative (no BEAGLE counterpart in the seam) ---------------- */
 
 /* Update_Eigen_Lr(b,tree), src/lk.c:1038-1114 / src/avx.c:21-105: fills the instance's dot_prod

@@ -48,7 +48,8 @@
 
 static int g_check = 0, g_device_pmat = 0, g_host = 0;
 static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat = 0, g_n_eig = 0, g_n_mixt = 0, g_n_mixt_skipped = 0;
-static double  g_worst_lnl = 0.0, g_worst_dlnl = 0.0, g_worst_mixt = 0.0;
+static double  g_worst_lnl = 0.0, g_worst_dlnl = 0.0, g_worst_mixt = 0.0, g_worst_mixt_dlnl = 0.0;
+static long    g_n_mixt_dlk = 0;
 
 static void die(const char *what)
 {
@@ -223,11 +224,11 @@ static double g_t0 = 0.0;
 static long   g_max_mixt = 0; /* GLUE_MAX_MIXT: stop after this many compared MIXT_Lk calls (bounded test runs) */
 static void report_xml_and_exit(void)
 {
-  printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"xml\": 1, \"seconds\": %.3f, \"calls\": {\"Lk\": %ld, \"MIXT_Lk\": %ld, \"MIXT_Lk_skipped\": %ld, "
+  printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"xml\": 1, \"seconds\": %.3f, \"calls\": {\"Lk\": %ld, \"MIXT_Lk\": %ld, \"MIXT_dLk\": %ld, \"MIXT_skipped\": %ld, "
          "\"Update_Partial_Lk\": %ld, \"Update_PMat\": %ld, \"Update_Eigen_Lr\": %ld, \"dLk\": %ld}, \"class_instances\": %d, "
-         "\"worst_rel_mixture_lnL\": %.3g}\n",
-         g_host ? "host" : "check", now_s() - g_t0, g_n_lk, g_n_mixt, g_n_mixt_skipped, g_n_upd, g_n_pmat, g_n_eig, g_n_dlk, g_nctx,
-         g_worst_mixt);
+         "\"worst_rel_mixture_lnL\": %.3g, \"worst_rel_mixture_dlnL\": %.3g}\n",
+         g_host ? "host" : "check", now_s() - g_t0, g_n_lk, g_n_mixt, g_n_mixt_dlk, g_n_mixt_skipped, g_n_upd, g_n_pmat, g_n_eig, g_n_dlk,
+         g_nctx, g_worst_mixt, g_worst_mixt_dlnl);
   fflush(stdout);
   _exit(0);
 }
@@ -267,7 +268,46 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
   double lnl = 0.0;
   OK(phyhip_calculate_mixture_log_likelihood(ids, K, par, chi, pms, proba, rw, ew, r_sum, e_sum, sum_p, &lnl));
   track(&g_worst_mixt, lnl, ref, 1.0);
-  if (g_max_mixt && g_n_mixt - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
+  if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
+  return ref;
+}
+
+static void report_xml_and_exit(void);
+/* MIXT_dLk (src/mixt.c:2962-3340), check mode: after the original, the device repeats the eigen-basis evaluation over the
+   class instances (their dot_prod was refreshed through the Update_Eigen_Lr wrapper) and lnL / dlnL are compared. */
+phydbl MIXT_dLk(phydbl *l, t_edge *mixt_b, t_tree *mixt_tree)
+{
+  static phydbl (*real)(phydbl *, t_edge *, t_tree *) = NULL;
+  if (!real) real = (phydbl (*)(phydbl *, t_edge *, t_tree *))dlsym(RTLD_NEXT, "MIXT_dLk");
+  double       x = *l;
+  const phydbl ref = real(l, mixt_b, mixt_tree);
+  if (g_host) return ref;
+  if (!g_check) { fprintf(stderr, "glue_driver: mixtures run in check mode only (GLUE_MODE=check)\n"); exit(5); }
+  ++g_n_mixt_dlk;
+  if (mixt_tree->n_root || mixt_tree->next_mixt || mixt_tree->mod->ras->invar == YES || mixt_tree->mod->gamma_mgf_bl == YES)
+  { ++g_n_mixt_skipped; return ref; }
+  int    ids[kMaxClasses], lft[kMaxClasses], rgt[kMaxClasses], K = 0;
+  double proba[kMaxClasses], rw[kMaxClasses], ew[kMaxClasses];
+  t_edge *b = mixt_b->next;
+  for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
+  {
+    if (K == kMaxClasses || t->mod->ras->invar == YES) { ++g_n_mixt_skipped; return ref; }
+    ctx_t *c = ensure_instance(t);
+    push_model(c);
+    ids[K] = c->inst;
+    edge_sides(c, b, &lft[K], &rgt[K]);
+    proba[K] = mixt_tree->mod->ras->gamma_r_proba->v[t->mod->ras->parent_class_number];
+    rw[K] = t->mod->r_mat_weight->v; ew[K] = t->mod->e_frq_weight->v;
+    ++K;
+  }
+  const double r_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->r_mat_weight);
+  const double e_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->e_frq_weight);
+  const double sum_p = MIXT_Get_Sum_Of_Probas_Across_Mixtures(r_sum, e_sum, mixt_tree);
+  double lnl = 0.0, dlnl = 0.0;
+  OK(phyhip_calculate_mixture_eigen_lnl_dlnl(ids, K, lft, rgt, &x, proba, rw, ew, r_sum, e_sum, sum_p, &lnl, &dlnl));
+  track(&g_worst_mixt, lnl, ref, 1.0);
+  track(&g_worst_mixt_dlnl, dlnl, mixt_tree->c_dlnL, 1.0);
+  if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
   return ref;
 }
 

@@ -11,7 +11,10 @@
  *     likelihood unscaled_site_lk_cat and the scale exponent sum at the evaluation edge
  *   mixture level: pattern weights, tips, edges, per-site log-likelihoods c_lnL_sorted, lnL
  *
- * usage: phyml_mixt_driver <out.phyg> <call index> -- --xml=<file>
+ * In "dlk" mode the dump is taken at a MIXT_dLk call (src/mixt.c:2962-3340) instead: the branch length it was given, the
+ * returned lnL and dlnL, and per class the eigen-basis products dot_prod (src/lk.c:1038-1114) it combined.
+ *
+ * usage: phyml_mixt_driver <out.phyg> <call index> [lk|dlk] -- --xml=<file>
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -21,7 +24,8 @@
 #undef main
 #include "mixt.h"
 
-static int         g_want = 0, g_calls = 0;
+static int         g_want = 0, g_calls = 0, g_dlk_mode = 0, g_dlk_calls = 0;
+static double      g_dlk_l = 0.0, g_dlk_dlnl = 0.0;
 static const char *g_path = NULL;
 
 static void dump_mixture(t_edge *mixt_b_in, t_tree *mixt_tree, phydbl lnl)
@@ -38,6 +42,7 @@ static void dump_mixture(t_edge *mixt_b_in, t_tree *mixt_tree, phydbl lnl)
   fwrite("PHYG", 1, 4, g_out);
   rec_scalar("n_otu", n); rec_scalar("n_pattern", P); rec_scalar("ns", S); rec_scalar("n_classes", K);
   rec_scalar("lnL", lnl); rec_scalar("eval_edge", mixt_b->num);
+  if (g_dlk_mode) { rec_scalar("dlk_l", g_dlk_l); rec_scalar("dlnL", g_dlk_dlnl); }
   rec_scalar("datatype", mixt_tree->io->datatype);
   rec_f64("wght", mixt_tree->data->wght, P);
   rec_f64("c_lnL_sorted", mixt_tree->c_lnL_sorted, P);
@@ -107,6 +112,7 @@ static void dump_mixture(t_edge *mixt_b_in, t_tree *mixt_tree, phydbl lnl)
       free(f);
     }
     { uint64_t d[2] = {(uint64_t)S, (uint64_t)S}; rec(NM("Pij_eval_edge"), 0, 2, d, b->Pij_rr); }
+    if (g_dlk_mode) rec_f64_2(NM("dot_prod"), t->dot_prod, P, S);
 #undef NM
   }
   fclose(g_out);
@@ -120,19 +126,35 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
   static phydbl (*real)(t_edge *, t_tree *) = NULL;
   if (!real) real = (phydbl (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "MIXT_Lk");
   const phydbl v = real(mixt_b, mixt_tree);
-  if (g_calls++ == g_want) dump_mixture(mixt_b, mixt_tree, v);
+  if (!g_dlk_mode && g_calls++ == g_want) dump_mixture(mixt_b, mixt_tree, v);
+  return v;
+}
+
+phydbl MIXT_dLk(phydbl *l, t_edge *mixt_b, t_tree *mixt_tree)
+{
+  static phydbl (*real)(phydbl *, t_edge *, t_tree *) = NULL;
+  if (!real) real = (phydbl (*)(phydbl *, t_edge *, t_tree *))dlsym(RTLD_NEXT, "MIXT_dLk");
+  const double x = *l;
+  const phydbl v = real(l, mixt_b, mixt_tree);
+  if (g_dlk_mode && g_dlk_calls++ == g_want)
+  {
+    g_dlk_l = x; g_dlk_dlnl = mixt_tree->c_dlnL; g_calls = g_dlk_calls;
+    dump_mixture(mixt_b, mixt_tree, v);
+  }
   return v;
 }
 
 int main(int argc, char **argv)
 {
-  if (argc < 5 || strcmp(argv[3], "--")) { fprintf(stderr, "usage: %s <out.phyg> <call index> -- --xml=<file>\n", argv[0]); return 2; }
+  int sep = 3;
+  if (argc > 4 && (!strcmp(argv[3], "dlk") || !strcmp(argv[3], "lk"))) { g_dlk_mode = !strcmp(argv[3], "dlk"); sep = 4; }
+  if (argc < sep + 2 || strcmp(argv[sep], "--")) { fprintf(stderr, "usage: %s <out.phyg> <call index> [lk|dlk] -- --xml=<file>\n", argv[0]); return 2; }
   g_path = argv[1];
   g_want = atoi(argv[2]);
-  int    pargc = argc - 3;
+  int    pargc = argc - sep;
   char **pargv = malloc(sizeof(char *) * (pargc + 1));
   pargv[0] = argv[0];
-  for (int k = 1; k < pargc; ++k) pargv[k] = argv[3 + k];
+  for (int k = 1; k < pargc; ++k) pargv[k] = argv[sep + k];
   pargv[pargc] = NULL;
   Get_Input(pargc, pargv); /* XML mode runs the whole analysis inside (src/cl.c:335) */
   fprintf(stderr, "mixt_driver: the run ended before MIXT_Lk call %d\n", g_want);

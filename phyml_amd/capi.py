@@ -42,6 +42,7 @@ SYMBOLS = [
     "phyhip_set_scale_factors", "phyhip_get_numerical_warning", "phyhip_update_eigen_lr",
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
+    "phyhip_calculate_mixture_eigen_lnl_dlnl",
 ]
 
 _lib = None
@@ -244,3 +245,16 @@ def mixture_log_likelihood(instance_ids, parents, children, matrices, proba, r_m
                                                    da(r_mat_weight), da(e_frq_weight), C.c_double(r_sum), C.c_double(e_sum),
                                                    C.c_double(sum_probas), C.byref(out)))
     return out.value
+
+
+def mixture_eigen_lnl_dlnl(instance_ids, lefts, rights, l, proba, r_mat_weight, e_frq_weight, r_sum, e_sum, sum_probas):
+    """phyhip_calculate_mixture_eigen_lnl_dlnl: MIXT_dLk over class instances; returns (clamped l, lnL, dlnL)."""
+    L = load()
+    n = len(instance_ids)
+    ia = lambda v: (C.c_int * n)(*[int(x) for x in v])
+    da = lambda v: (C.c_double * n)(*[float(x) for x in v])
+    lv, lnl, dlnl = C.c_double(l), C.c_double(0.0), C.c_double(0.0)
+    _chk(L.phyhip_calculate_mixture_eigen_lnl_dlnl(ia(instance_ids), n, ia(lefts), ia(rights), C.byref(lv), da(proba),
+                                                   da(r_mat_weight), da(e_frq_weight), C.c_double(r_sum), C.c_double(e_sum),
+                                                   C.c_double(sum_probas), C.byref(lnl), C.byref(dlnl)))
+    return lv.value, lnl.value, dlnl.value

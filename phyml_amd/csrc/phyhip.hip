@@ -168,6 +168,7 @@ struct Instance
   bool   pm_copy = true;       // PHYHIP_PM_COPY=0: kernels read the P-matrix work list from pinned host memory (slower for 20 states)
   bool   split_reduce = false, split_reduce_forced = false; // PHYHIP_SPLIT_REDUCE: separate final_reduce_kernel instead of the fused last-workgroup sum
   unsigned *d_tickets = nullptr;
+  double   *d_mixexpl = nullptr; // expl pairs of the classes of a mixture evaluation (first instance only)
   int    ablate = 0;         // PHYHIP_ABLATE: timing-only kernel variants (results invalid)
   bool   no_loads = false;   // PHYHIP_NOLOADS: zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
@@ -800,6 +801,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
   if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce() { I->split_reduce = atoi(e) != 0; I->split_reduce_forced = true; }
   if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
+  HIPCHK(hipMalloc((void **)&I->d_mixexpl, sizeof(double) * kMaxMixClasses * 2 * 20));
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
   HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned)));
   if (const char *e = getenv("PHYHIP_DIST")) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
@@ -840,7 +842,7 @@ int phyhip_finalize_instance(int instance)
   collect_profile(I);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag, I->d_tickets};
+                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
@@ -1213,6 +1215,92 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
   int rc = wait_result(I0);
   if (rc) return rc;
   *outLnL = I0->h_result[0];
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, const int *left, const int *right, double *l,
+                                            const double *classProba, const double *rMatWeight, const double *eFrqWeight,
+                                            double rMatWeightSum, double eFrqWeightSum, double sumProbas, double *outLnL,
+                                            double *outDLnL)
+{
+  if (count < 1 || count > kMaxMixClasses) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "1..%d mixture classes", kMaxMixClasses);
+  if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN");
+  Instance *I0 = nullptr;
+  std::vector<double> expl;
+  std::vector<Instance *> cls;
+  for (int k = 0; k < count; ++k)
+  {
+    GET_INST(I, instances[k]);
+    if (k == 0)
+    {
+      I0 = I;
+      if (*l < I->l_min) *l = I->l_min; // src/lk.c:672-673 (dLk clamps before diverting to MIXT_dLk)
+      else if (*l > I->l_max) *l = I->l_max;
+      expl.assign((size_t)count * 2 * I->S, 0.0);
+    }
+    if (I->C != 1 || I->P != I0->P || I->dev != I0->dev || I->S != I0->S)
+      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture class %d: needs one category, the same shape and the same device", k);
+    int rc = check_partial_index(I, left[k], true);
+    if (rc) return rc;
+    if ((rc = check_partial_index(I, right[k], true))) return rc;
+    if ((rc = flush(I, nullptr))) return rc; // queued partial updates write the scale vectors read below
+    // src/mixt.c:3056-3114
+    const double rr  = 1.0 * I->br_len_mult * I->h_rates[0];
+    double       len = (*l) * rr;
+    if (len < I->l_min) len = I->l_min;
+    else if (len > I->l_max) len = I->l_max;
+    for (int s = 0; s < I->S; ++s)
+    {
+      const double ev = I->h_eval[s], ex = exp(ev * len);
+      expl[(size_t)k * 2 * I->S + 2 * s]     = ex;
+      expl[(size_t)k * 2 * I->S + 2 * s + 1] = ex * ev * rr;
+    }
+    cls.push_back(I);
+  }
+  // expl pairs of all classes: staged copy into the first instance's matrix scratch area
+  void        *st = nullptr;
+  const size_t eb = expl.size() * sizeof(double);
+  int rc = I0->ring.alloc(eb, I0->stream, &st);
+  if (rc) return rc;
+  memcpy(st, expl.data(), eb);
+  HIPCHK(hipMemcpyAsync(I0->d_mixexpl, st, eb, hipMemcpyHostToDevice, I0->stream));
+  auto launch = [&](auto s_) -> int {
+    constexpr int S_ = decltype(s_)::value;
+    MixDlkParams<S_> q;
+    memset(&q, 0, sizeof q);
+    for (int k = 0; k < count; ++k)
+    {
+      Instance *I = cls[k];
+      if (I != I0)
+      {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, I->stream));
+        HIPCHK(hipStreamWaitEvent(I0->stream, ev, 0));
+        HIPCHK(hipEventDestroy(ev));
+      }
+      q.dot[k] = I->d_dot;
+      q.scale_l[k] = left[k] < I->tips ? nullptr : I->d_scales + (size_t)(left[k] - I->tips) * I->Ppad;
+      q.scale_r[k] = right[k] < I->tips ? nullptr : I->d_scales + (size_t)(right[k] - I->tips) * I->Ppad;
+      q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
+    }
+    q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
+    q.expl = I0->d_mixexpl; q.wght = I0->d_wght;
+    const int grid = (int)((I0->P + 255) / 256);
+    q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
+    q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
+    q.fin.seq = ++I0->seq;
+    hipLaunchKernelGGL((mixture_dlk_kernel<S_>), dim3(grid), dim3(256), 0, I0->stream, q);
+    HIPCHK(hipGetLastError());
+    return 0;
+  };
+  if (I0->S == 4) rc = launch(std::integral_constant<int, 4>());
+  else if (I0->S == 20) rc = launch(std::integral_constant<int, 20>());
+  else return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "mixtures: 4 or 20 states");
+  if (rc) return rc;
+  if ((rc = wait_result(I0))) return rc;
+  *outLnL = I0->h_result[0];
+  if (outDLnL) *outDLnL = I0->h_result[1];
   return PHYHIP_SUCCESS;
 }
 

@@ -1190,6 +1190,79 @@ __global__ __launch_bounds__(256) void mixture_combine_kernel(const MixParams q)
   }
 }
 
+// MIXT_dLk (src/mixt.c:2962-3340): lnL and dlnL/dl of a mixture in the eigen basis.  Per class and pattern lk and dlk come
+// from that class's dot_prod with its own expl pairs in the AVX order (src/avx.c:250-276), are brought to a common scale
+// with 2^-sum of the class edge's scale exponents (1023 cap above 1024, :3176-3194), weighted like MIXT_Lk (:3214-3226),
+// and enter lnL += w log(site_lk), dlnL += w site_dlk / site_lk (:3308-3309).  No +I.
+template <int S> struct MixDlkParams
+{
+  int           count;
+  long long     P;
+  const double *dot[kMaxMixClasses];                 // per class: dot_prod [P][S]
+  const int    *scale_l[kMaxMixClasses], *scale_r[kMaxMixClasses]; // scale exponents of the two edge sides (nullptr: tip)
+  double        proba[kMaxMixClasses], r_w[kMaxMixClasses], e_w[kMaxMixClasses];
+  double        r_sum, e_sum, sum_probas;
+  const double *expl;                                // device: [count][2*S] (value, derivative) pairs
+  const double *wght;
+  FinishParams  fin;
+};
+
+template <int S> __global__ __launch_bounds__(256) void mixture_dlk_kernel(const MixDlkParams<S> q)
+{
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double          c_lnl = 0.0, c_dlnl = 0.0;
+  if (p < q.P)
+  {
+    const double wt = q.wght[p];
+    double       site_lk = 0.0, site_dlk = 0.0;
+    for (int k = 0; k < q.count; ++k)
+    {
+      const double2 *s2 = reinterpret_cast<const double2 *>(q.dot[k] + (size_t)p * S);
+      const double  *ex = q.expl + (size_t)k * 2 * S;
+      double         z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
+#pragma unroll
+      for (int i = 0; i < S / 2; ++i)
+      {
+        const double2 v = s2[i];
+        z0 = __builtin_fma(v.x, ex[4 * i], z0);
+        z1 = __builtin_fma(v.x, ex[4 * i + 1], z1);
+        z2 = __builtin_fma(v.y, ex[4 * i + 2], z2);
+        z3 = __builtin_fma(v.y, ex[4 * i + 3], z3);
+      }
+      int sum = (q.scale_l[k] ? q.scale_l[k][p] : 0) + (q.scale_r[k] ? q.scale_r[k][p] : 0);
+      if (sum > 1024) { sum = 1023; raise_warn(q.fin.warn); }
+      const double lk  = ldexp(z0 + z2, -sum); // == / pow(2, sum)
+      const double dlk = ldexp(z1 + z3, -sum);
+      if (wt > kSmall)
+      {
+        site_lk  += lk * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
+        site_dlk += dlk * 1.0 * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
+      }
+    }
+    if (wt > kSmall)
+    {
+      c_lnl  = wt * log(site_lk);
+      c_dlnl = wt * (site_dlk / site_lk);
+    }
+  }
+  __shared__ double ws[2][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    c_lnl += __shfl_down(c_lnl, off, 64);
+    c_dlnl += __shfl_down(c_dlnl, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { ws[0][wid] = c_lnl; ws[1][wid] = c_dlnl; }
+  __syncthreads();
+  if (wid == 0)
+  {
+    double v[2] = {0.0, 0.0};
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { v[0] += ws[0][k]; v[1] += ws[1][k]; }
+    finish_sums<2>(q.fin, v, lane);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K5: transition matrices on the device (src/models.c:257-326 behind src/lk.c:2280-2316)
 //     one block per matrix; thread (c,i) builds row i of category c

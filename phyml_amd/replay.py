@@ -144,3 +144,31 @@ def mixture_combine(unscaled, fact, factors, r_sum, e_sum, sum_probas, wght):
     for p in range(P):
         lnl += wght[p] * logs[p]
     return lnl, logs
+
+
+def mixture_dlk(dot_prods, facts, models, factors, r_sum, e_sum, sum_probas, wght, l):
+    """MIXT_dLk (src/mixt.c:2962-3340), no +I, from the per-class eigen-basis products: returns (lnL, dlnL)."""
+    P = len(wght)
+    site_lk = np.zeros(P); site_dlk = np.zeros(P)
+    l_min, l_max = float(models[0]["l_min"][0]), float(models[0]["l_max"][0])
+    l = min(max(l, l_min), l_max)  # src/lk.c:672-673
+    for dp, f, md, (proba, rw, ew) in zip(dot_prods, facts, models, factors):
+        rr = 1.0 * float(md["br_len_mult"][0]) * float(md["gamma_rr"][0])  # src/mixt.c:3060-3063
+        ln = min(max(l * rr, float(md["l_min"][0])), float(md["l_max"][0]))
+        ev = np.asarray(md["e_val"], dtype=np.float64)
+        ex = np.exp(ev * ln)
+        dx = ex * ev * rr
+        dp = np.asarray(dp, dtype=np.float64)
+        # src/avx.c:250-276: even states accumulate in one lane pair, odd states in the other
+        lk = (dp[:, 0::2] * ex[0::2]).sum(axis=1) + (dp[:, 1::2] * ex[1::2]).sum(axis=1)
+        dlk = (dp[:, 0::2] * dx[0::2]).sum(axis=1) + (dp[:, 1::2] * dx[1::2]).sum(axis=1)
+        s = np.where(np.asarray(f) > 1024, 1023.0, np.asarray(f, dtype=np.float64))
+        mult = np.power(2.0, s)
+        coef = lambda x: x * proba * rw / r_sum * ew / e_sum / sum_probas
+        site_lk = site_lk + coef(lk / mult)
+        site_dlk = site_dlk + coef(dlk / mult * 1.0)
+    lnl = dlnl = 0.0
+    for p in range(P):
+        lnl += wght[p] * np.log(site_lk[p])
+        dlnl += wght[p] * (site_dlk[p] / site_lk[p])
+    return lnl, dlnl

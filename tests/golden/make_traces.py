@@ -96,6 +96,16 @@ def main():
         print(r.stdout[-3000:])
         raise SystemExit("mixture driver failed")
     print(f"{'mixture_lg4x':22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
+    # ... and one MIXT_dLk call of the real analysis (41st of the first branch-length round)
+    shutil.copy(os.path.join(HERE, "lg4x", "lg4x_check.xml"), os.path.join(tmp, "examples", "lg4x", "lg4x_check.xml"))
+    out = os.path.join(HERE, "mixture_lg4x_dlk.phyg")
+    r = subprocess.run([mixt, out, "40", "dlk", "--", "--xml=../examples/lg4x/lg4x_check.xml"], cwd=os.path.join(tmp, "run"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    m = re.search(r"MIXT_DRIVER .*", r.stdout)
+    if r.returncode != 0 or not m:
+        print(r.stdout[-3000:])
+        raise SystemExit("mixture driver (dlk) failed")
+    print(f"{'mixture_lg4x_dlk':22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
     shutil.rmtree(tmp, ignore_errors=True)
 
 

@@ -49,3 +49,39 @@ def test_lg4x_mixture_on_device(host_pmat):
     finally:
         for t in trees:
             t.close()
+
+
+@pytest.mark.parametrize("host_pmat", [True, False])
+def test_lg4x_mixture_dlk_on_device(host_pmat):
+    """MIXT_dLk (src/mixt.c:2962-3340) through phyhip_calculate_mixture_eigen_lnl_dlnl against a call dumped from the
+    reference's own LG4X analysis: class partials recomputed on both sides, Update_Eigen_Lr per class, combination."""
+    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
+    models, factors = replay.mixture_classes(d)
+    n, P, S = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0])
+    tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
+    e = int(d["eval_edge"][0])
+    trees = []
+    try:
+        for md in models:
+            t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, 1, host_pmat=host_pmat)
+            t.tip_root = 0
+            t.set_model(md["pi"], md["gamma_rr"], md["gamma_r_proba"], md["e_val"], md["r_e_vect"], md["l_e_vect"],
+                        float(md["l_min"][0]), float(md["l_max"][0]), float(md["br_len_mult"][0]), 1, 0, 0.0)
+            t.Make_Tree_For_Lk(d["wght"], None)
+            t.set_tips(tip_partials=tv)
+            t.Set_Both_Sides(1)
+            t.Lk()
+            t.Update_Eigen_Lr(e)   # MIXT_Update_Eigen_Lr: per class
+            trees.append(t)
+        ids = [t.tree.contents.b_inst for t in trees]
+        lv, lnl, dlnl = capi.mixture_eigen_lnl_dlnl(ids, [t.side_buffer(e, 0) for t in trees], [t.side_buffer(e, 1) for t in trees],
+                                                    float(d["dlk_l"][0]), [f[0] for f in factors], [f[1] for f in factors],
+                                                    [f[2] for f in factors], float(d["r_mat_weight_sum"][0]),
+                                                    float(d["e_frq_weight_sum"][0]), float(d["sum_probas"][0]))
+        ref_lnl, ref_dlnl = float(d["lnL"][0]), float(d["dlnL"][0])
+        tol = 1e-12 if host_pmat else 1e-10
+        assert abs(lnl - ref_lnl) <= tol * abs(ref_lnl), (lnl, ref_lnl)
+        assert abs(dlnl - ref_dlnl) <= 1e-8 * max(1.0, abs(ref_dlnl)), (dlnl, ref_dlnl)
+    finally:
+        for t in trees:
+            t.close()

@@ -87,7 +87,8 @@ def test_real_search_with_device_built_matrices(tmp_path):
 def test_lg4x_mixture_analysis_check_mode(tmp_path):
     """The reference's LG4X mixture analysis (examples/lg4x: four class trees, free rates, SPR + parameter optimisation,
     XML mode) with the class trees mirrored on the device: every MIXT_Lk evaluation at the P-matrix level is repeated by
-    phyhip_calculate_mixture_log_likelihood over the four class instances and compared (first 4000 evaluations)."""
+    phyhip_calculate_mixture_log_likelihood, every MIXT_dLk by phyhip_calculate_mixture_eigen_lnl_dlnl, over the four class
+    instances, and compared (first 6000 evaluations)."""
     if not os.path.exists(GLUE):
         pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
     base = str(tmp_path)
@@ -95,12 +96,14 @@ def test_lg4x_mixture_analysis_check_mode(tmp_path):
     for f in os.listdir(os.path.join(GOLDEN, "lg4x")):
         shutil.copy(os.path.join(GOLDEN, "lg4x", f), os.path.join(base, "examples", "lg4x", f))
     shutil.copy(os.path.join(GOLDEN, "examples_proteic.phy"), os.path.join(base, "examples", "proteic"))
-    env = dict(os.environ, GLUE_MODE="check", GLUE_MAX_MIXT="4000")
+    env = dict(os.environ, GLUE_MODE="check", GLUE_MAX_MIXT="6000")
     r = subprocess.run([GLUE, "--", "--xml=../examples/lg4x/lg4x_check.xml"], cwd=os.path.join(base, "run"), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
     assert r.returncode == 0 and m, r.stdout[-2000:]
     info = json.loads(m.group(1))
     assert info["class_instances"] == 4
-    assert info["calls"]["MIXT_Lk"] - info["calls"]["MIXT_Lk_skipped"] >= 4000
+    assert info["calls"]["MIXT_Lk"] + info["calls"]["MIXT_dLk"] - info["calls"]["MIXT_skipped"] >= 6000
+    assert info["calls"]["MIXT_Lk"] - info["calls"]["MIXT_skipped"] > 500 and info["calls"]["MIXT_dLk"] > 1000, info
     assert info["worst_rel_mixture_lnL"] < 1e-10, info
+    assert info["worst_rel_mixture_dlnL"] < 1e-6, info

@@ -47,3 +47,29 @@ def test_lg4x_mixture_matches_reference():
                                          factors, float(d["r_mat_weight_sum"][0]), float(d["e_frq_weight_sum"][0]),
                                          float(d["sum_probas"][0]), d["wght"])
     assert np.array_equal(logs2, d["c_lnL_sorted"]) and lnl2 == float(d["lnL"][0])
+
+
+def test_lg4x_mixture_dlk_matches_reference():
+    """A MIXT_dLk call of the reference's own LG4X analysis (41st call of the first branch-length round): per-class
+    eigen-basis products from the oracle's Update_Eigen_Lr on freshly computed partials, and the restated combination."""
+    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
+    models, factors = replay.mixture_classes(d)
+    e = int(d["eval_edge"][0])
+    dots, facts = [], []
+    for k, md in enumerate(models):
+        ot = class_tree(d, md)
+        ot.lk(both_sides=True)
+        ot.update_eigen_lr(e)
+        ref_dp = d[f"class{k}_dot_prod"]
+        assert np.max(np.abs(ot.dot_prod - ref_dp) / np.maximum(np.abs(ref_dp), 1e-300)) < 1e-12
+        left, rght = ot._side(e, 0), ot._side(e, 1)
+        f = (ot.scale[(e, 0)] if (e, 0) in ot.scale else 0) + (ot.scale[(e, 1)] if (e, 1) in ot.scale else 0)
+        assert np.array_equal(np.asarray(f, dtype=np.int64) + np.zeros(ot.P, dtype=np.int64), d[f"class{k}_fact"])
+        dots.append(ot.dot_prod.copy()); facts.append(d[f"class{k}_fact"])
+    args = (models, factors, float(d["r_mat_weight_sum"][0]), float(d["e_frq_weight_sum"][0]), float(d["sum_probas"][0]), d["wght"],
+            float(d["dlk_l"][0]))
+    lnl, dlnl = replay.mixture_dlk(dots, facts, *args)
+    assert abs(lnl - float(d["lnL"][0])) < 1e-12 * abs(lnl)
+    assert abs(dlnl - float(d["dlnL"][0])) < 1e-9 * max(1.0, abs(float(d["dlnL"][0])))
+    lnl2, dlnl2 = replay.mixture_dlk([d[f"class{k}_dot_prod"] for k in range(4)], facts, *args)
+    assert abs(lnl2 - float(d["lnL"][0])) < 1e-13 * abs(lnl2) and abs(dlnl2 - float(d["dlnL"][0])) < 1e-10 * max(1.0, abs(dlnl2))
