@@ -183,3 +183,38 @@ def test_tips_from_characters(name, golden):
         assert abs(lnl - float(d["lnL"][0])) <= 1e-12 * abs(lnl)
     finally:
         t.close()
+
+
+def test_cfg4_shard_size_cross_checks_the_two_nucleotide_mappings():
+    """125 000 patterns (one cfg4 shard) run on the one-lane-per-pattern mapping (G = 1), its halves on the two-lanes-per-
+    pattern mapping (G = 2, chosen below ~82 k patterns): the shard lnLs must add up to the whole (1e-12) and the lnL must be
+    the same at every evaluation edge (src/lk.c:2642-2684)."""
+    wl = workloads.make("cfg4_nt_100x125k")
+    tree, st, blk, cfg = wl["tree"], wl["states"], wl["model"], wl["cfg"]
+    n, P = tree.n_otu, st.shape[1]
+    assert P == 125000
+
+    def build(lo, hi):
+        t = lktree.LkTree(n, tree.edge_left, tree.edge_rght, tree.edge_len, hi - lo, 4, 4)
+        t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"],
+                    float(blk["l_min"][0]), float(blk["l_max"][0]))
+        t.Make_Tree_For_Lk(np.ones(hi - lo))
+        t.set_tips(tip_states=st[:, lo:hi].astype(np.int32))
+        return t
+
+    t = build(0, P)
+    try:
+        t.Set_Both_Sides(True)
+        lnl = t.Lk(None)
+        for e in (0, 11, t.ne - 1):
+            assert abs(t.Lk(e) - lnl) / abs(lnl) < 1e-11
+    finally:
+        t.close()
+    parts = 0.0
+    for lo, hi in ((0, 60000), (60000, P)):
+        s = build(lo, hi)
+        try:
+            parts += s.Lk(None)
+        finally:
+            s.close()
+    assert abs(parts - lnl) / abs(lnl) < 1e-12, (parts, lnl)
