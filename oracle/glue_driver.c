@@ -27,7 +27,7 @@
  *   host              every call is forwarded to the reference untouched (no device): the CPU-only run of the same
  *                     command, same output format -- how the expected values of tests/golden/search_expected.json are made
  *
- * Mixtures (XML mode, e.g. examples/lg4x): check mode only.  Every class tree of the mixture (src/mixt.c:2603-2640) gets
+ * Mixtures (XML mode, e.g. examples/lg4x; one partition element, no +I): every class tree of the mixture (src/mixt.c:2603-2640) gets
  * its own instance; MIXT_Update_Partial_Lk / MIXT_Update_PMat_At_Given_Edge loop over the class trees and come back
  * through the wrappers; MIXT_Lk is interposed too and, after the original, repeats the evaluation with
  * phyhip_calculate_mixture_log_likelihood over the class instances (GLUE_MAX_MIXT=n stops after n comparisons).
@@ -50,6 +50,7 @@ static int g_check = 0, g_device_pmat = 0, g_host = 0;
 static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat = 0, g_n_eig = 0, g_n_mixt = 0, g_n_mixt_skipped = 0;
 static double  g_worst_lnl = 0.0, g_worst_dlnl = 0.0, g_worst_mixt = 0.0, g_worst_mixt_dlnl = 0.0;
 static long    g_n_mixt_dlk = 0;
+static double  g_last_mixt_lnl = 0.0, g_best_full_lnl = -1e300;
 
 static void die(const char *what)
 {
@@ -220,95 +221,150 @@ static double device_edge_value(t_tree *tree, const t_edge *b)
   return lnl;
 }
 
+/* the class trees of a mixture and what the combination needs from each (src/mixt.c:1048-1053) */
+typedef struct
+{
+  int    K, ids[kMaxClasses], lft[kMaxClasses], rgt[kMaxClasses], pms[kMaxClasses];
+  double proba[kMaxClasses], rw[kMaxClasses], ew[kMaxClasses], r_sum, e_sum, sum_p;
+} mix_t;
+static int gather_classes(t_edge *e, t_tree *mixt_tree, mix_t *m)
+{
+  m->K = 0;
+  t_edge *b = e->next;
+  for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
+  {
+    if (m->K == kMaxClasses || t->mod->ras->invar == YES) return 0;
+    ctx_t *c = ensure_instance(t);
+    push_model(c);
+    m->ids[m->K] = c->inst;
+    edge_sides(c, b, &m->lft[m->K], &m->rgt[m->K]);
+    m->pms[m->K] = mat_id(c, b->Pij_rr);
+    m->proba[m->K] = mixt_tree->mod->ras->gamma_r_proba->v[t->mod->ras->parent_class_number];
+    m->rw[m->K] = t->mod->r_mat_weight->v; m->ew[m->K] = t->mod->e_frq_weight->v;
+    ++m->K;
+  }
+  m->r_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->r_mat_weight);
+  m->e_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->e_frq_weight);
+  m->sum_p = MIXT_Get_Sum_Of_Probas_Across_Mixtures(m->r_sum, m->e_sum, mixt_tree);
+  return 1;
+}
+static int mixture_supported(const t_tree *mixt_tree)
+{
+  return !(mixt_tree->n_root || mixt_tree->next_mixt || mixt_tree->mod->ras->invar == YES || mixt_tree->mod->gamma_mgf_bl == YES);
+}
+
 static double g_t0 = 0.0;
 static long   g_max_mixt = 0; /* GLUE_MAX_MIXT: stop after this many compared MIXT_Lk calls (bounded test runs) */
 static void report_xml_and_exit(void)
 {
   printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"xml\": 1, \"seconds\": %.3f, \"calls\": {\"Lk\": %ld, \"MIXT_Lk\": %ld, \"MIXT_dLk\": %ld, \"MIXT_skipped\": %ld, "
          "\"Update_Partial_Lk\": %ld, \"Update_PMat\": %ld, \"Update_Eigen_Lr\": %ld, \"dLk\": %ld}, \"class_instances\": %d, "
-         "\"worst_rel_mixture_lnL\": %.3g, \"worst_rel_mixture_dlnL\": %.3g}\n",
-         g_host ? "host" : "check", now_s() - g_t0, g_n_lk, g_n_mixt, g_n_mixt_dlk, g_n_mixt_skipped, g_n_upd, g_n_pmat, g_n_eig, g_n_dlk,
-         g_nctx, g_worst_mixt, g_worst_mixt_dlnl);
+         "\"worst_rel_mixture_lnL\": %.3g, \"worst_rel_mixture_dlnL\": %.3g, \"last_mixture_lnL\": %.17g, \"best_full_lnL\": %.17g}\n",
+         g_host ? "host" : (g_check ? "check" : "device"), now_s() - g_t0, g_n_lk, g_n_mixt, g_n_mixt_dlk, g_n_mixt_skipped, g_n_upd, g_n_pmat, g_n_eig, g_n_dlk,
+         g_nctx, g_worst_mixt, g_worst_mixt_dlnl, g_last_mixt_lnl, g_best_full_lnl);
   fflush(stdout);
   _exit(0);
 }
 
-/* MIXT_Lk (src/mixt.c:730-1160), check mode: the original runs (its per-class matrix refreshes and partial updates reach
-   the class instances through the wrappers above), then the device repeats the evaluation of the same edge over the
-   class instances and the two results are compared. */
+/* MIXT_Lk (src/mixt.c:730-1160).
+   check mode: the original runs (its per-class matrix refreshes and partial updates reach the class instances through the
+   wrappers above), then the device repeats the evaluation of the same edge over the class instances; results compared.
+   device mode: the control flow of src/mixt.c:754-860 with the reference's own per-class loops (MIXT_Update_PMat_At_Given_Edge,
+   MIXT_Post/Pre_Order_Lk, which come back through the wrappers), the device combination in place of the site loop. */
 phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
 {
   static phydbl (*real)(t_edge *, t_tree *) = NULL;
   if (!real) real = (phydbl (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "MIXT_Lk");
-  const phydbl ref = real(mixt_b, mixt_tree);
-  if (g_host) return ref;
-  if (!g_check) { fprintf(stderr, "glue_driver: mixtures run in check mode only (GLUE_MODE=check)\n"); exit(5); }
+  if (g_host) { g_last_mixt_lnl = real(mixt_b, mixt_tree); return g_last_mixt_lnl; }
   ++g_n_mixt;
-  if (mixt_tree->n_root || mixt_tree->next_mixt || mixt_tree->mod->ras->invar == YES || mixt_tree->next->use_eigen_lr == YES)
-  { ++g_n_mixt_skipped; return ref; } /* eigen-basis evaluations, partitions and +I mixtures: not on the device yet */
-  t_edge *e = mixt_b ? mixt_b : mixt_tree->a_nodes[0]->b[0]; /* src/mixt.c:889 */
-  int    ids[kMaxClasses], par[kMaxClasses], chi[kMaxClasses], pms[kMaxClasses], K = 0;
-  double proba[kMaxClasses], rw[kMaxClasses], ew[kMaxClasses];
-  t_edge *b = e->next;
-  for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
+  mix_t m;
+  if (g_check)
   {
-    if (K == kMaxClasses || t->mod->ras->invar == YES) { ++g_n_mixt_skipped; return ref; }
-    ctx_t *c = ensure_instance(t);
-    push_model(c);
-    ids[K] = c->inst;
-    edge_sides(c, b, &par[K], &chi[K]);
-    pms[K] = mat_id(c, b->Pij_rr);
-    proba[K] = mixt_tree->mod->ras->gamma_r_proba->v[t->mod->ras->parent_class_number];
-    rw[K] = t->mod->r_mat_weight->v; ew[K] = t->mod->e_frq_weight->v;
-    ++K;
+    const phydbl ref = real(mixt_b, mixt_tree);
+    g_last_mixt_lnl = ref;
+    t_edge *e = mixt_b ? mixt_b : mixt_tree->a_nodes[0]->b[0]; /* src/mixt.c:889 */
+    if (!mixture_supported(mixt_tree) || mixt_tree->next->use_eigen_lr == YES || !gather_classes(e, mixt_tree, &m))
+    { ++g_n_mixt_skipped; return ref; } /* eigen-basis Lk, partitions and +I mixtures: not on the device */
+    double lnl = 0.0;
+    OK(phyhip_calculate_mixture_log_likelihood(m.ids, m.K, m.lft, m.rgt, m.pms, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl));
+    track(&g_worst_mixt, lnl, ref, 1.0);
+    if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
+    return ref;
   }
-  const double r_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->r_mat_weight);
-  const double e_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->e_frq_weight);
-  const double sum_p = MIXT_Get_Sum_Of_Probas_Across_Mixtures(r_sum, e_sum, mixt_tree);
+  /* ---- device mode ---- */
+  if (!mixture_supported(mixt_tree) || mixt_tree->next->use_eigen_lr == YES)
+  { fprintf(stderr, "glue_driver: this mixture (rooted / partitioned / +I / eigen-basis Lk) runs in check mode only\n"); exit(5); }
+  if (!mixt_b)
+  { /* src/mixt.c:754-782 */
+    Update_RAS(mixt_tree->mod);
+    for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next)
+      if (!Update_Boundaries(t->mod) || !Update_Efrq(t->mod) || !Update_Eigen(t->mod)) { fprintf(stderr, "glue_driver: model update failed\n"); exit(5); }
+    for (int br = 0; br < 2 * mixt_tree->n_otu - 3; ++br) MIXT_Update_PMat_At_Given_Edge(mixt_tree->a_edges[br], mixt_tree); /* :784-787 */
+    MIXT_Post_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);                                    /* :850-857 */
+    if (mixt_tree->both_sides == YES) MIXT_Pre_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);
+  }
+  else MIXT_Update_PMat_At_Given_Edge(mixt_b, mixt_tree); /* :806 */
+  t_edge *e = mixt_b ? mixt_b : mixt_tree->a_nodes[0]->b[0];
+  {
+    t_edge *b = e->next;
+    for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
+    {
+      t->c_lnL = 0.0; t->numerical_warning = NO;
+      if (t->update_eigen_lr == YES) Update_Eigen_Lr(b, t); /* :929 */
+    }
+  }
+  if (!gather_classes(e, mixt_tree, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
   double lnl = 0.0;
-  OK(phyhip_calculate_mixture_log_likelihood(ids, K, par, chi, pms, proba, rw, ew, r_sum, e_sum, sum_p, &lnl));
-  track(&g_worst_mixt, lnl, ref, 1.0);
-  if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
-  return ref;
+  OK(phyhip_calculate_mixture_log_likelihood(m.ids, m.K, m.lft, m.rgt, m.pms, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl));
+  mixt_tree->numerical_warning = NO;
+  {
+    int w = 0;
+    OK(phyhip_get_numerical_warning(m.ids[0], &w));
+    if (w) mixt_tree->numerical_warning = YES;
+  }
+  mixt_tree->c_lnL = lnl;
+  g_last_mixt_lnl = lnl;
+  if (!mixt_b && lnl > g_best_full_lnl) g_best_full_lnl = lnl;
+  if (g_max_mixt && g_n_mixt + g_n_mixt_dlk >= g_max_mixt) report_xml_and_exit();
+  return lnl;
 }
 
 static void report_xml_and_exit(void);
-/* MIXT_dLk (src/mixt.c:2962-3340), check mode: after the original, the device repeats the eigen-basis evaluation over the
-   class instances (their dot_prod was refreshed through the Update_Eigen_Lr wrapper) and lnL / dlnL are compared. */
+/* MIXT_dLk (src/mixt.c:2962-3340): check mode compares, device mode serves the call (MIXT_Update_Eigen_Lr loops over the
+   class trees and comes back through the Update_Eigen_Lr wrapper). */
 phydbl MIXT_dLk(phydbl *l, t_edge *mixt_b, t_tree *mixt_tree)
 {
   static phydbl (*real)(phydbl *, t_edge *, t_tree *) = NULL;
   if (!real) real = (phydbl (*)(phydbl *, t_edge *, t_tree *))dlsym(RTLD_NEXT, "MIXT_dLk");
-  double       x = *l;
-  const phydbl ref = real(l, mixt_b, mixt_tree);
-  if (g_host) return ref;
-  if (!g_check) { fprintf(stderr, "glue_driver: mixtures run in check mode only (GLUE_MODE=check)\n"); exit(5); }
+  if (g_host) return real(l, mixt_b, mixt_tree);
   ++g_n_mixt_dlk;
-  if (mixt_tree->n_root || mixt_tree->next_mixt || mixt_tree->mod->ras->invar == YES || mixt_tree->mod->gamma_mgf_bl == YES)
-  { ++g_n_mixt_skipped; return ref; }
-  int    ids[kMaxClasses], lft[kMaxClasses], rgt[kMaxClasses], K = 0;
-  double proba[kMaxClasses], rw[kMaxClasses], ew[kMaxClasses];
-  t_edge *b = mixt_b->next;
-  for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
+  mix_t m;
+  if (g_check)
   {
-    if (K == kMaxClasses || t->mod->ras->invar == YES) { ++g_n_mixt_skipped; return ref; }
-    ctx_t *c = ensure_instance(t);
-    push_model(c);
-    ids[K] = c->inst;
-    edge_sides(c, b, &lft[K], &rgt[K]);
-    proba[K] = mixt_tree->mod->ras->gamma_r_proba->v[t->mod->ras->parent_class_number];
-    rw[K] = t->mod->r_mat_weight->v; ew[K] = t->mod->e_frq_weight->v;
-    ++K;
+    double       x = *l;
+    const phydbl ref = real(l, mixt_b, mixt_tree);
+    if (!mixture_supported(mixt_tree) || !gather_classes(mixt_b, mixt_tree, &m)) { ++g_n_mixt_skipped; return ref; }
+    double lnl = 0.0, dlnl = 0.0;
+    OK(phyhip_calculate_mixture_eigen_lnl_dlnl(m.ids, m.K, m.lft, m.rgt, &x, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl, &dlnl));
+    track(&g_worst_mixt, lnl, ref, 1.0);
+    track(&g_worst_mixt_dlnl, dlnl, mixt_tree->c_dlnL, 1.0);
+    if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
+    return ref;
   }
-  const double r_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->r_mat_weight);
-  const double e_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->e_frq_weight);
-  const double sum_p = MIXT_Get_Sum_Of_Probas_Across_Mixtures(r_sum, e_sum, mixt_tree);
+  if (!mixture_supported(mixt_tree)) { fprintf(stderr, "glue_driver: this mixture runs in check mode only\n"); exit(5); }
+  if (mixt_tree->update_eigen_lr == YES) MIXT_Update_Eigen_Lr(mixt_b, mixt_tree); /* src/mixt.c:2990-2991 */
+  {
+    t_edge *b = mixt_b; /* src/mixt.c:2993-3000: l must be the length of this edge */
+    while (b && &(b->l->v) != l) b = b->next;
+    if (!b) { fprintf(stderr, "glue_driver: MIXT_dLk with a length that is not the edge's own\n"); exit(5); }
+  }
+  if (!gather_classes(mixt_b, mixt_tree, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
   double lnl = 0.0, dlnl = 0.0;
-  OK(phyhip_calculate_mixture_eigen_lnl_dlnl(ids, K, lft, rgt, &x, proba, rw, ew, r_sum, e_sum, sum_p, &lnl, &dlnl));
-  track(&g_worst_mixt, lnl, ref, 1.0);
-  track(&g_worst_mixt_dlnl, dlnl, mixt_tree->c_dlnL, 1.0);
-  if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
-  return ref;
+  OK(phyhip_calculate_mixture_eigen_lnl_dlnl(m.ids, m.K, m.lft, m.rgt, l, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl, &dlnl));
+  for (t_tree *t = mixt_tree; t; t = t->next) { t->c_lnL = .0; t->c_dlnL = .0; } /* :3026-3032 */
+  mixt_tree->c_lnL  = lnl;
+  mixt_tree->c_dlnL = dlnl;
+  return mixt_tree->c_lnL;
 }
 
 phydbl Lk(t_edge *b, t_tree *tree)
@@ -318,7 +374,7 @@ phydbl Lk(t_edge *b, t_tree *tree)
   ++g_n_lk;
   if (!b) ++g_n_lk_full;
   if (g_host || tree->is_mixt_tree) return real(b, tree); /* mixture: src/lk.c:465-472 diverts to MIXT_Lk (above) */
-  if (tree->mixt_tree && !g_check) { fprintf(stderr, "glue_driver: mixtures run in check mode only\n"); exit(5); }
+  if (tree->mixt_tree && !g_check) { fprintf(stderr, "glue_driver: Lk() on a class tree outside MIXT_Lk is served in check mode only\n"); exit(5); }
   if (g_check)
   {
     const phydbl ref = real(b, tree); /* drives the device through the nested surface calls as well */
@@ -365,7 +421,7 @@ phydbl dLk(phydbl *l, t_edge *b, t_tree *tree)
   static phydbl (*real)(phydbl *, t_edge *, t_tree *) = NULL;
   if (!real) real = (phydbl (*)(phydbl *, t_edge *, t_tree *))dlsym(RTLD_NEXT, "dLk");
   ++g_n_dlk;
-  if (g_host || tree->is_mixt_tree || tree->mixt_tree) return real(l, b, tree); /* MIXT_dLk stays on the host (check mode) */
+  if (g_host || tree->is_mixt_tree || tree->mixt_tree) return real(l, b, tree); /* mixture: src/lk.c:679-685 diverts to MIXT_dLk */
   ctx_t *c = ensure_instance(tree);
   if (g_check)
   {

@@ -107,3 +107,24 @@ def test_lg4x_mixture_analysis_check_mode(tmp_path):
     assert info["calls"]["MIXT_Lk"] - info["calls"]["MIXT_skipped"] > 500 and info["calls"]["MIXT_dLk"] > 1000, info
     assert info["worst_rel_mixture_lnL"] < 1e-10, info
     assert info["worst_rel_mixture_dlnL"] < 1e-6, info
+
+
+def test_lg4x_mixture_analysis_driven_by_the_device(tmp_path):
+    """The same analysis with MIXT_Lk / MIXT_dLk SERVED by the device (class partials never computed on the host): the
+    first 8000 evaluations of the run; the optimiser must be climbing from the initial -12496.58 like the reference does."""
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
+    base = str(tmp_path)
+    os.makedirs(os.path.join(base, "examples", "lg4x")); os.makedirs(os.path.join(base, "run"))
+    for f in os.listdir(os.path.join(GOLDEN, "lg4x")):
+        shutil.copy(os.path.join(GOLDEN, "lg4x", f), os.path.join(base, "examples", "lg4x", f))
+    shutil.copy(os.path.join(GOLDEN, "examples_proteic.phy"), os.path.join(base, "examples", "proteic"))
+    env = dict(os.environ, GLUE_MODE="device", GLUE_MAX_MIXT="8000")
+    r = subprocess.run([GLUE, "--", "--xml=../examples/lg4x/lg4x_check.xml"], cwd=os.path.join(base, "run"), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:]
+    info = json.loads(m.group(1))
+    assert info["mode"] == "device" and info["class_instances"] == 4
+    assert info["calls"]["MIXT_Lk"] + info["calls"]["MIXT_dLk"] >= 8000
+    assert -12496.6 < info["best_full_lnL"] < -12300.0 and info["best_full_lnL"] > -12490.0, info
