@@ -175,6 +175,7 @@ struct Instance
 
   bool       prof = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  hipEvent_t ev_sync = nullptr; // orders this instance's stream before another instance's (mixture evaluations)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pairs;
   double     prof_ms = 0.0, prof_updates = 0.0;
   int        prof_n = 0;
@@ -669,6 +670,25 @@ extern "C" {
 
 const char *phyhip_get_last_error(void) { return g_err.c_str(); }
 
+// Frees everything an instance owns (also a partially built one: every pointer starts as nullptr).
+static void release_instance(Instance *I)
+{
+  if (I->stream) (void)hipStreamSynchronize(I->stream);
+  void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
+                  I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
+                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (I->h_result) (void)hipHostFree(I->h_result);
+  if (I->h_warn) (void)hipHostFree(I->h_warn);
+  if (I->ev_sync) (void)hipEventDestroy(I->ev_sync);
+  I->ring.destroy();
+  if (I->own_stream && I->stream) (void)hipStreamDestroy(I->stream);
+  delete I;
+}
+
+static int build_instance(Instance *I, const hipDeviceProp_t &prop);
+
 int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
                            int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
                            int scaleBufferCount, const int *resourceList, int resourceCount, long preferenceFlags,
@@ -700,7 +720,42 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   Instance *I = new Instance();
   I->dev = dev; I->tips = tipCount; I->nbuf = partialsBufferCount; I->S = stateCount; I->C = categoryCount;
   I->CP = next_pow2(categoryCount); I->P = patternCount; I->nmat = matrixBufferCount;
+  {
+    const int rc = build_instance(I, prop);
+    if (rc < 0)
+    { // a failed allocation half-way must not leak what was allocated before it
+      release_instance(I);
+      return rc;
+    }
+  }
+
+  if (returnInfo)
+  {
+    memset(returnInfo, 0, sizeof *returnInfo);
+    returnInfo->resourceNumber = dev;
+    snprintf(returnInfo->resourceName, sizeof returnInfo->resourceName, "%s", prop.name);
+    snprintf(returnInfo->implName, sizeof returnInfo->implName, "phyhip-%s", prop.gcnArchName);
+    returnInfo->computeUnits   = prop.multiProcessorCount;
+    returnInfo->globalMemBytes = (long long)prop.totalGlobalMem;
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (size_t i = 0; i < g_inst.size(); ++i)
+    if (!g_inst[i])
+    {
+      g_inst[i] = I;
+      return (int)i;
+    }
+  g_inst.push_back(I);
+  return (int)g_inst.size() - 1;
+}
+
+// Device memory, staging, launch geometry and environment switches of a new instance.
+static int build_instance(Instance *I, const hipDeviceProp_t &prop)
+{
+  int rc = 0;
+  (void)prop;
   HIPCHK(hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
 
   I->perm = (I->S == 20) && (I->C <= 4) && !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA")));
   I->soa  = (I->S == 4) && (I->C <= 4) && !(getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
@@ -789,7 +844,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   HIPCHK(hipMalloc((void **)&I->d_ops, (size_t)I->ops_slots * I->ops_slot_bytes));
   size_t chunk = std::max<size_t>(64 * 1024, std::max(I->ops_slot_bytes,
                                                        (size_t)I->C * I->S * I->S * sizeof(double) * 4));
-  int rc = I->ring.init(chunk);
+  rc = I->ring.init(chunk);
   if (rc) return rc;
   I->ring.before_rotate = [I]() { return I->up_idx.empty() ? 0 : flush_uploads(I); };
   I->mat_in_queue.assign(I->nmat, 0);
@@ -815,24 +870,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   }
   I->masks_dirty = true;
 
-  if (returnInfo)
-  {
-    memset(returnInfo, 0, sizeof *returnInfo);
-    returnInfo->resourceNumber = dev;
-    snprintf(returnInfo->resourceName, sizeof returnInfo->resourceName, "%s", prop.name);
-    snprintf(returnInfo->implName, sizeof returnInfo->implName, "phyhip-%s", prop.gcnArchName);
-    returnInfo->computeUnits   = prop.multiProcessorCount;
-    returnInfo->globalMemBytes = (long long)prop.totalGlobalMem;
-  }
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (size_t i = 0; i < g_inst.size(); ++i)
-    if (!g_inst[i])
-    {
-      g_inst[i] = I;
-      return (int)i;
-    }
-  g_inst.push_back(I);
-  return (int)g_inst.size() - 1;
+  return 0;
 }
 
 int phyhip_finalize_instance(int instance)
@@ -840,20 +878,11 @@ int phyhip_finalize_instance(int instance)
   GET_INST(I, instance);
   (void)hipStreamSynchronize(I->stream);
   collect_profile(I);
-  void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
-                  I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
-  if (I->h_result) (void)hipHostFree(I->h_result);
-  if (I->h_warn) (void)hipHostFree(I->h_warn);
-  I->ring.destroy();
-  if (I->own_stream && I->stream) (void)hipStreamDestroy(I->stream);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     g_inst[instance] = nullptr;
   }
-  delete I;
+  release_instance(I);
   return PHYHIP_SUCCESS;
 }
 
@@ -1195,11 +1224,8 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
     if ((rc = flush(I, &ee))) return rc;
     if (I != I0)
     { // the combination runs on the first instance's stream, after every class stream
-      hipEvent_t ev;
-      HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      HIPCHK(hipEventRecord(ev, I->stream));
-      HIPCHK(hipStreamWaitEvent(I0->stream, ev, 0));
-      HIPCHK(hipEventDestroy(ev));
+      HIPCHK(hipEventRecord(I->ev_sync, I->stream));
+      HIPCHK(hipStreamWaitEvent(I0->stream, I->ev_sync, 0));
     }
     q.site_cat[k] = I->d_site_cat; q.fact[k] = I->d_fact;
     q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
@@ -1273,11 +1299,8 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
       Instance *I = cls[k];
       if (I != I0)
       {
-        hipEvent_t ev;
-        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(ev, I->stream));
-        HIPCHK(hipStreamWaitEvent(I0->stream, ev, 0));
-        HIPCHK(hipEventDestroy(ev));
+        HIPCHK(hipEventRecord(I->ev_sync, I->stream));
+        HIPCHK(hipStreamWaitEvent(I0->stream, I->ev_sync, 0));
       }
       q.dot[k] = I->d_dot;
       q.scale_l[k] = left[k] < I->tips ? nullptr : I->d_scales + (size_t)(left[k] - I->tips) * I->Ppad;
