@@ -1429,8 +1429,13 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   memset(&q, 0, sizeof q);
   q.dot_prod = I->d_dot; q.wght = I->d_wght; q.fact = I->d_fact; q.cat_w = I->d_catw; q.pi = I->d_pi; q.invar = I->d_invar;
   q.P = I->P; q.C = I->C; q.invar_model = I->invar_model; q.apply_scaling = I->apply_scaling; q.with_derivative = deriv ? 1 : 0;
-  q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = I->grid; q.fin.warn = I->d_warn;
-  const bool fused = fuse_reduce(I, I->grid);
+  // grid-stride kernel.  Measured (us per dLk incl. launch and host hand-over): 512 workgroups + fused final sum win up to
+  // ~100 MB of dot_prod (20 states x 100 k patterns: 33 vs 48); beyond, filling every wave slot (2048 workgroups, separate
+  // final sum) streams better (4 states x 1 M patterns: 45 vs 64; the one-workgroup-per-256-lanes form took 75)
+  const size_t dot_bytes = (size_t)I->P * I->C * I->S * sizeof(double);
+  const int    dgrid = std::min(I->grid, dot_bytes > (size_t)100 << 20 ? 2048 : 512);
+  q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = dgrid; q.fin.warn = I->d_warn;
+  const bool fused = fuse_reduce(I, dgrid);
   if (fused)
   {
     q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
@@ -1462,14 +1467,14 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   }
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
-    hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q);
+    hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, I->stream, q);
     return 0;
   });
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   if (!fused)
   {
-    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, I->grid, 2, I->grid,
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, dgrid, 2, dgrid,
                        I->d_result, I->h_result, I->d_warn, I->h_warn, ++I->seq);
     HIPCHK(hipGetLastError());
   }

@@ -1005,111 +1005,120 @@ struct DlkParams
 template <int S, int CP>
 __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
 {
-  const long long gl  = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long p0  = gl / CP;
-  const int       c0  = (int)(gl % CP);
-  const bool      act = (p0 < q.P) && (c0 < q.C);
-  const long long p   = (p0 < q.P) ? p0 : (q.P - 1);
-  const int       c   = (c0 < q.C) ? c0 : 0;
+  // grid-stride over (pattern, category) lanes: a bounded number of workgroups streams dot_prod, each thread
+  // accumulating its patterns, so that the per-workgroup sums stay few enough for the fused final sum
+  const long long total = (((long long)q.P * CP + 255) / 256) * 256;
+  double          tot_lnl = 0.0, tot_dlnl = 0.0;
+  for (long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x; gl < total; gl += (long long)gridDim.x * blockDim.x)
+  {
+    const long long p0  = gl / CP;
+    const int       c0  = (int)(gl % CP);
+    const bool      act = (p0 < q.P) && (c0 < q.C);
+    const long long p   = (p0 < q.P) ? p0 : (q.P - 1);
+    const int       c   = (c0 < q.C) ? c0 : 0;
 
-  double dp[S];
-  {
-    const double2 *s2 = reinterpret_cast<const double2 *>(q.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S);
-#pragma unroll
-    for (int j = 0; j < S / 2; ++j)
+    double dp[S];
     {
-      const double2 v = s2[j];
-      dp[2 * j] = v.x;
-      dp[2 * j + 1] = v.y;
-    }
-  }
-  double lkc, dlkc = 0.0;
-  if (q.with_derivative)
-  { // four lanes (lk,dlk,lk,dlk) over pairs of states, then lane0+lane2 / lane1+lane3 (src/avx.c:257-274)
-    const double *ex = q.expl + c * 2 * S;
-    double        z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
+      const double2 *s2 = reinterpret_cast<const double2 *>(q.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S);
 #pragma unroll
-    for (int i = 0; i < S / 2; ++i)
-    {
-      z0 = __builtin_fma(dp[2 * i], ex[4 * i], z0);
-      z1 = __builtin_fma(dp[2 * i], ex[4 * i + 1], z1);
-      z2 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 2], z2);
-      z3 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 3], z3);
-    }
-    lkc  = z0 + z2;
-    dlkc = z1 + z3;
-  }
-  else
-  { // elementwise product, blockwise lane sums, horizontal norm (src/avx.c:227-244)
-    const double *ex = q.expl + c * S;
-    double        l4[4] = {0., 0., 0., 0.};
-#pragma unroll
-    for (int b4 = 0; b4 < S / 4; ++b4)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) l4[kk] = l4[kk] + dp[b4 * 4 + kk] * ex[b4 * 4 + kk];
-    lkc = (l4[0] + l4[2]) + (l4[1] + l4[3]);
-  }
-  const double w  = (c0 < q.C) ? q.cat_w[c] : 0.0;
-  const double t1 = (c0 < q.C) ? lkc * w : 0.0, t2 = (c0 < q.C) ? dlkc * w : 0.0;
-  double       lk = 0.0, dlk = 0.0;
-#pragma unroll
-  for (int cc = 0; cc < CP; ++cc)
-  {
-    const double a = (CP == 1) ? t1 : __shfl(t1, cc, CP);
-    const double b = (CP == 1) ? t2 : __shfl(t2, cc, CP);
-    if (cc < q.C)
-    {
-      lk += a;
-      dlk += b;
-    }
-  }
-  double c_lnl = 0.0, c_dlnl = 0.0;
-  if (act && c == 0)
-  {
-    const double wt = q.wght[p];
-    if (wt > kSmall)
-    {
-      int f = q.fact[p];
-      if (q.invar_model)
-      { // src/lk.c:1005-1025 (dLk) / :910-931 (Lk in the eigen basis)
-        const int iv  = q.invar[p];
-        double    inv = 0.0;
-        bool      issue = false;
-        if (iv >= 0)
-        {
-          inv = q.pi[iv];
-          if (q.apply_scaling)
-          {
-            int e = f;
-            do
-            {
-              const int piece = e < 63 ? e : 63;
-              inv *= (double)(1ull << piece);
-              e -= piece;
-            } while (e != 0);
-          }
-          issue = isinf(inv);
-        }
-        if (issue)
-        {
-          if (q.with_derivative) { lk = inv * q.pinvar; dlk = 0.0; }
-          else { f = 0; lk = q.pi[iv] * q.pinvar; }
-        }
-        else
-        {
-          lk  = lk * (1. - q.pinvar) + inv * q.pinvar;
-          dlk = dlk * (1. - q.pinvar);
-        }
-      }
-      if (lk < kSmall)
+      for (int j = 0; j < S / 2; ++j)
       {
-        lk = kSmall;
-        raise_warn(q.fin.warn);
+        const double2 v = s2[j];
+        dp[2 * j] = v.x;
+        dp[2 * j + 1] = v.y;
       }
-      c_dlnl = wt * (dlk / lk);                          // src/lk.c:742-744
-      c_lnl  = wt * (log(lk) - kLog2 * (double)f);       // src/lk.c:745
     }
+    double lkc, dlkc = 0.0;
+    if (q.with_derivative)
+    { // four lanes (lk,dlk,lk,dlk) over pairs of states, then lane0+lane2 / lane1+lane3 (src/avx.c:257-274)
+      const double *ex = q.expl + c * 2 * S;
+      double        z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
+#pragma unroll
+      for (int i = 0; i < S / 2; ++i)
+      {
+        z0 = __builtin_fma(dp[2 * i], ex[4 * i], z0);
+        z1 = __builtin_fma(dp[2 * i], ex[4 * i + 1], z1);
+        z2 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 2], z2);
+        z3 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 3], z3);
+      }
+      lkc  = z0 + z2;
+      dlkc = z1 + z3;
+    }
+    else
+    { // elementwise product, blockwise lane sums, horizontal norm (src/avx.c:227-244)
+      const double *ex = q.expl + c * S;
+      double        l4[4] = {0., 0., 0., 0.};
+#pragma unroll
+      for (int b4 = 0; b4 < S / 4; ++b4)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) l4[kk] = l4[kk] + dp[b4 * 4 + kk] * ex[b4 * 4 + kk];
+      lkc = (l4[0] + l4[2]) + (l4[1] + l4[3]);
+    }
+    const double w  = (c0 < q.C) ? q.cat_w[c] : 0.0;
+    const double t1 = (c0 < q.C) ? lkc * w : 0.0, t2 = (c0 < q.C) ? dlkc * w : 0.0;
+    double       lk = 0.0, dlk = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc)
+    {
+      const double a = (CP == 1) ? t1 : __shfl(t1, cc, CP);
+      const double b = (CP == 1) ? t2 : __shfl(t2, cc, CP);
+      if (cc < q.C)
+      {
+        lk += a;
+        dlk += b;
+      }
+    }
+    double c_lnl = 0.0, c_dlnl = 0.0;
+    if (act && c == 0)
+    {
+      const double wt = q.wght[p];
+      if (wt > kSmall)
+      {
+        int f = q.fact[p];
+        if (q.invar_model)
+        { // src/lk.c:1005-1025 (dLk) / :910-931 (Lk in the eigen basis)
+          const int iv  = q.invar[p];
+          double    inv = 0.0;
+          bool      issue = false;
+          if (iv >= 0)
+          {
+            inv = q.pi[iv];
+            if (q.apply_scaling)
+            {
+              int e = f;
+              do
+              {
+                const int piece = e < 63 ? e : 63;
+                inv *= (double)(1ull << piece);
+                e -= piece;
+              } while (e != 0);
+            }
+            issue = isinf(inv);
+          }
+          if (issue)
+          {
+            if (q.with_derivative) { lk = inv * q.pinvar; dlk = 0.0; }
+            else { f = 0; lk = q.pi[iv] * q.pinvar; }
+          }
+          else
+          {
+            lk  = lk * (1. - q.pinvar) + inv * q.pinvar;
+            dlk = dlk * (1. - q.pinvar);
+          }
+        }
+        if (lk < kSmall)
+        {
+          lk = kSmall;
+          raise_warn(q.fin.warn);
+        }
+        c_dlnl = wt * (dlk / lk);                          // src/lk.c:742-744
+        c_lnl  = wt * (log(lk) - kLog2 * (double)f);       // src/lk.c:745
+      }
+    }
+    tot_lnl += c_lnl;
+    tot_dlnl += c_dlnl;
   }
+  double c_lnl = tot_lnl, c_dlnl = tot_dlnl;
   __shared__ double ws[2][4];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
