@@ -165,6 +165,7 @@ struct Instance
   int    apply_scaling = 1, invar_model = 0;
   bool   want_site_outputs = true;
   int    prefetch_dist = 2;  // PHYHIP_DIST: load-stage distance of the nt pipeline (1 or 2)
+  bool   fold_pmats = true;    // PHYHIP_FOLD_PMATS=0: always rebuild transition matrices with a separate pmat_kernel launch
   bool   pm_copy = true;       // PHYHIP_PM_COPY=0: kernels read the P-matrix work list from pinned host memory (slower for 20 states)
   bool   split_reduce = false, split_reduce_forced = false; // PHYHIP_SPLIT_REDUCE: separate final_reduce_kernel instead of the fused last-workgroup sum
   unsigned *d_tickets = nullptr;
@@ -358,7 +359,12 @@ int flush(Instance *I, const EdgeEval *ee)
 {
   const int n_ops = (int)I->pending.size();
   int rc = 0;
-  if ((!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
+  // a short list of device-built matrices is folded into the lane-per-pattern nucleotide kernel's prologue when the grid
+  // is small (measured: 16.7 vs 17.8 us per scalar-returning call on a 382-pattern search prefix; at 100 000 patterns
+  // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
+  const bool fold_pm = I->soa && I->fold_pmats && I->grid_nt2 <= 512 && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
+                       I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !(I->ablate & 8);
+  if (!fold_pm && (!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
   if (n_ops == 0 && !ee) return 0;
   rc = upload_masks(I);
   if (rc) return rc;
@@ -366,6 +372,16 @@ int flush(Instance *I, const EdgeEval *ee)
   TreeParams q = base_params(I);
   RO         ro = base_ro(I, nullptr);
   bool       fused_sum = false;
+  if (fold_pm)
+  {
+    q.n_fresh = (int)I->pm_idx.size();
+    for (int k = 0; k < q.n_fresh; ++k) { q.fresh_idx[k] = I->pm_idx[k]; q.fresh_len[k] = I->pm_len[k]; }
+    q.m_evec = I->d_evec; q.m_ivec = I->d_ivec; q.m_eval = I->d_eval; q.m_rates = I->d_catr;
+    q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats_rw = I->d_pmats;
+    for (int m : I->pm_idx) I->pm_slot[m] = -1;
+    I->pm_idx.clear();
+    I->pm_len.clear();
+  }
   const bool fat = ((I->S == 4) && !I->generic_nt) || I->perm;
   const IssueRec *d_irec = nullptr;
   const ExecRec  *d_xrec = nullptr;
@@ -856,6 +872,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
   if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce() { I->split_reduce = atoi(e) != 0; I->split_reduce_forced = true; }
   if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_FOLD_PMATS")) I->fold_pmats = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_mixexpl, sizeof(double) * kMaxMixClasses * 2 * 20));
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
   HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned)));

@@ -101,6 +101,15 @@ struct TreeParams
   int                *warn_host;
   unsigned long long  seq;
   int            *warn;
+  // Short lists of transition matrices to rebuild (SPR: three per candidate, src/spr.c:643-646) ride here and are built
+  // by every workgroup of the lane-per-pattern nucleotide kernel in its prologue: no separate pmat_kernel launch, no
+  // dependent-launch gap.  (pmat_kernel's arithmetic, src/models.c:257-326.)
+  int             n_fresh;
+  int             fresh_idx[8];
+  double          fresh_len[8];
+  const double   *m_evec, *m_ivec, *m_eval, *m_rates; // U, U^-1, eigenvalues, category rates
+  double          br_len_mult, l_min, l_max;
+  double         *pmats_rw;
 };
 
 // ---------------------------------------------------------------------------------------------

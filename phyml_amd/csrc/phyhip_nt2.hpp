@@ -38,7 +38,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int C, int G = 1, bool DBG = false>
 __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec,
-                                                             const double *__restrict__ pmats,
+                                                             const double *pmats, // (not restrict: the prologue may rewrite entries)
                                                              const uint8_t *__restrict__ tip_codes,
                                                              unsigned long long *dbg = nullptr)
 {
@@ -142,6 +142,35 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
         }
     }
   };
+
+  if (q.n_fresh > 0)
+  { // rebuild the queued matrices (see TreeParams::n_fresh): entry (c, i, j) = lane (and lane + 64 ...), exactly as
+    // pmat_kernel computes it; every workgroup writes the same values, and reads them only after its own writes landed
+    for (int m = 0; m < q.n_fresh; ++m)
+    {
+      double *out = q.pmats_rw + (size_t)q.fresh_idx[m] * (C * 16);
+      for (int e = lane; e < C * 16; e += 64)
+      {
+        const int c = e >> 4, i = (e >> 2) & 3, j = e & 3;
+        double    len = (q.fresh_len[m] > 0.0 ? q.fresh_len[m] : 0.0) * q.m_rates[c]; // src/lk.c:2296
+        len *= q.br_len_mult;
+        if (len < q.l_min) len = q.l_min;
+        else if (len > q.l_max) len = q.l_max;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_fma(q.m_evec[i * 4 + k] * exp(q.m_eval[k] * len), q.m_ivec[k * 4 + j], acc);
+        acc = (acc < kSmallPij) ? kSmallPij : acc; // src/models.c:293
+        // row sum in ascending j over the four lanes of the row (src/models.c:296-297)
+        const double t0 = __shfl(acc, (lane & ~3) + 0, 64), t1 = __shfl(acc, (lane & ~3) + 1, 64),
+                     t2 = __shfl(acc, (lane & ~3) + 2, 64), t3 = __shfl(acc, (lane & ~3) + 3, 64);
+        const double sum = (((0.0 + t0) + t1) + t2) + t3;
+        out[e] = acc / sum;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("" ::: "memory"); // nothing that reads the matrices moves above this point
+    __builtin_amdgcn_wave_barrier();
+  }
 
   double   FA[CS], FB[CS]; // results of the last two operations (alternating)
   unsigned scA = 0, scB = 0;
