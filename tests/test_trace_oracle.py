@@ -35,3 +35,30 @@ def test_oracle_reproduces_recorded_search(name):
     # the search moved: likelihoods differ across the stream and improve over it
     lnl = ref_out[kinds == replay.EDGE_LNL]
     assert lnl.max() - lnl.min() > 1.0
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_recorded_stream_is_well_formed(name):
+    """Every buffer a record reads was written by an earlier record, every matrix was set before its first use, every dLk
+    follows an Update_Eigen_Lr, ids stay inside what an instance sized like the reference's slab holds."""
+    d = phyg.load(os.path.join(GOLDEN, name + ".phyg"))
+    tr, _, _ = replay.recorded_trace(d)
+    n = int(d["n_otu"][0])
+    written, mats, have_dot = set(), set(), False
+    for k, a, b, c, dd, e in zip(tr["kind"], tr["a"], tr["b"], tr["c"], tr["d"], tr["e"]):
+        if k == replay.SET_PMAT:
+            mats.add(a)
+        elif k == replay.UPDATE:
+            assert a >= n and c in mats and e in mats
+            for child in (b, dd):
+                assert child < n or child in written
+            written.add(a)
+        elif k == replay.EDGE_LNL:
+            assert a in written and (b < n or b in written) and c in mats
+        elif k == replay.EIGEN_LR:
+            assert a in written and (b < n or b in written)
+            have_dot = True
+        elif k in (replay.DLK, replay.EIGEN_LNL):
+            assert have_dot
+    assert max(written) < n + 3 * n - 2 and max(mats) < 2 * n - 1
+    assert int(d["trace_n_buffers"][0]) == len(written) and int(d["trace_n_matrices"][0]) == len(mats)
