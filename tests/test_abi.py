@@ -94,3 +94,34 @@ def test_tip_character_encoders_match_reference_tip_vectors():
             buf[:] = -1.0
             fn(C.c_char(bytes([c])), 0, buf.ctypes.data_as(C.c_void_p))
             assert np.array_equal(buf[:ns], np.asarray(vec).reshape(-1, ns)[i]), chr(c)
+
+
+def test_host_layer_pmat_matches_reference_matrices():
+    """The host layer's own PMat (src/models.c:257-373: eigen form, 1e-100 floor, row renormalisation; l < 0 -> identity)
+    -- the bit-exact route behind phyhip_set_transition_matrix -- against the matrices dumped from the reference and
+    against the oracle, without a GPU."""
+    import ctypes as C
+    import numpy as np
+    from conftest import GOLDEN
+    from phyml_amd import lktree, phyg
+    import orc
+    H = lktree.load()
+    H.PMat.argtypes = [C.c_double, C.POINTER(lktree.t_mod), C.c_int, C.c_void_p]
+    H.PMat.restype = None
+    for name in ("nucleic_gtr_g4", "proteic_lg_g4", "synth_nt_300x40"):
+        d = phyg.load(os.path.join(GOLDEN, name + ".phyg"))
+        m = orc.Model(d)
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect)]
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        mod = lktree.t_mod(m.ns, m.ncatg, dp(arrs[0]), dp(arrs[1]), dp(arrs[2]), dp(arrs[3]), dp(arrs[4]), dp(arrs[5]), m.l_min, m.l_max,
+                           m.br_len_mult, 0, 0.0)
+        ref = d["Pij_rr"]
+        out = np.zeros((m.ncatg, m.ns, m.ns))
+        for e in range(ref.shape[0]):
+            for c in range(m.ncatg):
+                ln = max(0.0, float(d["edge_len"][e])) * float(m.gamma_rr[c]) * m.br_len_mult   # src/lk.c:2296-2300
+                ln = min(max(ln, m.l_min), m.l_max)
+                H.PMat(C.c_double(ln), C.byref(mod), c * m.ns * m.ns, out.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(out, ref[e]), (name, e)
+        H.PMat(C.c_double(-1.0), C.byref(mod), 0, out.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(out[0], np.eye(m.ns))
