@@ -299,11 +299,18 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
     Update_RAS(mixt_tree->mod);
     for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next)
       if (!Update_Boundaries(t->mod) || !Update_Efrq(t->mod) || !Update_Eigen(t->mod)) { fprintf(stderr, "glue_driver: model update failed\n"); exit(5); }
+    if (g_device_pmat) /* device-built matrices need the refreshed class rates / eigen systems on the device first */
+      for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) push_model(ensure_instance(t));
     for (int br = 0; br < 2 * mixt_tree->n_otu - 3; ++br) MIXT_Update_PMat_At_Given_Edge(mixt_tree->a_edges[br], mixt_tree); /* :784-787 */
     MIXT_Post_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);                                    /* :850-857 */
     if (mixt_tree->both_sides == YES) MIXT_Pre_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);
   }
-  else MIXT_Update_PMat_At_Given_Edge(mixt_b, mixt_tree); /* :806 */
+  else
+  {
+    if (g_device_pmat)
+      for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) push_model(ensure_instance(t));
+    MIXT_Update_PMat_At_Given_Edge(mixt_b, mixt_tree); /* :806 */
+  }
   t_edge *e = mixt_b ? mixt_b : mixt_tree->a_nodes[0]->b[0];
   {
     t_edge *b = e->next;
