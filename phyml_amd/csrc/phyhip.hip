@@ -661,6 +661,11 @@ int wait_result(Instance *I)
     }
   }
   HIPCHK(hipStreamSynchronize(I->stream));
+  if (*reinterpret_cast<volatile unsigned long long *>(I->h_result + 2) != I->seq)
+  { // the stream drained without the hand-over (a faulted launch): do not return a stale scalar, re-arm the ticket counter
+    (void)hipMemsetAsync(I->d_tickets, 0, sizeof(unsigned), I->stream);
+    return fail(PHYHIP_ERROR_GENERAL, "evaluation %llu finished without handing its result over", I->seq);
+  }
   return 0;
 }
 
