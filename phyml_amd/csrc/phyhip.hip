@@ -218,7 +218,7 @@ size_t buf_elems(const Instance *I) { return (size_t)I->Ppad * I->C * I->S; }
 size_t dev_off(const Instance *I, long long p, int c, int s)
 {
   if (I->perm) return aa_off(p, I->C, c, s);
-  return (size_t)(c * I->S + s) * I->Ppad + (size_t)p; // pattern-minor
+  return ((size_t)(c * 2 + (s >> 1)) * I->Ppad + (size_t)p) * 2 + (size_t)(s & 1); // pattern-minor, state pairs of 16 bytes
 }
 
 TreeParams base_params(Instance *I)
@@ -785,7 +785,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   // category groups of the lane-per-pattern kernel (phyhip_nt2.hpp): split a pattern over 2 lanes while the
   // alignment is too short to give every SIMD two waves of 64 patterns
   I->nt_groups = 1;
-  if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 1280) I->nt_groups = 2; // measured: G=2 wins at 50k (223 vs 247 us), G=1 from 125k
+  // measured (us per traversal, G=2 / G=1): 50 k 195 / 206, 75 k 301 / 363, 125 k 444 / 456, 250 k 837 / 848, 1 M 3293 / 3246
+  if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 4096) I->nt_groups = 2;
   if (const char *e = getenv("PHYHIP_NT_GROUPS"))
   {
     const int g = atoi(e);

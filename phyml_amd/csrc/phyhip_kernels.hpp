@@ -183,15 +183,12 @@ __device__ __forceinline__ void issue_side(const TreeParams &q, const RO &ro, in
   if (r.tip)
     r.code = ro.tip_codes[(size_t)idx * q.Ppad + p];
   else if (S == 4 && q.perm == 2)
-  { // pattern-minor (SoA) layout of the lane-per-pattern nucleotide kernel: entry (c,s) of pattern p at (c*4+s)*Ppad + p
-    const size_t  b    = (size_t)(idx - q.tip_count);
-    const double *base = q.partials + b * (size_t)q.Ppad * (q.C * S) + (size_t)(c * S) * q.Ppad + p;
+  { // pattern-minor layout of the lane-per-pattern nucleotide kernel (phyhip_nt2.hpp): the state pair (2h, 2h+1) of
+    // category c of pattern p is one 16-byte element at ((c*2 + h) * Ppad + p)
+    const size_t   b    = (size_t)(idx - q.tip_count);
+    const double2 *base = reinterpret_cast<const double2 *>(q.partials + b * (size_t)q.Ppad * (q.C * S)) + (size_t)(c * 2) * q.Ppad + p;
 #pragma unroll
-    for (int j = 0; j < S / 2; ++j)
-    {
-      r.v[j].x = base[(size_t)(2 * j) * q.Ppad];
-      r.v[j].y = base[(size_t)(2 * j + 1) * q.Ppad];
-    }
+    for (int j = 0; j < S / 2; ++j) r.v[j] = base[(size_t)j * q.Ppad];
     if (c == 0) r.sc = q.scales[b * q.Ppad + p];
   }
   else if (S == 20 && q.perm)

@@ -11,8 +11,9 @@
 //   * lets tips use the reference's own shortcut: an unambiguous tip contributes the COLUMN P[.][s] of its
 //     matrix (Exex / Exin, src/avx.c:527-564) -- a 32-byte LDS lookup per category instead of a 4x4 product.
 //
-// Layout ("pattern-minor", SoA): buffer[c*4 + s][pattern], patterns padded to 64.  A wave's access to one
-// (category, state) row is one contiguous 512-byte transaction, so lane = pattern stays fully coalesced.
+// Layout ("pattern-minor"): buffer[c*2 + s/2][pattern][s%2], patterns padded to 64: a lane's state pair is one 16-byte
+// element, a wave's access to one (category, state pair) row is one contiguous 1 KiB transaction (dwordx4 per lane:
+// half the vector-memory instructions of an 8-byte form -- the per-CU vector-memory path is instruction-rate bound).
 // The host-facing layout ([pattern][category][state]) is restored by phyhip_get_partials.
 //
 // Everything else is the pipeline of traverse_nt_kernel: host-prepared buffer descriptors (size 0 = load
@@ -59,12 +60,13 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
   const int      grp  = lane / PW, pl = lane % PW;        // category group, pattern within the wave
   const int      c0   = grp * CL;                         // first category of this lane
   const unsigned p    = blockIdx.x * (unsigned)PW + pl;   // < Ppad by construction of the grid
-  const unsigned rowb = (unsigned)(q.Ppad * 8);           // bytes between consecutive (c,s) rows
-  const unsigned voff8 = p * 8u + (unsigned)(c0 * S) * rowb, voff4 = p * 4u;
+  constexpr int  HP   = CS / 2;                           // 16-byte state pairs per lane
+  const unsigned rowb = (unsigned)(q.Ppad * 16);          // bytes between consecutive (c, state pair) rows
+  const unsigned voff16 = p * 16u + (unsigned)(c0 * 2) * rowb, voff4 = p * 4u;
 
   struct Raw
   {
-    u32x2    a[CS], b[CS]; // child 1 / child 2 entries
+    u32x4    a[HP], b[HP]; // child 1 / child 2 entries, as state pairs
     unsigned sa, sb;       // scale exponents
     unsigned ca, cb;       // tip bytes (allowed-state masks)
   };
@@ -73,16 +75,16 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
   auto rsrc = [](const Desc &d) {
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
   };
-  auto as_d = [](const u32x2 &v) { double d; __builtin_memcpy(&d, &v, 8); return d; };
+  auto first_d = [](const u32x4 &v) { double d; __builtin_memcpy(&d, &v, 8); return d; };
 
   // issue every load an operation needs (which ones are live was decided by the host)
   auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc) {
     const __amdgpu_buffer_rsrc_t d1r = rsrc(o.c1_data), d2r = rsrc(o.c2_data), g1r = rsrc(o.c1_scale),
                                  g2r = rsrc(o.c2_scale), y1r = rsrc(o.c1_tip), y2r = rsrc(o.c2_tip);
 #pragma unroll
-    for (int e = 0; e < CS; ++e) r.a[e] = __builtin_amdgcn_raw_buffer_load_b64(d1r, voff8, (unsigned)e * rowb, 0);
+    for (int e = 0; e < HP; ++e) r.a[e] = __builtin_amdgcn_raw_buffer_load_b128(d1r, voff16, (unsigned)e * rowb, 0);
 #pragma unroll
-    for (int e = 0; e < CS; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b64(d2r, voff8, (unsigned)e * rowb, 0);
+    for (int e = 0; e < HP; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b128(d2r, voff16, (unsigned)e * rowb, 0);
     r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, voff4, 0, 0);
     r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, voff4, 0, 0);
     r.ca = __builtin_amdgcn_raw_buffer_load_b8(y1r, p, 0, 0);
@@ -110,10 +112,13 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
         u[c * 4 + i] = a;
       }
   };
-  auto matvec_r = [&](const double2 *M, const u32x2 (&xr)[CS], double (&u)[CS]) {
-    double x[CS];
+  auto unpack = [](const u32x4 (&xr)[HP], double (&x)[CS]) {
 #pragma unroll
-    for (int e = 0; e < CS; ++e) x[e] = as_d(xr[e]);
+    for (int e = 0; e < HP; ++e) __builtin_memcpy(&x[2 * e], &xr[e], 16);
+  };
+  auto matvec_r = [&](const double2 *M, const u32x4 (&xr)[HP], double (&u)[CS]) {
+    double x[CS];
+    unpack(xr, x);
     matvec_x(M, x, u);
   };
   // tip child with allowed-state mask m: u[c*4+i] = sum_{j in m} P[c][i][j] (ascending j).  An unambiguous tip
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       }
       else if (fl & kOpF11) { matvec_x(buf, Fprev, u1); s1 = scprev; one1 = (Fprev[0] == 1.0); }
       else if (fl & kOpF12) { matvec_x(buf, Fout, u1); s1 = scout; one1 = (Fout[0] == 1.0); }
-      else { matvec_r(buf, R.a, u1); s1 = R.sa; one1 = (as_d(R.a[0]) == 1.0); }
+      else { matvec_r(buf, R.a, u1); s1 = R.sa; one1 = (first_d(R.a[0]) == 1.0); }
       PHY_STAMP(k, 1)
       // ---- child 2 ----
       if (fl & kOpTip2)
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       }
       else if (fl & kOpF21) { matvec_x(buf + C * 8, Fprev, u2); s2 = scprev; one2 = (Fprev[0] == 1.0); }
       else if (fl & kOpF22) { matvec_x(buf + C * 8, Fout, u2); s2 = scout; one2 = (Fout[0] == 1.0); }
-      else { matvec_r(buf + C * 8, R.b, u2); s2 = R.sb; one2 = (as_d(R.b[0]) == 1.0); }
+      else { matvec_r(buf + C * 8, R.b, u2); s2 = R.sb; one2 = (first_d(R.b[0]) == 1.0); }
 
       PHY_STAMP(k, 2)
       // all-ones shortcut (src/avx.c:575-587): a category whose eight child entries are exactly 1.0 yields 1.0.
@@ -231,6 +236,9 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       unsigned ones_mask = 0; // bit c: category c is all ones in both children
       if (__builtin_amdgcn_ballot_w64(one1 && one2))
       {
+        double ra[CS], rb[CS];
+        unpack(R.a, ra);
+        unpack(R.b, rb);
 #pragma unroll
         for (int c = 0; c < CL; ++c)
         {
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
             a1 = true;
 #pragma unroll
             for (int j = 0; j < S; ++j)
-              a1 = a1 && (((fl & kOpF11) ? Fprev[c * 4 + j] : (fl & kOpF12) ? Fout[c * 4 + j] : as_d(R.a[c * 4 + j])) == 1.0);
+              a1 = a1 && (((fl & kOpF11) ? Fprev[c * 4 + j] : (fl & kOpF12) ? Fout[c * 4 + j] : ra[c * 4 + j]) == 1.0);
           }
           if (fl & kOpTip2) a2 = (R.cb == 15u);
           else
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
             a2 = true;
 #pragma unroll
             for (int j = 0; j < S; ++j)
-              a2 = a2 && (((fl & kOpF21) ? Fprev[c * 4 + j] : (fl & kOpF22) ? Fout[c * 4 + j] : as_d(R.b[c * 4 + j])) == 1.0);
+              a2 = a2 && (((fl & kOpF21) ? Fprev[c * 4 + j] : (fl & kOpF22) ? Fout[c * 4 + j] : rb[c * 4 + j]) == 1.0);
           }
           ones_mask |= (a1 && a2) ? (1u << c) : 0u;
         }
@@ -288,11 +296,11 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       {
         const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
 #pragma unroll
-        for (int e = 0; e < CS; ++e)
+        for (int e = 0; e < HP; ++e)
         {
-          u32x2 w;
-          __builtin_memcpy(&w, &Fout[e], 8);
-          __builtin_amdgcn_raw_buffer_store_b64(w, dr, voff8, (unsigned)e * rowb, 0);
+          u32x4 w;
+          __builtin_memcpy(&w, &Fout[2 * e], 16);
+          __builtin_amdgcn_raw_buffer_store_b128(w, dr, voff16, (unsigned)e * rowb, 0);
         }
         __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff4, 0, 0);
       }
@@ -336,9 +344,13 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       }
       else
       {
-        const double *src = q.partials + (size_t)(idx - tips) * bufsz + (size_t)(c0 * S) * q.Ppad + p;
+        const double2 *src = reinterpret_cast<const double2 *>(q.partials + (size_t)(idx - tips) * bufsz) + (size_t)(c0 * 2) * q.Ppad + p;
 #pragma unroll
-        for (int e = 0; e < CS; ++e) v[e] = src[(size_t)e * q.Ppad];
+        for (int e = 0; e < HP; ++e)
+        {
+          const double2 t2 = src[(size_t)e * q.Ppad];
+          v[2 * e] = t2.x; v[2 * e + 1] = t2.y;
+        }
         sc = (unsigned)q.scales[(size_t)(idx - tips) * q.Ppad + p];
       }
     };
