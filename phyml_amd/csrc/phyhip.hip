@@ -463,6 +463,9 @@ int flush(Instance *I, const EdgeEval *ee)
           data  = desc(I->d_partials + b * buf_elems(I), ld ? bufbytes : 0, pmoff);
           scale = desc(I->d_scales + b * I->Ppad, ld ? (size_t)I->Ppad * 4 : 0, 0);
           tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->Ppad, t ? (size_t)I->Ppad : 0, 0);
+          // lane-per-pattern nucleotide kernel: ONE auxiliary dword load per child -- the scale descriptor of a tip
+          // child points at its tip row instead (spare word 1: the kernel then reads the aligned dword holding the byte)
+          if (I->soa && t) scale = desc(I->d_tipcodes + (size_t)c * I->Ppad, (size_t)I->Ppad, 1);
         };
         child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes);
         child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);

@@ -67,8 +67,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
   struct Raw
   {
     u32x4    a[HP], b[HP]; // child 1 / child 2 entries, as state pairs
-    unsigned sa, sb;       // scale exponents
-    unsigned ca, cb;       // tip bytes (allowed-state masks)
+    unsigned sa, sb;       // internal child: scale exponent; tip child: the aligned 4 bytes that hold its state byte
   };
   const __amdgpu_buffer_rsrc_t pm_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pmats), 0, 0x7fffffff, 0x00020000);
@@ -79,16 +78,15 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
 
   // issue every load an operation needs (which ones are live was decided by the host)
   auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc) {
-    const __amdgpu_buffer_rsrc_t d1r = rsrc(o.c1_data), d2r = rsrc(o.c2_data), g1r = rsrc(o.c1_scale),
-                                 g2r = rsrc(o.c2_scale), y1r = rsrc(o.c1_tip), y2r = rsrc(o.c2_tip);
+    // one auxiliary dword per child: a tip child has no scale vector and an internal child no tip byte, so the host
+    // points the same descriptor at whichever row exists (spare word x = 1: tip row, addressed by aligned dword)
+    const __amdgpu_buffer_rsrc_t d1r = rsrc(o.c1_data), d2r = rsrc(o.c2_data), g1r = rsrc(o.c1_scale), g2r = rsrc(o.c2_scale);
 #pragma unroll
     for (int e = 0; e < HP; ++e) r.a[e] = __builtin_amdgcn_raw_buffer_load_b128(d1r, voff16, (unsigned)e * rowb, 0);
 #pragma unroll
     for (int e = 0; e < HP; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b128(d2r, voff16, (unsigned)e * rowb, 0);
-    r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, voff4, 0, 0);
-    r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, voff4, 0, 0);
-    r.ca = __builtin_amdgcn_raw_buffer_load_b8(y1r, p, 0, 0);
-    r.cb = __builtin_amdgcn_raw_buffer_load_b8(y2r, p, 0, 0);
+    r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, o.c1_scale.x ? (p & ~3u) : voff4, 0, 0);
+    r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, o.c2_scale.x ? (p & ~3u) : voff4, 0, 0);
     // this lane's 16-byte piece of [matrix 1 | matrix 2] (C*16 doubles each)
     int ch = (lane < 16 * C) ? lane : 0;
     const int      mat = ch / (8 * C), within = ch - mat * 8 * C;
@@ -210,11 +208,13 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       double         u1[CS], u2[CS];
       unsigned       s1, s2;
       bool           one1, one2; // first-entry test of the all-ones shortcut
+      const unsigned tsh = (p & 3u) * 8u; // position of this pattern's byte inside a tip row's dword
+      const unsigned tca = (R.sa >> tsh) & 255u, tcb = (R.sb >> tsh) & 255u;
       // ---- child 1 ----
       if (fl & kOpTip1)
       {
-        tip_u(bufd, buf, R.ca, u1);
-        s1 = 0; one1 = (R.ca == 15u);
+        tip_u(bufd, buf, tca, u1);
+        s1 = 0; one1 = (tca == 15u);
       }
       else if (fl & kOpF11) { matvec_x(buf, Fprev, u1); s1 = scprev; one1 = (Fprev[0] == 1.0); }
       else if (fl & kOpF12) { matvec_x(buf, Fout, u1); s1 = scout; one1 = (Fout[0] == 1.0); }
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       // ---- child 2 ----
       if (fl & kOpTip2)
       {
-        tip_u(bufd + C * 16, buf + C * 8, R.cb, u2);
-        s2 = 0; one2 = (R.cb == 15u);
+        tip_u(bufd + C * 16, buf + C * 8, tcb, u2);
+        s2 = 0; one2 = (tcb == 15u);
       }
       else if (fl & kOpF21) { matvec_x(buf + C * 8, Fprev, u2); s2 = scprev; one2 = (Fprev[0] == 1.0); }
       else if (fl & kOpF22) { matvec_x(buf + C * 8, Fout, u2); s2 = scout; one2 = (Fout[0] == 1.0); }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
         for (int c = 0; c < CL; ++c)
         {
           bool a1, a2;
-          if (fl & kOpTip1) a1 = (R.ca == 15u);
+          if (fl & kOpTip1) a1 = (tca == 15u);
           else
           {
             a1 = true;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
             for (int j = 0; j < S; ++j)
               a1 = a1 && (((fl & kOpF11) ? Fprev[c * 4 + j] : (fl & kOpF12) ? Fout[c * 4 + j] : ra[c * 4 + j]) == 1.0);
           }
-          if (fl & kOpTip2) a2 = (R.cb == 15u);
+          if (fl & kOpTip2) a2 = (tcb == 15u);
           else
           {
             a2 = true;
