@@ -463,7 +463,8 @@ int flush(Instance *I, const EdgeEval *ee)
           data  = desc(I->d_partials + b * buf_elems(I), ld ? bufbytes : 0, pmoff);
           scale = desc(I->d_scales + b * I->Ppad, ld ? (size_t)I->Ppad * 4 : 0, 0);
           tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->Ppad, t ? (size_t)I->Ppad : 0, 0);
-          // lane-per-pattern nucleotide kernel: ONE auxiliary dword load per child -- the scale descriptor of a tip
+          // lane-per-pattern nucleotide kernel: ONE auxiliary dword load per child (measured for the 20-state kernel too:
+          // 640 vs 590 us -- slower there) -- the scale descriptor of a tip
           // child points at its tip row instead (spare word 1: the kernel then reads the aligned dword holding the byte)
           if (I->soa && t) scale = desc(I->d_tipcodes + (size_t)c * I->Ppad, (size_t)I->Ppad, 1);
         };
