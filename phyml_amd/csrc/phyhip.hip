@@ -527,6 +527,7 @@ int flush(Instance *I, const EdgeEval *ee)
               fprintf(stderr, "step %2d:", k);
               for (int i = 1; i < 7; ++i) fprintf(stderr, " %6lld", (long long)(h[k * 8 + i] - h[k * 8 + i - 1]));
               if (k + 1 < 64) fprintf(stderr, "  | next %6lld", (long long)(h[(k + 1) * 8] - h[k * 8 + 6]));
+              fprintf(stderr, "  | load issue %6lld of segment 4", (long long)(h[k * 8 + 7] - h[k * 8 + 3]));
               fprintf(stderr, "\n");
             }
           }

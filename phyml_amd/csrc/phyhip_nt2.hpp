@@ -195,6 +195,9 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     auto step = [&](const int k, const int parity, Raw &R, u32x4 &PC, double (&Fout)[CS], unsigned &scout,
                     const double (&Fprev)[CS], const unsigned scprev) {
       PHY_STAMP(k, 0)
+      // the execute record of operation k+1 is the first thing the next step needs (its flags steer the operand
+      // selection): its scalar load goes out first so that it has the whole step to come back from L2
+      const ExecRec nx1 = xrec[(k + 1 < last) ? k + 1 : last];
       double2 *buf = reinterpret_cast<double2 *>(&lds_p[parity][0]);
       {
         double2 v;
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       PHY_STAMP(k, 3)
       // prefetch operation k+2 into the registers just freed; then the scalar records of the next step
       issue(nx2, R, PC);
+      PHY_STAMP(k, 7)
       const IssueRec nx3 = irec[(k + 3 < last) ? k + 3 : last];
-      const ExecRec  nx1 = xrec[(k + 1 < last) ? k + 1 : last];
       __builtin_amdgcn_wave_barrier();
       PHY_STAMP(k, 4)
 
