@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
   {
     const int lane = e & 63, t = (e >> 6) % kAaT, half = ((e >> 6) / kAaT) & 1, c = (e >> 6) / (2 * kAaT);
     const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
-    dst[(size_t)(c * 2 + half) * kAaBlock + aa_slot(t, lane)] = src[(size_t)c * 400 + i * 20 + j];
+    dst[(size_t)c * 2 * kAaBlock + aa_afrag_slot(half, t, lane)] = src[(size_t)c * 400 + i * 20 + j];
   }
 }
 
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadPar
     {
       const int lane = e & 63, t = (e >> 6) % kAaT, half = ((e >> 6) / kAaT) & 1, c = (e >> 6) / (2 * kAaT);
       const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
-      dst[(size_t)(c * 2 + half) * kAaBlock + aa_slot(t, lane)] = mat[(size_t)c * 400 + i * 20 + j];
+      dst[(size_t)c * 2 * kAaBlock + aa_afrag_slot(half, t, lane)] = mat[(size_t)c * 400 + i * 20 + j];
     }
   }
 }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
   const unsigned  blk_bytes  = (unsigned)(((size_t)tile * tile_elems + (size_t)c * kAaBlock) * 8);
   const unsigned  voff_d16 = blk_bytes + lane * 16, voff_d8 = blk_bytes + 2048 + lane * 8; // chunk pairs | chunk 4
   const unsigned  voff_s = (unsigned)p0 * 4u, voff_t = (unsigned)p0;
-  const unsigned  voff_a16 = (unsigned)c * 2 * kAaBlock * 8 + lane * 16, voff_a8 = (unsigned)c * 2 * kAaBlock * 8 + 2048 + lane * 8;
+  const unsigned  voff_a16 = (unsigned)c * 2 * kAaBlock * 8 + lane * 16; // this category's A table, this lane's pairs
 
   __shared__ unsigned xchm[2][CP][16]; // per-pattern maxima (high words), double-buffered by step parity
   __shared__ double   xchl[CP][16];    // category likelihoods of the edge evaluation
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
     unsigned sa, sb, ca, cb;
   };
   struct AFrag
-  {
-    Frag lo, hi; // rows 0..15 | rows 16..19 of one child's matrix
+  { // one child's matrix for this category: rows 0..15 (five k-chunks) then rows 16..19 (five k-chunks), ten values
+    u32x4 q[5];
   };
   const __amdgpu_buffer_rsrc_t af_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<double *>(afrag), 0, (int)((size_t)n_frag_mats * frag_mat * 8), 0x00020000);
@@ -221,18 +221,26 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
     r.ca = __builtin_amdgcn_raw_buffer_load_b8(rsrc(o.c1_tip), voff_t, 0, 0);
     r.cb = __builtin_amdgcn_raw_buffer_load_b8(rsrc(o.c2_tip), voff_t, 0, 0);
   };
+  auto load_afrag = [&](AFrag &A, unsigned off) {
+#pragma unroll
+    for (int g = 0; g < 5; ++g) A.q[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, voff_a16 + g * 1024, off, 0);
+  };
   auto issue_matrices = [&](unsigned off1, unsigned off2, AFrag &A1, AFrag &A2) {
-    load_frag(A1.lo, af_rsrc, voff_a16, voff_a8, off1);
-    load_frag(A2.lo, af_rsrc, voff_a16, voff_a8, off2);
-    load_frag(A1.hi, af_rsrc, voff_a16 + kAaBlock * 8, voff_a8 + kAaBlock * 8, off1);
-    load_frag(A2.hi, af_rsrc, voff_a16 + kAaBlock * 8, voff_a8 + kAaBlock * 8, off2);
+    load_afrag(A1, off1);
+    load_afrag(A2, off2);
+  };
+  auto unpack_afrag = [](const AFrag &A, double (&lo)[T], double (&hi)[T]) {
+    double v[2 * T];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) __builtin_memcpy(&v[2 * g], &A.q[g], 16);
+#pragma unroll
+    for (int t = 0; t < T; ++t) { lo[t] = v[t]; hi[t] = v[T + t]; }
   };
   // u[t] = sum over input states of P[c][state kk + 4t][.] * x[.]: rows 0..15 on the 16x16x4 shape, rows 16..19 on
   // the four-block 4x4x4 shape, five k-chunks each, ascending
   auto matvec = [&](const AFrag &A, const double (&x)[T], double (&u)[T]) {
     double alo[T], ahi[T];
-    unpack(A.lo, alo);
-    unpack(A.hi, ahi);
+    unpack_afrag(A, alo, ahi);
     v4d    lo = {0., 0., 0., 0.};
     double hi = 0.;
 #pragma unroll
@@ -329,10 +337,8 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
         // select (628 vs 589 us), all of them after the MFMA chain (627 vs 576 us).  The A fragments of operation k+1 follow the last MFMA that reads this operation's, into
         // the same registers.
         double a1lo[T], a1hi[T], a2lo[T], a2hi[T];
-        unpack(A1.lo, a1lo);
-        unpack(A1.hi, a1hi);
-        unpack(A2.lo, a2lo);
-        unpack(A2.hi, a2hi);
+        unpack_afrag(A1, a1lo, a1hi);
+        unpack_afrag(A2, a2lo, a2hi);
         v4d    lo1 = {0., 0., 0., 0.}, lo2 = {0., 0., 0., 0.};
         double hi1 = 0., hi2 = 0.;
         issue_children(nx1, Rn);
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // one vector-memory read
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * T, 0);  // the 4x4x4 chain
-        __builtin_amdgcn_sched_group_barrier(0x020, 12, 0);     // A fragments of operation k+1
+        __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);     // A fragments of operation k+1
         u1[0] = lo1[0]; u1[1] = lo1[1]; u1[2] = lo1[2]; u1[3] = lo1[3]; u1[4] = hi1;
         u2[0] = lo2[0]; u2[1] = lo2[1]; u2[2] = lo2[2]; u2[3] = lo2[3]; u2[4] = hi2;
       }
@@ -447,8 +453,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
     side(q.e_child, y, sr);
     {
       AFrag A;
-      load_frag(A.lo, af_rsrc, voff_a16, voff_a8, (unsigned)((size_t)q.e_pm * frag_mat * 8));
-      load_frag(A.hi, af_rsrc, voff_a16 + kAaBlock * 8, voff_a8 + kAaBlock * 8, (unsigned)((size_t)q.e_pm * frag_mat * 8));
+      load_afrag(A, (unsigned)((size_t)q.e_pm * frag_mat * 8));
       matvec(A, x, u); // rows: right-side state
     }
     double part = 0.0;

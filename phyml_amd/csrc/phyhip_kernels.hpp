@@ -162,6 +162,13 @@ struct RO
 // the five k-chunk values a lane owns are stored as two 16-byte pairs (chunks 0|1 and 2|3) and one single
 // (chunk 4), each group contiguous over the 64 lanes, so a fragment set moves as 2 x dwordx4 + 1 x dwordx2.
 __host__ __device__ inline int aa_slot(int t, int lane) { return t < 4 ? (t >> 1) * 128 + lane * 2 + (t & 1) : 256 + lane; }
+// A-operand table of one (matrix, category): 640 doubles -- a lane's ten values (rows 0..15: k-chunks 0..4, then rows
+// 16..19: k-chunks 0..4) as five 16-byte pairs, each pair contiguous over the 64 lanes: five dwordx4 loads per matrix
+__host__ __device__ inline int aa_afrag_slot(int half, int t, int lane)
+{
+  const int v = half * 5 + t;
+  return (v >> 1) * 128 + lane * 2 + (v & 1);
+}
 
 // child fetch in two phases so that ALL loads of an operation are in flight before the first wait:
 //   issue_side  -- only issues the loads (tip: one code byte; internal: S doubles + the scale word)
@@ -1361,7 +1368,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
     {
       const int lane = e & 63, t = (e >> 6) % 5, half = ((e >> 6) / 5) & 1, c = (e >> 6) / 10;
       const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
-      dst[(size_t)(c * 2 + half) * 320 + aa_slot(t, lane)] = tmp[(c * S + i) * S + j] / rsum[c * S + i];
+      dst[(size_t)c * 640 + aa_afrag_slot(half, t, lane)] = tmp[(c * S + i) * S + j] / rsum[c * S + i];
     }
   }
 }
