@@ -171,6 +171,7 @@ struct Instance
   unsigned *d_tickets = nullptr;
   double   *d_mixexpl = nullptr; // expl pairs of the classes of a mixture evaluation (first instance only)
   int    ablate = 0;         // PHYHIP_ABLATE: timing-only kernel variants (results invalid)
+  bool   eager_pmats = true; // PHYHIP_EAGER_PMAT=0: whole-tree matrix batches wait for the traversal launch too
   bool   no_loads = false;   // PHYHIP_NOLOADS: zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
 
@@ -881,6 +882,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
+  if (const char *e = getenv("PHYHIP_EAGER_PMAT")) I->eager_pmats = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce() { I->split_reduce = atoi(e) != 0; I->split_reduce_forced = true; }
   if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_FOLD_PMATS")) I->fold_pmats = atoi(e) != 0;
@@ -1129,6 +1131,9 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
       I->pm_len.push_back(edgeLengths[i]);
     }
   }
+  // A whole-tree batch (Update_All_PMat, src/lk.c:500-512) is launched now rather than with the traversal: the device
+  // rebuilds the matrices while the host walks the tree and fills the operation list.
+  if (count >= kEagerPmBatch && I->eager_pmats) return flush_pmats(I);
   return PHYHIP_SUCCESS;
 }
 

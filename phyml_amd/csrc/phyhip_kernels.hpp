@@ -1290,6 +1290,7 @@ template <int S> __global__ __launch_bounds__(256) void mixture_dlk_kernel(const
 //     one block per matrix; thread (c,i) builds row i of category c
 // ---------------------------------------------------------------------------------------------
 constexpr int kSmallPm = 8; // up to this many (index, length) pairs travel inside the kernel arguments
+constexpr int kEagerPmBatch = 32; // a single call queueing at least this many matrices launches their rebuild at once
 struct PmatParams
 {
   const int    *indices; // [count]  (nullptr: use small_idx / small_len)
