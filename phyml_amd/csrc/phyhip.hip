@@ -159,6 +159,10 @@ struct Instance
   std::unordered_map<uint32_t, int>      mask_code;
   bool                                   masks_dirty = false;
   std::vector<double>                    h_rates, h_eval;
+  std::vector<double>                    h_model;      // host shadow of d_model: a setter called with unchanged values
+  std::vector<unsigned char>             h_model_set;  // ... (callers re-push the model before every evaluation) costs nothing
+  std::vector<short>                     h_invar;
+  bool                                   h_invar_set = false;
   StagingRing                            ring;
 
   double l_min = 1.e-8, l_max = 100., br_len_mult = 1.0, pinvar = 0.0; // src/init.c:711-714
@@ -830,6 +834,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->d_pi = I->d_model; I->d_catw = I->d_pi + I->S; I->d_catr = I->d_catw + I->C; I->d_eval = I->d_catr + I->C;
   I->d_evec = I->d_eval + I->S; I->d_ivec = I->d_evec + (size_t)I->S * I->S;
   I->h_rates.assign(I->C, 1.0);
+  I->h_model.assign(model_doubles, 0.0);
+  I->h_model_set.assign(model_doubles, 0);
   I->h_eval.assign(I->S, 0.0);
   HIPCHK(hipMalloc((void **)&I->d_site_lnl, I->P * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_site_lk, I->P * sizeof(double)));
@@ -1024,9 +1030,13 @@ int phyhip_set_pattern_weights(int instance, const double *w)
 
 static int small_upload(Instance *I, double *dst, const double *src, size_t n)
 {
+  const size_t off = (size_t)(dst - I->d_model);
+  if (I->h_model_set[off] && !memcmp(I->h_model.data() + off, src, n * sizeof(double))) return PHYHIP_SUCCESS;
   int rc = flush_sync(I); // model blocks change rarely; keep it simple and ordered
   if (rc) return rc;
   HIPCHK(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+  memcpy(I->h_model.data() + off, src, n * sizeof(double));
+  I->h_model_set[off] = 1;
   return PHYHIP_SUCCESS;
 }
 
@@ -1066,21 +1076,30 @@ int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, co
 int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br_len_mult, int apply_lk_scaling)
 {
   GET_INST(I, instance);
+  const int sc = apply_lk_scaling ? 1 : 0;
+  if (I->l_min == l_min && I->l_max == l_max && I->br_len_mult == br_len_mult && I->apply_scaling == sc) return PHYHIP_SUCCESS;
   int rc = flush(I, nullptr);
   if (rc) return rc;
-  I->l_min = l_min; I->l_max = l_max; I->br_len_mult = br_len_mult; I->apply_scaling = apply_lk_scaling ? 1 : 0;
+  I->l_min = l_min; I->l_max = l_max; I->br_len_mult = br_len_mult; I->apply_scaling = sc;
   return PHYHIP_SUCCESS;
 }
 
 int phyhip_set_invariant_sites(int instance, int invar_model, double pinvar, const short *invar)
 {
   GET_INST(I, instance);
-  int rc = flush_sync(I);
+  if (!invar && invar_model) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "invar_model set but invar == NULL");
+  const bool same_sites = !invar || (I->h_invar_set && !memcmp(I->h_invar.data(), invar, I->P * sizeof(short)));
+  if (same_sites && I->invar_model == (invar_model ? 1 : 0) && I->pinvar == pinvar) return PHYHIP_SUCCESS;
+  int rc = same_sites ? flush(I, nullptr) : flush_sync(I); // the two scalars travel in the kernel arguments
   if (rc) return rc;
   I->invar_model = invar_model ? 1 : 0;
   I->pinvar      = pinvar;
-  if (invar) HIPCHK(hipMemcpy(I->d_invar, invar, I->P * sizeof(short), hipMemcpyHostToDevice));
-  else if (invar_model) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "invar_model set but invar == NULL");
+  if (!same_sites)
+  {
+    HIPCHK(hipMemcpy(I->d_invar, invar, I->P * sizeof(short), hipMemcpyHostToDevice));
+    I->h_invar.assign(invar, invar + I->P);
+    I->h_invar_set = true;
+  }
   return PHYHIP_SUCCESS;
 }
 

@@ -218,3 +218,29 @@ def test_cfg4_shard_size_cross_checks_the_two_nucleotide_mappings():
         finally:
             s.close()
     assert abs(parts - lnl) / abs(lnl) < 1e-12, (parts, lnl)
+
+
+@pytest.mark.parametrize("ns", [4, 20])
+def test_model_setters_skip_unchanged_values_and_follow_changes(ns):
+    """The model setters keep a host shadow: pushing the same block again (what update_beagle_* style callers do before
+    every evaluation) must be a no-op, and any changed value must reach the device."""
+    t, ot, *_ = synthetic_pair(9, 150, ns, 4, seed=31, host_pmat=False)
+    try:
+        m = ot.m
+        a0 = t.Lk(None)
+        assert abs(a0 - ot.lk(None)) <= 1e-12 * abs(a0)
+        t.set_model(m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, 1.0, 1)
+        assert t.Lk(None) == a0
+        rr = m.gamma_rr[::-1].copy()                                   # same multiset of rates, other weights attached
+        t.set_model(m.pi, rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, 1.0, 1)
+        b = t.Lk(None)
+        assert b != a0
+        pi2 = np.roll(m.pi, 1)
+        t.set_model(pi2, rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, 1.0, 1)
+        assert t.Lk(None) != b
+        t.set_model(m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, 2.0, 1)
+        assert t.Lk(None) != a0                                        # br_len_mult travels with the options
+        t.set_model(m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, 1.0, 1)
+        assert t.Lk(None) == a0
+    finally:
+        t.close()
