@@ -136,6 +136,7 @@ struct Instance
   double   *h_result   = nullptr; // pinned, device-visible: [0..1] results, [2] sequence number (as u64)
   unsigned long long seq = 0;     // evaluations handed to the host so far
   bool      spin_wait  = true;    // PHYHIP_SPIN=0: always hipStreamSynchronize
+  bool      warn_current = false; // *h_warn belongs to the evaluation the host last waited for (none launched since)
   int      *d_warn     = nullptr;
   int      *h_warn     = nullptr;
   void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
@@ -489,6 +490,7 @@ int flush(Instance *I, const EdgeEval *ee)
   }
   if (ee)
   {
+    I->warn_current = false;
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
     const int nblk = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     fused_sum = fuse_reduce(I, nblk);
@@ -665,6 +667,7 @@ int wait_result(Instance *I)
       if (*flag == I->seq)
       {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        I->warn_current = true;
         return 0;
       }
       __builtin_ia32_pause();
@@ -676,6 +679,7 @@ int wait_result(Instance *I)
     (void)hipMemsetAsync(I->d_tickets, 0, sizeof(unsigned), I->stream);
     return fail(PHYHIP_ERROR_GENERAL, "evaluation %llu finished without handing its result over", I->seq);
   }
+  I->warn_current = true;
   return 0;
 }
 
@@ -1445,9 +1449,12 @@ int phyhip_set_scale_factors(int instance, int bufferIndex, const int *in)
 int phyhip_get_numerical_warning(int instance, int *out)
 {
   GET_INST(I, instance);
-  int rc = flush_sync(I);
-  if (rc) return rc;
-  *out = *I->h_warn; // written by the final reduction of the last edge evaluation
+  if (!(I->warn_current && I->pending.empty()))
+  { // an evaluation whose result the host did not wait for (device-side output) may still be running
+    int rc = flush_sync(I);
+    if (rc) return rc;
+  }
+  *out = *I->h_warn; // written by the final reduction of the last edge evaluation, ahead of its sequence number
   return PHYHIP_SUCCESS;
 }
 
