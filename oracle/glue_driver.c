@@ -37,6 +37,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <link.h>
 
 #define main ref_driver_main_unused
 #include "ref_driver.c"
@@ -51,6 +52,69 @@ static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat =
 static double  g_worst_lnl = 0.0, g_worst_dlnl = 0.0, g_worst_mixt = 0.0, g_worst_mixt_dlnl = 0.0;
 static long    g_n_mixt_dlk = 0;
 static double  g_last_mixt_lnl = 0.0, g_best_full_lnl = -1e300;
+/* branch-support phase (aLRT_From_String, src/utilities.c:9282): alrt.c reads the per-pattern log-likelihoods of the last
+   Lk() (src/alrt.c:453,555,682), so every device evaluation is followed by the download hook of SURVEY 8(f) rank 3 */
+static int     g_site_outputs = 0;
+static long    g_n_site_dl = 0;
+static double  g_worst_site_lnl = 0.0;
+
+/* ---- the reference's random stream ------------------------------------------------------------------------------
+   PhyML draws from libc's global rand() (SPR's Rgamma jitter src/spr.c:813, Permutate, the RELL resampling of the SH-like
+   supports src/alrt.c:1148).  libamdhip64 and libhsa-runtime64 import rand/srand too, so in a process that talks to the
+   GPU the global stream is no longer the one `--r_seed` set up, and host / check / device runs of one command would not be
+   comparable where PhyML is stochastic.  rand/srand are therefore interposed like the likelihood surface: callers inside
+   libphyml_ref.so or this executable get a private stream -- glibc's own generator (random_r on a private TYPE_3 state
+   gives exactly the srand/rand sequence) -- everybody else gets libc's global one. */
+static uintptr_t g_ref_lo[4], g_ref_hi[4];
+static int       g_ref_n = -1;
+static int       note_object(struct dl_phdr_info *info, size_t size, void *data)
+{
+  (void)size; (void)data;
+  const char *nm = info->dlpi_name ? info->dlpi_name : "";
+  if (nm[0] && !strstr(nm, "libphyml_ref")) return 0; /* "" is the executable */
+  for (int k = 0; k < info->dlpi_phnum && g_ref_n < 4; ++k)
+    if (info->dlpi_phdr[k].p_type == PT_LOAD && (info->dlpi_phdr[k].p_flags & PF_X))
+    {
+      g_ref_lo[g_ref_n] = info->dlpi_addr + info->dlpi_phdr[k].p_vaddr;
+      g_ref_hi[g_ref_n] = g_ref_lo[g_ref_n] + info->dlpi_phdr[k].p_memsz;
+      ++g_ref_n;
+    }
+  return 0;
+}
+static int from_reference(const void *ret)
+{
+  if (g_ref_n < 0) { g_ref_n = 0; dl_iterate_phdr(note_object, NULL); }
+  for (int k = 0; k < g_ref_n; ++k) if ((uintptr_t)ret >= g_ref_lo[k] && (uintptr_t)ret < g_ref_hi[k]) return 1;
+  return 0;
+}
+static struct random_data g_rng;
+static char               g_rng_state[128];
+static int                g_rng_ready = 0;
+static void               private_seed(unsigned seed)
+{
+  if (!g_rng_ready) { memset(&g_rng, 0, sizeof g_rng); initstate_r(seed, g_rng_state, sizeof g_rng_state, &g_rng); g_rng_ready = 1; }
+  else srandom_r(seed, &g_rng);
+}
+void srand(unsigned seed)
+{
+  static void (*real)(unsigned) = NULL;
+  if (from_reference(__builtin_return_address(0))) { private_seed(seed); return; }
+  if (!real) real = (void (*)(unsigned))dlsym(RTLD_NEXT, "srand");
+  real(seed);
+}
+int rand(void)
+{
+  static int (*real)(void) = NULL;
+  if (from_reference(__builtin_return_address(0)))
+  {
+    int32_t r;
+    if (!g_rng_ready) private_seed(1); /* glibc: rand() before srand() behaves as srand(1) */
+    random_r(&g_rng, &r);
+    return (int)r;
+  }
+  if (!real) real = (int (*)(void))dlsym(RTLD_NEXT, "rand");
+  return real();
+}
 
 static void die(const char *what)
 {
@@ -122,7 +186,13 @@ static ctx_t *ensure_instance(t_tree *tree)
   for (int i = 0; i < g_nctx; ++i) if (g_ctx[i].tree == tree) return &g_ctx[i];
   if (tree->is_mixt_tree || tree->n_root || tree->mod->gamma_mgf_bl == YES || tree->mod->log_l == YES || tree->mod->use_m4mod)
   { fprintf(stderr, "glue_driver: unsupported tree kind (rooted / mgf / log_l / m4, or the mixture tree itself)\n"); exit(5); }
-  if (!tree->mixt_tree && g_nctx > 0) { fprintf(stderr, "glue_driver: a second ordinary tree object reached the likelihood surface\n"); exit(5); }
+  if (!tree->mixt_tree && g_nctx > 0)
+  { /* a fresh tree object for the same data (aLRT_From_String rebuilds the tree from its Newick string and calls
+       Make_Tree_For_Lk again; under BEAGLE it creates a fresh instance there too, src/utilities.c:9314): the old instance goes */
+    if (g_nctx != 1 || g_ctx[0].tree->mixt_tree) { fprintf(stderr, "glue_driver: an ordinary tree after class trees\n"); exit(5); }
+    OK(phyhip_finalize_instance(g_ctx[0].inst));
+    g_nctx = 0;
+  }
   if (g_nctx == MAXCTX) { fprintf(stderr, "glue_driver: too many class trees\n"); exit(5); }
   ctx_t *c = &g_ctx[g_nctx++];
   memset(c, 0, sizeof *c);
@@ -207,6 +277,29 @@ void Update_Eigen_Lr(t_edge *b, t_tree *tree)
   if (g_check) real(b, tree);
 }
 
+static void site_outputs(t_tree *tree, ctx_t *c)
+{ /* what Lk_Core leaves per pattern for host readers (src/lk.c:855-857): device mode writes them where alrt.c / io.c look,
+     check mode compares them with what the original just wrote */
+  const int P = tree->data->n_pattern, C = tree->mod->ras->n_catg;
+  ++g_n_site_dl;
+  if (!g_check)
+  {
+    OK(phyhip_get_site_outputs(c->inst, tree->c_lnL_sorted, tree->cur_site_lk, tree->unscaled_site_lk_cat, tree->fact_sum_scale));
+    return;
+  }
+  double *lnl = malloc(sizeof(double) * P), *cat = malloc(sizeof(double) * P * C);
+  int    *f = malloc(sizeof(int) * P);
+  OK(phyhip_get_site_outputs(c->inst, lnl, NULL, cat, f));
+  for (int p = 0; p < P; ++p)
+  {
+    if (tree->data->wght[p] <= SMALL) continue; /* skipped by both (src/lk.c:627) */
+    track(&g_worst_site_lnl, lnl[p], tree->c_lnL_sorted[p], 1.0);
+    if (f[p] != tree->fact_sum_scale[p]) { fprintf(stderr, "glue_driver: scale exponent of pattern %d differs\n", p); exit(6); }
+    for (int k = 0; k < C; ++k) track(&g_worst_site_lnl, cat[p * C + k], tree->unscaled_site_lk_cat[p * C + k], 1e-300);
+  }
+  free(lnl); free(cat); free(f);
+}
+
 static double device_edge_value(t_tree *tree, const t_edge *b)
 {
   ctx_t *c = ensure_instance(tree);
@@ -217,6 +310,7 @@ static double device_edge_value(t_tree *tree, const t_edge *b)
     int l, r, pm = mat_id(c, b->Pij_rr), zero = 0;
     edge_sides(c, b, &l, &r);
     OK(phyhip_calculate_edge_log_likelihoods(c->inst, &l, &r, &pm, NULL, NULL, &zero, &zero, NULL, 1, &lnl, NULL, NULL));
+    if (g_site_outputs) site_outputs(tree, c);
   }
   return lnl;
 }
@@ -494,14 +588,21 @@ int main(int argc, char **argv)
   /* src/main.c:281-282 */
   Set_Both_Sides(YES, tree);
   Lk(NULL, tree);
-  const double dt = now_s() - t0;
+  const double lnl_final = tree->c_lnL;
   char *nwk = Write_Tree(tree);
+  char *support_nwk = NULL;
+  if (tree->io->ratio_test != NO)
+  { /* src/main.c:371-375: fast branch supports on the most likely tree (a new tree object, a new instance) */
+    g_site_outputs = 1;
+    support_nwk = aLRT_From_String(Write_Tree(tree), tree->data, tree->mod, tree->io);
+  }
+  const double dt = now_s() - t0;
   printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"device_pmat\": %d, \"lnL_init\": %.17g, \"lnL_final\": %.17g, \"seconds\": %.3f, "
          "\"calls\": {\"Lk\": %ld, \"Lk_full\": %ld, \"Update_Partial_Lk\": %ld, \"dLk\": %ld, \"Update_PMat\": %ld, "
          "\"Update_Eigen_Lr\": %ld}, \"worst_rel_lnL\": %.3g, \"worst_rel_dlnL\": %.3g, \"buffers\": %d, \"matrices\": %d, "
-         "\"tree\": \"%s\"}\n",
-         g_host ? "host" : (g_check ? "check" : "device"), g_device_pmat, lnl_init, tree->c_lnL, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
-         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, nwk ? nwk : "");
+         "\"site_output_downloads\": %ld, \"worst_rel_site_output\": %.3g, \"support_tree\": \"%s\", \"tree\": \"%s\"}\n",
+         g_host ? "host" : (g_check ? "check" : "device"), g_device_pmat, lnl_init, lnl_final, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
+         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, support_nwk ? support_nwk : "", nwk ? nwk : "");
   fflush(stdout);
   for (int k = 0; k < g_nctx; ++k) OK(phyhip_finalize_instance(g_ctx[k].inst));
   _exit(0);

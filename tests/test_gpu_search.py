@@ -7,8 +7,10 @@ with Lk / dLk / Update_Partial_Lk / Update_PMat_At_Given_Edge / Update_Eigen_Lr 
   check mode   the reference's own arithmetic runs alongside and steers the search; EVERY scalar of the search (tens of
                thousands of Lk(b), ~100 000 dLk) is compared call by call with what the device returns: the worst
                relative difference must stay below 1e-10 (north star: 1e-6)
-  device mode  the search is driven only by device results and must end in the neighbourhood of the reference's end
-               point on the same machine (sanity check: the heuristic is chaotic in the last bits of every lnL)
+  device mode  the search is driven only by device results and must follow the reference-steered run on the same machine
+               (the driver gives PhyML a private rand() stream, see glue_driver.c: the runs of record make exactly the same
+               calls and agree to 1e-13 at the end; a last-bit tie broken the other way would still be legitimate, hence
+               the two-level assertion)
 
 The CPU-only end point recorded in the build container (tests/golden/search_expected.json) is a sanity anchor only: the
 search trajectory depends on the last bits of libm's exp/log, which differ between host CPUs.
@@ -65,15 +67,21 @@ def test_real_search_driven_by_the_device(name, tmp_path):
     ref = run_search(name, "check", tmp_path)       # what the reference does on this machine
     info = run_search(name, "device", tmp_path)     # the same search, device results only
     assert abs(info["lnL_init"] - ref["lnL_init"]) <= 1e-12 * abs(ref["lnL_init"])
-    # The heuristic is chaotic in the last bits of every lnL (the device differs from the AVX path by ~1e-15 relative, as
-    # two host CPUs differ from each other through libm): call counts, intermediate trees and even the local optimum
-    # reached differ between runs -- the reference's own end point on examples/nucleic was -5580.1235 on one box and
-    # -5583.0951 on another.  So this is the sanity check SURVEY 8d asks for, not the parity gate (that is check mode):
-    # the device-driven search must end in the same neighbourhood (1e-3 relative; typically 1e-7).
+    # The device differs from the AVX path by ~1e-15 relative per call; a decision of the heuristic that hangs on such a
+    # difference may legitimately go the other way (two host CPUs differ from each other the same way through libm: the
+    # reference's own end point on examples/nucleic was -5580.1235 on one box and -5583.0951 on another).  So: the end point
+    # must be in the same neighbourhood (SURVEY 8d's sanity check), and when the trajectory is the same -- it was, call for
+    # call, in every run since PhyML got its private rand() stream -- the end points must agree to 1e-9.
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"check": {k: ref[k] for k in ("lnL_final", "calls", "seconds")}, "device": {k: info[k] for k in ("lnL_final", "calls", "seconds")}},
+                  open(os.path.join(out, "search_end_points_%s.json" % name), "w"))
     assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-3 * abs(ref["lnL_final"]), (info["lnL_final"], ref["lnL_final"])
     assert info["lnL_final"] > info["lnL_init"] + 10.0
     for k in ("Lk", "dLk", "Update_Partial_Lk"):
         assert 0.5 * ref["calls"][k] < info["calls"][k] < 2.0 * ref["calls"][k]
+    if info["calls"] == ref["calls"]:
+        assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-9 * abs(ref["lnL_final"])
 
 
 def test_real_search_with_device_built_matrices(tmp_path):
@@ -128,3 +136,68 @@ def test_lg4x_mixture_analysis_driven_by_the_device(tmp_path):
     assert info["mode"] == "device" and info["class_instances"] == 4
     assert info["calls"]["MIXT_Lk"] + info["calls"]["MIXT_dLk"] >= 8000
     assert -12496.6 < info["best_full_lnL"] < -12300.0 and info["best_full_lnL"] > -12490.0, info
+
+
+# ---- fast branch supports (src/alrt.c) on device-resident state: the download hooks of SURVEY 8(f) rank 3 -------------
+
+SUPPORT_ARGS = ["-d", "nt", "-m", "GTR", "-f", "0.3,0.2,0.2,0.3", "-c", "4", "-a", "0.8", "-o", "n", "-b", "-4", "--r_seed", "1"]
+
+
+def run_supports(mode, tmp_path):
+    key = ("supports", mode)
+    if key in _cache:
+        return _cache[key]
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built")
+    wd = os.path.join(str(tmp_path), "sup_" + mode)
+    os.makedirs(wd, exist_ok=True)
+    shutil.copy(os.path.join(GOLDEN, "examples_nucleic.phy"), os.path.join(wd, "nucleic"))
+    r = subprocess.run([GLUE, "--gtr-rr", "1,2.5,0.8,1.2,3.0,1", "--", "-i", "nucleic"] + SUPPORT_ARGS, cwd=wd,
+                       env=dict(os.environ, GLUE_MODE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:]
+    _cache[key] = json.loads(m.group(1))
+    return _cache[key]
+
+
+def _numbers(nwk):
+    """(support values, branch lengths, topology with the numbers removed) of a Newick string written by Write_Tree."""
+    sup = [float(x) for x in re.findall(r"\)([0-9.eE+-]+):", nwk)]
+    bl = [float(x) for x in re.findall(r":([0-9.eE+-]+)", nwk)]
+    return sup, bl, re.sub(r"\)[0-9.eE+-]+:", "):", re.sub(r":[0-9.eE+-]+", ":", nwk))
+
+
+def test_branch_supports_per_site_outputs_match_the_reference(tmp_path):
+    """SH-like supports (`-b -4`): alrt.c reads c_lnL_sorted of the last Lk() for each of the three NNI configurations
+    (src/alrt.c:453,555,682).  Check mode: after every device evaluation of the support phase the per-pattern outputs
+    (log-likelihood, per-category likelihoods, scale exponent) are downloaded and compared with what Lk_Core just wrote."""
+    info = run_supports("check", tmp_path)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({k: v for k, v in info.items() if k != "tree"}, open(os.path.join(out, "supports_check_mode.json"), "w"))
+    assert info["site_output_downloads"] > 1000, info
+    assert info["worst_rel_site_output"] < 1e-9, info
+    assert info["worst_rel_lnL"] < 1e-10 and info["worst_rel_dlnL"] < 1e-6, info
+    assert info["support_tree"].count(")") > 40
+
+
+def test_branch_supports_from_device_resident_state(tmp_path):
+    """Device mode: the host buffers alrt.c reads are filled by phyhip_get_site_outputs only; supports, branch lengths and
+    topology must come out as in the CPU-only run of the same command on this machine.  (The driver gives the reference a
+    private rand() stream -- see glue_driver.c -- so the RELL resampling of Statistics_To_SH, src/alrt.c:1148, draws the
+    same replicates in every mode; what is left are the ~1e-15 relative differences of the optimised NNI configurations,
+    which can move a replicate or two out of 10 000 where configurations are almost tied.)"""
+    host = run_supports("host", tmp_path)
+    dev = run_supports("device", tmp_path)
+    assert dev["site_output_downloads"] > 1000
+    hs, hb, ht = _numbers(host["support_tree"])
+    ds, db, dt = _numbers(dev["support_tree"])
+    assert ht == dt and len(hs) == len(ds) > 40
+    diffs = sorted(abs(a - b) for a, b in zip(hs, ds))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"host": hs, "device": ds, "host_seconds": host["seconds"], "device_seconds": dev["seconds"]},
+                  open(os.path.join(out, "supports_host_vs_device.json"), "w"))
+    assert diffs[-1] <= 0.005 and diffs[len(diffs) // 2] <= 2e-4, list(zip(hs, ds))
+    assert max(abs(a - b) for a, b in zip(hb, db)) <= 1e-6
+    assert abs(dev["lnL_final"] - host["lnL_final"]) <= 1e-12 * abs(host["lnL_final"])
