@@ -132,6 +132,7 @@ typedef struct
   t_tree     *tree;
   int         inst;
   const void *bufptr[MAXID]; int nbuf, bufcap;
+  int        *scaleptr[MAXID]; /* host sum_scale vector of each partials buffer (known once it was a destination) */
   const void *matptr[MAXID]; int nmat, matcap;
 } ctx_t;
 static ctx_t g_ctx[MAXCTX];
@@ -255,6 +256,7 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
                      &p_lk_v2, &sum_scale_v2, d, b, tree);
   phyhip_operation op;
   op.destinationPartials = buf_id(c, p_lk);
+  c->scaleptr[op.destinationPartials - tree->n_otu] = sum_scale;
   op.destinationScaleWrite = op.destinationScaleRead = PHYHIP_OP_NONE;
   op.child1Partials = n_v1->tax ? n_v1->num : buf_id(c, p_lk_v1);
   op.child1TransitionMatrix = mat_id(c, Pij1);
@@ -543,6 +545,40 @@ phydbl dLk(phydbl *l, t_edge *b, t_tree *tree)
   return tree->c_lnL;
 }
 
+/* Host readers of device-resident state: ancestral.c walks p_lk_left/rght and sum_scale_left/rght of
+   every edge (src/ancestral.c:677-869).  Device mode: every device buffer is downloaded to the host vector it stands
+   for (phyhip_get_partials / phyhip_get_scale_factors, the beagleGetPartials hook of src/beagle_utils.c:252).  Check mode:
+   the downloads are compared bit for bit with the host vectors the reference computed itself. */
+static long g_mirror_buffers = 0, g_mirror_mismatch = 0;
+static void mirror_partials(t_tree *tree)
+{
+  ctx_t       *c = ensure_instance(tree);
+  const int    P = tree->data->n_pattern, C = tree->mod->ras->n_catg, S = tree->mod->ns;
+  const size_t n = (size_t)P * C * S;
+  double      *tmp = malloc(sizeof(double) * n);
+  int         *sc = malloc(sizeof(int) * P);
+  for (int i = 0; i < c->nbuf; ++i)
+  {
+    double *host = (double *)c->bufptr[i];
+    if (!c->scaleptr[i]) continue; /* never a destination: a spare SPR buffer */
+    ++g_mirror_buffers;
+    if (!g_check)
+    {
+      OK(phyhip_get_partials(c->inst, tree->n_otu + i, PHYHIP_OP_NONE, host));
+      OK(phyhip_get_scale_factors(c->inst, tree->n_otu + i, c->scaleptr[i]));
+      continue;
+    }
+    OK(phyhip_get_partials(c->inst, tree->n_otu + i, PHYHIP_OP_NONE, tmp));
+    OK(phyhip_get_scale_factors(c->inst, tree->n_otu + i, sc));
+    for (int p = 0; p < P; ++p)
+    {
+      if (tree->data->wght[p] <= SMALL) continue;
+      if (memcmp(tmp + (size_t)p * C * S, host + (size_t)p * C * S, sizeof(double) * C * S) || sc[p] != c->scaleptr[i][p]) ++g_mirror_mismatch;
+    }
+  }
+  free(tmp); free(sc);
+}
+
 /* ---------------------------------------------------------------------------------------------------------------- */
 
 int main(int argc, char **argv)
@@ -590,6 +626,15 @@ int main(int argc, char **argv)
   Lk(NULL, tree);
   const double lnl_final = tree->c_lnL;
   char *nwk = Write_Tree(tree);
+  if (tree->io->ancestral == YES)
+  { /* src/main.c:288: marginal ancestral reconstruction reads the partial vectors of the evaluation above */
+    if (!g_host)
+    {
+      mirror_partials(tree);
+      site_outputs(tree, ensure_instance(tree));
+    }
+    Ancestral_Sequences(tree, YES);
+  }
   char *support_nwk = NULL;
   if (tree->io->ratio_test != NO)
   { /* src/main.c:371-375: fast branch supports on the most likely tree (a new tree object, a new instance) */
@@ -600,9 +645,10 @@ int main(int argc, char **argv)
   printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"device_pmat\": %d, \"lnL_init\": %.17g, \"lnL_final\": %.17g, \"seconds\": %.3f, "
          "\"calls\": {\"Lk\": %ld, \"Lk_full\": %ld, \"Update_Partial_Lk\": %ld, \"dLk\": %ld, \"Update_PMat\": %ld, "
          "\"Update_Eigen_Lr\": %ld}, \"worst_rel_lnL\": %.3g, \"worst_rel_dlnL\": %.3g, \"buffers\": %d, \"matrices\": %d, "
-         "\"site_output_downloads\": %ld, \"worst_rel_site_output\": %.3g, \"support_tree\": \"%s\", \"tree\": \"%s\"}\n",
+         "\"site_output_downloads\": %ld, \"worst_rel_site_output\": %.3g, \"mirrored_buffers\": %ld, \"mirror_mismatches\": %ld, "
+         "\"support_tree\": \"%s\", \"tree\": \"%s\"}\n",
          g_host ? "host" : (g_check ? "check" : "device"), g_device_pmat, lnl_init, lnl_final, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
-         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, support_nwk ? support_nwk : "", nwk ? nwk : "");
+         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, g_mirror_buffers, g_mirror_mismatch, support_nwk ? support_nwk : "", nwk ? nwk : "");
   fflush(stdout);
   for (int k = 0; k < g_nctx; ++k) OK(phyhip_finalize_instance(g_ctx[k].inst));
   _exit(0);

@@ -201,3 +201,45 @@ def test_branch_supports_from_device_resident_state(tmp_path):
     assert diffs[-1] <= 0.005 and diffs[len(diffs) // 2] <= 2e-4, list(zip(hs, ds))
     assert max(abs(a - b) for a, b in zip(hb, db)) <= 1e-6
     assert abs(dev["lnL_final"] - host["lnL_final"]) <= 1e-12 * abs(host["lnL_final"])
+
+
+# ---- ancestral reconstruction (src/ancestral.c) from downloaded partial vectors ---------------------------------------
+
+def run_ancestral(mode, tmp_path):
+    key = ("ancestral", mode)
+    if key in _cache:
+        return _cache[key]
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built")
+    wd = os.path.join(str(tmp_path), "anc_" + mode)
+    os.makedirs(wd, exist_ok=True)
+    shutil.copy(os.path.join(GOLDEN, "examples_nucleic.phy"), os.path.join(wd, "nucleic"))
+    args = [a for a in SUPPORT_ARGS]
+    args[args.index("-b") + 1] = "0"
+    r = subprocess.run([GLUE, "--gtr-rr", "1,2.5,0.8,1.2,3.0,1", "--", "-i", "nucleic"] + args + ["--ancestral"], cwd=wd,
+                       env=dict(os.environ, GLUE_MODE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:]
+    rows = []
+    for line in open(os.path.join(wd, "nucleic_phyml_ancestral_seq.txt")):
+        f = line.split()
+        if len(f) == 7 and f[0].isdigit():
+            rows.append((int(f[0]), int(f[1]), [float(x) for x in f[2:6]], f[6]))
+    _cache[key] = (json.loads(m.group(1)), rows)
+    return _cache[key]
+
+
+def test_ancestral_reconstruction_from_downloaded_partials(tmp_path):
+    """`--ancestral`: ancestral.c walks the partial and scale vectors of every edge on the host (src/ancestral.c:677-869).
+    Check mode: every device buffer is downloaded (phyhip_get_partials / phyhip_get_scale_factors) and compared BIT FOR BIT
+    with the host vector the reference computed for the same edge side.  Device mode: the host vectors are filled from the
+    downloads only and the reference's reconstruction must print the CPU-only run's marginal probabilities and states."""
+    info, _ = run_ancestral("check", tmp_path)
+    assert info["mirrored_buffers"] >= 2 * (2 * 54 - 3) - 54 and info["mirror_mismatches"] == 0, info
+    (_, host), (dinfo, dev) = run_ancestral("host", tmp_path), run_ancestral("device", tmp_path)
+    assert dinfo["mirrored_buffers"] == info["mirrored_buffers"]
+    assert len(host) == len(dev) > 10000
+    for h, d in zip(host, dev):
+        assert h[0] == d[0] and h[1] == d[1] and h[3] == d[3], (h, d)
+        for a, b in zip(h[2], d[2]):
+            assert abs(a - b) <= 1e-5 * max(abs(a), 1e-30) + 1e-300, (h, d)
