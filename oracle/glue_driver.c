@@ -635,6 +635,12 @@ int main(int argc, char **argv)
     }
     Ancestral_Sequences(tree, YES);
   }
+  if (tree->io->print_site_lnl)
+  { /* src/main.c:323, src/io.c:1870-2013: per-site likelihoods, per-category likelihoods and posterior mean rates */
+    if (!g_host) site_outputs(tree, ensure_instance(tree));
+    Print_Site_Lk(tree, tree->io->fp_out_lk);
+    fflush(tree->io->fp_out_lk);
+  }
   char *support_nwk = NULL;
   if (tree->io->ratio_test != NO)
   { /* src/main.c:371-375: fast branch supports on the most likely tree (a new tree object, a new instance) */

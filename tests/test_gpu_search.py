@@ -216,7 +216,7 @@ def run_ancestral(mode, tmp_path):
     shutil.copy(os.path.join(GOLDEN, "examples_nucleic.phy"), os.path.join(wd, "nucleic"))
     args = [a for a in SUPPORT_ARGS]
     args[args.index("-b") + 1] = "0"
-    r = subprocess.run([GLUE, "--gtr-rr", "1,2.5,0.8,1.2,3.0,1", "--", "-i", "nucleic"] + args + ["--ancestral"], cwd=wd,
+    r = subprocess.run([GLUE, "--gtr-rr", "1,2.5,0.8,1.2,3.0,1", "--", "-i", "nucleic"] + args + ["--ancestral", "--print_site_lnl"], cwd=wd,
                        env=dict(os.environ, GLUE_MODE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
     assert r.returncode == 0 and m, r.stdout[-2000:]
@@ -225,21 +225,32 @@ def run_ancestral(mode, tmp_path):
         f = line.split()
         if len(f) == 7 and f[0].isdigit():
             rows.append((int(f[0]), int(f[1]), [float(x) for x in f[2:6]], f[6]))
-    _cache[key] = (json.loads(m.group(1)), rows)
+    sites = []
+    for line in open(os.path.join(wd, "nucleic_phyml_lk.txt")):
+        f = line.split()
+        if len(f) == 10 and f[0].isdigit():
+            sites.append([float(x) for x in f])
+    _cache[key] = (json.loads(m.group(1)), rows, sites)
     return _cache[key]
 
 
-def test_ancestral_reconstruction_from_downloaded_partials(tmp_path):
-    """`--ancestral`: ancestral.c walks the partial and scale vectors of every edge on the host (src/ancestral.c:677-869).
+def test_ancestral_reconstruction_and_site_likelihoods_from_downloads(tmp_path):
+    """`--ancestral --print_site_lnl`: ancestral.c walks the partial and scale vectors of every edge on the host (src/ancestral.c:677-869).
     Check mode: every device buffer is downloaded (phyhip_get_partials / phyhip_get_scale_factors) and compared BIT FOR BIT
     with the host vector the reference computed for the same edge side.  Device mode: the host vectors are filled from the
     downloads only and the reference's reconstruction must print the CPU-only run's marginal probabilities and states."""
-    info, _ = run_ancestral("check", tmp_path)
+    info = run_ancestral("check", tmp_path)[0]
     assert info["mirrored_buffers"] >= 2 * (2 * 54 - 3) - 54 and info["mirror_mismatches"] == 0, info
-    (_, host), (dinfo, dev) = run_ancestral("host", tmp_path), run_ancestral("device", tmp_path)
+    (_, host, hsites), (dinfo, dev, dsites) = run_ancestral("host", tmp_path), run_ancestral("device", tmp_path)
     assert dinfo["mirrored_buffers"] == info["mirrored_buffers"]
     assert len(host) == len(dev) > 10000
     for h, d in zip(host, dev):
         assert h[0] == d[0] and h[1] == d[1] and h[3] == d[3], (h, d)
         for a, b in zip(h[2], d[2]):
             assert abs(a - b) <= 1e-5 * max(abs(a), 1e-30) + 1e-300, (h, d)
+    # `--print_site_lnl` (src/io.c:1870-2013) of the same runs: site likelihood, scale exponent, per-category likelihoods,
+    # posterior mean rate per alignment column, from phyhip_get_site_outputs
+    assert len(hsites) == len(dsites) > 800
+    for h, d in zip(hsites, dsites):
+        for a, b in zip(h, d):
+            assert abs(a - b) <= 1e-5 * abs(a), (h, d)
