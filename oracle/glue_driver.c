@@ -55,6 +55,7 @@ static double  g_last_mixt_lnl = 0.0, g_best_full_lnl = -1e300;
 /* branch-support phase (aLRT_From_String, src/utilities.c:9282): alrt.c reads the per-pattern log-likelihoods of the last
    Lk() (src/alrt.c:453,555,682), so every device evaluation is followed by the download hook of SURVEY 8(f) rank 3 */
 static int     g_site_outputs = 0;
+static long    g_n_dropped = 0, g_n_created = 0;
 static long    g_n_site_dl = 0;
 static double  g_worst_site_lnl = 0.0;
 
@@ -197,6 +198,7 @@ static ctx_t *ensure_instance(t_tree *tree)
   if (g_nctx == MAXCTX) { fprintf(stderr, "glue_driver: too many class trees\n"); exit(5); }
   ctx_t *c = &g_ctx[g_nctx++];
   memset(c, 0, sizeof *c);
+  ++g_n_created;
   const int n = tree->n_otu, P = tree->data->n_pattern, S = tree->mod->ns, C = tree->mod->ras->n_catg;
   c->tree = tree;
   c->bufcap = 3 * n - 2;  /* internal edge sides + both sides of the two spare SPR edges (src/make.c:96-104) */
@@ -217,6 +219,27 @@ static void track(double *worst, double dev, double ref, double floor_)
 }
 
 /* ---- the interposed surface ---------------------------------------------------------------------------------- */
+
+/* Bootstrap (src/utilities.c:3884-4110) builds a new tree object per replicate that ALIASES the original's buffers
+   (Share_Lk_Struct, :4046), rewrites the tip vectors in place (Init_Partial_Lk_Tips_Double, :4050) and carries resampled
+   pattern weights; the object of the previous replicate has been freed and its address may be reused.  So when the tips of
+   a tree are (re)initialised, whatever instance stood for that address is dropped; the next surface call creates a fresh
+   one with the new tips and weights (the re-uploadable weights / tips of SURVEY Appendix A). */
+void Init_Partial_Lk_Tips_Double(t_tree *tree)
+{
+  static void (*real)(t_tree *) = NULL;
+  if (!real) real = (void (*)(t_tree *))dlsym(RTLD_NEXT, "Init_Partial_Lk_Tips_Double");
+  real(tree);
+  if (g_host) return;
+  for (int i = 0; i < g_nctx; ++i)
+    if (g_ctx[i].tree == tree)
+    {
+      OK(phyhip_finalize_instance(g_ctx[i].inst));
+      g_ctx[i] = g_ctx[--g_nctx];
+      ++g_n_dropped;
+      break;
+    }
+}
 
 void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
 {
@@ -642,7 +665,11 @@ int main(int argc, char **argv)
     fflush(tree->io->fp_out_lk);
   }
   char *support_nwk = NULL;
-  if (tree->io->ratio_test != NO)
+  if (tree->io->do_boot || tree->io->do_tbe || tree->io->do_bayesboot)
+  { /* src/main.c:351-369: every replicate is a new tree object on resampled weights (see Init_Partial_Lk_Tips_Double above) */
+    support_nwk = Bootstrap_From_String(Write_Tree(tree), tree->data, tree->mod, tree->io);
+  }
+  else if (tree->io->ratio_test != NO)
   { /* src/main.c:371-375: fast branch supports on the most likely tree (a new tree object, a new instance) */
     g_site_outputs = 1;
     support_nwk = aLRT_From_String(Write_Tree(tree), tree->data, tree->mod, tree->io);
@@ -651,10 +678,10 @@ int main(int argc, char **argv)
   printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"device_pmat\": %d, \"lnL_init\": %.17g, \"lnL_final\": %.17g, \"seconds\": %.3f, "
          "\"calls\": {\"Lk\": %ld, \"Lk_full\": %ld, \"Update_Partial_Lk\": %ld, \"dLk\": %ld, \"Update_PMat\": %ld, "
          "\"Update_Eigen_Lr\": %ld}, \"worst_rel_lnL\": %.3g, \"worst_rel_dlnL\": %.3g, \"buffers\": %d, \"matrices\": %d, "
-         "\"site_output_downloads\": %ld, \"worst_rel_site_output\": %.3g, \"mirrored_buffers\": %ld, \"mirror_mismatches\": %ld, "
+         "\"site_output_downloads\": %ld, \"worst_rel_site_output\": %.3g, \"mirrored_buffers\": %ld, \"mirror_mismatches\": %ld, \"instances_created\": %ld, "
          "\"support_tree\": \"%s\", \"tree\": \"%s\"}\n",
          g_host ? "host" : (g_check ? "check" : "device"), g_device_pmat, lnl_init, lnl_final, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
-         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, g_mirror_buffers, g_mirror_mismatch, support_nwk ? support_nwk : "", nwk ? nwk : "");
+         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, g_mirror_buffers, g_mirror_mismatch, g_n_created, support_nwk ? support_nwk : "", nwk ? nwk : "");
   fflush(stdout);
   for (int k = 0; k < g_nctx; ++k) OK(phyhip_finalize_instance(g_ctx[k].inst));
   _exit(0);

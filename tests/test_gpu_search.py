@@ -254,3 +254,40 @@ def test_ancestral_reconstruction_and_site_likelihoods_from_downloads(tmp_path):
     for h, d in zip(hsites, dsites):
         for a, b in zip(h, d):
             assert abs(a - b) <= 1e-5 * abs(a), (h, d)
+
+
+# ---- bootstrap (src/utilities.c:3884-4110): a new tree object per replicate on resampled pattern weights -----------------
+
+def run_bootstrap(mode, tmp_path):
+    key = ("bootstrap", mode)
+    if key in _cache:
+        return _cache[key]
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built")
+    wd = os.path.join(str(tmp_path), "boot_" + mode)
+    os.makedirs(wd, exist_ok=True)
+    shutil.copy(os.path.join(GOLDEN, "examples_nucleic.phy"), os.path.join(wd, "nucleic"))
+    args = ["-d", "nt", "-m", "GTR", "-f", "0.3,0.2,0.2,0.3", "-c", "4", "-a", "0.8", "-o", "l", "-b", "4", "--r_seed", "1"]
+    r = subprocess.run([GLUE, "--gtr-rr", "1,2.5,0.8,1.2,3.0,1", "--", "-i", "nucleic"] + args, cwd=wd,
+                       env=dict(os.environ, GLUE_MODE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:]
+    _cache[key] = json.loads(m.group(1))
+    return _cache[key]
+
+
+def test_bootstrap_replicates_on_resampled_weights(tmp_path):
+    """`-b 4 -o l`: every replicate is a fresh tree object that aliases the original's buffers, rewrites the tips and
+    carries resampled weights; the driver answers with a fresh instance per replicate (weights and tips uploaded again).
+    Check mode: every scalar of the four replicate optimisations against the reference's own; device mode: the CPU-only
+    run's bootstrap counts, topology and branch lengths."""
+    chk = run_bootstrap("check", tmp_path)
+    assert chk["instances_created"] >= 6, chk
+    assert chk["worst_rel_lnL"] < 1e-10 and chk["worst_rel_dlnL"] < 1e-6, chk
+    host, dev = run_bootstrap("host", tmp_path), run_bootstrap("device", tmp_path)
+    assert dev["calls"] == host["calls"]
+    hs, hb, ht = _numbers(host["support_tree"])
+    ds, db, dt = _numbers(dev["support_tree"])
+    assert ht == dt and hs == ds and len(hs) > 40 and max(hs) == 4.0
+    assert max(abs(a - b) for a, b in zip(hb, db)) <= 1e-7
+    assert abs(dev["lnL_final"] - host["lnL_final"]) <= 1e-10 * abs(host["lnL_final"])
