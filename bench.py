@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- full-tree Lk() throughput of the HIP likelihood engine on MI355X (BASELINE.json metric).
 
-One "step" = one complete `Lk(NULL, tree)`: refresh every edge's transition matrices (device PMat from
-the eigen system), the whole post-order partial-likelihood traversal (n-2 site-updates per pattern),
-the root-edge reduction, and the scalar back on the host -- everything the reference's Lk(NULL) does
-(src/lk.c:443-649) on inputs already resident in HBM.  Workload at N=1: BASELINE configs[1]
-(100 taxa x 50 000 nt patterns, GTR+G4).  N>1 ranks shard patterns (weak scaling: 50 000 patterns per
-GPU, no data-path collective, one RCCL all-reduce of the per-shard lnL per evaluation).
+One "step" = one complete `Lk(NULL, tree)`: refresh every edge's transition matrices (device PMat from the eigen
+system), the whole post-order partial-likelihood traversal (n-2 site-updates per pattern), the root-edge reduction and
+the scalar back on the host -- everything the reference's Lk(NULL) does (src/lk.c:443-649), inputs resident in HBM.
 
+  --gpus 1            BASELINE configs[1] (cfg2: 100 taxa x 50 000 nt patterns, GTR+G4) on one MI355X; the JSON line
+                      also carries `roofline`, `cpu_baseline` (real PhyML AVX, 1 host core, same box, same run) and,
+                      under `extra`, the 20-state configuration (cfg3: 200 taxa x 10 000 aa patterns, LG+G4).
+  --gpus N (N > 1)    BASELINE configs[3] (cfg4: 100 taxa x 1 000 000 nt patterns), STRONG scaling: contiguous pattern
+                      shards of 1e6/N per GPU, ONE RCCL all-reduce of {warning, lnL} per evaluation inside libphyhip.so.
+                      Launched by the driver as N ranks (torch.distributed.run, WORLD_SIZE = N): one process per GPU,
+                      phyhip_comm_init_rank on an id broadcast through torch.distributed.  Launched bare
+                      (`python bench.py --gpus N`): ONE process drives all N devices through the sharded instance of
+                      the C ABI (phyhip_create_instance with a resource list of N devices, ncclCommInitAll).
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -22,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+METRIC = "M partial-lk site-updates/sec on full-tree Lk()"
 
 
 def cpu_baseline(wl, sample_patterns, reps):
@@ -81,15 +90,234 @@ def measured_roofline():
         return None
 
 
+def kernel_source_hash():
+    """Identity of the kernels a counter profile belongs to: hash of every source under phyml_amd/csrc."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "phyml_amd", "csrc")
+    for f in sorted(os.listdir(base)):
+        p = os.path.join(base, f)
+        if os.path.isfile(p) and not f.startswith("membench"):
+            h.update(f.encode()); h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload):
-    """HBM bytes per traversal launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/): 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes."""
-    f = os.path.join(ROOT, "profiles", f"r01_pmc_{workload}.json")
+    """HBM bytes per traversal launch from the rocprofv3 PMC passes of this same command (tools/profile_pmc.sh writes
+    profiles/r02_pmc_<workload>.json with the kernel-source hash it was taken on): 2 x FETCH_SIZE (gfx950 correction,
+    MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  A profile taken on other kernel sources is refused
+    (null): counters do not travel across kernel changes."""
+    f = os.path.join(ROOT, "profiles", f"r02_pmc_{workload}.json")
     try:
         d = json.load(open(f))
+        if d.get("kernel_source_hash") != kernel_source_hash():
+            return None
         return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
     except Exception:  # noqa: BLE001
         return None
+
+
+def build_tree(wl, device=None, devices=None):
+    from phyml_amd import lktree
+    tree, st, blk, cfg = wl["tree"], wl["states"], wl["model"], wl["cfg"]
+    n, P, S = tree.n_otu, st.shape[1], cfg["ns"]
+    C = int(blk["ncatg"][0])
+    t = lktree.LkTree(n, tree.edge_left, tree.edge_rght, tree.edge_len, P, S, C, device=device, devices=devices)
+    t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"],
+                float(blk["l_min"][0]), float(blk["l_max"][0]), 1.0, 1)
+    t.Make_Tree_For_Lk(np.ones(P))
+    t.set_tips(tip_states=st.astype(np.int32))
+    return t
+
+
+def timed_steps(t, steps, warmup, sync, barrier=None):
+    lnl = None
+    for _ in range(warmup):
+        lnl = t.Lk(None)
+    t.inst.profile(1)
+    if barrier:
+        barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lnl = t.Lk(None)
+    sync()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, lnl
+
+
+def roofline_block(t, n, P, S, C, workload_key, with_traffic, shards=1):
+    """SURVEY 8(d) figure (algorithmic bytes / kernel time) plus the honest companions: the traffic model of the launch
+    (results written once, children read unless forwarded in registers or tips), the write stream alone, and -- when a
+    counter profile of these very kernel sources is committed -- the HBM bytes the counters saw."""
+    from phyml_amd import workloads
+    kern_ms, kern_n, _ = t.inst.profile_read()
+    rd, wr = t.inst.profile_read_traffic()
+    kdur = kern_ms / max(kern_n, 1) * 1e-3
+    alg_bytes = workloads.algorithmic_bytes_per_pattern(n, S, C) * float(P)
+    achieved = alg_bytes / kdur / 1e9 if kdur > 0 else 0.0
+    rd, wr = rd / max(kern_n, 1) / shards, wr / max(kern_n, 1) / shards  # per launch of ONE shard
+    traffic = pmc_traffic(workload_key) if with_traffic else None
+    r = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+         "kernel": ("traverse_nt2_kernel" if C <= 4 else "traverse_nt_kernel") if S == 4 else "traverse_aa_kernel",
+         "kernel_avg_us": kdur * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+         "algorithmic_bytes_per_site_update": alg_bytes / (float(P) * (n - 2)),
+         "min_traffic_bytes": rd + wr, "min_read_bytes": rd, "write_bytes": wr,
+         "frac_of_min_traffic": (rd + wr) / kdur / 8e12 if kdur > 0 else 0.0,
+         "frac_of_write_stream": wr / kdur / 8e12 if kdur > 0 else 0.0}
+    if traffic:
+        r["hbm_achieved"] = traffic / kdur / 1e9
+        r["hbm_frac"] = traffic / kdur / 8e12
+    return r, kdur
+
+
+def run_single(args, torch):
+    """N = 1: cfg2 on cuda:0 (the line BENCH records), cfg3 under `extra`."""
+    from phyml_amd import synth, workloads
+    torch.cuda.set_device(0)
+    wl = workloads.make(args.workload, n_pattern=args.patterns)
+    tree, st, cfg = wl["tree"], wl["states"], wl["cfg"]
+    n, P, S, C = tree.n_otu, st.shape[1], cfg["ns"], int(wl["model"]["ncatg"][0])
+    t = build_tree(wl, device=0)
+    dt, lnl = timed_steps(t, args.steps, args.warmup, torch.cuda.synchronize)
+    value = float(P) * (n - 2) * args.steps / dt / 1e6
+    roof, kdur = roofline_block(t, n, P, S, C, args.workload, args.patterns is None)
+    out = {"metric": METRIC, "value": value, "unit": "M site-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": f"{args.workload}: {n} taxa x {P} {'nt' if S == 4 else 'aa'} patterns, "
+                                  f"{'GTR' if S == 4 else 'LG'}+G{C}, fixed random tree, full post-order Lk(NULL) incl. P-matrix refresh and root-edge reduce",
+                      "patterns_per_gpu": P, "taxa": n, "states": S, "rate_categories": C, "parallelism": "single GPU"},
+           "lnL": lnl, "roofline": roof}
+    if S == 20:
+        out["mfma"] = mfma_block(P, C, n, kdur)
+    mr = measured_roofline()
+    if mr:
+        roof["measured_read_GBps"] = mr["read_GBps"]
+        roof["measured_write_GBps"] = mr["write_GBps"]
+        roof["frac_of_measured_read"] = roof["achieved"] / mr["read_GBps"]
+        roof["write_stream_frac_of_measured_write"] = roof["write_bytes"] / kdur / 1e9 / mr["write_GBps"]
+    exp = workloads.manifest()["expected"].get(args.workload)
+    if exp and P == exp["n_pattern"]:
+        out["lnL_reference_avx"] = exp["lnL"]
+        out["lnL_rel_err"] = abs(lnl - exp["lnL"]) / abs(exp["lnL"])
+        out["input_checksum_ok"] = bool(synth.states_checksum(st) == exp["checksum"])
+    t.close()
+    if not args.no_extra and args.workload == "cfg2_nt_100x50k" and args.patterns is None:
+        out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch)}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample, args.cpu_reps)
+    return out
+
+
+def mfma_block(P, C, n, kdur):
+    # 20-state path: FP64 MFMA work issued per launch, per (tile, category, operation): rows 0..15 as ten 16x16x4
+    # (2048 flop) and rows 16..19 as ten four-block 4x4x4 (512 flop) -- all of it useful
+    flops = float((P + 15) // 16) * C * (n - 2) * (10 * 2048.0 + 10 * 512.0)
+    return {"achieved": flops / kdur / 1e12, "peak": 78.6, "unit": "TFLOP/s issued (f64 16x16x4 + 4x4x4_4b)",
+            "frac": flops / kdur / 1e12 / 78.6, "useful_frac_of_issued": 1.0}
+
+
+def extra_line(name, args, torch):
+    """A second, driver-timed configuration reported under `extra` (same protocol, same run)."""
+    from phyml_amd import synth, workloads
+    wl = workloads.make(name)
+    tree, st, cfg = wl["tree"], wl["states"], wl["cfg"]
+    n, P, S, C = tree.n_otu, st.shape[1], cfg["ns"], int(wl["model"]["ncatg"][0])
+    t = build_tree(wl, device=0)
+    dt, lnl = timed_steps(t, args.steps, args.warmup, torch.cuda.synchronize)
+    roof, kdur = roofline_block(t, n, P, S, C, name, True)
+    exp = workloads.manifest()["expected"][name]
+    line = {"value": float(P) * (n - 2) * args.steps / dt / 1e6, "unit": "M site-updates/s", "ms_per_step": dt / args.steps * 1e3,
+            "steps": args.steps, "lnL": lnl, "lnL_rel_err": abs(lnl - exp["lnL"]) / abs(exp["lnL"]),
+            "input_checksum_ok": bool(synth.states_checksum(st) == exp["checksum"]), "roofline": roof}
+    if S == 20:
+        line["mfma"] = mfma_block(P, C, n, kdur)
+    t.close()
+    return line
+
+
+def run_sharded(args, torch):
+    """N > 1: cfg4 (100 taxa x 1 M nt patterns), strong scaling, the all-reduce inside libphyhip.so."""
+    from phyml_amd import capi, shard, workloads
+    name = "cfg4_nt_100x1M"
+    total = workloads.CONFIGS[name]["n_pattern"] if args.patterns is None else int(args.patterns)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    multiproc = world > 1 or os.environ.get("PHYHIP_BENCH_FORCE_DIST") == "1"
+    exp = workloads.manifest()["expected"].get(name)
+    if multiproc:
+        if world != args.gpus and not (world == 1 and os.environ.get("PHYHIP_BENCH_FORCE_DIST") == "1"):
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        lo, hi = shard.shard_range(total, rank, world)
+        wl = workloads.make(name, n_pattern=hi - lo, pattern_offset=lo)
+        t = build_tree(wl, device=local)
+        # the library's own communicator: id from rank 0, broadcast through torch.distributed (as an MPI host would MPI_Bcast it)
+        ids = [capi.comm_get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        t.inst.comm_init_rank(world, rank, ids[0])
+        ranks_seen = t.inst.comm_size()
+        barrier = dist.barrier
+        n_gpus, mode = world, "one process per GPU: phyhip_comm_init_rank + ncclAllReduce inside libphyhip.so"
+    else:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) visible")
+        wl = workloads.make(name, n_pattern=total)
+        t = build_tree(wl, devices=list(range(args.gpus)))
+        ranks_seen = t.inst.comm_size()
+        barrier = None
+        n_gpus, mode = args.gpus, "one process, sharded instance: ncclCommInitAll + ncclAllReduce inside libphyhip.so"
+
+    def sync():
+        for d in range(torch.cuda.device_count() if not multiproc else 1):
+            torch.cuda.synchronize(local if multiproc else d)
+
+    tree, cfg = wl["tree"], wl["cfg"]
+    n, S, C = tree.n_otu, cfg["ns"], int(wl["model"]["ncatg"][0])
+    dt, lnl = timed_steps(t, args.steps, args.warmup, sync, barrier)
+    if multiproc:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    P_local = wl["states"].shape[1] if multiproc else total // n_gpus
+    roof, kdur = roofline_block(t, n, P_local, S, C, name, False, shards=1 if multiproc else n_gpus)
+    t.close()
+    out = None
+    if rank == 0:
+        value = float(total) * (n - 2) * args.steps / dt / 1e6
+        out = {"metric": METRIC, "value": value, "unit": "M site-updates/s", "n_gpus": n_gpus, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{name}: {n} taxa x {total} nt patterns in {n_gpus} contiguous shards of {total // n_gpus}, GTR+G{C}, "
+                                      "fixed random tree, full post-order Lk(NULL) incl. P-matrix refresh, root-edge reduce and ONE RCCL "
+                                      "all-reduce of {warning, lnL} per evaluation",
+                          "patterns_total": total, "patterns_per_gpu": total // n_gpus, "taxa": n, "states": S, "rate_categories": C,
+                          "parallelism": f"pattern-shard x{n_gpus}", "mode": mode, "rccl_ranks": ranks_seen},
+               "lnL": lnl, "roofline": roof}
+        roof["note"] = "per-GPU figures of rank 0's shard"
+        if exp and total == exp["n_pattern"]:
+            out["lnL_reference_avx"] = exp["lnL"]
+            out["lnL_rel_err"] = abs(lnl - exp["lnL"]) / abs(exp["lnL"])
+        if not args.no_extra:
+            # the strong-scaling reference: the same 1 M patterns on ONE of these GPUs, same protocol, same run
+            wl1 = workloads.make(name, n_pattern=total)
+            t1 = build_tree(wl1, device=local if multiproc else 0)
+            dt1, lnl1 = timed_steps(t1, args.steps, args.warmup, sync)
+            t1.close()
+            v1 = float(total) * (n - 2) * args.steps / dt1 / 1e6
+            out["strong_scaling"] = {"single_gpu_value": v1, "single_gpu_ms_per_step": dt1 / args.steps * 1e3,
+                                     "single_gpu_lnL": lnl1, "speedup": value / v1, "efficiency": value / v1 / n_gpus}
+    if multiproc:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out, multiproc
 
 
 def main():
@@ -97,128 +325,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg2_nt_100x50k")
-    ap.add_argument("--patterns", type=int, default=None, help="patterns per GPU (default: the workload's)")
+    ap.add_argument("--workload", default="cfg2_nt_100x50k", help="N = 1 only")
+    ap.add_argument("--patterns", type=int, default=None, help="pattern count override (N = 1: of the workload; N > 1: total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 line (N = 1) / the single-GPU reference (N > 1)")
     ap.add_argument("--cpu-sample", type=int, default=50000)
     ap.add_argument("--cpu-reps", type=int, default=30)
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
-    force_dist = os.environ.get("PHYHIP_BENCH_FORCE_DIST") == "1"   # exercise the sharded path with one rank
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    multiproc = False
+    if args.gpus == 1 and os.environ.get("PHYHIP_BENCH_FORCE_DIST") != "1":
+        out = run_single(args, torch)
     else:
-        torch.cuda.set_device(0)
-
-    from phyml_amd import lktree, shard, workloads
-    wl = workloads.make(args.workload, n_pattern=args.patterns,
-                        seed=None if world == 1 else workloads.CONFIGS[args.workload]["seed"] + 1000 * rank)
-    tree, st, blk, cfg = wl["tree"], wl["states"], wl["model"], wl["cfg"]
-    n, P, S = tree.n_otu, st.shape[1], cfg["ns"]
-    C = int(blk["ncatg"][0])
-
-    t = lktree.LkTree(n, tree.edge_left, tree.edge_rght, tree.edge_len, P, S, C, device=local)
-    t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"],
-                float(blk["l_min"][0]), float(blk["l_max"][0]), 1.0, 1)
-    t.Make_Tree_For_Lk(np.ones(P))
-    t.set_tips(tip_states=st.astype(np.int32))
-    dev_lnl = torch.zeros(2, dtype=torch.float64, device=f"cuda:{local}")
-    stream = torch.cuda.current_stream()
-    t.inst.set_stream(stream.cuda_stream)
-
-    def step():
-        if dist is None:
-            return t.Lk(None)
-        # sharded evaluation: per-shard lnL stays on the device, ONE all-reduce over RCCL, then the host reads it
-        t.Lk_Shard_Device(dev_lnl.data_ptr())
-        shard.allreduce_sum(dev_lnl, dist)
-        return float(dev_lnl[0].item())
-
-    lnl = None
-    for _ in range(args.warmup):
-        lnl = step()
-    t.inst.profile(1)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lnl = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kern_ms, kern_n, kern_upd = t.inst.profile_read()
-
-    out = None
-    if rank == 0:
-        updates_per_step = float(P) * (n - 2) * world
-        value = updates_per_step * args.steps / dt / 1e6
-        alg_bytes = workloads.algorithmic_bytes_per_pattern(n, S, C) * float(P)   # per launch (this rank)
-        kdur = kern_ms / max(kern_n, 1) * 1e-3
-        achieved = alg_bytes / kdur / 1e9 if kdur > 0 else 0.0
-        out = {
-            "metric": "M partial-lk site-updates/sec on full-tree Lk()", "value": value, "unit": "M site-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n} taxa x {P} {'nt' if S == 4 else 'aa'} patterns per GPU, "
-                                   f"{'GTR' if S == 4 else 'LG'}+G{C}, fixed random tree, full post-order Lk(NULL) incl. P-matrix refresh and root-edge reduce",
-                       "patterns_per_gpu": P, "taxa": n, "states": S, "rate_categories": C,
-                       "parallelism": f"pattern-shard x{world}" if world > 1 else "single GPU"},
-            "lnL": lnl,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": pmc_traffic(args.workload) if (world == 1 and args.patterns is None) else None,
-                         "kernel": ("traverse_nt2_kernel" if C <= 4 else "traverse_nt_kernel") if S == 4 else "traverse_aa_kernel", "kernel_avg_us": kdur * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_per_site_update": alg_bytes / (float(P) * (n - 2))},
-        }
-        if S == 20:
-            # 20-state path: FP64 MFMA work issued per launch, per (tile, category, operation): rows 0..15 as ten
-            # 16x16x4 (2048 flop) and rows 16..19 as ten four-block 4x4x4 (512 flop) -- all of it useful
-            mfma_flops = float((P + 15) // 16) * C * (n - 2) * (10 * 2048.0 + 10 * 512.0)
-            out["mfma"] = {"achieved": mfma_flops / kdur / 1e12, "peak": 78.6,
-                           "unit": "TFLOP/s issued (f64 16x16x4 + 4x4x4_4b)",
-                           "frac": mfma_flops / kdur / 1e12 / 78.6, "useful_frac_of_issued": 1.0}
-        if world == 1:
-            mr = measured_roofline()
-            if mr:
-                out["roofline"]["measured_read_GBps"] = mr["read_GBps"]
-                out["roofline"]["measured_write_GBps"] = mr["write_GBps"]
-                out["roofline"]["frac_of_measured_read"] = achieved / mr["read_GBps"]
-        exp = workloads.manifest()["expected"].get(args.workload)
-        if exp and world == 1 and P == exp["n_pattern"]:
-            from phyml_amd import synth
-            out["lnL_reference_avx"] = exp["lnL"]
-            out["lnL_rel_err"] = abs(lnl - exp["lnL"]) / abs(exp["lnL"])
-            out["input_checksum_ok"] = bool(synth.states_checksum(st) == exp["checksum"])
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample, args.cpu_reps)
-    t.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
+        out, multiproc = run_sharded(args, torch)
+    if out is not None:
         # the ONE JSON line goes out last, after RCCL has finished any chatter of its own on stdout
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     # RCCL prints a version banner on stdout while the interpreter shuts down; leave before that so the JSON
     # line stays the last (and, single-GPU, the only) line on stdout
     sys.stdout.flush(); sys.stderr.flush()
-    if dist is not None:
+    if multiproc:
         os._exit(0)  # (not when single-process: profilers such as rocprofv3 flush their traces at normal exit)
 
 

@@ -50,6 +50,11 @@ extern "C" {
 
 #define PHYHIP_OP_NONE (-1)   /* BEAGLE_OP_NONE */
 
+/* requirementFlags bit of phyhip_create_instance: build the sharded (multi-device) form even for a resource list of
+   ONE device -- same code path, communicator of one rank (used by the single-GPU tests of that path). */
+#define PHYHIP_FLAG_SHARDED (1L << 40)
+#define PHYHIP_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
 /* BeagleOperation (src/beagle_utils.c:243).  The two scale-index fields are accepted and ignored:
    scale vectors are implicit, one per partials buffer, as in PhyML. */
 typedef struct
@@ -77,8 +82,15 @@ typedef struct
 /* ---- instance lifetime ------------------------------------------------------------------ */
 
 /* replaces beagleCreateInstance, src/beagle_utils.c:119-133.
-   compactBufferCount, scaleBufferCount, preferenceFlags, requirementFlags are accepted for signature
-   compatibility; resourceList[0] (if given) is the HIP device ordinal, else env PHYHIP_DEVICE, else 0.
+   compactBufferCount, scaleBufferCount, preferenceFlags are accepted for signature compatibility;
+   resourceList[0] (if given) is the HIP device ordinal, else env PHYHIP_DEVICE, else 0.
+   MULTI-GPU: a resource list of G > 1 devices creates ONE sharded instance -- patterns are split into G
+   contiguous ranges [g*P/G, (g+1)*P/G), one per listed device (a device may be listed more than once), everything
+   per-pattern (tips, weights, invariant sites, partials, scale vectors, per-site outputs) is sliced / concatenated by
+   the entry points below, the model and the transition matrices are replicated, and every scalar-returning evaluation
+   (phyhip_calculate_edge_log_likelihoods, phyhip_calculate_eigen_lnl[_dlnl]) ends in ONE RCCL all-reduce over the
+   communicators of ncclCommInitAll: {warning flag, lnL} for Lk (the sum of src/lk.c:856), {warning, lnL, dlnL} for dLk
+   (src/lk.c:744-745).  The caller sees the same API and the same numbers; mixtures are not sharded.
    Returns the instance id (>= 0) or a negative error. */
 int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
                            int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
@@ -167,8 +179,9 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parentBufferI
                                           double *outSumLogLikelihood, double *outSumFirstDerivative,
                                           double *outSumSecondDerivative);
 
-/* Same evaluation, but the per-shard sum stays in device memory (deviceOut[0] = lnL) and the call does
-   not synchronise: the multi-GPU path all-reduces deviceOut over RCCL on the same stream. */
+/* Same evaluation, but the sum stays in device memory (deviceOut[0] = lnL) and the call does not synchronise
+   (callers that run their own collective; the library's own multi-GPU forms are described at phyhip_create_instance
+   and phyhip_comm_init_rank). */
 int phyhip_calculate_edge_log_likelihoods_device(int instance, int parentBufferIndex, int childBufferIndex,
                                                  int probabilityIndex, double *deviceOut);
 
@@ -232,6 +245,19 @@ int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL);
 
 int phyhip_get_dot_prod(int instance, double *outDotProd);
 
+/* ---- multi-GPU, one process per GPU (MPI-style hosts; PhyML's MPI build runs one process per rank) -------------- */
+
+/* ncclGetUniqueId: rank 0 calls it and broadcasts the PHYHIP_UNIQUE_ID_BYTES bytes by whatever means the host has (MPI_Bcast). */
+int phyhip_comm_get_unique_id(char *outId);
+/* ncclCommInitRank on the instance's device and stream.  The instance holds this rank's contiguous pattern shard (the
+   caller slices its inputs); from now on phyhip_calculate_edge_log_likelihoods and phyhip_calculate_eigen_lnl[_dlnl]
+   return the sum over ALL ranks on every rank (one all-reduce per evaluation, as for the sharded instance). */
+int phyhip_comm_init_rank(int instance, int nranks, int rank, const char *uniqueId);
+/* number of ranks in the instance's communicator(s) (1: no communicator) */
+int phyhip_comm_size(int instance, int *outRanks);
+/* pattern range and device of shard `shard` of an instance; returns the number of shards (1 for a plain instance) */
+int phyhip_get_shard_range(int instance, int shard, int *outDevice, int *outFirstPattern, int *outPatternCount);
+
 /* ---- stream / timing plumbing ---------------------------------------------------------------- */
 
 /* Run on the caller's HIP stream (e.g. torch's current stream) instead of the instance's own. */
@@ -242,6 +268,11 @@ int phyhip_synchronize(int instance);
    enable != 0 starts (and resets) accumulation. */
 int phyhip_profile(int instance, int enable);
 int phyhip_profile_read(int instance, double *outTraversalMs, int *outLaunches, double *outSiteUpdates);
+/* Traffic model of the launches profiled since phyhip_profile(instance, 1): the bytes those traversal launches had to
+   move if nothing but the kernel's own register forwarding saved any -- every result written once, every child read
+   unless it is a tip (1 byte) or one of the two previous results.  The honest floor under the algorithmic byte count of
+   SURVEY 8(d), which also charges the forwarded reads. */
+int phyhip_profile_read_traffic(int instance, double *outReadBytes, double *outWriteBytes);
 
 #ifdef __cplusplus
 }

@@ -42,10 +42,21 @@ SYMBOLS = [
     "phyhip_set_scale_factors", "phyhip_get_numerical_warning", "phyhip_update_eigen_lr",
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
-    "phyhip_calculate_mixture_eigen_lnl_dlnl",
+    "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
+    "phyhip_get_shard_range", "phyhip_profile_read_traffic",
 ]
 
+FLAG_SHARDED = 1 << 40  # PHYHIP_FLAG_SHARDED
+UNIQUE_ID_BYTES = 128
+
 _lib = None
+
+
+def comm_get_unique_id() -> bytes:
+    """phyhip_comm_get_unique_id (rank 0; broadcast the bytes to the other ranks)."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _chk(load().phyhip_comm_get_unique_id(buf))
+    return buf.raw
 
 
 def load():
@@ -77,17 +88,20 @@ class Instance:
     """Thin object wrapper: one method per C entry point, numpy in / numpy out."""
 
     def __init__(self, tip_count, partials_buffer_count, state_count, pattern_count, matrix_buffer_count,
-                 category_count, device=None):
+                 category_count, device=None, devices=None, force_sharded=False):
         L = load()
         self.L = L
         self.tips, self.nbuf, self.S, self.P, self.nmat, self.C = (tip_count, partials_buffer_count, state_count,
                                                                   pattern_count, matrix_buffer_count, category_count)
         self.details = InstanceDetails()
-        res = (C.c_int * 1)(device if device is not None else 0)
+        if devices is not None:  # sharded instance: one pattern range per listed device, RCCL all-reduce inside the library
+            res, nres = (C.c_int * len(devices))(*[int(d) for d in devices]), len(devices)
+        else:
+            res, nres = ((C.c_int * 1)(device), 1) if device is not None else (None, 0)
         self.id = _chk(L.phyhip_create_instance(tip_count, partials_buffer_count, 0, state_count, pattern_count, 1,
-                                                matrix_buffer_count, category_count, 0,
-                                                res if device is not None else None, 1 if device is not None else 0,
-                                                C.c_long(0), C.c_long(0), C.byref(self.details)))
+                                                matrix_buffer_count, category_count, 0, res, nres,
+                                                C.c_long(0), C.c_long(FLAG_SHARDED if force_sharded else 0),
+                                                C.byref(self.details)))
 
     def close(self):
         if self.id is not None:
@@ -218,6 +232,26 @@ class Instance:
         _chk(self.L.phyhip_get_dot_prod(self.id, _ptr(out)))
         return out
 
+    # -- multi-GPU
+    def comm_init_rank(self, nranks, rank, unique_id: bytes):
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        _chk(self.L.phyhip_comm_init_rank(self.id, int(nranks), int(rank), C.c_char_p(unique_id)))
+
+    def comm_size(self):
+        n = C.c_int(0)
+        _chk(self.L.phyhip_comm_size(self.id, C.byref(n)))
+        return n.value
+
+    def shard_ranges(self):
+        """[(device, first pattern, pattern count)] of the instance's shards."""
+        out, k, n = [], 0, 1
+        while k < n:
+            d, lo, cnt = C.c_int(0), C.c_int(0), C.c_int(0)
+            n = _chk(self.L.phyhip_get_shard_range(self.id, k, C.byref(d), C.byref(lo), C.byref(cnt)))
+            out.append((d.value, lo.value, cnt.value))
+            k += 1
+        return out
+
     # -- plumbing
     def set_stream(self, stream_handle):
         _chk(self.L.phyhip_set_stream(self.id, C.c_void_p(stream_handle)))
@@ -232,6 +266,11 @@ class Instance:
         ms = C.c_double(0); n = C.c_int(0); u = C.c_double(0)
         _chk(self.L.phyhip_profile_read(self.id, C.byref(ms), C.byref(n), C.byref(u)))
         return ms.value, n.value, u.value
+
+    def profile_read_traffic(self):
+        r = C.c_double(0); w = C.c_double(0)
+        _chk(self.L.phyhip_profile_read_traffic(self.id, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
 
 def mixture_log_likelihood(instance_ids, parents, children, matrices, proba, r_mat_weight, e_frq_weight, r_sum, e_sum, sum_probas):

@@ -6,6 +6,8 @@
 #include "phyhip_aa.hpp"
 #include "phyhip_nt2.hpp"
 
+#include <rccl/rccl.h>
+
 #include <cfloat>
 #include <functional>
 #include <cmath>
@@ -13,12 +15,22 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 using namespace phyhip;
+
+// Timing-only kernel variants (PHYHIP_ABLATE, PHYHIP_NOLOADS: results invalid) and the first-generation nucleotide
+// kernel as an A/B reference for C <= 4 exist only in builds with -DPHYHIP_DIAG (tools/build_diag.sh); the product
+// library reads none of those switches.
+#ifdef PHYHIP_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
 
 namespace
 {
@@ -106,8 +118,12 @@ struct StagingRing
   }
 };
 
+struct Collective;
+
 struct Instance
 {
+  Collective *co         = nullptr; // one-process-per-GPU mode: communicator attached by phyhip_comm_init_rank
+  double     *d_red      = nullptr; // ... and this shard's {warning, lnL, dlnL} reduction buffer (owned by co)
   int         dev        = 0;
   hipStream_t stream     = nullptr;
   bool        own_stream = true;
@@ -175,9 +191,10 @@ struct Instance
   bool   split_reduce = false, split_reduce_forced = false; // PHYHIP_SPLIT_REDUCE: separate final_reduce_kernel instead of the fused last-workgroup sum
   unsigned *d_tickets = nullptr;
   double   *d_mixexpl = nullptr; // expl pairs of the classes of a mixture evaluation (first instance only)
-  int    ablate = 0;         // PHYHIP_ABLATE: timing-only kernel variants (results invalid)
+  int    ablate = 0;         // PHYHIP_ABLATE (-DPHYHIP_DIAG builds only): timing-only kernel variants (results invalid)
+  unsigned long long *d_dbg = nullptr; // cycle stamps of PHYHIP_ABLATE=8
   bool   eager_pmats = true; // PHYHIP_EAGER_PMAT=0: whole-tree matrix batches wait for the traversal launch too
-  bool   no_loads = false;   // PHYHIP_NOLOADS: zero-size every child load (timing only)
+  bool   no_loads = false;   // PHYHIP_NOLOADS (-DPHYHIP_DIAG builds only): zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
 
   bool       prof = false;
@@ -185,6 +202,7 @@ struct Instance
   hipEvent_t ev_sync = nullptr; // orders this instance's stream before another instance's (mixture evaluations)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pairs;
   double     prof_ms = 0.0, prof_updates = 0.0;
+  double     prof_rd_bytes = 0.0, prof_wr_bytes = 0.0; // traffic model of the profiled launches (phyhip_profile_read_traffic)
   int        prof_n = 0;
 };
 
@@ -270,6 +288,7 @@ struct EdgeEval
   int     parent, child, pm;
   double *dev_out;  // optional user device pointer
   bool    to_host;
+  double *warn_out; // sharded evaluation: device double receiving the numerical-warning flag (or nullptr)
 };
 
 // Host-computed matrices queued by phyhip_set_transition_matrix: one launch per kUploadBatch of them.
@@ -361,7 +380,7 @@ static bool fuse_reduce(const Instance *I, int nblocks)
 }
 
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
-int flush(Instance *I, const EdgeEval *ee)
+int flush_impl(Instance *I, const EdgeEval *ee)
 {
   const int n_ops = (int)I->pending.size();
   int rc = 0;
@@ -384,16 +403,14 @@ int flush(Instance *I, const EdgeEval *ee)
     for (int k = 0; k < q.n_fresh; ++k) { q.fresh_idx[k] = I->pm_idx[k]; q.fresh_len[k] = I->pm_len[k]; }
     q.m_evec = I->d_evec; q.m_ivec = I->d_ivec; q.m_eval = I->d_eval; q.m_rates = I->d_catr;
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats_rw = I->d_pmats;
-    for (int m : I->pm_idx) I->pm_slot[m] = -1;
-    I->pm_idx.clear();
-    I->pm_len.clear();
+    // (the matrix queue is cleared only after the launch that rebuilds it has been issued, see below)
   }
   const bool fat = ((I->S == 4) && !I->generic_nt) || I->perm;
   const IssueRec *d_irec = nullptr;
   const ExecRec  *d_xrec = nullptr;
   q.last_dest = -1;
   const int kind = fat ? I->prefetch_dist : 0;
-  int       hit  = -1;
+  int       hit  = -1, new_slot = -1;
   if (n_ops > 0)
   { // an operation list identical to one still sitting in a device slot (repeated Lk(NULL) on one topology) is
     // neither rebuilt nor re-uploaded
@@ -417,9 +434,8 @@ int flush(Instance *I, const EdgeEval *ee)
   else if (n_ops > 0)
   {
     char *dst = I->d_ops + (size_t)I->ops_slot * I->ops_slot_bytes;
-    I->slot_ops[I->ops_slot]  = I->pending;
-    I->slot_kind[I->ops_slot] = kind;
-    I->ops_slot = (I->ops_slot + 1) % I->ops_slots;
+    new_slot  = I->ops_slot;
+    I->slot_kind[new_slot] = -1; // the slot's old content is gone; it holds the new list only once the copy was issued
     void *st = nullptr;
     if (!fat)
     {
@@ -487,6 +503,9 @@ int flush(Instance *I, const EdgeEval *ee)
       q.last_dest = I->pending[n_ops - 1].dest;
     }
     q.n_ops = fat ? n_ops + (n_ops & 1) : n_ops;
+    I->slot_ops[new_slot]  = I->pending;
+    I->slot_kind[new_slot] = kind;
+    I->ops_slot = (new_slot + 1) % I->ops_slots;
   }
   if (ee)
   {
@@ -499,6 +518,7 @@ int flush(Instance *I, const EdgeEval *ee)
       q.tickets = I->d_tickets; q.result = ee->dev_out ? ee->dev_out : I->d_result;
       q.result_host = ee->to_host ? I->h_result : nullptr; q.warn_host = I->h_warn;
       q.seq = ee->to_host ? ++I->seq : 0ull;
+      q.warn_out = ee->warn_out;
     }
     if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
   }
@@ -515,9 +535,10 @@ int flush(Instance *I, const EdgeEval *ee)
     {
       if (I->soa)
       { // lane-per-pattern kernel, instantiated on the exact category count
+#ifdef PHYHIP_DIAG
         if ((I->ablate & 8) && I->C == 4 && I->nt_groups <= 2)
         { // PHYHIP_ABLATE=8: cycle stamps of one wave, printed to stderr (diagnostics; costs a sync)
-          static unsigned long long *d_dbg = nullptr;
+          unsigned long long *&d_dbg = I->d_dbg;
           if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
           if (I->nt_groups == 2)
             hipLaunchKernelGGL((traverse_nt2_kernel<4, 2, true>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes, d_dbg);
@@ -540,6 +561,7 @@ int flush(Instance *I, const EdgeEval *ee)
           }
           return 0;
         }
+#endif
 #define NT2CASE(c_, g_) hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes, (unsigned long long *)nullptr); return 0;
         switch (I->C * 8 + I->nt_groups)
         {
@@ -555,8 +577,8 @@ int flush(Instance *I, const EdgeEval *ee)
 #undef NT2CASE
       }
     }
-    if constexpr (S_ == 4)
-    {
+    if constexpr (S_ == 4 && (CP_ == 8 || kDiag))
+    { // first-generation lane = (pattern, category) pipeline: the production kernel for 5..8 categories
       if (!I->generic_nt)
       {
         if (I->prefetch_dist == 1)
@@ -565,6 +587,7 @@ int flush(Instance *I, const EdgeEval *ee)
                              ro.tip_codes);
           return 0;
         }
+#ifdef PHYHIP_DIAG
         if constexpr (CP_ == 4)
         {
           switch (I->ablate)
@@ -575,6 +598,7 @@ int flush(Instance *I, const EdgeEval *ee)
             default: break;
           }
         }
+#endif
         hipLaunchKernelGGL((traverse_nt_kernel<CP_>), dim3(I->grid_nt), dim3(I->block_nt), 0, I->stream, q, d_irec, d_xrec, ro.pmats,
                            ro.tip_codes);
         return 0;
@@ -584,10 +608,11 @@ int flush(Instance *I, const EdgeEval *ee)
     {
       if (I->perm)
       {
+#ifdef PHYHIP_DIAG
         if constexpr (CP_ == 4)
           if (I->ablate & 8)
           { // PHYHIP_ABLATE=8: cycle stamps of one wave, printed to stderr (diagnostics; costs a sync per launch)
-            static unsigned long long *d_dbg = nullptr;
+            unsigned long long *&d_dbg = I->d_dbg;
             if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
             hipLaunchKernelGGL((traverse_aa_kernel<CP_, true>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
                                (const double *)I->d_afrag, I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size(),
@@ -608,6 +633,7 @@ int flush(Instance *I, const EdgeEval *ee)
             }
             return 0;
           }
+#endif
         hipLaunchKernelGGL((traverse_aa_kernel<CP_>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
                            (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks,
                            (int)I->masks.size(), I->ablate);
@@ -624,6 +650,30 @@ int flush(Instance *I, const EdgeEval *ee)
     HIPCHK(hipEventRecord(e1, I->stream));
     I->prof_pairs.emplace_back(e0, e1);
     I->prof_updates += (double)n_ops * (double)I->P;
+    // Minimum traffic of this launch if nothing but the kernel's own register forwarding saved a byte: every result is
+    // written once; a child is read unless it is a tip (1 byte per pattern) or the result of one of the previous two
+    // operations (forwarded in registers -- exactly the flags computed for the operation records above).
+    {
+      const double rec = (double)I->C * I->S * 8.0 + 4.0;
+      double       rd = 0.0, wr = (double)n_ops * rec;
+      for (int k = 0; k < n_ops; ++k)
+      {
+        const DevOp &o  = I->pending[k];
+        const int    e1 = k >= 1 ? I->pending[k - 1].dest : -1;
+        const int    e2 = (k >= 2 && fat && I->prefetch_dist == 2) ? I->pending[k - 2].dest : -1;
+        for (int c : {o.c1, o.c2})
+          rd += c < I->tips ? 1.0 : ((fat && (c == e1 || c == e2)) ? 0.0 : rec);
+      }
+      if (ee)
+      { // root edge: both sides unless just produced, pattern weight in; per-pattern outputs out
+        for (int c : {ee->parent, ee->child})
+          rd += c < I->tips ? 1.0 : ((fat && n_ops > 0 && c == I->pending[n_ops - 1].dest) ? 0.0 : rec);
+        rd += 8.0;
+        wr += 4.0 + (I->want_site_outputs ? 16.0 + 8.0 * I->C : 0.0);
+      }
+      I->prof_rd_bytes += rd * (double)I->P;
+      I->prof_wr_bytes += wr * (double)I->P;
+    }
   }
   HIPCHK(hipGetLastError());
   if (ee && !fused_sum)
@@ -632,12 +682,30 @@ int flush(Instance *I, const EdgeEval *ee)
     const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, nsum, 1,
                        nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn,
-                       ee->to_host ? ++I->seq : 0ull);
+                       ee->to_host ? ++I->seq : 0ull, ee->warn_out);
     HIPCHK(hipGetLastError());
+  }
+  if (fold_pm)
+  {
+    for (int m : I->pm_idx) I->pm_slot[m] = -1;
+    I->pm_idx.clear();
+    I->pm_len.clear();
   }
   I->pending.clear();
   std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
   return 0;
+}
+
+int flush(Instance *I, const EdgeEval *ee)
+{
+  const int rc = flush_impl(I, ee);
+  if (rc)
+  { // a failed launch leaves no half-queued state behind: the operations are dropped (the caller gets the error and
+    // PhyML's glue exits on it), queued matrix rebuilds stay queued, no device slot claims a list it never received
+    I->pending.clear();
+    std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
+  }
+  return rc;
 }
 
 int flush_sync(Instance *I)
@@ -656,13 +724,16 @@ int check_partial_index(const Instance *I, int idx, bool allow_tip)
 }
 
 // Wait until the final reduction has published evaluation `seq` in host-mapped memory.  Spinning on the
-// sequence word avoids the stream-synchronise wake-up latency; after ~2 ms of spinning fall back to it.
+// sequence word avoids the stream-synchronise wake-up latency; after 2 ms of spinning (elapsed time, checked every
+// 256 polls) fall back to it: evaluations of very large alignments take milliseconds and must not burn a core.
 int wait_result(Instance *I)
 {
   if (I->spin_wait)
   {
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(I->h_result + 2);
-    for (long it = 0; it < 4000000; ++it)
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long it = 0;; ++it)
     {
       if (*flag == I->seq)
       {
@@ -671,6 +742,12 @@ int wait_result(Instance *I)
         return 0;
       }
       __builtin_ia32_pause();
+      if ((it & 255) == 255)
+      {
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) break;
+      }
     }
   }
   HIPCHK(hipStreamSynchronize(I->stream));
@@ -699,6 +776,8 @@ int collect_profile(Instance *I)
   return 0;
 }
 
+#include "phyhip_shard.hpp"
+
 } // namespace
 
 extern "C" {
@@ -711,7 +790,7 @@ static void release_instance(Instance *I)
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl};
+                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
@@ -729,7 +808,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
                            int scaleBufferCount, const int *resourceList, int resourceCount, long preferenceFlags,
                            long requirementFlags, phyhip_instance_details *returnInfo)
 {
-  (void)compactBufferCount; (void)eigenBufferCount; (void)scaleBufferCount; (void)preferenceFlags; (void)requirementFlags;
+  (void)compactBufferCount; (void)eigenBufferCount; (void)scaleBufferCount; (void)preferenceFlags;
   if (tipCount < 2 || partialsBufferCount <= tipCount || patternCount < 1 || matrixBufferCount < 1 || categoryCount < 1)
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "bad instance dimensions");
   if (stateCount != 4 && stateCount != 20)
@@ -743,6 +822,14 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(PHYHIP_ERROR_NO_RESOURCE, "no HIP device visible: libphyhip has no CPU fallback");
+  if (resourceList && (resourceCount > 1 || (resourceCount == 1 && (requirementFlags & PHYHIP_FLAG_SHARDED))))
+  { // sharded instance: one per-device instance per entry of the resource list + the RCCL communicators
+    for (int g = 0; g < resourceCount; ++g)
+      if (resourceList[g] < 0 || resourceList[g] >= ndev)
+        return fail(PHYHIP_ERROR_NO_RESOURCE, "device %d not present (%d visible)", resourceList[g], ndev);
+    return create_group(tipCount, partialsBufferCount, stateCount, patternCount, matrixBufferCount, categoryCount, resourceList,
+                        resourceCount, returnInfo);
+  }
   int dev = 0;
   if (resourceList && resourceCount > 0) dev = resourceList[0];
   else if (const char *e = getenv("PHYHIP_DEVICE")) dev = atoi(e);
@@ -793,7 +880,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
 
   I->perm = (I->S == 20) && (I->C <= 4) && !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA")));
-  I->soa  = (I->S == 4) && (I->C <= 4) && !(getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
+  I->soa  = (I->S == 4) && (I->C <= 4) && !(kDiag && getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
             !(getenv("PHYHIP_GENERIC_NT") && atoi(getenv("PHYHIP_GENERIC_NT")));
   I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
   // category groups of the lane-per-pattern kernel (phyhip_nt2.hpp): split a pattern over 2 lanes while the
@@ -891,16 +978,22 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
+#ifdef PHYHIP_DIAG
   if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
+  if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
+#endif
   if (const char *e = getenv("PHYHIP_EAGER_PMAT")) I->eager_pmats = atoi(e) != 0;
-  if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce() { I->split_reduce = atoi(e) != 0; I->split_reduce_forced = true; }
+  if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce()
+  {
+    I->split_reduce        = atoi(e) != 0;
+    I->split_reduce_forced = true;
+  }
   if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_FOLD_PMATS")) I->fold_pmats = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_mixexpl, sizeof(double) * kMaxMixClasses * 2 * 20));
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
   HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned)));
   if (const char *e = getenv("PHYHIP_DIST")) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
-  if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
 
   // codes 0..S-1 are the single states
   for (int s = 0; s < I->S; ++s)
@@ -915,6 +1008,15 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
 
 int phyhip_finalize_instance(int instance)
 {
+  if (Group *G = get_group(instance))
+  {
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      g_groups[instance - kGroupBase] = nullptr;
+    }
+    release_group(G);
+    return PHYHIP_SUCCESS;
+  }
   GET_INST(I, instance);
   (void)hipStreamSynchronize(I->stream);
   collect_profile(I);
@@ -922,6 +1024,7 @@ int phyhip_finalize_instance(int instance)
     std::lock_guard<std::mutex> lk(g_mu);
     g_inst[instance] = nullptr;
   }
+  if (I->co) release_collective(I->co);
   release_instance(I);
   return PHYHIP_SUCCESS;
 }
@@ -954,6 +1057,8 @@ static int code_for_mask(Instance *I, uint32_t m, int *code)
 
 int phyhip_set_tip_partials(int instance, int tipIndex, const double *inPartials)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_set_tip_partials(id, tipIndex, inPartials + lo * G->S); });
   GET_INST(I, instance);
   if (tipIndex < 0 || tipIndex >= I->tips) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip index %d", tipIndex);
   std::vector<uint8_t> codes((size_t)I->P);
@@ -980,6 +1085,8 @@ int phyhip_set_tip_partials(int instance, int tipIndex, const double *inPartials
 
 int phyhip_set_tip_states(int instance, int tipIndex, const int *inStates)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_set_tip_states(id, tipIndex, inStates + lo); });
   GET_INST(I, instance);
   if (tipIndex < 0 || tipIndex >= I->tips) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip index %d", tipIndex);
   std::vector<uint8_t> codes((size_t)I->P);
@@ -1002,6 +1109,8 @@ int phyhip_set_tip_states(int instance, int tipIndex, const int *inStates)
 
 int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_set_partials(id, bufferIndex, inPartials + lo * G->C * G->S); });
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
@@ -1025,6 +1134,8 @@ int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials)
 
 int phyhip_set_pattern_weights(int instance, const double *w)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_set_pattern_weights(id, w + lo); });
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
@@ -1046,6 +1157,7 @@ static int small_upload(Instance *I, double *dst, const double *src, size_t n)
 
 int phyhip_set_category_rates(int instance, const double *r)
 {
+  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_set_category_rates(id, r); });
   GET_INST(I, instance);
   I->h_rates.assign(r, r + I->C);
   return small_upload(I, I->d_catr, r, I->C);
@@ -1053,6 +1165,7 @@ int phyhip_set_category_rates(int instance, const double *r)
 
 int phyhip_set_category_weights(int instance, int idx, const double *w)
 {
+  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_set_category_weights(id, idx, w); });
   GET_INST(I, instance);
   if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "categoryWeightsIndex must be 0");
   return small_upload(I, I->d_catw, w, I->C);
@@ -1060,6 +1173,7 @@ int phyhip_set_category_weights(int instance, int idx, const double *w)
 
 int phyhip_set_state_frequencies(int instance, int idx, const double *pi)
 {
+  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_set_state_frequencies(id, idx, pi); });
   GET_INST(I, instance);
   if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "stateFrequenciesIndex must be 0");
   return small_upload(I, I->d_pi, pi, I->S);
@@ -1067,6 +1181,8 @@ int phyhip_set_state_frequencies(int instance, int idx, const double *pi)
 
 int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, const double *ivec, const double *eval)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long, long long) { return phyhip_set_eigen_decomposition(id, idx, evec, ivec, eval); });
   GET_INST(I, instance);
   if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
   I->h_eval.assign(eval, eval + I->S);
@@ -1079,6 +1195,8 @@ int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, co
 
 int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br_len_mult, int apply_lk_scaling)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long, long long) { return phyhip_set_phyml_options(id, l_min, l_max, br_len_mult, apply_lk_scaling); });
   GET_INST(I, instance);
   const int sc = apply_lk_scaling ? 1 : 0;
   if (I->l_min == l_min && I->l_max == l_max && I->br_len_mult == br_len_mult && I->apply_scaling == sc) return PHYHIP_SUCCESS;
@@ -1090,6 +1208,8 @@ int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br
 
 int phyhip_set_invariant_sites(int instance, int invar_model, double pinvar, const short *invar)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_set_invariant_sites(id, invar_model, pinvar, invar ? invar + lo : nullptr); });
   GET_INST(I, instance);
   if (!invar && invar_model) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "invar_model set but invar == NULL");
   const bool same_sites = !invar || (I->h_invar_set && !memcmp(I->h_invar.data(), invar, I->P * sizeof(short)));
@@ -1128,6 +1248,10 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
                                       const int *firstDerivativeIndices, const int *secondDerivativeIndices,
                                       const double *edgeLengths, int count)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long, long long) {
+      return phyhip_update_transition_matrices(id, eigenIndex, probabilityIndices, firstDerivativeIndices, secondDerivativeIndices, edgeLengths, count);
+    });
   GET_INST(I, instance);
   if (eigenIndex != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
   if (firstDerivativeIndices || secondDerivativeIndices)
@@ -1162,6 +1286,8 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
 
 int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *inMatrix, double paddedValue)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long, long long) { return phyhip_set_transition_matrix(id, matrixIndex, inMatrix, paddedValue); });
   (void)paddedValue;
   GET_INST(I, instance);
   int rc = matrices_touch(I, &matrixIndex, 1);
@@ -1186,6 +1312,7 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
 
 int phyhip_get_transition_matrix(int instance, int matrixIndex, double *outMatrix)
 {
+  if (Group *G = get_group(instance)) return phyhip_get_transition_matrix(G->sub_id[0], matrixIndex, outMatrix); // replicated
   GET_INST(I, instance);
   if (matrixIndex < 0 || matrixIndex >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", matrixIndex);
   int rc = flush_sync(I);
@@ -1199,6 +1326,8 @@ int phyhip_get_transition_matrix(int instance, int matrixIndex, double *outMatri
 
 int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int cumulativeScaleIndex)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long, long long) { return phyhip_update_partials(id, ops, n, cumulativeScaleIndex); });
   (void)cumulativeScaleIndex;
   GET_INST(I, instance);
   for (int i = 0; i < n; ++i)
@@ -1229,16 +1358,26 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
                                           double *outSum, double *outD1, double *outD2)
 {
   (void)cs;
-  GET_INST(I, instance);
+  Group *G = get_group(instance);
+  GET_INST(I, G ? G->sub_id[0] : instance);
   if (count != 1) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "count must be 1");
   if (d1 || d2 || outD1 || outD2)
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "derivatives: use phyhip_calculate_eigen_lnl_dlnl (PhyML's dLk path)");
   if ((cw && cw[0] != 0) || (sf && sf[0] != 0)) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "weights/frequencies index must be 0");
+  if (G) return group_edge_lnl(G, parent[0], child[0], pm[0], outSum);
   int rc = check_partial_index(I, parent[0], true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, child[0], true))) return rc;
   if (pm[0] < 0 || pm[0] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm[0]);
-  EdgeEval ee{parent[0], child[0], pm[0], nullptr, true};
+  if (I->co)
+  { // one process per GPU: this rank's shard sum stays on the device and goes through the all-reduce
+    EdgeEval ee{parent[0], child[0], pm[0], I->d_red + 1, false, I->d_red};
+    if ((rc = flush(I, &ee))) return rc;
+    if ((rc = reduce_and_publish(*I->co, 2, I))) return rc;
+    *outSum = I->h_result[0];
+    return PHYHIP_SUCCESS;
+  }
+  EdgeEval ee{parent[0], child[0], pm[0], nullptr, true, nullptr};
   rc = flush(I, &ee);
   if (rc) return rc;
   if ((rc = wait_result(I))) return rc;
@@ -1248,12 +1387,14 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
 
 int phyhip_calculate_edge_log_likelihoods_device(int instance, int parent, int child, int pm, double *deviceOut)
 {
+  if (get_group(instance))
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "a sharded instance reduces inside phyhip_calculate_edge_log_likelihoods");
   GET_INST(I, instance);
   int rc = check_partial_index(I, parent, true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, child, true))) return rc;
   if (pm < 0 || pm >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm);
-  EdgeEval ee{parent, child, pm, deviceOut, false};
+  EdgeEval ee{parent, child, pm, deviceOut, false, nullptr};
   return flush(I, &ee);
 }
 
@@ -1276,7 +1417,7 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
     if ((rc = check_partial_index(I, child[k], true))) return rc;
     if (pm[k] < 0 || pm[k] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm[k]);
     // the class's own edge evaluation: leaves unscaled_site_lk_cat and fact_sum_scale in its device arrays, no host sync
-    EdgeEval ee{parent[k], child[k], pm[k], I->d_result, false};
+    EdgeEval ee{parent[k], child[k], pm[k], I->d_result, false, nullptr};
     if ((rc = flush(I, &ee))) return rc;
     if (I != I0)
     { // the combination runs on the first instance's stream, after every class stream
@@ -1385,6 +1526,8 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
 
 int phyhip_get_site_log_likelihoods(int instance, double *out)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_get_site_log_likelihoods(id, out + lo); });
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
@@ -1394,6 +1537,11 @@ int phyhip_get_site_log_likelihoods(int instance, double *out)
 
 int phyhip_get_site_outputs(int instance, double *c_lnL_sorted, double *cur_site_lk, double *unscaled, int *fact)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) {
+      return phyhip_get_site_outputs(id, c_lnL_sorted ? c_lnL_sorted + lo : nullptr, cur_site_lk ? cur_site_lk + lo : nullptr,
+                                     unscaled ? unscaled + lo * G->C : nullptr, fact ? fact + lo : nullptr);
+    });
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
@@ -1406,6 +1554,8 @@ int phyhip_get_site_outputs(int instance, double *c_lnL_sorted, double *cur_site
 
 int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *out)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_get_partials(id, bufferIndex, scaleIndex, out + lo * G->C * G->S); });
   (void)scaleIndex;
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
@@ -1428,6 +1578,8 @@ int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *o
 
 int phyhip_get_scale_factors(int instance, int bufferIndex, int *out)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_get_scale_factors(id, bufferIndex, out + lo); });
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
@@ -1438,6 +1590,8 @@ int phyhip_get_scale_factors(int instance, int bufferIndex, int *out)
 
 int phyhip_set_scale_factors(int instance, int bufferIndex, const int *in)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_set_scale_factors(id, bufferIndex, in + lo); });
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
@@ -1448,6 +1602,12 @@ int phyhip_set_scale_factors(int instance, int bufferIndex, const int *in)
 
 int phyhip_get_numerical_warning(int instance, int *out)
 {
+  if (Group *G = get_group(instance))
+  {
+    if (!G->warn_valid) return fail(PHYHIP_ERROR_GENERAL, "no evaluation yet");
+    *out = G->last_warn;
+    return PHYHIP_SUCCESS;
+  }
   GET_INST(I, instance);
   if (!(I->warn_current && I->pending.empty()))
   { // an evaluation whose result the host did not wait for (device-side output) may still be running
@@ -1462,6 +1622,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
 
 int phyhip_update_eigen_lr(int instance, int left, int rght)
 {
+  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_update_eigen_lr(id, left, rght); });
   GET_INST(I, instance);
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
@@ -1479,7 +1640,10 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   return PHYHIP_SUCCESS;
 }
 
-static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dlnl)
+// dev_out != nullptr (sharded evaluation): the two sums stay in device memory (dev_out[0..1]), the warning flag goes to
+// *warn_out as a double, nothing is handed to the host and the call does not wait.
+static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dlnl, double *dev_out = nullptr,
+                      double *warn_out = nullptr)
 {
   if ((size_t)I->C * 2 * I->S > (size_t)kMaxExpl) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "expl table too large");
   int rc = flush(I, nullptr);
@@ -1497,8 +1661,9 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   const bool fused = fuse_reduce(I, dgrid);
   if (fused)
   {
-    q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
-    q.fin.seq = ++I->seq;
+    q.fin.tickets = I->d_tickets; q.fin.result = dev_out ? dev_out : I->d_result;
+    q.fin.result_host = dev_out ? nullptr : I->h_result; q.fin.warn_host = I->h_warn;
+    q.fin.seq = dev_out ? 0ull : ++I->seq; q.fin.warn_out = warn_out;
   }
   for (int c = 0; c < I->C; ++c)
   {
@@ -1534,8 +1699,14 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   if (!fused)
   {
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, dgrid, 2, dgrid,
-                       I->d_result, I->h_result, I->d_warn, I->h_warn, ++I->seq);
+                       dev_out ? dev_out : I->d_result, dev_out ? (double *)nullptr : I->h_result, I->d_warn, I->h_warn,
+                       dev_out ? 0ull : ++I->seq, warn_out);
     HIPCHK(hipGetLastError());
+  }
+  if (dev_out)
+  {
+    I->warn_current = false;
+    return PHYHIP_SUCCESS;
   }
   if ((rc = wait_result(I))) return rc;
   *lnl = I->h_result[0];
@@ -1543,23 +1714,123 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   return PHYHIP_SUCCESS;
 }
 
+// dLk / eigen-basis Lk on the shards + the collective (count 3: warning, lnL, dlnL)
+static int group_eigen_eval(Group *G, double l, bool deriv, double *lnl, double *dlnl)
+{
+  for (size_t g = 0; g < G->sub.size(); ++g)
+  {
+    Instance *I = G->sub[g];
+    int rc = set_dev(I->dev);
+    if (rc) return rc;
+    double *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
+    if ((rc = eigen_eval(I, l, deriv, nullptr, nullptr, slot + 1, slot))) return rc;
+  }
+  int rc = reduce_and_publish(*G->co, 3, G->sub[0]);
+  if (rc) return rc;
+  *lnl = G->sub[0]->h_result[0];
+  if (dlnl) *dlnl = G->sub[0]->h_result[1];
+  G->last_warn  = *G->sub[0]->h_warn;
+  G->warn_valid = true;
+  return PHYHIP_SUCCESS;
+}
+
+static int rank_eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dlnl)
+{
+  int rc = eigen_eval(I, l, deriv, nullptr, nullptr, I->d_red + 1, I->d_red);
+  if (rc) return rc;
+  if ((rc = reduce_and_publish(*I->co, 3, I))) return rc;
+  *lnl = I->h_result[0];
+  if (dlnl) *dlnl = I->h_result[1];
+  return PHYHIP_SUCCESS;
+}
+
 int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, double *outDLnL)
 {
-  GET_INST(I, instance);
+  Group *G = get_group(instance);
+  GET_INST(I, G ? G->sub_id[0] : instance);
   if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN"); // src/lk.c:671
   if (*l < I->l_min) *l = I->l_min;                                                     // src/lk.c:673-674
   else if (*l > I->l_max) *l = I->l_max;
+  if (G) return group_eigen_eval(G, *l, true, outLnL, outDLnL);
+  if (I->co) return rank_eigen_eval(I, *l, true, outLnL, outDLnL);
   return eigen_eval(I, *l, true, outLnL, outDLnL);
 }
 
 int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL)
 {
+  if (Group *G = get_group(instance)) return group_eigen_eval(G, l, false, outLnL, nullptr);
   GET_INST(I, instance);
+  if (I->co) return rank_eigen_eval(I, l, false, outLnL, nullptr);
   return eigen_eval(I, l, false, outLnL, nullptr);
+}
+
+// ---- multi-GPU: one process per GPU ------------------------------------------------------------------------------
+
+int phyhip_comm_get_unique_id(char *outId)
+{
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == PHYHIP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(outId, &id, sizeof id);
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_comm_init_rank(int instance, int nranks, int rank, const char *uniqueId)
+{
+  if (get_group(instance)) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "a sharded instance already owns its communicators");
+  GET_INST(I, instance);
+  if (I->co) return fail(PHYHIP_ERROR_GENERAL, "instance %d already has a communicator", instance);
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "rank %d of %d", rank, nranks);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  ncclUniqueId id;
+  memcpy(&id, uniqueId, sizeof id);
+  DevCtx c;
+  c.dev = I->dev; c.stream = I->stream; c.nsub = 1;
+  NCCLCHK(ncclCommInitRank(&c.comm, nranks, id, rank));
+  HIPCHK(hipMalloc((void **)&c.d_red, sizeof(double) * kRedStride));
+  HIPCHK(hipMemset(c.d_red, 0, sizeof(double) * kRedStride));
+  I->co = new Collective();
+  I->co->ctx.push_back(c);
+  I->co->nranks = nranks;
+  I->d_red      = c.d_red;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_comm_size(int instance, int *outRanks)
+{
+  if (Group *G = get_group(instance))
+  {
+    *outRanks = G->co->nranks;
+    return PHYHIP_SUCCESS;
+  }
+  GET_INST(I, instance);
+  *outRanks = I->co ? I->co->nranks : 1;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_shard_range(int instance, int shard, int *outDevice, int *outFirstPattern, int *outPatternCount)
+{
+  if (Group *G = get_group(instance))
+  {
+    if (shard < 0 || shard >= (int)G->sub.size()) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "shard %d of %d", shard, (int)G->sub.size());
+    if (outDevice) *outDevice = G->sub[shard]->dev;
+    if (outFirstPattern) *outFirstPattern = (int)G->lo[shard];
+    if (outPatternCount) *outPatternCount = (int)G->n[shard];
+    return (int)G->sub.size();
+  }
+  GET_INST(I, instance);
+  if (shard != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "shard %d of 1", shard);
+  if (outDevice) *outDevice = I->dev;
+  if (outFirstPattern) *outFirstPattern = 0;
+  if (outPatternCount) *outPatternCount = (int)I->P;
+  return 1;
 }
 
 int phyhip_get_dot_prod(int instance, double *out)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_get_dot_prod(id, out + lo * G->C * G->S); });
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
@@ -1571,34 +1842,55 @@ int phyhip_get_dot_prod(int instance, double *out)
 
 int phyhip_set_stream(int instance, void *hipStream)
 {
+  if (get_group(instance)) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "a sharded instance owns one stream per device");
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
   if (I->own_stream && I->stream) (void)hipStreamDestroy(I->stream);
   I->stream     = (hipStream_t)hipStream;
   I->own_stream = false;
+  if (I->co) I->co->ctx[0].stream = I->stream;
   return PHYHIP_SUCCESS;
 }
 
 int phyhip_synchronize(int instance)
 {
+  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_synchronize(id); });
   GET_INST(I, instance);
   return flush_sync(I);
 }
 
 int phyhip_profile(int instance, int enable)
 {
+  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_profile(id, enable); });
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
   collect_profile(I);
   I->prof = enable != 0;
-  I->prof_ms = 0.0; I->prof_n = 0; I->prof_updates = 0.0;
+  I->prof_ms = 0.0; I->prof_n = 0; I->prof_updates = 0.0; I->prof_rd_bytes = 0.0; I->prof_wr_bytes = 0.0;
   return PHYHIP_SUCCESS;
 }
 
 int phyhip_profile_read(int instance, double *ms, int *launches, double *updates)
 {
+  if (Group *G = get_group(instance))
+  { // slowest shard's kernel time, its launch count, site-updates of all shards
+    double tms = 0.0, tup = 0.0;
+    int    tn  = 0;
+    const int rc = group_each(G, [&](int id, long long, long long) {
+      double m = 0.0, u = 0.0;
+      int    k = 0;
+      const int r = phyhip_profile_read(id, &m, &k, &u);
+      if (m > tms) { tms = m; tn = k; }
+      tup += u;
+      return r;
+    });
+    if (ms) *ms = tms;
+    if (launches) *launches = tn;
+    if (updates) *updates = tup;
+    return rc;
+  }
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
@@ -1606,6 +1898,27 @@ int phyhip_profile_read(int instance, double *ms, int *launches, double *updates
   if (ms) *ms = I->prof_ms;
   if (launches) *launches = I->prof_n;
   if (updates) *updates = I->prof_updates;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_profile_read_traffic(int instance, double *outReadBytes, double *outWriteBytes)
+{
+  if (Group *G = get_group(instance))
+  {
+    double r = 0.0, w = 0.0;
+    const int rc = group_each(G, [&](int id, long long, long long) {
+      double a = 0.0, b = 0.0;
+      const int k = phyhip_profile_read_traffic(id, &a, &b);
+      r += a; w += b;
+      return k;
+    });
+    if (outReadBytes) *outReadBytes = r;
+    if (outWriteBytes) *outWriteBytes = w;
+    return rc;
+  }
+  GET_INST(I, instance);
+  if (outReadBytes) *outReadBytes = I->prof_rd_bytes;
+  if (outWriteBytes) *outWriteBytes = I->prof_wr_bytes;
   return PHYHIP_SUCCESS;
 }
 

@@ -101,6 +101,7 @@ struct TreeParams
   int                *warn_host;
   unsigned long long  seq;
   int            *warn;
+  double             *warn_out;    // sharded evaluation: the flag as a double next to the shard's sum (rides in the all-reduce)
   // Short lists of transition matrices to rebuild (SPR: three per candidate, src/spr.c:643-646) ride here and are built
   // by every workgroup of the lane-per-pattern nucleotide kernel in its prologue: no separate pmat_kernel launch, no
   // dependent-launch gap.  (pmat_kernel's arithmetic, src/models.c:257-326.)
@@ -285,6 +286,7 @@ struct FinishParams
   double             *result_host; // host-mapped {sum 0, sum 1, seq} or nullptr
   int                *warn, *warn_host;
   unsigned long long  seq;
+  double             *warn_out;    // device double that receives the warning flag (sharded evaluation) or nullptr
 };
 
 __device__ __forceinline__ void raise_warn(int *warn)
@@ -351,6 +353,7 @@ template <int NS> __device__ __forceinline__ void finish_sums(const FinishParams
     __hip_atomic_store(f.warn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(f.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f.warn_host) *f.warn_host = w;
+    if (f.warn_out) *f.warn_out = (double)w;
     if (f.result_host)
     {
 #pragma unroll
@@ -368,7 +371,7 @@ __device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s,
 {
   FinishParams f;
   f.tickets = q.tickets; f.block_sums = q.block_sums; f.stride = 0; f.result = q.result; f.result_host = q.result_host;
-  f.warn = q.warn; f.warn_host = q.warn_host; f.seq = q.seq;
+  f.warn = q.warn; f.warn_host = q.warn_host; f.seq = q.seq; f.warn_out = q.warn_out;
   const double v[1] = {s};
   finish_sums<1>(f, v, lane);
 }
@@ -904,7 +907,8 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
 // (SPR enters the surface ~10^5 times per search, each time waiting for one scalar).
 __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restrict__ in, int n, int nstreams, int stride,
                                                           double *__restrict__ out, double *__restrict__ out_host,
-                                                          int *warn, int *warn_host, unsigned long long seq)
+                                                          int *warn, int *warn_host, unsigned long long seq,
+                                                          double *warn_out)
 {
   __shared__ double sh[256];
   for (int k = 0; k < nstreams; ++k)
@@ -932,6 +936,7 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restr
     {
       const int w = *warn;
       if (warn_host) *warn_host = w;
+      if (warn_out) *warn_out = (double)w;
       *warn = 0;
     }
     if (out_host)

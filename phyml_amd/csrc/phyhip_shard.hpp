@@ -1,0 +1,280 @@
+// phyhip_shard.hpp -- the multi-GPU side of libphyhip.so: pattern shards and the ONE
+// collective of the path, an RCCL all-reduce of the per-shard log-likelihood (src/lk.c:856: c_lnL is a plain sum over
+// patterns; src/lk.c:744-745: so are c_lnL and c_dlnL of dLk).  Included by phyhip.hip inside its anonymous namespace.
+//
+// Two ways in, one mechanism:
+//   * single process, G devices (what a C host like PhyML uses): phyhip_create_instance with a resource list of G
+//     devices returns ONE instance id backed by G per-device instances over contiguous pattern ranges
+//     [g*P/G, (g+1)*P/G) and one communicator per device from ncclCommInitAll.  Setters slice per-pattern inputs and
+//     replicate the model; getters concatenate; an evaluation launches every shard, all-reduces on every device's stream
+//     inside one ncclGroupStart/End, and hands device 0's copy to the host.
+//   * one process per GPU (MPI-style hosts, bench.py under torchrun): phyhip_comm_init_rank attaches a communicator built
+//     from a broadcast ncclUniqueId to a plain instance holding that rank's shard; the same evaluation entry points then
+//     return the all-reduced value on every rank.
+//
+// The reduced vector is {numerical warning, lnL[, dlnL]}: count 2 for Lk, 3 for dLk -- the warning flag of
+// src/lk.c:847-851 rides as one more double so that no second collective or extra synchronisation exists.
+// The payload is 16-24 bytes: the collective is pure latency; the xGMI links' bandwidth never matters here.
+#pragma once
+
+// (<rccl/rccl.h> is included by phyhip.hip at global scope)
+
+#define NCCLCHK(call)                                                                                        \
+  do                                                                                                         \
+  {                                                                                                          \
+    ncclResult_t r_ = (call);                                                                                \
+    if (r_ != ncclSuccess)                                                                                   \
+      return fail(PHYHIP_ERROR_GENERAL, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+constexpr int kRedStride = 4; // doubles per reduction slot: {warning, lnL, dlnL, pad}
+
+// slot 0 += slots 1..n of one device, fixed order (several shards on one device: tests on a single-GPU box, or more
+// shards than devices)
+__global__ void shard_local_sum_kernel(double *slots, int n, int count)
+{
+  const int t = threadIdx.x;
+  if (t >= count) return;
+  double v = 0.0;
+  for (int k = 1; k <= n; ++k) v += slots[k * kRedStride + t];
+  slots[t] = v;
+}
+
+// after the all-reduce: {warning, lnL, dlnL} -> host-mapped result block + sequence number (what the fused final sum
+// of a single-device evaluation does itself)
+__global__ void shard_publish_kernel(const double *red, double *result_host, int *warn_host, unsigned long long seq)
+{
+  if (threadIdx.x != 0) return;
+  *warn_host     = red[0] != 0.0 ? 1 : 0;
+  result_host[0] = red[1];
+  result_host[1] = red[2];
+  __threadfence_system();
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(result_host + 2), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct DevCtx
+{
+  int         dev    = 0;
+  hipStream_t stream = nullptr;    // the stream every shard on this device runs on (= its first shard's own stream)
+  ncclComm_t  comm   = nullptr;
+  double     *d_red  = nullptr;    // [(1 + nsub)][kRedStride]: slot 0 is the all-reduce buffer
+  int         nsub   = 0;
+};
+
+struct Collective
+{
+  std::vector<DevCtx> ctx;
+  int                 nranks = 0; // communicator size (all processes)
+  bool                own_comms = true;
+};
+
+static int set_dev(int dev)
+{
+  if (g_cur_dev != dev)
+  {
+    HIPCHK(hipSetDevice(dev));
+    g_cur_dev = dev;
+  }
+  return 0;
+}
+
+// where shard number `k` of its device writes {warning, lnL, dlnL}
+static double *shard_slot(const DevCtx &c, int k) { return c.d_red + (size_t)(c.nsub > 1 ? k + 1 : 0) * kRedStride; }
+
+// Per-device local sums, ONE all-reduce (count doubles) on every device's stream, result of the first device to the
+// host through I0's result block.  I0 must live on ctx[0] and run on its stream.
+static int reduce_and_publish(Collective &co, int count, Instance *I0)
+{
+  int rc = 0;
+  for (auto &c : co.ctx)
+    if (c.nsub > 1)
+    {
+      if ((rc = set_dev(c.dev))) return rc;
+      hipLaunchKernelGGL(shard_local_sum_kernel, dim3(1), dim3(64), 0, c.stream, c.d_red, c.nsub, count);
+      HIPCHK(hipGetLastError());
+    }
+  const bool grouped = co.ctx.size() > 1;
+  if (grouped) NCCLCHK(ncclGroupStart());
+  for (auto &c : co.ctx)
+  {
+    if ((rc = set_dev(c.dev))) return rc;
+    NCCLCHK(ncclAllReduce(c.d_red, c.d_red, (size_t)count, ncclDouble, ncclSum, c.comm, c.stream));
+  }
+  if (grouped) NCCLCHK(ncclGroupEnd());
+  if ((rc = set_dev(co.ctx[0].dev))) return rc;
+  hipLaunchKernelGGL(shard_publish_kernel, dim3(1), dim3(64), 0, co.ctx[0].stream, (const double *)co.ctx[0].d_red, I0->h_result,
+                     I0->h_warn, ++I0->seq);
+  HIPCHK(hipGetLastError());
+  return wait_result(I0);
+}
+
+static void release_collective(Collective *co)
+{
+  if (!co) return;
+  for (auto &c : co->ctx)
+  {
+    (void)hipSetDevice(c.dev);
+    g_cur_dev = c.dev;
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    if (c.comm && co->own_comms) (void)ncclCommDestroy(c.comm);
+    if (c.d_red) (void)hipFree(c.d_red);
+  }
+  delete co;
+}
+
+// ---- single process, several devices ----------------------------------------------------------------------------
+
+constexpr int kGroupBase = 1 << 20; // instance ids >= kGroupBase name sharded instances
+
+struct Group
+{
+  int                     S = 0, C = 0, tips = 0, nbuf = 0, nmat = 0;
+  long long               P = 0;
+  std::vector<int>        sub_id;  // plain instance ids, in pattern order
+  std::vector<Instance *> sub;
+  std::vector<long long>  lo, n;   // pattern range of each shard
+  std::vector<int>        ctx_of, k_of; // device context of each shard, and its number on that device
+  Collective             *co = nullptr;
+  int                     last_warn = 0;
+  bool                    warn_valid = false;
+};
+
+std::vector<Group *> g_groups;
+
+Group *get_group(int id)
+{
+  if (id < kGroupBase) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int k = id - kGroupBase;
+  if (k >= (int)g_groups.size()) return nullptr;
+  return g_groups[k];
+}
+
+template <typename F> int group_each(Group *G, F &&f)
+{
+  for (size_t g = 0; g < G->sub_id.size(); ++g)
+  {
+    const int rc = f(G->sub_id[g], G->lo[g], G->n[g]);
+    if (rc < 0) return rc;
+  }
+  return PHYHIP_SUCCESS;
+}
+
+static void release_group(Group *G)
+{
+  release_collective(G->co); // drains every device's stream and destroys the communicators while the streams still exist
+  G->co = nullptr;
+  for (int id : G->sub_id)
+    if (id >= 0)
+    {
+      Instance *I = get(id);
+      if (I && !I->own_stream) I->stream = nullptr; // shared stream: owned by the device's first shard
+      (void)phyhip_finalize_instance(id);
+    }
+  delete G;
+}
+
+static int create_group(int tipCount, int partialsBufferCount, int stateCount, int patternCount, int matrixBufferCount,
+                        int categoryCount, const int *resourceList, int resourceCount, phyhip_instance_details *returnInfo)
+{
+  if (patternCount < resourceCount)
+    return fail(PHYHIP_ERROR_OUT_OF_RANGE, "%d patterns cannot be sharded over %d devices", patternCount, resourceCount);
+  Group *G = new Group();
+  G->S = stateCount; G->C = categoryCount; G->tips = tipCount; G->nbuf = partialsBufferCount; G->nmat = matrixBufferCount;
+  G->P = patternCount;
+  G->co = new Collective();
+  const long long base = patternCount / resourceCount, rem = patternCount % resourceCount;
+  for (int g = 0; g < resourceCount; ++g)
+  {
+    const long long lo = g * base + std::min<long long>(g, rem), n = base + (g < rem ? 1 : 0);
+    const int       dev = resourceList[g];
+    phyhip_instance_details det;
+    const int id = phyhip_create_instance(tipCount, partialsBufferCount, 0, stateCount, (int)n, 1, matrixBufferCount, categoryCount,
+                                          0, &dev, 1, 0, 0, &det);
+    if (id < 0)
+    {
+      release_group(G);
+      return id;
+    }
+    if (g == 0 && returnInfo) *returnInfo = det;
+    Instance *I = get(id);
+    int ci = -1;
+    for (size_t k = 0; k < G->co->ctx.size(); ++k)
+      if (G->co->ctx[k].dev == dev) ci = (int)k;
+    if (ci < 0)
+    {
+      DevCtx c;
+      c.dev = dev; c.stream = I->stream;
+      G->co->ctx.push_back(c);
+      ci = (int)G->co->ctx.size() - 1;
+    }
+    else
+    { // a second shard on a device runs on the first one's stream: the local sum is then ordered by the stream alone
+      (void)hipStreamDestroy(I->stream);
+      I->stream = G->co->ctx[ci].stream;
+      I->own_stream = false;
+    }
+    G->sub_id.push_back(id); G->sub.push_back(I); G->lo.push_back(lo); G->n.push_back(n);
+    G->ctx_of.push_back(ci); G->k_of.push_back(G->co->ctx[ci].nsub++);
+  }
+  const int    nctx = (int)G->co->ctx.size();
+  std::vector<int>        devs(nctx);
+  std::vector<ncclComm_t> comms(nctx);
+  for (int k = 0; k < nctx; ++k) devs[k] = G->co->ctx[k].dev;
+  {
+    const ncclResult_t r = ncclCommInitAll(comms.data(), nctx, devs.data());
+    if (r != ncclSuccess)
+    {
+      release_group(G);
+      return fail(PHYHIP_ERROR_GENERAL, "ncclCommInitAll over %d device(s) failed: %s", nctx, ncclGetErrorString(r));
+    }
+  }
+  G->co->nranks = nctx;
+  for (int k = 0; k < nctx; ++k)
+  {
+    DevCtx &c = G->co->ctx[k];
+    c.comm = comms[k];
+    hipError_t e = hipSetDevice(c.dev);
+    g_cur_dev = c.dev;
+    const size_t bytes = sizeof(double) * kRedStride * (size_t)(1 + c.nsub);
+    if (e == hipSuccess) e = hipMalloc((void **)&c.d_red, bytes);
+    if (e == hipSuccess) e = hipMemset(c.d_red, 0, bytes);
+    if (e != hipSuccess)
+    {
+      release_group(G);
+      return fail(PHYHIP_ERROR_OUT_OF_MEMORY, "reduction buffer: %s", hipGetErrorString(e));
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (size_t i = 0; i < g_groups.size(); ++i)
+    if (!g_groups[i])
+    {
+      g_groups[i] = G;
+      return kGroupBase + (int)i;
+    }
+  g_groups.push_back(G);
+  return kGroupBase + (int)g_groups.size() - 1;
+}
+
+// Lk(b) / Lk(NULL) on a sharded instance: every shard's traversal + edge evaluation (no host synchronisation), then the
+// collective.  Launches go out shard by shard from the one host thread; the devices run concurrently.
+static int group_edge_lnl(Group *G, int parent, int child, int pm, double *out)
+{
+  for (size_t g = 0; g < G->sub.size(); ++g)
+  {
+    Instance *I = G->sub[g];
+    int rc = set_dev(I->dev);
+    if (rc) return rc;
+    if ((rc = check_partial_index(I, parent, true)) || (rc = check_partial_index(I, child, true))) return rc;
+    if (pm < 0 || pm >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm);
+    double  *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
+    EdgeEval ee{parent, child, pm, slot + 1, false, slot};
+    if ((rc = flush(I, &ee))) return rc;
+  }
+  int rc = reduce_and_publish(*G->co, 2, G->sub[0]);
+  if (rc) return rc;
+  *out          = G->sub[0]->h_result[0];
+  G->last_warn  = *G->sub[0]->h_warn;
+  G->warn_valid = true;
+  return PHYHIP_SUCCESS;
+}

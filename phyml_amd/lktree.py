@@ -92,7 +92,7 @@ class LkTree:
     """Owns a C `t_tree` + `t_mod`.  Methods are one-line forwards to the C functions of the same name."""
 
     def __init__(self, n_otu, edge_left, edge_rght, edge_len, n_pattern, ns, ncatg, device=None, node_v=None,
-                 node_b=None, host_pmat=False):
+                 node_b=None, host_pmat=False, devices=None, force_sharded=False):
         L = load()
         self.L = L
         self.n, self.P, self.S, self.C = int(n_otu), int(n_pattern), int(ns), int(ncatg)
@@ -108,6 +108,9 @@ class LkTree:
         self.tree.contents.mod = self.mod
         self.tree.contents.host_pmat = 1 if host_pmat else 0
         self.device = -1 if device is None else int(device)
+        # multi-GPU: pattern shards over `devices` inside libphyhip.so (one RCCL all-reduce per evaluation)
+        self.devices = None if devices is None else [int(x) for x in devices]
+        self.force_sharded = bool(force_sharded)
         self._made = False
         self.inst = None
 
@@ -131,8 +134,12 @@ class LkTree:
     def Make_Tree_For_Lk(self, wght, invar=None):
         w = np.ascontiguousarray(wght, dtype=np.float64); assert w.size == self.P
         iv = None if invar is None else np.ascontiguousarray(invar, dtype=np.int16)
-        self.L.Make_Tree_For_Lk(self.tree, self.P, _dp(w), None if iv is None else iv.ctypes.data_as(C.c_void_p),
-                                self.device)
+        ivp = None if iv is None else iv.ctypes.data_as(C.c_void_p)
+        if self.devices is not None:
+            dv = (C.c_int * len(self.devices))(*self.devices)
+            self.L.Make_Tree_For_Lk_On_Devices(self.tree, self.P, _dp(w), ivp, dv, len(self.devices), int(self.force_sharded))
+        else:
+            self.L.Make_Tree_For_Lk(self.tree, self.P, _dp(w), ivp, self.device)
         _raise_if_error()
         self._made = True
         self.inst = _InstanceView(self.tree.contents.b_inst, self)

@@ -117,11 +117,13 @@ def random_tree(n_otu: int, seed: int, lmin=0.02, lmax=0.15) -> EdgeTree:
 _SIM_RATES = (0.1369537815, 0.4767518619, 1.0, 2.3862943611)
 
 
-def simulate_states(tree: EdgeTree, n_sites: int, n_states: int, seed: int, rate_scale=1.0) -> np.ndarray:
+def simulate_states(tree: EdgeTree, n_sites: int, n_states: int, seed: int, rate_scale=1.0, site_offset=0) -> np.ndarray:
     """Evolve uniform-root states down the tree under an equal-rates (JC-like) process with 4 site-rate
-    classes.  Returns uint8 [n_otu, n_sites] state indices.  Deterministic given (tree, seed)."""
+    classes.  Returns uint8 [n_otu, n_sites] state indices.  Deterministic given (tree, seed); every column
+    depends only on its own index, so columns [site_offset, site_offset + n_sites) of a longer alignment can be
+    generated on their own (pattern shards of the multi-GPU configuration)."""
     nb = tree.neighbours()
-    site = np.arange(n_sites, dtype=np.uint64)
+    site = np.arange(site_offset, site_offset + n_sites, dtype=np.uint64)
     rate_cls = (hash_u64(seed, 10, site) >> np.uint64(62)).astype(np.int64)  # 0..3
     out = np.zeros((tree.n_otu, n_sites), dtype=np.uint8)
     root = tree.n_otu

@@ -5,14 +5,14 @@ import orc
 from phyml_amd import lktree
 
 
-def device_tree_from_golden(d, host_pmat=True):
+def device_tree_from_golden(d, host_pmat=True, devices=None, force_sharded=False):
     """Device tree with the reference's own neighbour order (node_v/node_b of the dump); tips come from the
     oracle's tip encoder.  host_pmat=True: the C host layer's own PMat() + upload (bit-exact route, src/lk.c:2360);
     False: device PMat from the eigen system (src/lk.c:2344)."""
     ot = orc.tree_from_golden(d)
     m = ot.m
     t = lktree.LkTree(ot.n, d["edge_left"], d["edge_rght"], d["edge_len"], ot.P, m.ns, m.ncatg,
-                      node_v=d["node_v"], node_b=d["node_b"], host_pmat=host_pmat)
+                      node_v=d["node_v"], node_b=d["node_b"], host_pmat=host_pmat, devices=devices, force_sharded=force_sharded)
     t.tip_root = ot.tip_root
     t.set_model(m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, m.br_len_mult,
                 int(d["apply_lk_scaling"][0]), m.invar_model, m.pinvar)
@@ -21,7 +21,8 @@ def device_tree_from_golden(d, host_pmat=True):
     return t, ot
 
 
-def synthetic_pair(n_otu, P, ns, C, seed, lmin=0.02, lmax=0.3, wght=None, apply_scaling=1, host_pmat=True, ambiguous_every=0):
+def synthetic_pair(n_otu, P, ns, C, seed, lmin=0.02, lmax=0.3, wght=None, apply_scaling=1, host_pmat=True, ambiguous_every=0,
+                   devices=None, force_sharded=False):
     """Device tree + oracle tree on a seeded synthetic alignment with C rate classes (rates/weights made up,
     normalised) and the committed model block's eigen system."""
     from phyml_amd import synth, workloads
@@ -45,7 +46,8 @@ def synthetic_pair(n_otu, P, ns, C, seed, lmin=0.02, lmax=0.3, wght=None, apply_
         v, s, a = orc.init_tip(m.datatype, chars[t])
         tv.append(v); ds.append(s); amb_.append(a)
     ot = orc.OracleTree(m, n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, wg, tv, ds, amb_, apply_scaling=apply_scaling)
-    t = lktree.LkTree(n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, P, ns, C, host_pmat=host_pmat)
+    t = lktree.LkTree(n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, P, ns, C, host_pmat=host_pmat, devices=devices,
+                      force_sharded=force_sharded)
     t.set_model(m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, 1.0, apply_scaling)
     t.Make_Tree_For_Lk(wg)
     t.set_tips(tip_partials=tv)

@@ -1,0 +1,238 @@
+"""Multi-GPU path of the C ABI on real hardware: pattern shards inside libphyhip.so, ONE RCCL all-reduce of
+{warning, lnL[, dlnL]} per evaluation, and the 1 M-pattern configuration (BASELINE configs[3]) against the reference's
+own shard log-likelihoods (tests/golden/make_cfg4.py: the real PhyML on the eight 125 000-pattern shards).
+
+On a one-GPU box the sharded instance is exercised as (a) one shard + a one-rank communicator and (b) several shards on
+device 0 (local fixed-order sum + the one-rank all-reduce) -- every slicing / concatenating entry point and the RCCL call
+path run; with two or more devices visible the same tests also run on distinct devices."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import orc  # noqa: F401
+from conftest import FIXTURES
+from gpu_common import device_tree_from_golden, synthetic_pair
+from phyml_amd import capi, lktree, synth, workloads
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _layouts():
+    lay = [("one_shard_forced", [0], True), ("two_shards_dev0", [0, 0], False), ("three_shards_dev0", [0, 0, 0], False)]
+    if _n_devices() >= 2:
+        lay += [("two_devices", [0, 1], False), ("two_devices_two_shards_each", [0, 1, 0, 1], False)]
+    return lay
+
+
+LAYOUTS = _layouts()
+
+
+@pytest.mark.parametrize("layout", LAYOUTS, ids=[x[0] for x in LAYOUTS])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_sharded_instance_matches_reference(name, layout, golden):
+    """Everything the single-device parity tests check, through a sharded instance: lnL and lnL at several edges against
+    the reference (1e-12), partial vectors and scale vectors bit-equal to the oracle, per-site outputs, the eigen-basis
+    products and dLk triples (the count-3 all-reduce)."""
+    _, devs, force = layout
+    d = golden(name)
+    if len(devs) > int(d["wght"].size):
+        pytest.skip("fewer patterns than shards")
+    t, ot = device_tree_from_golden(d, devices=devs, force_sharded=force)
+    try:
+        rng = t.inst.shard_ranges()
+        assert len(rng) == len(devs) and [r[0] for r in rng] == devs
+        assert rng[0][1] == 0 and sum(r[2] for r in rng) == t.P and all(a[1] + a[2] == b[1] for a, b in zip(rng, rng[1:]))
+        assert t.inst.comm_size() == len(set(devs))
+        t.Set_Both_Sides(True)
+        lnl = t.Lk(None)
+        ref = d["lnL"][0]
+        assert abs(lnl - ref) / abs(ref) < 1e-12
+        assert t.inst.numerical_warning() == 0
+        w = d["wght"] > 0
+        ot.lk(None, both_sides=True)
+        for (e, side), p in ot.plk.items():
+            assert np.array_equal(t.partials(e, side)[w], p[w]), (e, side)
+            assert np.array_equal(t.scale_factors(e, side)[w], ot.scale[(e, side)][w])
+        site, cur, cat, fact = t.inst.site_outputs()
+        assert np.array_equal(fact[w], d["fact_sum_scale"][w])
+        assert np.max(np.abs(site[w] - d["c_lnL_sorted"][w])) < 1e-10
+        assert np.allclose(cat[w], d["unscaled_site_lk_cat"][w], rtol=1e-12, atol=0)
+        got = np.array([t.Lk(e) for e in range(0, t.ne, 7)])
+        exp = d["edge_lnL"][0:t.ne:7]
+        assert np.max(np.abs(got - exp) / np.abs(exp)) < 1e-12
+        for k, e in enumerate(d["eigen_edges"]):
+            e = int(e)
+            t.Set_Update_Eigen_Lr(True); t.Set_Use_Eigen_Lr(False)
+            t.Lk(e)
+            t.Set_Update_Eigen_Lr(False); t.Set_Use_Eigen_Lr(True)
+            assert np.allclose(t.inst.get_dot_prod()[w], d[f"dot_prod_{e}"][w], rtol=1e-12, atol=1e-300)
+            for j in range(3):
+                l_in, lnl_ref, dlnl_ref = d["dlk_triples"][k, j]
+                l_out, v = t.dLk(l_in, e)
+                assert l_out == l_in
+                assert abs(v - lnl_ref) / abs(lnl_ref) < 1e-12
+                assert abs(t.c_dlnL - dlnl_ref) <= 1e-8 * max(1.0, abs(dlnl_ref))
+            assert abs(t.Lk(e) - d[f"eig_lnL_{e}"][0]) / abs(d[f"eig_lnL_{e}"][0]) < 1e-12
+            t.Set_Use_Eigen_Lr(False)
+    finally:
+        t.close()
+
+
+def test_sharded_instance_spr_call_pattern_matches_single_device():
+    """A seeded SPR / Br_Len_Opt call stream (phyml_amd/replay.py) through a sharded instance returns the scalars the
+    single-device instance returns (1e-12; the shard sums are added in a different order)."""
+    from phyml_amd import replay
+    res = []
+    for devs in (None, [0, 0, 0]):
+        t, ot, tree, st = synthetic_pair(40, 3000, 4, 4, seed=77, devices=devs)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            tr = replay.make_trace(40, tree.edge_left, tree.edge_rght, tree.edge_len, 60, seed=5, walk_every=3, opt_every=4, n_dlk=4)
+            res.append(t.Replay_Surface_Trace(tr))
+        finally:
+            t.close()
+    (a, a2), (b, b2) = res
+    m = a != 0
+    assert m.any() and np.max(np.abs(a[m] - b[m]) / np.abs(a[m])) < 1e-12
+    assert np.max(np.abs(a2 - b2) / np.maximum(1.0, np.abs(a2))) < 1e-9
+
+
+def test_numerical_warning_rides_in_the_all_reduce():
+    """A pattern whose likelihood underflows with scaling off raises tree->numerical_warning (src/lk.c:847-851) in ONE
+    shard only; the flag must come back through the collective."""
+    for devs in (None, [0, 0]):
+        t, ot, *_ = synthetic_pair(300, 64, 4, 4, seed=9, lmin=1.0, lmax=3.0, apply_scaling=0, devices=devs)
+        try:
+            lnl = t.Lk(None)
+            assert np.isfinite(lnl)
+            assert t.inst.numerical_warning() == 1
+        finally:
+            t.close()
+
+
+def test_one_process_per_gpu_communicator_single_rank(golden):
+    """phyhip_comm_get_unique_id / phyhip_comm_init_rank (what bench.py under torchrun and an MPI host use): with one rank
+    the evaluation still runs shard-sum -> ncclAllReduce -> publish and must return the reference's lnL and dLk."""
+    d = golden("nucleic_gtr_g4_inv")
+    t, ot = device_tree_from_golden(d)
+    try:
+        t.inst.comm_init_rank(1, 0, capi.comm_get_unique_id())
+        assert t.inst.comm_size() == 1
+        lnl = t.Lk(None)
+        assert abs(lnl - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-12
+        e = int(d["eigen_edges"][0])
+        t.Set_Update_Eigen_Lr(True); t.Lk(e); t.Set_Update_Eigen_Lr(False)
+        l_in, lnl_ref, dlnl_ref = d["dlk_triples"][0, 1]
+        _, v = t.dLk(l_in, e)
+        assert abs(v - lnl_ref) / abs(lnl_ref) < 1e-12 and abs(t.c_dlnL - dlnl_ref) <= 1e-8 * max(1.0, abs(dlnl_ref))
+    finally:
+        t.close()
+
+
+def _cfg_tree(name, lo, n, devices=None, force_sharded=False):
+    cfg = workloads.CONFIGS[name]
+    wl = workloads.make(name, n_pattern=n, pattern_offset=lo)
+    tree, st, blk = wl["tree"], wl["states"], wl["model"]
+    t = lktree.LkTree(tree.n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, n, cfg["ns"], 4, devices=devices,
+                      force_sharded=force_sharded)
+    t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"],
+                float(blk["l_min"][0]), float(blk["l_max"][0]))
+    t.Make_Tree_For_Lk(np.ones(n))
+    t.set_tips(tip_states=st.astype(np.int32))
+    return t, st
+
+
+@pytest.mark.parametrize("g", [0, 3, 7])
+def test_cfg4_shards_match_the_reference(g):
+    """125 000-pattern shard g of the 1 M-pattern alignment: input checksum and lnL against the real reference's value."""
+    exp = workloads.manifest()["expected"]["cfg4_nt_100x1M"]
+    lo = g * 125000
+    t, st = _cfg_tree("cfg4_nt_100x1M", lo, 125000)
+    try:
+        assert synth.states_checksum(st) == exp["shard_checksum"][g]
+        lnl = t.Lk(None)
+        assert abs(lnl - exp["shard_lnL"][g]) / abs(exp["shard_lnL"][g]) < 1e-12
+    finally:
+        t.close()
+
+
+def test_cfg4_one_million_patterns_against_the_reference():
+    """BASELINE configs[3] at full size, 100 taxa x 1 000 000 patterns: on one device, and as a sharded instance (8 shards
+    like the 8-GPU run when 8 devices are visible, else 8 shards over the visible devices) -- lnL within 1e-6 of the sum
+    of the reference's shard values (north-star gate; 1e-12 held), same value at another evaluation edge."""
+    exp = workloads.manifest()["expected"]["cfg4_nt_100x1M"]
+    ref = exp["lnL"]
+    t, st = _cfg_tree("cfg4_nt_100x1M", 0, 1000000)
+    try:
+        lnl = t.Lk(None)
+        assert abs(lnl - ref) / abs(ref) < 1e-6
+        assert abs(lnl - ref) / abs(ref) < 1e-12
+    finally:
+        t.close()
+    nd = _n_devices()
+    devs = [g % nd for g in range(8)]
+    t = None
+    wl = workloads.make("cfg4_nt_100x1M")
+    tree, blk = wl["tree"], wl["model"]
+    t = lktree.LkTree(tree.n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, 1000000, 4, 4, devices=devs)
+    try:
+        t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"],
+                    float(blk["l_min"][0]), float(blk["l_max"][0]))
+        t.Make_Tree_For_Lk(np.ones(1000000))
+        t.set_tips(tip_states=st.astype(np.int32))
+        assert [r[2] for r in t.inst.shard_ranges()] == [125000] * 8
+        lnl8 = t.Lk(None)
+        assert abs(lnl8 - ref) / abs(ref) < 1e-12
+        t.Set_Both_Sides(True)
+        t.Lk(None)
+        assert abs(t.Lk(17) - ref) / abs(ref) < 1e-11
+    finally:
+        t.close()
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("name", ["nucleic_gtr_g4", "proteic_lg_g4"])
+def test_split_and_fused_final_sum_agree(name, split, golden, monkeypatch):
+    """PHYHIP_SPLIT_REDUCE=0/1 (fused last-workgroup sum vs separate final_reduce_kernel) both give the golden lnL."""
+    monkeypatch.setenv("PHYHIP_SPLIT_REDUCE", split)
+    d = golden(name)
+    t, ot = device_tree_from_golden(d)
+    try:
+        lnl = t.Lk(None)
+        assert abs(lnl - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-12
+        e = int(d["eigen_edges"][0])
+        t.Set_Update_Eigen_Lr(True); t.Lk(e); t.Set_Update_Eigen_Lr(False)
+        l_in, lnl_ref, dlnl_ref = d["dlk_triples"][0, 0]
+        _, v = t.dLk(l_in, e)
+        assert abs(v - lnl_ref) / abs(lnl_ref) < 1e-12
+    finally:
+        t.close()
+
+
+def test_device_output_path_on_the_callers_stream(golden):
+    """phyhip_set_stream + Lk_Shard_Device / phyhip_calculate_edge_log_likelihoods_device: the evaluation runs on the
+    caller's stream and leaves lnL in the caller's device memory without synchronising."""
+    import torch
+    d = golden("nucleic_gtr_g4")
+    t, ot = device_tree_from_golden(d)
+    try:
+        s = torch.cuda.Stream()
+        out = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+        t.inst.set_stream(s.cuda_stream)
+        with torch.cuda.stream(s):
+            t.Lk_Shard_Device(out.data_ptr())
+            twice = out * 2.0               # ordered behind the evaluation by the stream alone
+        s.synchronize()
+        ref = d["lnL"][0]
+        assert abs(float(out[0]) - ref) / abs(ref) < 1e-12
+        assert float(twice[0]) == 2.0 * float(out[0])
+        assert abs(t.Lk(None) - ref) / abs(ref) < 1e-12   # and the host-returning form still works on that stream
+    finally:
+        t.close()

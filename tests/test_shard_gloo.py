@@ -1,6 +1,8 @@
-"""The N>1 path on CPU: world_size-2 gloo processes each evaluate their contiguous pattern shard (with the
-CPU oracle standing in for the device kernels -- there is no GPU here) and all-reduce ONE scalar; the result
-must equal the unsharded reference lnL.  This is the logic bench.py runs over RCCL with one process per GPU."""
+"""The N>1 host logic on CPU: world_size-2 gloo processes do what bench.py's ranks do around the engine -- take their
+contiguous pattern range, regenerate exactly their columns of the shared alignment, receive a 128-byte communicator id
+from rank 0, evaluate (the CPU oracle stands in for the device kernels: there is no GPU here), sum ONE scalar over the
+ranks, and agree on the maximum elapsed time.  The result must equal the unsharded reference lnL.  The engine's own
+sharded path (RCCL inside libphyhip.so) is covered on hardware by tests/test_gpu_shard.py."""
 import os
 import sys
 
@@ -30,9 +32,15 @@ def _worker(rank, world, port, name, q):
     ot = orc.OracleTree(m, n, d["edge_left"], d["edge_rght"], d["edge_len"], d["wght"][lo:hi], tv, ds, amb,
                         invar=d["invar"][lo:hi], apply_scaling=int(d["apply_lk_scaling"][0]))
     ot.set_adjacency(d["node_v"], d["node_b"]); ot.tip_root = int(d["tip_root"][0])
+    ids = [bytes(range(128)) if rank == 0 else None]      # stands for phyhip_comm_get_unique_id() on rank 0
+    dist.broadcast_object_list(ids, src=0)
+    assert ids[0] == bytes(range(128))
     t = torch.tensor([ot.lk(None)], dtype=torch.float64)
     part = float(t[0])
-    shard.allreduce_sum(t, dist)
+    dist.all_reduce(t)
+    tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    assert float(tt[0]) == float(world)
     q.put((rank, lo, hi, part, float(t[0])))
     dist.destroy_process_group()
 
@@ -55,6 +63,17 @@ def test_two_shards_allreduce(name, golden):
     assert tot0 == tot1                                    # every rank holds the same reduced value
     assert abs(tot0 - ref) / abs(ref) < 1e-12              # shard lnL is additive
     assert abs((p0 + p1) - tot0) <= 1e-9
+
+
+def test_rank_local_generation_equals_slices_of_the_whole_alignment():
+    """Every rank regenerates only its own columns (workloads.make(pattern_offset=lo)); together they are the alignment."""
+    from phyml_amd import shard, workloads
+    whole = workloads.make("cfg4_nt_100x1M", n_pattern=4001)["states"]
+    for world in (2, 3, 8):
+        for r in range(world):
+            lo, hi = shard.shard_range(4001, r, world)
+            part = workloads.make("cfg4_nt_100x1M", n_pattern=hi - lo, pattern_offset=lo)["states"]
+            assert np.array_equal(part, whole[:, lo:hi])
 
 
 def test_shard_ranges_cover():
