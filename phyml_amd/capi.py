@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libphyhip.so")
+# PHYHIP_LIBDIR: another build of the same libraries (tools/build_diag.sh puts the -DPHYHIP_DIAG build in phyml_amd/lib_diag)
+LIB_DIR = os.environ.get("PHYHIP_LIBDIR") or os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libphyhip.so")
 
 
 class PhyhipError(RuntimeError):

@@ -4,6 +4,10 @@
 #include "../../include/phyhip.h"
 #include "phyhip_kernels.hpp"
 #include "phyhip_aa.hpp"
+#ifdef PHYHIP_DIAG
+#include "experimental/phyhip_aa2.hpp" // measured alternatives of the 20-state kernel (slower), A/B only
+#include "experimental/phyhip_aa3.hpp"
+#endif
 #include "phyhip_nt2.hpp"
 
 #include <rccl/rccl.h>
@@ -130,6 +134,8 @@ struct Instance
   int         tips = 0, nbuf = 0, S = 0, C = 0, CP = 0, nmat = 0;
   long long   P = 0, Ppad = 0; // Ppad: patterns per buffer as allocated (P, or P rounded up to 16 when perm)
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
+  int         aa_tiles = 1;            // -DPHYHIP_DIAG builds: PHYHIP_AA_TILES = 2 | 4 pattern tiles per wave (experimental/phyhip_aa3.hpp)
+  bool        aa_wave_per_tile = false; // -DPHYHIP_DIAG builds: PHYHIP_AA_GEN=2, one wave per tile walks all categories (experimental/phyhip_aa2.hpp)
   bool        soa = false;     // 4-state buffers pattern-minor, lane-per-pattern kernel (phyhip_nt2.hpp)
   int         grid_nt2 = 0;
   int         nt_groups = 1; // lanes per pattern in the lane-per-pattern nucleotide kernel
@@ -609,6 +615,43 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       if (I->perm)
       {
 #ifdef PHYHIP_DIAG
+        if (I->aa_wave_per_tile)
+        {
+#ifdef PHYHIP_DIAG
+          if ((I->ablate & 8) && I->C == 4)
+          { // cycle stamps of one wave: phase starts c = 0..3, epilogue start, operation end
+            unsigned long long *&d_dbg = I->d_dbg;
+            if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
+            hipLaunchKernelGGL((traverse_aa2_kernel<4, true>), dim3(I->grid_aa), dim3(64), 0, I->stream, q, d_irec, d_xrec,
+                               (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks,
+                               (int)I->masks.size(), d_dbg);
+            static int printed = 0;
+            if (printed++ == 5)
+            {
+              unsigned long long h[64 * 8];
+              HIPCHK(hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, I->stream));
+              HIPCHK(hipStreamSynchronize(I->stream));
+              for (int k = 0; k < 64 && k < q.n_ops; ++k)
+              {
+                fprintf(stderr, "op %2d: phases", k);
+                for (int i = 1; i < 6; ++i) fprintf(stderr, " %6lld", (long long)(h[k * 8 + i] - h[k * 8 + i - 1]));
+                if (k + 1 < 64) fprintf(stderr, "  | to next %6lld | total %6lld", (long long)(h[(k + 1) * 8] - h[k * 8 + 5]), (long long)(h[(k + 1) * 8] - h[k * 8]));
+                fprintf(stderr, "\n");
+              }
+            }
+            return 0;
+          }
+#endif
+#define AA2CASE(c_) case c_: hipLaunchKernelGGL((traverse_aa2_kernel<c_>), dim3(I->grid_aa), dim3(64), 0, I->stream, q, d_irec, d_xrec, (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size()); return 0;
+          switch (I->C)
+          {
+            AA2CASE(1) AA2CASE(2) AA2CASE(3) AA2CASE(4)
+            default: break;
+          }
+#undef AA2CASE
+        }
+#endif
+#ifdef PHYHIP_DIAG
         if constexpr (CP_ == 4)
           if (I->ablate & 8)
           { // PHYHIP_ABLATE=8: cycle stamps of one wave, printed to stderr (diagnostics; costs a sync per launch)
@@ -633,6 +676,18 @@ int flush_impl(Instance *I, const EdgeEval *ee)
             }
             return 0;
           }
+#endif
+#ifdef PHYHIP_DIAG
+        if (I->aa_tiles == 2 || I->aa_tiles == 4)
+        {
+          if (I->aa_tiles == 2)
+            hipLaunchKernelGGL((traverse_aa3_kernel<CP_, 2>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
+                               (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size());
+          else
+            hipLaunchKernelGGL((traverse_aa3_kernel<CP_, 4>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
+                               (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size());
+          return 0;
+        }
 #endif
         hipLaunchKernelGGL((traverse_aa_kernel<CP_>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
                            (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks,
@@ -880,6 +935,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
 
   I->perm = (I->S == 20) && (I->C <= 4) && !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA")));
+  if (const char *e = getenv("PHYHIP_AA_GEN")) I->aa_wave_per_tile = kDiag && atoi(e) == 2;
   I->soa  = (I->S == 4) && (I->C <= 4) && !(kDiag && getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
             !(getenv("PHYHIP_GENERIC_NT") && atoi(getenv("PHYHIP_GENERIC_NT")));
   I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
@@ -905,7 +961,11 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     const size_t fb = (size_t)I->nmat * I->C * 2 * kAaT * 64 * sizeof(double);
     HIPCHK(hipMalloc((void **)&I->d_afrag, fb));
     HIPCHK(hipMemset(I->d_afrag, 0, fb));
-    I->grid_aa = (int)(I->Ppad / 16); // one workgroup (C waves) per tile of 16 patterns
+    // one workgroup (C waves) per aa_tiles tiles of 16 patterns (phyhip_aa3.hpp; 1: phyhip_aa.hpp)
+    if (const char *e = getenv("PHYHIP_AA_TILES")) I->aa_tiles = atoi(e);
+    if (!kDiag || (I->aa_tiles != 2 && I->aa_tiles != 4)) I->aa_tiles = 1;
+    if (I->aa_wave_per_tile) I->aa_tiles = 1;
+    I->grid_aa = (int)((I->Ppad / 16 + I->aa_tiles - 1) / I->aa_tiles);
   }
   HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->Ppad));
   HIPCHK(hipMemset(I->d_tipcodes, 0, (size_t)I->tips * I->Ppad));
@@ -949,7 +1009,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
     if (!getenv("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
     if (I->soa) I->prefetch_dist = 2;
-    if (I->perm) I->prefetch_dist = 1; // the 20-state kernel forwards only the previous result
+    if (I->perm) I->prefetch_dist = 1; // the 20-state kernels forward only the previous result
   }
   HIPCHK(hipMalloc((void **)&I->d_block,
                    (size_t)2 * std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2)) * sizeof(double)));
@@ -993,7 +1053,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipMalloc((void **)&I->d_mixexpl, sizeof(double) * kMaxMixClasses * 2 * 20));
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
   HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned)));
-  if (const char *e = getenv("PHYHIP_DIST")) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
+  if (const char *e = getenv("PHYHIP_DIST"))
+    if (!I->perm) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
 
   // codes 0..S-1 are the single states
   for (int s = 0; s < I->S; ++s)

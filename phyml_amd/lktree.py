@@ -15,7 +15,7 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LK_LIB_PATH = os.path.join(_HERE, "lib", "libphyhip_lk.so")
+LK_LIB_PATH = os.path.join(capi.LIB_DIR, "libphyhip_lk.so")
 
 
 class t_node(C.Structure):

@@ -23,8 +23,8 @@ def main():
     args = ap.parse_args()
     from phyml_amd import lktree, replay, synth, workloads
     blk = workloads.model_block("model_gtr_g4")
-    tree = synth.random_tree(args.taxa, 9, 0.02, 0.15)
-    st = synth.simulate_states(tree, args.patterns, 4, 9)
+    tree = synth.random_tree(args.taxa, 9, 0.02, 0.15)   # defaults = workloads cfg5_nt_500x100k (tests/test_gpu_cfg5.py checks
+    st = synth.simulate_states(tree, args.patterns, 4, 9)  # every scalar of this call pattern against the oracle at this size)
     C = int(blk["ncatg"][0])
     t = lktree.LkTree(args.taxa, tree.edge_left, tree.edge_rght, tree.edge_len, args.patterns, 4, C)
     t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"])
