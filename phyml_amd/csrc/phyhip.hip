@@ -193,7 +193,7 @@ struct Instance
   bool   want_site_outputs = true;
   int    prefetch_dist = 2;  // PHYHIP_DIST: load-stage distance of the nt pipeline (1 or 2)
   bool   fold_pmats = true;    // PHYHIP_FOLD_PMATS=0: always rebuild transition matrices with a separate pmat_kernel launch
-  bool   pm_copy = true;       // PHYHIP_PM_COPY=0: kernels read the P-matrix work list from pinned host memory (slower for 20 states)
+  bool   pm_copy = false;      // PHYHIP_PM_COPY=1: copy the P-matrix work list to the device first (measured: +2 us per step at cfg2, +3..6 at cfg3)
   bool   split_reduce = false, split_reduce_forced = false; // PHYHIP_SPLIT_REDUCE: separate final_reduce_kernel instead of the fused last-workgroup sum
   unsigned *d_tickets = nullptr;
   double   *d_mixexpl = nullptr; // expl pairs of the classes of a mixture evaluation (first instance only)
@@ -375,14 +375,17 @@ int flush_pmats(Instance *I)
   return 0;
 }
 
-// Final sum inside the producing kernel (last workgroup) or as a separate 1-block kernel?  Measured on MI355X: fused
-// saves the second launch (~3.4 us + gap) whenever the grid is small -- every SPR / Br_Len_Opt call on small and
-// mid-sized alignments -- and ~10 us per call for 20 states at any size; for 4 states on large grids the ticket draw of
-// ~1500 workgroups costs the kernel what the launch cost the stream.  PHYHIP_SPLIT_REDUCE=0/1 forces either.
+// Final sum inside the producing kernel (last workgroup) or as a separate 1-block kernel?  Measured on MI355X (round 2,
+// tools/gpu_step_ab.sh, with PHYHIP_SPLIT_REDUCE actually honoured): fused saves the second launch (~3.4 us + gap)
+// whenever the grid is small -- every SPR / Br_Len_Opt call on small and mid-sized alignments.  On large grids it costs
+// the traversal kernel ~6-10 % (cfg2 198 vs 186 us, 125 000 patterns 469 vs 414, 1 M 3.54 vs 3.22 ms, cfg3 574 vs 553):
+// a workgroup must see its block sum acknowledged by memory before it draws its ticket, i.e. it waits for ALL its
+// outstanding result stores instead of retiring behind them, and holds its wave slot meanwhile.  PHYHIP_SPLIT_REDUCE=0/1
+// forces either.
 static bool fuse_reduce(const Instance *I, int nblocks)
 {
   if (I->split_reduce_forced) return !I->split_reduce;
-  return I->perm || nblocks <= 512;
+  return nblocks <= 512;
 }
 
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
@@ -808,7 +811,7 @@ int wait_result(Instance *I)
   HIPCHK(hipStreamSynchronize(I->stream));
   if (*reinterpret_cast<volatile unsigned long long *>(I->h_result + 2) != I->seq)
   { // the stream drained without the hand-over (a faulted launch): do not return a stale scalar, re-arm the ticket counter
-    (void)hipMemsetAsync(I->d_tickets, 0, sizeof(unsigned), I->stream);
+    (void)hipMemsetAsync(I->d_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), I->stream);
     return fail(PHYHIP_ERROR_GENERAL, "evaluation %llu finished without handing its result over", I->seq);
   }
   I->warn_current = true;
@@ -1051,8 +1054,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_FOLD_PMATS")) I->fold_pmats = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_mixexpl, sizeof(double) * kMaxMixClasses * 2 * 20));
-  HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned)));
-  HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned)));
+  HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
+  HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups)));
   if (const char *e = getenv("PHYHIP_DIST"))
     if (!I->perm) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
 
