@@ -161,6 +161,9 @@ struct Instance
   bool      warn_current = false; // *h_warn belongs to the evaluation the host last waited for (none launched since)
   int      *d_warn     = nullptr;
   int      *h_warn     = nullptr;
+  HostBlock *h_blocks  = nullptr; // host-mapped {block sum, tag} records of the host-side final sum
+  int       host_sum_n = 0;       // > 0: the evaluation in flight is finished by the host from this many records
+  bool      host_sum   = true;    // PHYHIP_HOST_SUM=0: large grids use final_reduce_kernel instead
   void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
   int       pm_scratch_cap = 0;
   char     *d_ops      = nullptr; // ring of op lists on the device (slim DevOp or fat IssueRec+ExecRec)
@@ -199,6 +202,7 @@ struct Instance
   double   *d_mixexpl = nullptr; // expl pairs of the classes of a mixture evaluation (first instance only)
   int    ablate = 0;         // PHYHIP_ABLATE (-DPHYHIP_DIAG builds only): timing-only kernel variants (results invalid)
   unsigned long long *d_dbg = nullptr; // cycle stamps of PHYHIP_ABLATE=8
+  bool   args_recs = true;   // PHYHIP_ARGS_RECS=0: operation records of 1-2-operation launches go through the slot ring too
   bool   eager_pmats = true; // PHYHIP_EAGER_PMAT=0: whole-tree matrix batches wait for the traversal launch too
   bool   no_loads = false;   // PHYHIP_NOLOADS (-DPHYHIP_DIAG builds only): zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
@@ -419,7 +423,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   const ExecRec  *d_xrec = nullptr;
   q.last_dest = -1;
   const int kind = fat ? I->prefetch_dist : 0;
-  int       hit  = -1, new_slot = -1;
+  int       hit  = -1, new_slot = -1, host_sum_n = 0;
   if (n_ops > 0)
   { // an operation list identical to one still sitting in a device slot (repeated Lk(NULL) on one topology) is
     // neither rebuilt nor re-uploaded
@@ -443,8 +447,16 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   else if (n_ops > 0)
   {
     char *dst = I->d_ops + (size_t)I->ops_slot * I->ops_slot_bytes;
-    new_slot  = I->ops_slot;
-    I->slot_kind[new_slot] = -1; // the slot's old content is gone; it holds the new list only once the copy was issued
+    // one or two operations of the lane-per-pattern nucleotide kernel travel in the kernel arguments (phyhip_nt2.hpp):
+    // no staging, no copy command, and the device slots keep the long lists they cache
+    const bool in_args = fat && I->soa && I->args_recs && n_ops <= 2;
+    IssueRec   arg_ir[2];
+    ExecRec    arg_xr[2];
+    if (!in_args)
+    {
+      new_slot = I->ops_slot;
+      I->slot_kind[new_slot] = -1; // the slot's old content is gone; it holds the new list only once the copy was issued
+    }
     void *st = nullptr;
     if (!fat)
     {
@@ -461,10 +473,13 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       // inputs, same output, same address) whose forwarding flags are computed for its own position.
       const int    n_rec = n_ops + (n_ops & 1);
       const size_t ib = sizeof(IssueRec) * n_rec, xb = sizeof(ExecRec) * n_rec;
-      rc = I->ring.alloc(ib + xb, I->stream, &st);
-      if (rc) return rc;
-      IssueRec *ir = reinterpret_cast<IssueRec *>(st);
-      ExecRec  *xr = reinterpret_cast<ExecRec *>((char *)st + ib);
+      if (!in_args)
+      {
+        rc = I->ring.alloc(ib + xb, I->stream, &st);
+        if (rc) return rc;
+      }
+      IssueRec *ir = in_args ? arg_ir : reinterpret_cast<IssueRec *>(st);
+      ExecRec  *xr = in_args ? arg_xr : reinterpret_cast<ExecRec *>((char *)st + ib);
       const size_t   bufbytes = buf_elems(I) * sizeof(double);
       // spare word of the data descriptors: byte offset of the child's matrix (natural table, or the MFMA
       // A-fragment table for the 20-state kernel)
@@ -506,21 +521,34 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         xr[k].dst_scale = desc(I->d_scales + b * I->Ppad, (size_t)I->Ppad * 4, 0);
       }
       // (reading short lists straight from the pinned staging memory instead was measured: no gain)
-      HIPCHK(hipMemcpyAsync(dst, st, ib + xb, hipMemcpyHostToDevice, I->stream));
-      d_irec = reinterpret_cast<const IssueRec *>(dst);
-      d_xrec = reinterpret_cast<const ExecRec *>(dst + ib);
+      if (in_args)
+      {
+        q.recs_in_args = 1;
+        q.arg_ir[0] = ir[0]; q.arg_ir[1] = ir[1];
+        q.arg_xr[0] = xr[0]; q.arg_xr[1] = xr[1];
+      }
+      else
+      {
+        HIPCHK(hipMemcpyAsync(dst, st, ib + xb, hipMemcpyHostToDevice, I->stream));
+        d_irec = reinterpret_cast<const IssueRec *>(dst);
+        d_xrec = reinterpret_cast<const ExecRec *>(dst + ib);
+      }
       q.last_dest = I->pending[n_ops - 1].dest;
     }
     q.n_ops = fat ? n_ops + (n_ops & 1) : n_ops;
-    I->slot_ops[new_slot]  = I->pending;
-    I->slot_kind[new_slot] = kind;
-    I->ops_slot = (new_slot + 1) % I->ops_slots;
+    if (new_slot >= 0)
+    {
+      I->slot_ops[new_slot]  = I->pending;
+      I->slot_kind[new_slot] = kind;
+      I->ops_slot = (new_slot + 1) % I->ops_slots;
+    }
   }
   if (ee)
   {
     I->warn_current = false;
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
     const int nblk = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
+    // (fusing on large grids was measured for one-operation launches too: 61.6 vs 41.9 us per SPR candidate at cfg5)
     fused_sum = fuse_reduce(I, nblk);
     if (fused_sum)
     { // the traversal kernel's last workgroup finishes the sum and reports to the host
@@ -528,6 +556,13 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       q.result_host = ee->to_host ? I->h_result : nullptr; q.warn_host = I->h_warn;
       q.seq = ee->to_host ? ++I->seq : 0ull;
       q.warn_out = ee->warn_out;
+    }
+    if (!fused_sum && ee->to_host && !ee->dev_out && I->host_sum)
+    { // large grid: the workgroups post their sums to the host, which adds them (wait_result)
+      q.host_blocks = I->h_blocks; q.host_tag = ++I->seq;
+      q.warn        = I->h_warn;   // raised straight in host-mapped memory
+      *I->h_warn    = 0;
+      host_sum_n    = nblk;
     }
     if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
   }
@@ -571,7 +606,14 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           return 0;
         }
 #endif
-#define NT2CASE(c_, g_) hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, ro.tip_codes, (unsigned long long *)nullptr); return 0;
+#define NT2CASE(c_, g_)                                                                                                     \
+  if (q.recs_in_args)                                                                                                       \
+    hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, true>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
+                       ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
+  else                                                                                                                      \
+    hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, \
+                       ro.tip_codes, (unsigned long long *)nullptr);                                                        \
+  return 0;
         switch (I->C * 8 + I->nt_groups)
         {
           case 1 * 8 + 1: NT2CASE(1, 1)
@@ -734,7 +776,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     }
   }
   HIPCHK(hipGetLastError());
-  if (ee && !fused_sum)
+  I->host_sum_n = host_sum_n;
+  if (ee && !fused_sum && !host_sum_n)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
     const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
@@ -784,8 +827,58 @@ int check_partial_index(const Instance *I, int idx, bool allow_tip)
 // Wait until the final reduction has published evaluation `seq` in host-mapped memory.  Spinning on the
 // sequence word avoids the stream-synchronise wake-up latency; after 2 ms of spinning (elapsed time, checked every
 // 256 polls) fall back to it: evaluations of very large alignments take milliseconds and must not burn a core.
+// The host's side of the final sum on large grids: poll the {sum, tag} records the workgroups posted (they arrive roughly in
+// launch order), then add them exactly as final_reduce_kernel does -- 256 strided accumulators, then a binary tree -- so
+// that the value does not depend on which path produced it.
+int wait_host_sum(Instance *I)
+{
+  const int                n   = I->host_sum_n;
+  const unsigned long long tag = I->seq;
+  volatile HostBlock      *hb  = I->h_blocks;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  bool synced = false;
+  for (int i = 0; i < n; ++i)
+  {
+    long it = 0;
+    while (hb[i].tag != tag)
+    {
+      __builtin_ia32_pause();
+      if ((++it & 255) == 0 && !synced)
+      {
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L || !I->spin_wait)
+        {
+          HIPCHK(hipStreamSynchronize(I->stream));
+          synced = true;
+          it = 0;
+        }
+      }
+      else if (synced && it > 100000000L)
+        return fail(PHYHIP_ERROR_GENERAL, "evaluation %llu finished without posting block sum %d", tag, i);
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  double acc[256];
+  for (int t = 0; t < 256; ++t)
+  {
+    double a = 0.0;
+    for (int i = t; i < n; i += 256) a += I->h_blocks[i].sum;
+    acc[t] = a;
+  }
+  for (int off = 128; off > 0; off >>= 1)
+    for (int t = 0; t < off; ++t) acc[t] += acc[t + off];
+  I->h_result[0]   = acc[0];
+  I->host_sum_n    = 0;
+  I->warn_current  = true;
+  *reinterpret_cast<volatile unsigned long long *>(I->h_result + 2) = tag;
+  return 0;
+}
+
 int wait_result(Instance *I)
 {
+  if (I->host_sum_n > 0) return wait_host_sum(I);
   if (I->spin_wait)
   {
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(I->h_result + 2);
@@ -853,6 +946,7 @@ static void release_instance(Instance *I)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
   if (I->h_warn) (void)hipHostFree(I->h_warn);
+  if (I->h_blocks) (void)hipHostFree(I->h_blocks);
   if (I->ev_sync) (void)hipEventDestroy(I->ev_sync);
   I->ring.destroy();
   if (I->own_stream && I->stream) (void)hipStreamDestroy(I->stream);
@@ -1024,6 +1118,12 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipMemset(I->d_warn, 0, sizeof(int)));
   HIPCHK(hipHostMalloc((void **)&I->h_warn, sizeof(int), hipHostMallocMapped));
   *I->h_warn = 0;
+  {
+    const size_t nb = (size_t)std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2));
+    HIPCHK(hipHostMalloc((void **)&I->h_blocks, nb * sizeof(HostBlock), hipHostMallocMapped));
+    memset(I->h_blocks, 0, nb * sizeof(HostBlock));
+  }
+  if (const char *e = getenv("PHYHIP_HOST_SUM")) I->host_sum = atoi(e) != 0;
 
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
@@ -1046,6 +1146,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
 #endif
   if (const char *e = getenv("PHYHIP_EAGER_PMAT")) I->eager_pmats = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_ARGS_RECS")) I->args_recs = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce()
   {
     I->split_reduce        = atoi(e) != 0;

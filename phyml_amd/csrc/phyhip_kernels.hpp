@@ -29,6 +29,12 @@ constexpr double kSmallPij      = 1.E-100;                     // SMALL_PIJ, src
 constexpr int    kMaxExpl       = 2 * 8 * 20;                  // dLk's expl table: [C<=8][2][S<=20]
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+struct HostBlock
+{ // one 16-byte store per workgroup: the sum, then the tag the host polls for
+  double             sum;
+  unsigned long long tag;
+};
+
 struct DevOp
 {
   int dest, c1, c2, pm1, pm2, pad;
@@ -111,6 +117,17 @@ struct TreeParams
   const double   *m_evec, *m_ivec, *m_eval, *m_rates; // U, U^-1, eigenvalues, category rates
   double          br_len_mult, l_min, l_max;
   double         *pmats_rw;
+  // One- and two-operation launches (an SPR regraft candidate is ONE update + the edge evaluation, src/spr.c:643-646)
+  // carry their operation records here, in the kernel arguments, instead of a staged copy into the device slot ring: one
+  // copy command less in front of the launch.
+  int             recs_in_args;
+  IssueRec        arg_ir[2];
+  ExecRec         arg_xr[2];
+  // Large grids, scalar wanted on the host: every workgroup posts {block sum, tag} straight into host-mapped memory and
+  // retires; the HOST adds the block sums (same grouping and order as final_reduce_kernel).  No second launch, no ticket
+  // draw, no waiting for the workgroup's result stores (see fuse_reduce() in phyhip.hip for what those cost).
+  HostBlock      *host_blocks;   // [gridDim.x] or nullptr
+  unsigned long long host_tag;   // sequence number of this evaluation
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -291,8 +308,9 @@ struct FinishParams
 };
 
 __device__ __forceinline__ void raise_warn(int *warn)
-{ // visible to whichever workgroup ends up doing the final reduction (other XCD, other L2)
-  __hip_atomic_store(warn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+{ // visible to whichever workgroup ends up doing the final reduction (other XCD, other L2) -- or to the host, when the
+  // flag lives in host-mapped memory (host-side final sum)
+  __hip_atomic_store(warn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Called by every lane of ONE wave per workgroup with the workgroup's sums in lane 0.  Without f.result the sums are
@@ -379,6 +397,18 @@ __device__ __forceinline__ void raise_warn(const TreeParams &q) { raise_warn(q.w
 
 __device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s, int lane)
 {
+  if (q.host_blocks)
+  {
+    if (lane == 0)
+    {
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 rec;
+      __builtin_memcpy(&rec, &s, 8);
+      rec.y = q.host_tag;
+      __builtin_nontemporal_store(rec, reinterpret_cast<u64x2 *>(q.host_blocks + blockIdx.x)); // one 16-byte write
+    }
+    return;
+  }
   FinishParams f;
   f.tickets = q.tickets; f.block_sums = q.block_sums; f.stride = 0; f.result = q.result; f.result_host = q.result_host;
   f.warn = q.warn; f.warn_host = q.warn_host; f.seq = q.seq; f.warn_out = q.warn_out;

@@ -36,7 +36,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // arithmetic and half the registers, two or three per SIMD.  The only cross-lane traffic is one 32-bit exchange per
 // operation (the rescaling maximum) and the category mixture of the edge evaluation.  G = 1 stays the choice for
 // large alignments, where the kernel is HBM-bound and fewer, fatter waves issue fewer instructions per pattern.
-template <int C, int G = 1, bool DBG = false>
+// ARGS: the (one or two) operation records are read from the kernel arguments (TreeParams::arg_ir / arg_xr) instead of
+// the device slot ring -- a separate instantiation, so that the long-list kernel carries no trace of it.
+template <int C, int G = 1, bool DBG = false, bool ARGS = false>
 __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec,
                                                              const double *pmats, // (not restrict: the prologue may rewrite entries)
@@ -185,10 +187,19 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     const int last = q.n_ops - 1; // host pads the list to an even length
     Raw       RA, RB;
     u32x4     PA, PB;
-    issue(irec[0], RA, PA);
-    issue(irec[(1 < last) ? 1 : last], RB, PB);
-    ExecRec  cur = xrec[0];
-    IssueRec nx2 = irec[(2 < last) ? 2 : last];
+    // records: device slot ring, or the kernel arguments for launches of one or two operations (last <= 1)
+    auto IR = [&](int i) -> IssueRec {
+      if constexpr (ARGS) return i ? q.arg_ir[1] : q.arg_ir[0];
+      else return irec[i];
+    };
+    auto XR = [&](int i) -> ExecRec {
+      if constexpr (ARGS) return i ? q.arg_xr[1] : q.arg_xr[0];
+      else return xrec[i];
+    };
+    issue(IR(0), RA, PA);
+    issue(IR((1 < last) ? 1 : last), RB, PB);
+    ExecRec  cur = XR(0);
+    IssueRec nx2 = IR((2 < last) ? 2 : last);
 
     // One pipeline step: operation k; its loads are in (R, PC); Fprev = result of k-1, Fout = result of k-2
     // on entry and the result of k on exit.
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       PHY_STAMP(k, 0)
       // the execute record of operation k+1 is the first thing the next step needs (its flags steer the operand
       // selection): its scalar load goes out first so that it has the whole step to come back from L2
-      const ExecRec nx1 = xrec[(k + 1 < last) ? k + 1 : last];
+      const ExecRec nx1 = XR((k + 1 < last) ? k + 1 : last);
       double2 *buf = reinterpret_cast<double2 *>(&lds_p[parity][0]);
       {
         double2 v;
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       // prefetch operation k+2 into the registers just freed; then the scalar records of the next step
       issue(nx2, R, PC);
       PHY_STAMP(k, 7)
-      const IssueRec nx3 = irec[(k + 3 < last) ? k + 3 : last];
+      const IssueRec nx3 = IR((k + 3 < last) ? k + 3 : last);
       __builtin_amdgcn_wave_barrier();
       PHY_STAMP(k, 4)
 

@@ -204,11 +204,14 @@ def test_cfg4_one_million_patterns_against_the_reference():
         t.close()
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("split,host_sum", [("0", "1"), ("1", "0"), ("1", "1")])
 @pytest.mark.parametrize("name", ["nucleic_gtr_g4", "proteic_lg_g4"])
-def test_split_and_fused_final_sum_agree(name, split, golden, monkeypatch):
-    """PHYHIP_SPLIT_REDUCE=0/1 (fused last-workgroup sum vs separate final_reduce_kernel) both give the golden lnL."""
+def test_the_three_final_sums_agree(name, split, host_sum, golden, monkeypatch):
+    """The three ways an evaluation's block sums become the scalar -- fused into the traversal kernel's last workgroup
+    (PHYHIP_SPLIT_REDUCE=0), a separate final_reduce_kernel (=1, PHYHIP_HOST_SUM=0), posted to the host and added there
+    (=1, PHYHIP_HOST_SUM=1: what large grids use) -- all give the golden lnL, dLk and warning flag."""
     monkeypatch.setenv("PHYHIP_SPLIT_REDUCE", split)
+    monkeypatch.setenv("PHYHIP_HOST_SUM", host_sum)
     d = golden(name)
     t, ot = device_tree_from_golden(d)
     try:
@@ -220,6 +223,29 @@ def test_split_and_fused_final_sum_agree(name, split, golden, monkeypatch):
         l_in, lnl_ref, dlnl_ref = d["dlk_triples"][0, 0]
         _, v = t.dLk(l_in, e)
         assert abs(v - lnl_ref) / abs(lnl_ref) < 1e-12
+        assert t.inst.numerical_warning() == 0
+    finally:
+        t.close()
+
+
+def test_host_side_final_sum_is_bit_identical_to_the_device_one(monkeypatch):
+    """Large grid (more than 512 workgroups): the host adds the posted block sums in final_reduce_kernel's order, so the
+    scalar is the same double whichever path produced it; the numerical-warning flag arrives through host-mapped memory."""
+    vals = []
+    for hs in ("0", "1"):
+        monkeypatch.setenv("PHYHIP_HOST_SUM", hs)
+        t, ot, *_ = synthetic_pair(12, 40000, 4, 4, seed=31)
+        try:
+            vals.append((t.Lk(None), t.inst.numerical_warning()))
+            ref = ot.lk(None)
+            assert abs(vals[-1][0] - ref) / abs(ref) < 1e-12
+        finally:
+            t.close()
+    assert vals[0] == vals[1] and vals[0][1] == 0
+    monkeypatch.setenv("PHYHIP_HOST_SUM", "1")
+    t, ot, *_ = synthetic_pair(900, 40000, 4, 4, seed=9, lmin=1.0, lmax=3.0, apply_scaling=0)
+    try:
+        assert np.isfinite(t.Lk(None)) and t.inst.numerical_warning() == 1
     finally:
         t.close()
 
