@@ -20,7 +20,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -1413,9 +1417,10 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
                                       const int *firstDerivativeIndices, const int *secondDerivativeIndices,
                                       const double *edgeLengths, int count)
 {
-  if (Group *G = get_group(instance))
-    return group_each(G, [&](int id, long long, long long) {
-      return phyhip_update_transition_matrices(id, eigenIndex, probabilityIndices, firstDerivativeIndices, secondDerivativeIndices, edgeLengths, count);
+  if (Group *G = get_group(instance)) // (a whole-tree batch launches the rebuild at once: on the shard's helper thread)
+    return group_parallel(G, [&](int g) {
+      return phyhip_update_transition_matrices(G->sub_id[g], eigenIndex, probabilityIndices, firstDerivativeIndices,
+                                               secondDerivativeIndices, edgeLengths, count);
     });
   GET_INST(I, instance);
   if (eigenIndex != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
@@ -1787,7 +1792,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
 
 int phyhip_update_eigen_lr(int instance, int left, int rght)
 {
-  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_update_eigen_lr(id, left, rght); });
+  if (Group *G = get_group(instance)) return group_parallel(G, [&](int g) { return phyhip_update_eigen_lr(G->sub_id[g], left, rght); });
   GET_INST(I, instance);
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
@@ -1882,15 +1887,12 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
 // dLk / eigen-basis Lk on the shards + the collective (count 3: warning, lnL, dlnL)
 static int group_eigen_eval(Group *G, double l, bool deriv, double *lnl, double *dlnl)
 {
-  for (size_t g = 0; g < G->sub.size(); ++g)
-  {
-    Instance *I = G->sub[g];
-    int rc = set_dev(I->dev);
-    if (rc) return rc;
+  int rc = group_parallel(G, [&](int g) -> int {
     double *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
-    if ((rc = eigen_eval(I, l, deriv, nullptr, nullptr, slot + 1, slot))) return rc;
-  }
-  int rc = reduce_and_publish(*G->co, 3, G->sub[0]);
+    return eigen_eval(G->sub[g], l, deriv, nullptr, nullptr, slot + 1, slot);
+  });
+  if (rc) return rc;
+  rc = reduce_and_publish(*G->co, 3, G->sub[0]);
   if (rc) return rc;
   *lnl = G->sub[0]->h_result[0];
   if (dlnl) *dlnl = G->sub[0]->h_result[1];

@@ -124,6 +124,65 @@ static void release_collective(Collective *co)
 
 // ---- single process, several devices ----------------------------------------------------------------------------
 
+// One helper thread per shard: a launch costs the calling thread 5-10 us, so eight devices driven by PhyML's single
+// thread would start their traversals up to ~100 us apart (a quarter of a 125 000-pattern shard's run time).  The main
+// thread posts the same job to every helper, each issues its shard's launches on its own device, the main thread joins
+// them and then issues the collective.  Helpers spin for ~0.1 ms after a job (evaluations come in bursts) and sleep on a
+// condition variable otherwise.
+struct ShardWorker
+{
+  std::thread                    th;
+  std::mutex                     m;
+  std::condition_variable        cv;
+  std::atomic<int>               state{0}; // 0 idle, 1 job posted, 2 job done
+  std::atomic<bool>              quit{false};
+  std::function<int()>           job;
+  int                            rc = 0;
+  std::string                    err;
+
+  void run()
+  {
+    for (;;)
+    {
+      int spins = 0;
+      while (state.load(std::memory_order_acquire) != 1)
+      {
+        if (quit.load(std::memory_order_acquire)) return;
+        if (++spins < 40000) __builtin_ia32_pause();
+        else
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait_for(lk, std::chrono::milliseconds(2),
+                      [&] { return state.load(std::memory_order_acquire) == 1 || quit.load(std::memory_order_acquire); });
+          spins = 0;
+        }
+      }
+      rc = job();
+      if (rc < 0) err = g_err;
+      state.store(2, std::memory_order_release);
+    }
+  }
+  void post(std::function<int()> f)
+  {
+    job = std::move(f);
+    state.store(1, std::memory_order_release);
+    cv.notify_one();
+  }
+  int join()
+  {
+    while (state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+    state.store(0, std::memory_order_release);
+    if (rc < 0) g_err = err;
+    return rc;
+  }
+  void stop()
+  {
+    quit.store(true, std::memory_order_release);
+    cv.notify_one();
+    if (th.joinable()) th.join();
+  }
+};
+
 constexpr int kGroupBase = 1 << 20; // instance ids >= kGroupBase name sharded instances
 
 struct Group
@@ -137,6 +196,7 @@ struct Group
   Collective             *co = nullptr;
   int                     last_warn = 0;
   bool                    warn_valid = false;
+  std::vector<ShardWorker *> workers; // one per shard when the shards sit on more than one device (or PHYHIP_SHARD_THREADS=1)
 };
 
 std::vector<Group *> g_groups;
@@ -160,8 +220,40 @@ template <typename F> int group_each(Group *G, F &&f)
   return PHYHIP_SUCCESS;
 }
 
+// run f(g) for every shard g: on the helper threads when the group has them, else in the calling thread
+template <typename F> int group_parallel(Group *G, F &&f)
+{
+  if (G->workers.empty())
+  {
+    for (size_t g = 0; g < G->sub.size(); ++g)
+    {
+      int rc = set_dev(G->sub[g]->dev);
+      if (rc || (rc = f((int)g)) < 0) return rc;
+    }
+    return PHYHIP_SUCCESS;
+  }
+  for (size_t g = 0; g < G->sub.size(); ++g)
+    G->workers[g]->post([G, g, &f]() -> int {
+      const int rc = set_dev(G->sub[g]->dev);
+      return rc ? rc : f((int)g);
+    });
+  int rc = PHYHIP_SUCCESS;
+  for (size_t g = 0; g < G->sub.size(); ++g)
+  {
+    const int r = G->workers[g]->join();
+    if (r < 0 && rc == PHYHIP_SUCCESS) rc = r;
+  }
+  return rc;
+}
+
 static void release_group(Group *G)
 {
+  for (ShardWorker *w : G->workers)
+  {
+    w->stop();
+    delete w;
+  }
+  G->workers.clear();
   release_collective(G->co); // drains every device's stream and destroys the communicators while the streams still exist
   G->co = nullptr;
   for (int id : G->sub_id)
@@ -245,6 +337,16 @@ static int create_group(int tipCount, int partialsBufferCount, int stateCount, i
       return fail(PHYHIP_ERROR_OUT_OF_MEMORY, "reduction buffer: %s", hipGetErrorString(e));
     }
   }
+  {
+    const char *e = getenv("PHYHIP_SHARD_THREADS");
+    if (e ? atoi(e) != 0 : nctx > 1)
+      for (int g = 0; g < resourceCount; ++g)
+      {
+        ShardWorker *w = new ShardWorker();
+        w->th = std::thread([w] { w->run(); });
+        G->workers.push_back(w);
+      }
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   for (size_t i = 0; i < g_groups.size(); ++i)
     if (!g_groups[i])
@@ -260,18 +362,17 @@ static int create_group(int tipCount, int partialsBufferCount, int stateCount, i
 // collective.  Launches go out shard by shard from the one host thread; the devices run concurrently.
 static int group_edge_lnl(Group *G, int parent, int child, int pm, double *out)
 {
-  for (size_t g = 0; g < G->sub.size(); ++g)
-  {
+  int rc = group_parallel(G, [&](int g) -> int {
     Instance *I = G->sub[g];
-    int rc = set_dev(I->dev);
-    if (rc) return rc;
-    if ((rc = check_partial_index(I, parent, true)) || (rc = check_partial_index(I, child, true))) return rc;
+    int r;
+    if ((r = check_partial_index(I, parent, true)) || (r = check_partial_index(I, child, true))) return r;
     if (pm < 0 || pm >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm);
     double  *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
     EdgeEval ee{parent, child, pm, slot + 1, false, slot};
-    if ((rc = flush(I, &ee))) return rc;
-  }
-  int rc = reduce_and_publish(*G->co, 2, G->sub[0]);
+    return flush(I, &ee);
+  });
+  if (rc) return rc;
+  rc = reduce_and_publish(*G->co, 2, G->sub[0]);
   if (rc) return rc;
   *out          = G->sub[0]->h_result[0];
   G->last_warn  = *G->sub[0]->h_warn;

@@ -84,12 +84,15 @@ def test_sharded_instance_matches_reference(name, layout, golden):
         t.close()
 
 
-def test_sharded_instance_spr_call_pattern_matches_single_device():
+def test_sharded_instance_spr_call_pattern_matches_single_device(monkeypatch):
     """A seeded SPR / Br_Len_Opt call stream (phyml_amd/replay.py) through a sharded instance returns the scalars the
-    single-device instance returns (1e-12; the shard sums are added in a different order)."""
+    single-device instance returns (1e-12; the shard sums are added in a different order) -- with the shards driven from
+    the calling thread and from the per-shard helper threads (what a multi-device group uses; PHYHIP_SHARD_THREADS=1
+    forces them for shards that share a device)."""
     from phyml_amd import replay
     res = []
-    for devs in (None, [0, 0, 0]):
+    for devs, threads in ((None, "0"), ([0, 0, 0], "0"), ([0, 0, 0], "1")):
+        monkeypatch.setenv("PHYHIP_SHARD_THREADS", threads)
         t, ot, tree, st = synthetic_pair(40, 3000, 4, 4, seed=77, devices=devs)
         try:
             t.Set_Both_Sides(True)
@@ -98,10 +101,13 @@ def test_sharded_instance_spr_call_pattern_matches_single_device():
             res.append(t.Replay_Surface_Trace(tr))
         finally:
             t.close()
-    (a, a2), (b, b2) = res
+    (a, a2) = res[0]
     m = a != 0
-    assert m.any() and np.max(np.abs(a[m] - b[m]) / np.abs(a[m])) < 1e-12
-    assert np.max(np.abs(a2 - b2) / np.maximum(1.0, np.abs(a2))) < 1e-9
+    assert m.any()
+    for (b, b2) in res[1:]:
+        assert np.max(np.abs(a[m] - b[m]) / np.abs(a[m])) < 1e-12
+        assert np.max(np.abs(a2 - b2) / np.maximum(1.0, np.abs(a2))) < 1e-9
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1], res[2][1])  # threads change nothing
 
 
 def test_numerical_warning_rides_in_the_all_reduce():
@@ -186,6 +192,7 @@ def test_cfg4_one_million_patterns_against_the_reference():
     nd = _n_devices()
     devs = [g % nd for g in range(8)]
     t = None
+    os.environ["PHYHIP_SHARD_THREADS"] = "1"   # the helper threads a real 8-device group runs with
     wl = workloads.make("cfg4_nt_100x1M")
     tree, blk = wl["tree"], wl["model"]
     t = lktree.LkTree(tree.n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, 1000000, 4, 4, devices=devs)
@@ -202,6 +209,7 @@ def test_cfg4_one_million_patterns_against_the_reference():
         assert abs(t.Lk(17) - ref) / abs(ref) < 1e-11
     finally:
         t.close()
+        os.environ.pop("PHYHIP_SHARD_THREADS", None)
 
 
 @pytest.mark.parametrize("split,host_sum", [("0", "1"), ("1", "0"), ("1", "1")])
