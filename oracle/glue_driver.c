@@ -204,7 +204,21 @@ static ctx_t *ensure_instance(t_tree *tree)
   c->bufcap = 3 * n - 2;  /* internal edge sides + both sides of the two spare SPR edges (src/make.c:96-104) */
   c->matcap = 2 * n - 1;
   if (c->bufcap > MAXID || c->matcap > MAXID) { fprintf(stderr, "glue_driver: tree too large for the index tables\n"); exit(5); }
-  c->inst = phyhip_create_instance(n, n + c->bufcap, 0, S, P, 1, c->matcap, C, 0, NULL, 0, 0, 0, NULL);
+  {
+    /* GLUE_DEVICES="0,1,2,3": the sharded (multi-GPU) instance of include/phyhip.h -- the resource list PhyML would pass
+       where the BEAGLE glue passes its own (src/beagle_utils.c:119-133).  Plain tree models only. */
+    int devs[64], nd = 0;
+    const char *e = getenv("GLUE_DEVICES");
+    if (e && !tree->is_mixt_tree && !tree->mixt_tree)
+      for (const char *p = e; *p && nd < 64;)
+      {
+        devs[nd++] = atoi(p);
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+    c->inst = phyhip_create_instance(n, n + c->bufcap, 0, S, P, 1, c->matcap, C, 0, nd ? devs : NULL, nd,
+                                     0, nd == 1 ? PHYHIP_FLAG_SHARDED : 0, NULL);
+  }
   if (c->inst < 0) die("phyhip_create_instance");
   OK(phyhip_set_pattern_weights(c->inst, tree->data->wght));
   for (int t = 0; t < n; ++t) OK(phyhip_set_tip_partials(c->inst, tree->a_nodes[t]->num, tree->a_nodes[t]->b[0]->p_lk_tip_r));

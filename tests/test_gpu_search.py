@@ -32,17 +32,19 @@ EXPECTED = json.load(open(os.path.join(GOLDEN, "search_expected.json")))
 _cache = {}
 
 
-def run_search(name, mode, tmp_path, device_pmat=False):
-    key = (name, mode, device_pmat)
+def run_search(name, mode, tmp_path, device_pmat=False, devices=None):
+    key = (name, mode, device_pmat, devices)
     if key in _cache:
         return _cache[key]
     if not os.path.exists(GLUE):
         pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
     e = EXPECTED[name]
-    wd = os.path.join(str(tmp_path), mode + ("_dp" if device_pmat else ""))
+    wd = os.path.join(str(tmp_path), mode + ("_dp" if device_pmat else "") + ("_sh" if devices else ""))
     os.makedirs(wd, exist_ok=True)
     shutil.copy(os.path.join(GOLDEN, "examples_" + e["example"] + ".phy"), os.path.join(wd, e["example"]))
     env = dict(os.environ, GLUE_MODE=mode, GLUE_DEVICE_PMAT="1" if device_pmat else "0")
+    if devices:
+        env["GLUE_DEVICES"] = devices
     r = subprocess.run([GLUE] + e["driver_opts"] + ["--", "-i", e["example"]] + e["phyml_args"], cwd=wd, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
@@ -82,6 +84,23 @@ def test_real_search_driven_by_the_device(name, tmp_path):
         assert 0.5 * ref["calls"][k] < info["calls"][k] < 2.0 * ref["calls"][k]
     if info["calls"] == ref["calls"]:
         assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-9 * abs(ref["lnL_final"])
+
+
+def test_real_search_on_a_sharded_instance(tmp_path):
+    """PhyML's real spr.c / optimiz.c on the MULTI-GPU form of the C ABI (GLUE_DEVICES: three pattern shards, one RCCL
+    all-reduce behind every Lk / dLk): every scalar against the reference's own arithmetic in check mode, and the
+    device-driven search must make the single-instance run's calls and end on its end point (the shard sums are added in
+    another order, 1e-15 relative per call, so the same tolerance rules as above apply)."""
+    import torch
+    devs = "0,1,0" if torch.cuda.device_count() >= 2 else "0,0,0"
+    chk = run_search("search_nucleic_spr", "check", tmp_path, devices=devs)
+    assert chk["calls"]["Lk"] > 10000 and chk["worst_rel_lnL"] < 1e-10 and chk["worst_rel_dlnL"] < 1e-6, chk
+    one = run_search("search_nucleic_spr", "device", tmp_path)
+    info = run_search("search_nucleic_spr", "device", tmp_path, devices=devs)
+    assert abs(info["lnL_init"] - one["lnL_init"]) <= 1e-12 * abs(one["lnL_init"])
+    assert abs(info["lnL_final"] - one["lnL_final"]) <= 1e-3 * abs(one["lnL_final"])
+    if info["calls"] == one["calls"]:
+        assert abs(info["lnL_final"] - one["lnL_final"]) <= 1e-9 * abs(one["lnL_final"])
 
 
 def test_real_search_with_device_built_matrices(tmp_path):
