@@ -11,6 +11,7 @@
  *   Post_Order_Lk / Pre_Order_Lk    src/lk.c:282/357 traversals issuing Update_Partial_Lk
  *   Update_All_Partial_Lk           src/lk.c:401
  *   Update_Partial_Lk_Along_A_Path  src/lk.c:2379
+ *   Update_Lk_At_Given_Edge(b,tree) src/lk.c:2478    both sides of b refreshed, then Lk(b)
  *   Update_Eigen_Lr(b,tree)         src/lk.c:1038
  *   Set_Both_Sides / Set_Use_Eigen_Lr / Set_Update_Eigen_Lr   src/utilities.c:11614-11640
  *   Make_Tree_For_Lk / Free_Tree_Lk src/make.c:17 / src/free.c:387   (device instance instead of the host slab)
@@ -124,6 +125,7 @@ void   Post_Order_Lk(t_node *a, t_node *d, t_tree *tree);
 void   Pre_Order_Lk(t_node *a, t_node *d, t_tree *tree);
 void   Update_All_Partial_Lk(t_tree *tree);
 void   Update_Partial_Lk_Along_A_Path(t_node **path, int path_length, t_tree *tree);
+phydbl Update_Lk_At_Given_Edge(t_edge *b_fcus, t_tree *tree); /* src/lk.c:2478-2484 */
 void   Update_Eigen_Lr(t_edge *b, t_tree *tree);
 void   Set_Both_Sides(int yesno, t_tree *tree);
 void   Set_Use_Eigen_Lr(int yesno, t_tree *tree);

@@ -528,6 +528,14 @@ phydbl Lk(t_edge *b, t_tree *tree)
   return tree->c_lnL;
 }
 
+phydbl Update_Lk_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
+{ /* src/lk.c:2478-2484: both sides of the edge, then Lk(b) -- two queued operations + the evaluation = one launch */
+  Update_Partial_Lk(tree, b_fcus, b_fcus->left);
+  Update_Partial_Lk(tree, b_fcus, b_fcus->rght);
+  tree->c_lnL = Lk(b_fcus, tree);
+  return tree->c_lnL;
+}
+
 void Lk_Shard_Device(t_tree *tree, double *device_out)
 {
   t_edge *b = Traverse_For_Lk(tree);

@@ -69,7 +69,7 @@ def load():
         L = C.CDLL(LK_LIB_PATH)
         L.Make_Tree_From_Edges.restype = C.POINTER(t_tree)
         L.Make_Model_Basic.restype = C.POINTER(t_mod)
-        for f in ("Lk", "dLk", "Br_Len_Opt"):
+        for f in ("Lk", "dLk", "Br_Len_Opt", "Update_Lk_At_Given_Edge"):
             getattr(L, f).restype = C.c_double
         # tests must survive the reference's print-and-Exit() convention
         L.Set_Exit_Handler(_exit_handler)
@@ -202,6 +202,10 @@ class LkTree:
 
     def Update_Partial_Lk(self, b, d):
         self.L.Update_Partial_Lk(self.tree, self.edge(b), self.node(d)); _raise_if_error()
+
+    def Update_Lk_At_Given_Edge(self, b):
+        v = self.L.Update_Lk_At_Given_Edge(self.edge(b), self.tree); _raise_if_error()
+        return v
 
     def Update_PMat_At_Given_Edge(self, b):
         self.L.Update_PMat_At_Given_Edge(self.edge(b), self.tree); _raise_if_error()

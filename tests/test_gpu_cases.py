@@ -244,3 +244,22 @@ def test_model_setters_skip_unchanged_values_and_follow_changes(ns):
         assert t.Lk(None) == a0
     finally:
         t.close()
+
+
+def test_update_lk_at_given_edge(golden):
+    """Update_Lk_At_Given_Edge (src/lk.c:2478-2484): both sides of the edge recomputed from their neighbours, then Lk(b) --
+    on an up-to-date tree it must return the tree's lnL at every edge, and it must repair a deliberately spoiled side."""
+    d = golden("nucleic_gtr_g4")
+    t, ot = gpu_common.device_tree_from_golden(d)
+    try:
+        t.Set_Both_Sides(True)
+        lnl = t.Lk(None)
+        for e in range(0, t.ne, 9):
+            assert abs(t.Update_Lk_At_Given_Edge(e) - lnl) / abs(lnl) < 1e-12
+        e = next(k for k in range(t.ne) if t.edge(k).contents.left.contents.tax == 0 and t.edge(k).contents.rght.contents.tax == 0)
+        buf = t.side_buffer(e, 0)
+        t.inst.set_partials(buf, np.full((t.P, t.C * t.S), 0.5))
+        assert abs(t.Lk(e) - lnl) / abs(lnl) > 1e-6          # spoiled
+        assert abs(t.Update_Lk_At_Given_Edge(e) - lnl) / abs(lnl) < 1e-12
+    finally:
+        t.close()
