@@ -54,6 +54,11 @@ extern "C" {
    ONE device -- same code path, communicator of one rank (used by the single-GPU tests of that path). */
 #define PHYHIP_FLAG_SHARDED (1L << 40)
 #define PHYHIP_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* requirementFlags bit: the categoryCount "categories" of the instance are the CLASSES of a mixture of class models
+   (src/mixt.c; e.g. the four classes of LG4X): class c has its own eigen system and frequencies (eigenIndex / 
+   stateFrequenciesIndex = c), its category rate is the class rate, every partials buffer carries one scale vector per
+   class, and evaluations go through phyhip_calculate_class_mixture_*.  20 states, up to 4 classes, one device. */
+#define PHYHIP_FLAG_CLASS_AXIS (1L << 41)
 
 /* BeagleOperation (src/beagle_utils.c:243).  The two scale-index fields are accepted and ignored:
    scale vectors are implicit, one per partials buffer, as in PhyML. */
@@ -190,7 +195,7 @@ int phyhip_calculate_edge_log_likelihoods_device(int instance, int parentBufferI
 int phyhip_get_site_log_likelihoods(int instance, double *outLogLikelihoods);
 
 /* The other per-pattern outputs of Lk_Core that host readers use (src/lk.c:855-857, 2791, 2801);
-   any pointer may be NULL. */
+   any pointer may be NULL.  (Class-axis instances: fact_sum_scale holds categoryCount x patternCount ints, [class][pattern].) */
 int phyhip_get_site_outputs(int instance, double *c_lnL_sorted, double *cur_site_lk,
                             double *unscaled_site_lk_cat, int *fact_sum_scale);
 
@@ -229,6 +234,24 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
                                             const int *rightBufferIndices, double *l, const double *classProba,
                                             const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
                                             double eFrqWeightSum, double sumProbas, double *outLnL, double *outDLnL);
+
+/* The same two evaluations on ONE instance created with PHYHIP_FLAG_CLASS_AXIS (class c = category c): the queued
+   partial updates of ALL classes and their edge evaluations are one traversal launch (one per class instance above),
+   followed by the combination.  The class trees of PhyML's mixture share their topology and their call sequence
+   (MIXT_Update_Partial_Lk / MIXT_Update_PMat_At_Given_Edge loop over them, src/mixt.c:1191-1250), so the glue queues an
+   operation once -- when the first class tree reports it.  parent / child / matrix indices as for
+   phyhip_calculate_edge_log_likelihoods; the per-pattern log-likelihoods are left for phyhip_get_site_log_likelihoods,
+   the per-class likelihoods in unscaled_site_lk_cat ([pattern][class]) of phyhip_get_site_outputs. */
+int phyhip_calculate_class_mixture_log_likelihood(int instance, int parentBufferIndex, int childBufferIndex, int probabilityIndex,
+                                                  const double *classProba, const double *rMatWeight, const double *eFrqWeight,
+                                                  double rMatWeightSum, double eFrqWeightSum, double sumProbas,
+                                                  double *outSumLogLikelihood);
+int phyhip_calculate_class_mixture_eigen_lnl_dlnl(int instance, int leftBufferIndex, int rightBufferIndex, double *l,
+                                                  const double *classProba, const double *rMatWeight, const double *eFrqWeight,
+                                                  double rMatWeightSum, double eFrqWeightSum, double sumProbas, double *outLnL,
+                                                  double *outDLnL);
+/* sum_scale vector of class classIndex of a partials buffer (class-axis instances; class 0 = phyhip_get_scale_factors) */
+int phyhip_get_class_scale_factors(int instance, int bufferIndex, int classIndex, int *outScaleFactors);
 
 /* ---- eigen-basis branch-length derivative (no BEAGLE counterpart in the seam) ---------------- */
 

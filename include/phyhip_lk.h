@@ -103,7 +103,7 @@ void    Free_Tree(t_tree *tree);
 void Make_Tree_For_Lk(t_tree *tree, int n_pattern, const phydbl *wght, const short *invar, int device);
 /* the multi-GPU form: pattern shards over `devices` (see phyhip_create_instance), one RCCL all-reduce per Lk()/dLk() */
 void Make_Tree_For_Lk_On_Devices(t_tree *tree, int n_pattern, const phydbl *wght, const short *invar, const int *devices,
-                                 int n_devices, int force_sharded);
+                                 int n_devices, int flags /* 1: sharded even for one device; 2: class axis */);
 void Free_Tree_Lk(t_tree *tree);
 /* tip data: 0/1 tip vector [pattern][state] (a_nodes[i]->b[0]->p_lk_tip_r) or compact states */
 void Init_Partial_Lk_Tips_Double_One_Tip(t_tree *tree, int tax_id, const phydbl *p_lk_tip);

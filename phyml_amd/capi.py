@@ -45,10 +45,12 @@ SYMBOLS = [
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
     "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
-    "phyhip_get_shard_range", "phyhip_profile_read_traffic",
+    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_calculate_class_mixture_log_likelihood",
+    "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors",
 ]
 
 FLAG_SHARDED = 1 << 40  # PHYHIP_FLAG_SHARDED
+FLAG_CLASS_AXIS = 1 << 41  # PHYHIP_FLAG_CLASS_AXIS
 UNIQUE_ID_BYTES = 128
 
 _lib = None
@@ -90,7 +92,7 @@ class Instance:
     """Thin object wrapper: one method per C entry point, numpy in / numpy out."""
 
     def __init__(self, tip_count, partials_buffer_count, state_count, pattern_count, matrix_buffer_count,
-                 category_count, device=None, devices=None, force_sharded=False):
+                 category_count, device=None, devices=None, force_sharded=False, class_axis=False):
         L = load()
         self.L = L
         self.tips, self.nbuf, self.S, self.P, self.nmat, self.C = (tip_count, partials_buffer_count, state_count,
@@ -102,7 +104,7 @@ class Instance:
             res, nres = ((C.c_int * 1)(device), 1) if device is not None else (None, 0)
         self.id = _chk(L.phyhip_create_instance(tip_count, partials_buffer_count, 0, state_count, pattern_count, 1,
                                                 matrix_buffer_count, category_count, 0, res, nres,
-                                                C.c_long(0), C.c_long(FLAG_SHARDED if force_sharded else 0),
+                                                C.c_long(0), C.c_long((FLAG_SHARDED if force_sharded else 0) | (FLAG_CLASS_AXIS if class_axis else 0)),
                                                 C.byref(self.details)))
 
     def close(self):
@@ -141,14 +143,37 @@ class Instance:
         a = _f64(w); assert a.size == self.C
         _chk(self.L.phyhip_set_category_weights(self.id, 0, _ptr(a)))
 
-    def set_state_frequencies(self, pi):
+    def set_state_frequencies(self, pi, index=0):
         a = _f64(pi); assert a.size == self.S
-        _chk(self.L.phyhip_set_state_frequencies(self.id, 0, _ptr(a)))
+        _chk(self.L.phyhip_set_state_frequencies(self.id, int(index), _ptr(a)))
 
-    def set_eigen_decomposition(self, evec, ivec, evals):
+    def set_eigen_decomposition(self, evec, ivec, evals, index=0):
         a, b, c = _f64(evec), _f64(ivec), _f64(evals)
         assert a.size == self.S * self.S and b.size == self.S * self.S and c.size == self.S
-        _chk(self.L.phyhip_set_eigen_decomposition(self.id, 0, _ptr(a), _ptr(b), _ptr(c)))
+        _chk(self.L.phyhip_set_eigen_decomposition(self.id, int(index), _ptr(a), _ptr(b), _ptr(c)))
+
+    # -- mixtures on the class axis (instance created with class_axis=True)
+    def class_mixture_log_likelihood(self, parent, child, pm, proba, r_w, e_w, r_sum, e_sum, sum_probas):
+        n = self.C
+        da = lambda v: (C.c_double * n)(*[float(x) for x in v])
+        out = C.c_double(0.0)
+        _chk(self.L.phyhip_calculate_class_mixture_log_likelihood(self.id, int(parent), int(child), int(pm), da(proba), da(r_w), da(e_w),
+                                                                 C.c_double(r_sum), C.c_double(e_sum), C.c_double(sum_probas), C.byref(out)))
+        return out.value
+
+    def class_mixture_eigen_lnl_dlnl(self, left, right, l, proba, r_w, e_w, r_sum, e_sum, sum_probas):
+        n = self.C
+        da = lambda v: (C.c_double * n)(*[float(x) for x in v])
+        lv, lnl, dlnl = C.c_double(l), C.c_double(0.0), C.c_double(0.0)
+        _chk(self.L.phyhip_calculate_class_mixture_eigen_lnl_dlnl(self.id, int(left), int(right), C.byref(lv), da(proba), da(r_w), da(e_w),
+                                                                 C.c_double(r_sum), C.c_double(e_sum), C.c_double(sum_probas),
+                                                                 C.byref(lnl), C.byref(dlnl)))
+        return lv.value, lnl.value, dlnl.value
+
+    def get_class_scale_factors(self, buf, k):
+        out = np.zeros(self.P, np.int32)
+        _chk(self.L.phyhip_get_class_scale_factors(self.id, int(buf), int(k), _ptr(out)))
+        return out
 
     def set_phyml_options(self, l_min=1e-8, l_max=100.0, br_len_mult=1.0, apply_lk_scaling=1):
         _chk(self.L.phyhip_set_phyml_options(self.id, C.c_double(l_min), C.c_double(l_max), C.c_double(br_len_mult),
@@ -195,8 +220,9 @@ class Instance:
         _chk(self.L.phyhip_get_site_log_likelihoods(self.id, _ptr(out)))
         return out
 
-    def site_outputs(self):
-        a = np.zeros(self.P); b = np.zeros(self.P); c = np.zeros((self.P, self.C)); f = np.zeros(self.P, np.int32)
+    def site_outputs(self, n_fact=1):
+        """n_fact: class-axis instances return fact_sum_scale as [class][pattern] (n_fact = class count)."""
+        a = np.zeros(self.P); b = np.zeros(self.P); c = np.zeros((self.P, self.C)); f = np.zeros(self.P * n_fact, np.int32)
         _chk(self.L.phyhip_get_site_outputs(self.id, _ptr(a), _ptr(b), _ptr(c), _ptr(f)))
         return a, b, c, f
 

@@ -176,11 +176,12 @@ void Make_Tree_For_Lk(t_tree *tree, int n_pattern, const phydbl *wght, const sho
   Make_Tree_For_Lk_On_Devices(tree, n_pattern, wght, invar, device >= 0 ? &device : NULL, device >= 0 ? 1 : 0, NO);
 }
 
-/* Same with a list of devices: more than one entry (or force_sharded) gives the sharded instance of include/phyhip.h --
+/* Same with a list of devices: more than one entry (or flags & 1) gives the sharded instance of include/phyhip.h --
    contiguous pattern ranges, one per device, and ONE RCCL all-reduce behind every Lk()/dLk().  Nothing else
-   in this file knows about it: tree->b_inst is used exactly like a single-device instance. */
+   in this file knows about it: tree->b_inst is used exactly like a single-device instance.  flags & 2: the categories are
+   the classes of a mixture (PHYHIP_FLAG_CLASS_AXIS); the per-class models beyond class 0 are pushed by the caller. */
 void Make_Tree_For_Lk_On_Devices(t_tree *tree, int n_pattern, const phydbl *wght, const short *invar, const int *devices,
-                                 int n_devices, int force_sharded)
+                                 int n_devices, int flags)
 {
   const int n = tree->n_otu, n_edges = 2 * n - 3;
   const t_mod *m = tree->mod;
@@ -210,7 +211,8 @@ void Make_Tree_For_Lk_On_Devices(t_tree *tree, int n_pattern, const phydbl *wght
   next += PHL_N_SPARE;
   phyhip_instance_details det;
   int inst = phyhip_create_instance(n, next, 0, m->ns, n_pattern, 1, n_edges + PHL_N_SPARE, m->n_catg, 0,
-                                    n_devices > 0 ? devices : NULL, n_devices, 0, force_sharded ? PHYHIP_FLAG_SHARDED : 0, &det);
+                                    n_devices > 0 ? devices : NULL, n_devices, 0,
+                                    ((flags & 1) ? PHYHIP_FLAG_SHARDED : 0) | ((flags & 2) ? PHYHIP_FLAG_CLASS_AXIS : 0), &det);
   if (inst < 0) { Lk_Exit("phyhip_create_instance", phyhip_get_last_error()); return; }
   tree->b_inst = inst;
   CHK(phyhip_set_pattern_weights(inst, tree->wght));

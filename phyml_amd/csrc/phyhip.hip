@@ -137,6 +137,8 @@ struct Instance
   bool        own_stream = true;
   int         tips = 0, nbuf = 0, S = 0, C = 0, CP = 0, nmat = 0;
   long long   P = 0, Ppad = 0; // Ppad: patterns per buffer as allocated (P, or P rounded up to 16 when perm)
+  bool        class_axis = false; // categories are the classes of a mixture (PHYHIP_FLAG_CLASS_AXIS; TreeParams::class_axis)
+  int         NE = 1;          // eigen systems / frequency vectors held: C with the class axis, else 1
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
   int         aa_tiles = 1;            // -DPHYHIP_DIAG builds: PHYHIP_AA_TILES = 2 | 4 pattern tiles per wave (experimental/phyhip_aa3.hpp)
   bool        aa_wave_per_tile = false; // -DPHYHIP_DIAG builds: PHYHIP_AA_GEN=2, one wave per tile walks all categories (experimental/phyhip_aa2.hpp)
@@ -251,6 +253,8 @@ int next_pow2(int x)
 }
 
 size_t buf_elems(const Instance *I) { return (size_t)I->Ppad * I->C * I->S; }
+// ints per partials buffer in the scale table: one exponent per pattern, or per (class, pattern) with the class axis
+size_t scale_elems(const Instance *I) { return (size_t)I->Ppad * (I->class_axis ? I->C : 1); }
 
 // element offset of (pattern, category, state) inside a device partials buffer of a non-host layout
 size_t dev_off(const Instance *I, long long p, int c, int s)
@@ -267,6 +271,7 @@ TreeParams base_params(Instance *I)
   q.wght = I->d_wght; q.P = I->P; q.Ppad = I->Ppad; q.perm = I->perm ? 1 : (I->soa ? 2 : 0); q.C = I->C; q.tip_count = I->tips;
   q.apply_scaling = I->apply_scaling; q.pi = I->d_pi; q.cat_w = I->d_catw; q.invar_model = I->invar_model;
   q.pinvar = I->pinvar; q.invar = I->d_invar; q.block_sums = I->d_block; q.warn = I->d_warn; q.fact = I->d_fact;
+  q.class_axis = I->class_axis ? 1 : 0;
   return q;
 }
 
@@ -372,7 +377,8 @@ int flush_pmats(Instance *I)
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
     const int threads = (I->S == 4) ? 64 : 256;
     q.afrag = I->perm ? I->d_afrag : nullptr; // 20 states: the MFMA A-operand fragments come out of the same kernel
-    const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)I->C * I->S * I->S + (size_t)2 * I->S * I->S);
+    q.class_axis = I->class_axis ? 1 : 0;
+    const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)I->C * I->S * I->S + (size_t)2 * I->NE * I->S * I->S);
     hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), lds, I->stream, q);
     HIPCHK(hipGetLastError());
     done += n;
@@ -511,7 +517,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           if (f2) fl |= f2bit;
           const size_t b = ld ? (size_t)(c - I->tips) : 0;
           data  = desc(I->d_partials + b * buf_elems(I), ld ? bufbytes : 0, pmoff);
-          scale = desc(I->d_scales + b * I->Ppad, ld ? (size_t)I->Ppad * 4 : 0, 0);
+          scale = desc(I->d_scales + b * scale_elems(I), ld ? scale_elems(I) * 4 : 0, 0);
           tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->Ppad, t ? (size_t)I->Ppad : 0, 0);
           // lane-per-pattern nucleotide kernel: ONE auxiliary dword load per child (measured for the 20-state kernel too:
           // 640 vs 590 us -- slower there) -- the scale descriptor of a tip
@@ -522,7 +528,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);
         const size_t b = (size_t)(o.dest - I->tips);
         xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), bufbytes, fl);
-        xr[k].dst_scale = desc(I->d_scales + b * I->Ppad, (size_t)I->Ppad * 4, 0);
+        xr[k].dst_scale = desc(I->d_scales + b * scale_elems(I), scale_elems(I) * 4, 0);
       }
       // (reading short lists straight from the pinned staging memory instead was measured: no gain)
       if (in_args)
@@ -553,7 +559,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
     const int nblk = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     // (fusing on large grids was measured for one-operation launches too: 61.6 vs 41.9 us per SPR candidate at cfg5)
-    fused_sum = fuse_reduce(I, nblk);
+    fused_sum = !I->class_axis && fuse_reduce(I, nblk);
     if (fused_sum)
     { // the traversal kernel's last workgroup finishes the sum and reports to the host
       q.tickets = I->d_tickets; q.result = ee->dev_out ? ee->dev_out : I->d_result;
@@ -561,7 +567,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       q.seq = ee->to_host ? ++I->seq : 0ull;
       q.warn_out = ee->warn_out;
     }
-    if (!fused_sum && ee->to_host && !ee->dev_out && I->host_sum)
+    if (!fused_sum && ee->to_host && !ee->dev_out && I->host_sum && !I->class_axis)
     { // large grid: the workgroups post their sums to the host, which adds them (wait_result)
       q.host_blocks = I->h_blocks; q.host_tag = ++I->seq;
       q.warn        = I->h_warn;   // raised straight in host-mapped memory
@@ -781,7 +787,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   }
   HIPCHK(hipGetLastError());
   I->host_sum_n = host_sum_n;
-  if (ee && !fused_sum && !host_sum_n)
+  if (ee && !fused_sum && !host_sum_n && !I->class_axis) // (class axis: the combination kernel follows, no sum here)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
     const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
@@ -978,6 +984,8 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(PHYHIP_ERROR_NO_RESOURCE, "no HIP device visible: libphyhip has no CPU fallback");
+  if ((requirementFlags & PHYHIP_FLAG_CLASS_AXIS) && resourceList && (resourceCount > 1 || (requirementFlags & PHYHIP_FLAG_SHARDED)))
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "mixtures are not sharded");
   if (resourceList && (resourceCount > 1 || (resourceCount == 1 && (requirementFlags & PHYHIP_FLAG_SHARDED))))
   { // sharded instance: one per-device instance per entry of the resource list + the RCCL communicators
     for (int g = 0; g < resourceCount; ++g)
@@ -995,7 +1003,11 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, dev));
 
+  const bool class_axis = (requirementFlags & PHYHIP_FLAG_CLASS_AXIS) != 0;
+  if (class_axis && (stateCount != 20 || categoryCount > 4))
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "the class axis is built for 20 states and up to 4 classes (one instance per class otherwise)");
   Instance *I = new Instance();
+  I->class_axis = class_axis; I->NE = class_axis ? categoryCount : 1;
   I->dev = dev; I->tips = tipCount; I->nbuf = partialsBufferCount; I->S = stateCount; I->C = categoryCount;
   I->CP = next_pow2(categoryCount); I->P = patternCount; I->nmat = matrixBufferCount;
   {
@@ -1035,7 +1047,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
 
-  I->perm = (I->S == 20) && (I->C <= 4) && !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA")));
+  I->perm = (I->S == 20) && (I->C <= 4) && (I->class_axis || !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA"))));
   if (const char *e = getenv("PHYHIP_AA_GEN")) I->aa_wave_per_tile = kDiag && atoi(e) == 2;
   I->soa  = (I->S == 4) && (I->C <= 4) && !(kDiag && getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
             !(getenv("PHYHIP_GENERIC_NT") && atoi(getenv("PHYHIP_GENERIC_NT")));
@@ -1055,8 +1067,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   const size_t be    = buf_elems(I);
   HIPCHK(hipMalloc((void **)&I->d_partials, n_int * be * sizeof(double)));
   HIPCHK(hipMemset(I->d_partials, 0, n_int * be * sizeof(double)));
-  HIPCHK(hipMalloc((void **)&I->d_scales, n_int * I->Ppad * sizeof(int)));
-  HIPCHK(hipMemset(I->d_scales, 0, n_int * I->Ppad * sizeof(int)));
+  HIPCHK(hipMalloc((void **)&I->d_scales, n_int * scale_elems(I) * sizeof(int)));
+  HIPCHK(hipMemset(I->d_scales, 0, n_int * scale_elems(I) * sizeof(int)));
   if (I->perm)
   {
     const size_t fb = (size_t)I->nmat * I->C * 2 * kAaT * 64 * sizeof(double);
@@ -1080,20 +1092,21 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     std::vector<double> ones((size_t)I->P, 1.0);
     HIPCHK(hipMemcpy(I->d_wght, ones.data(), I->P * sizeof(double), hipMemcpyHostToDevice));
   }
-  const size_t model_doubles = (size_t)2 * I->S + 2 * I->C + 2 * (size_t)I->S * I->S;
+  const size_t NE = (size_t)I->NE; // pi | catw | catr | eval | evec | ivec, the eigen data once per eigen system
+  const size_t model_doubles = NE * 2 * I->S + 2 * I->C + NE * 2 * (size_t)I->S * I->S;
   HIPCHK(hipMalloc((void **)&I->d_model, model_doubles * sizeof(double)));
   HIPCHK(hipMemset(I->d_model, 0, model_doubles * sizeof(double)));
-  I->d_pi = I->d_model; I->d_catw = I->d_pi + I->S; I->d_catr = I->d_catw + I->C; I->d_eval = I->d_catr + I->C;
-  I->d_evec = I->d_eval + I->S; I->d_ivec = I->d_evec + (size_t)I->S * I->S;
+  I->d_pi = I->d_model; I->d_catw = I->d_pi + NE * I->S; I->d_catr = I->d_catw + I->C; I->d_eval = I->d_catr + I->C;
+  I->d_evec = I->d_eval + NE * I->S; I->d_ivec = I->d_evec + NE * (size_t)I->S * I->S;
   I->h_rates.assign(I->C, 1.0);
   I->h_model.assign(model_doubles, 0.0);
   I->h_model_set.assign(model_doubles, 0);
-  I->h_eval.assign(I->S, 0.0);
+  I->h_eval.assign(NE * I->S, 0.0);
   HIPCHK(hipMalloc((void **)&I->d_site_lnl, I->P * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_site_lk, I->P * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_site_cat, (size_t)I->P * I->C * sizeof(double)));
-  HIPCHK(hipMalloc((void **)&I->d_fact, I->P * sizeof(int)));
-  HIPCHK(hipMemset(I->d_fact, 0, I->P * sizeof(int)));
+  HIPCHK(hipMalloc((void **)&I->d_fact, I->P * NE * sizeof(int))); // class axis: [class][pattern]
+  HIPCHK(hipMemset(I->d_fact, 0, I->P * NE * sizeof(int)));
   HIPCHK(hipMalloc((void **)&I->d_dot, be * sizeof(double)));
   HIPCHK(hipMemset(I->d_dot, 0, be * sizeof(double)));
 
@@ -1344,8 +1357,9 @@ int phyhip_set_state_frequencies(int instance, int idx, const double *pi)
 {
   if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_set_state_frequencies(id, idx, pi); });
   GET_INST(I, instance);
-  if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "stateFrequenciesIndex must be 0");
-  return small_upload(I, I->d_pi, pi, I->S);
+  // (class axis: idx is the class, as BEAGLE's stateFrequenciesIndex selects a frequency buffer)
+  if (idx < 0 || idx >= I->NE) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "stateFrequenciesIndex %d (0..%d)", idx, I->NE - 1);
+  return small_upload(I, I->d_pi + (size_t)idx * I->S, pi, I->S);
 }
 
 int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, const double *ivec, const double *eval)
@@ -1353,13 +1367,14 @@ int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, co
   if (Group *G = get_group(instance))
     return group_each(G, [&](int id, long long, long long) { return phyhip_set_eigen_decomposition(id, idx, evec, ivec, eval); });
   GET_INST(I, instance);
-  if (idx != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
-  I->h_eval.assign(eval, eval + I->S);
-  int rc = small_upload(I, I->d_evec, evec, (size_t)I->S * I->S);
+  if (idx < 0 || idx >= I->NE) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex %d (0..%d)", idx, I->NE - 1);
+  std::copy(eval, eval + I->S, I->h_eval.begin() + (size_t)idx * I->S);
+  const size_t SS = (size_t)I->S * I->S;
+  int rc = small_upload(I, I->d_evec + idx * SS, evec, SS);
   if (rc) return rc;
-  rc = small_upload(I, I->d_ivec, ivec, (size_t)I->S * I->S);
+  rc = small_upload(I, I->d_ivec + idx * SS, ivec, SS);
   if (rc) return rc;
-  return small_upload(I, I->d_eval, eval, I->S);
+  return small_upload(I, I->d_eval + (size_t)idx * I->S, eval, I->S);
 }
 
 int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br_len_mult, int apply_lk_scaling)
@@ -1535,6 +1550,7 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "derivatives: use phyhip_calculate_eigen_lnl_dlnl (PhyML's dLk path)");
   if ((cw && cw[0] != 0) || (sf && sf[0] != 0)) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "weights/frequencies index must be 0");
   if (G) return group_edge_lnl(G, parent[0], child[0], pm[0], outSum);
+  if (I->class_axis) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "class-axis instance: use phyhip_calculate_class_mixture_log_likelihood");
   int rc = check_partial_index(I, parent[0], true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, child[0], true))) return rc;
@@ -1598,7 +1614,7 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
     q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
   }
   q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
-  q.wght = I0->d_wght; q.site_lnl = I0->d_site_lnl;
+  q.wght = I0->d_wght; q.site_lnl = I0->d_site_lnl; q.cat_stride = 1;
   const int grid = (int)((I0->P + 255) / 256);
   q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
   q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
@@ -1675,7 +1691,7 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
       q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
     }
     q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
-    q.expl = I0->d_mixexpl; q.wght = I0->d_wght;
+    q.expl = I0->d_mixexpl; q.wght = I0->d_wght; q.dot_stride = S_;
     const int grid = (int)((I0->P + 255) / 256);
     q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
     q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
@@ -1691,6 +1707,97 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
   if ((rc = wait_result(I0))) return rc;
   *outLnL = I0->h_result[0];
   if (outDLnL) *outDLnL = I0->h_result[1];
+  return PHYHIP_SUCCESS;
+}
+
+// ---- mixtures on the class axis of ONE instance --------------------------------------------------------------------
+
+int phyhip_calculate_class_mixture_log_likelihood(int instance, int parent, int child, int pm, const double *classProba,
+                                                  const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
+                                                  double eFrqWeightSum, double sumProbas, double *outLnL)
+{
+  GET_INST(I, instance);
+  if (!I->class_axis) return fail(PHYHIP_ERROR_GENERAL, "instance %d was not created with PHYHIP_FLAG_CLASS_AXIS", instance);
+  int rc = check_partial_index(I, parent, true);
+  if (rc) return rc;
+  if ((rc = check_partial_index(I, child, true))) return rc;
+  if (pm < 0 || pm >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm);
+  // ONE traversal launch for all classes (queued updates + the per-class edge likelihoods and scale exponents) ...
+  EdgeEval ee{parent, child, pm, nullptr, false, nullptr};
+  if ((rc = flush(I, &ee))) return rc;
+  // ... and the site loop of MIXT_Lk (src/mixt.c:1027-1135) over them
+  MixParams q;
+  memset(&q, 0, sizeof q);
+  for (int k = 0; k < I->C; ++k)
+  {
+    q.site_cat[k] = I->d_site_cat + k; q.fact[k] = I->d_fact + (size_t)k * I->P;
+    q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
+  }
+  q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
+  q.wght = I->d_wght; q.site_lnl = I->d_site_lnl; q.cat_stride = I->C;
+  const int grid = (int)((I->P + 255) / 256);
+  q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
+  q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
+  q.fin.seq = ++I->seq;
+  hipLaunchKernelGGL(mixture_combine_kernel, dim3(grid), dim3(256), 0, I->stream, q);
+  HIPCHK(hipGetLastError());
+  if ((rc = wait_result(I))) return rc;
+  *outLnL = I->h_result[0];
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_calculate_class_mixture_eigen_lnl_dlnl(int instance, int left, int right, double *l, const double *classProba,
+                                                  const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
+                                                  double eFrqWeightSum, double sumProbas, double *outLnL, double *outDLnL)
+{
+  GET_INST(I, instance);
+  if (!I->class_axis) return fail(PHYHIP_ERROR_GENERAL, "instance %d was not created with PHYHIP_FLAG_CLASS_AXIS", instance);
+  if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN");
+  if (*l < I->l_min) *l = I->l_min; // src/lk.c:672-673 (dLk clamps before diverting to MIXT_dLk)
+  else if (*l > I->l_max) *l = I->l_max;
+  int rc = check_partial_index(I, left, true);
+  if (rc) return rc;
+  if ((rc = check_partial_index(I, right, true))) return rc;
+  if ((rc = flush(I, nullptr))) return rc; // queued partial updates write the scale vectors read below
+  std::vector<double> expl((size_t)I->C * 2 * I->S);
+  for (int k = 0; k < I->C; ++k)
+  { // src/mixt.c:3056-3114
+    const double rr  = 1.0 * I->br_len_mult * I->h_rates[k];
+    double       len = (*l) * rr;
+    if (len < I->l_min) len = I->l_min;
+    else if (len > I->l_max) len = I->l_max;
+    for (int s = 0; s < I->S; ++s)
+    {
+      const double ev = I->h_eval[(size_t)k * I->S + s], ex = exp(ev * len);
+      expl[(size_t)k * 2 * I->S + 2 * s]     = ex;
+      expl[(size_t)k * 2 * I->S + 2 * s + 1] = ex * ev * rr;
+    }
+  }
+  void        *st = nullptr;
+  const size_t eb = expl.size() * sizeof(double);
+  if ((rc = I->ring.alloc(eb, I->stream, &st))) return rc;
+  memcpy(st, expl.data(), eb);
+  HIPCHK(hipMemcpyAsync(I->d_mixexpl, st, eb, hipMemcpyHostToDevice, I->stream));
+  MixDlkParams<20> q;
+  memset(&q, 0, sizeof q);
+  for (int k = 0; k < I->C; ++k)
+  {
+    q.dot[k]     = I->d_dot + (size_t)k * I->S;
+    q.scale_l[k] = left < I->tips ? nullptr : I->d_scales + (size_t)(left - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
+    q.scale_r[k] = right < I->tips ? nullptr : I->d_scales + (size_t)(right - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
+    q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
+  }
+  q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
+  q.expl = I->d_mixexpl; q.wght = I->d_wght; q.dot_stride = I->C * I->S;
+  const int grid = (int)((I->P + 255) / 256);
+  q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
+  q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
+  q.fin.seq = ++I->seq;
+  hipLaunchKernelGGL((mixture_dlk_kernel<20>), dim3(grid), dim3(256), 0, I->stream, q);
+  HIPCHK(hipGetLastError());
+  if ((rc = wait_result(I))) return rc;
+  *outLnL = I->h_result[0];
+  if (outDLnL) *outDLnL = I->h_result[1];
   return PHYHIP_SUCCESS;
 }
 
@@ -1718,7 +1825,7 @@ int phyhip_get_site_outputs(int instance, double *c_lnL_sorted, double *cur_site
   if (c_lnL_sorted) HIPCHK(hipMemcpy(c_lnL_sorted, I->d_site_lnl, I->P * sizeof(double), hipMemcpyDeviceToHost));
   if (cur_site_lk) HIPCHK(hipMemcpy(cur_site_lk, I->d_site_lk, I->P * sizeof(double), hipMemcpyDeviceToHost));
   if (unscaled) HIPCHK(hipMemcpy(unscaled, I->d_site_cat, (size_t)I->P * I->C * sizeof(double), hipMemcpyDeviceToHost));
-  if (fact) HIPCHK(hipMemcpy(fact, I->d_fact, I->P * sizeof(int), hipMemcpyDeviceToHost));
+  if (fact) HIPCHK(hipMemcpy(fact, I->d_fact, I->P * I->NE * sizeof(int), hipMemcpyDeviceToHost)); // class axis: [class][pattern]
   return PHYHIP_SUCCESS;
 }
 
@@ -1746,6 +1853,18 @@ int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *o
   return PHYHIP_SUCCESS;
 }
 
+int phyhip_get_class_scale_factors(int instance, int bufferIndex, int classIndex, int *out)
+{
+  GET_INST(I, instance);
+  int rc = check_partial_index(I, bufferIndex, false);
+  if (rc) return rc;
+  if (classIndex < 0 || classIndex >= (I->class_axis ? I->C : 1)) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "class index %d", classIndex);
+  if ((rc = flush_sync(I))) return rc;
+  HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * scale_elems(I) + (size_t)classIndex * I->Ppad, I->P * sizeof(int),
+                   hipMemcpyDeviceToHost));
+  return PHYHIP_SUCCESS;
+}
+
 int phyhip_get_scale_factors(int instance, int bufferIndex, int *out)
 {
   if (Group *G = get_group(instance))
@@ -1754,7 +1873,7 @@ int phyhip_get_scale_factors(int instance, int bufferIndex, int *out)
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
   if ((rc = flush_sync(I))) return rc;
-  HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * I->Ppad, I->P * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * scale_elems(I), I->P * sizeof(int), hipMemcpyDeviceToHost));
   return PHYHIP_SUCCESS;
 }
 
@@ -1766,7 +1885,7 @@ int phyhip_set_scale_factors(int instance, int bufferIndex, const int *in)
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
   if ((rc = flush_sync(I))) return rc;
-  HIPCHK(hipMemcpy(I->d_scales + (size_t)(bufferIndex - I->tips) * I->Ppad, in, I->P * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(I->d_scales + (size_t)(bufferIndex - I->tips) * scale_elems(I), in, I->P * sizeof(int), hipMemcpyHostToDevice));
   return PHYHIP_SUCCESS;
 }
 

@@ -169,7 +169,9 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
   const size_t    frag_mat   = (size_t)C * 2 * kAaBlock;   // doubles per matrix in afrag
   const unsigned  blk_bytes  = (unsigned)(((size_t)tile * tile_elems + (size_t)c * kAaBlock) * 8);
   const unsigned  voff_d16 = blk_bytes + lane * 16, voff_d8 = blk_bytes + 2048 + lane * 8; // chunk pairs | chunk 4
-  const unsigned  voff_s = (unsigned)p0 * 4u, voff_t = (unsigned)p0;
+  // class axis (mixture classes as categories): every class has its own scale vector, [buffer][class][pattern]
+  const bool      cls    = q.class_axis != 0;
+  const unsigned  voff_s = ((cls ? (unsigned)c * (unsigned)q.Ppad : 0u) + (unsigned)p0) * 4u, voff_t = (unsigned)p0;
   const unsigned  voff_a16 = (unsigned)c * 2 * kAaBlock * 8 + lane * 16; // this category's A table, this lane's pairs
 
   __shared__ unsigned xchm[2][CP][16]; // per-pattern maxima (high words), double-buffered by step parity
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
       }
       mxh = maxu4(mxh);
       PHY_STAMP(k, 4)
-      if (CP > 1 && !(ablate & 2))
-      { // maximum over the categories of the pattern: one LDS round trip, one barrier
+      if (CP > 1 && !(ablate & 2) && !cls)
+      { // maximum over the categories of the pattern: one LDS round trip, one barrier (a mixture class rescales alone)
         if (kk == 0) xchm[parity][c][pp] = mxh;
         __syncthreads();
 #pragma unroll
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
         const double *src = q.partials + (size_t)(idx - tips) * buf_elems + (size_t)tile * tile_elems + (size_t)c * kAaBlock;
 #pragma unroll
         for (int t = 0; t < T; ++t) v[t] = src[aa_slot(t, lane)];
-        sc = (unsigned)q.scales[(size_t)(idx - tips) * q.Ppad + p0];
+        sc = (unsigned)q.scales[((size_t)(idx - tips) * (cls ? C : 1) + (cls ? c : 0)) * q.Ppad + p0];
       }
     };
     __syncthreads();
@@ -456,11 +458,17 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
       load_afrag(A, (unsigned)((size_t)q.e_pm * frag_mat * 8));
       matvec(A, x, u); // rows: right-side state
     }
+    const double *pi_c = q.pi + (cls ? c * 20 : 0);
     double part = 0.0;
 #pragma unroll
-    for (int t = 0; t < T; ++t) part += u[t] * (y[t] * q.pi[4 * t + kk]);
+    for (int t = 0; t < T; ++t) part += u[t] * (y[t] * pi_c[4 * t + kk]);
     const double lkc = sum4(part);
     if (pact && kk == 0 && q.site_cat) q.site_cat[(size_t)p0 * C + c] = lkc;
+    if (cls)
+    { // per class: its likelihood (above) and its scale exponent; the mixture is combined by class_combine_kernel
+      if (pact && kk == 0) q.fact[(size_t)c * q.P + p0] = q.apply_scaling ? (int)(sl + sr) : 0;
+      return;
+    }
     if (kk == 0) xchl[c][pp] = lkc;
     __syncthreads();
     if (c == 0 && kk == 0 && pact)

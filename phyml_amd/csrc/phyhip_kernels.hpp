@@ -128,6 +128,11 @@ struct TreeParams
   // draw, no waiting for the workgroup's result stores (see fuse_reduce() in phyhip.hip for what those cost).
   HostBlock      *host_blocks;   // [gridDim.x] or nullptr
   unsigned long long host_tag;   // sequence number of this evaluation
+  // Class axis (mixtures of class models on ONE instance, src/mixt.c): "category" c is class c of the mixture -- its own
+  // eigen system / frequencies (pi[c][S], matrices built per class), its own scale vector per partials buffer
+  // ([buffer][class][pattern]: every class tree rescales on its own, src/mixt.c:2603-2640), no mixing over categories in
+  // the edge evaluation (per-class likelihoods and scale exponents go out, class_combine_kernel repeats MIXT_Lk's site loop).
+  int             class_axis;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1014,19 +1019,21 @@ __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
   int               sl, sr;
   load_side<S, CP>(q, e.ro, e.left, p, c, x, sl);
   load_side<S, CP>(q, e.ro, e.rght, p, c, y, sr);
+  const int co = q.class_axis ? c : 0; // class axis: per-class frequencies and eigenvectors
+  const double *__restrict__ rev = e.r_e_vect + (size_t)co * S * S, *__restrict__ lev = e.l_e_vect + (size_t)co * S * S;
 #pragma unroll
-  for (int i = 0; i < S; ++i) lp[i] = x[i] * q.pi[i]; // src/avx.c:79
+  for (int i = 0; i < S; ++i) lp[i] = x[i] * q.pi[co * S + i]; // src/avx.c:79
   double d[S];
 #pragma unroll
   for (int k = 0; k < S; ++k)
   { // a[k] = sum_i R[i][k] lp[i];  b[k] = sum_i L[k][i] y[i]  (column-wise FMA chains, src/avx.c:81-82)
-    double a = e.r_e_vect[k] * lp[0];
-    double b = e.l_e_vect[k * S] * y[0];
+    double a = rev[k] * lp[0];
+    double b = lev[k * S] * y[0];
 #pragma unroll
     for (int i = 1; i < S; ++i)
     {
-      a = __builtin_fma(e.r_e_vect[i * S + k], lp[i], a);
-      b = __builtin_fma(e.l_e_vect[k * S + i], y[i], b);
+      a = __builtin_fma(rev[i * S + k], lp[i], a);
+      b = __builtin_fma(lev[k * S + i], y[i], b);
     }
     d[k] = a * b;
   }
@@ -1215,8 +1222,9 @@ struct MixParams
 {
   int           count;
   long long     P;
-  const double *site_cat[kMaxMixClasses]; // per class: [P] (C = 1)
+  const double *site_cat[kMaxMixClasses]; // per class: [P] (C = 1), or base + class with cat_stride = C (class axis)
   const int    *fact[kMaxMixClasses];
+  int           cat_stride;
   double        proba[kMaxMixClasses], r_w[kMaxMixClasses], e_w[kMaxMixClasses];
   double        r_sum, e_sum, sum_probas;
   const double *wght;
@@ -1235,7 +1243,7 @@ __global__ __launch_bounds__(256) void mixture_combine_kernel(const MixParams q)
     {
       int s = q.fact[k][p];
       if (s > 1024) { s = 1023; raise_warn(q.fin.warn); }
-      const double x = ldexp(q.site_cat[k][p], -s); // == site_lk_cat / pow(2, sum): exact power-of-two scaling
+      const double x = ldexp(q.site_cat[k][(size_t)p * q.cat_stride], -s); // == site_lk_cat / pow(2, sum): exact power-of-two scaling
       site_lk += x * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
     }
     if (site_lk < kSmall) { site_lk = kSmall; raise_warn(q.fin.warn); }
@@ -1265,7 +1273,8 @@ template <int S> struct MixDlkParams
 {
   int           count;
   long long     P;
-  const double *dot[kMaxMixClasses];                 // per class: dot_prod [P][S]
+  const double *dot[kMaxMixClasses];                 // per class: dot_prod [P][S] (dot_stride = S), or base + class * S with dot_stride = C * S
+  int           dot_stride;
   const int    *scale_l[kMaxMixClasses], *scale_r[kMaxMixClasses]; // scale exponents of the two edge sides (nullptr: tip)
   double        proba[kMaxMixClasses], r_w[kMaxMixClasses], e_w[kMaxMixClasses];
   double        r_sum, e_sum, sum_probas;
@@ -1284,7 +1293,7 @@ template <int S> __global__ __launch_bounds__(256) void mixture_dlk_kernel(const
     double       site_lk = 0.0, site_dlk = 0.0;
     for (int k = 0; k < q.count; ++k)
     {
-      const double2 *s2 = reinterpret_cast<const double2 *>(q.dot[k] + (size_t)p * S);
+      const double2 *s2 = reinterpret_cast<const double2 *>(q.dot[k] + (size_t)p * q.dot_stride);
       const double  *ex = q.expl + (size_t)k * 2 * S;
       double         z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
 #pragma unroll
@@ -1349,6 +1358,7 @@ struct PmatParams
   double        br_len_mult, l_min, l_max;
   double       *pmats;
   double       *afrag;       // 20-state MFMA A-operand copy (nullptr otherwise)
+  int           class_axis;  // U, V, R are [C] eigen systems: category c is class c of a mixture
 };
 
 __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
@@ -1369,9 +1379,10 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
   }
   double *tmp  = expt + C * S;         // [C][S][S] floored, un-normalised entries
   double *rsum = tmp + C * S * S;      // [C][S]
+  const int NE = q.class_axis ? C : 1; // eigen systems
   double *Us   = rsum + C * S;         // eigenvectors staged once per block
-  double *Vs   = Us + S * S;
-  for (int t = threadIdx.x; t < S * S; t += blockDim.x)
+  double *Vs   = Us + NE * S * S;
+  for (int t = threadIdx.x; t < NE * S * S; t += blockDim.x)
   {
     Us[t] = q.U[t];
     Vs[t] = q.V[t];
@@ -1383,15 +1394,16 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
     len *= q.br_len_mult;                             // :2297
     if (len < q.l_min) len = q.l_min;                 // :2299-2300
     else if (len > q.l_max) len = q.l_max;
-    expt[t] = exp(q.R[k] * len);                      // src/models.c:275
+    expt[t] = exp(q.R[(q.class_axis ? c * S : 0) + k] * len); // src/models.c:275
   }
   __syncthreads();
   // one thread per entry: acc = sum_k (U[i][k]*expt[c][k]) * V[k][j], ascending k with FMA (src/models.c:278-292)
   for (int e = threadIdx.x; e < C * S * S; e += blockDim.x)
   {
     const int c = e / (S * S), i = (e / S) % S, j = e % S;
+    const double *Uc = Us + (q.class_axis ? c * S * S : 0), *Vc = Vs + (q.class_axis ? c * S * S : 0);
     double    acc = 0.0;
-    for (int k = 0; k < S; ++k) acc = __builtin_fma(Us[i * S + k] * expt[c * S + k], Vs[k * S + j], acc);
+    for (int k = 0; k < S; ++k) acc = __builtin_fma(Uc[i * S + k] * expt[c * S + k], Vc[k * S + j], acc);
     tmp[e] = (acc < kSmallPij) ? kSmallPij : acc; // :293
   }
   __syncthreads();

@@ -92,7 +92,7 @@ class LkTree:
     """Owns a C `t_tree` + `t_mod`.  Methods are one-line forwards to the C functions of the same name."""
 
     def __init__(self, n_otu, edge_left, edge_rght, edge_len, n_pattern, ns, ncatg, device=None, node_v=None,
-                 node_b=None, host_pmat=False, devices=None, force_sharded=False):
+                 node_b=None, host_pmat=False, devices=None, force_sharded=False, class_axis=False):
         L = load()
         self.L = L
         self.n, self.P, self.S, self.C = int(n_otu), int(n_pattern), int(ns), int(ncatg)
@@ -111,6 +111,7 @@ class LkTree:
         # multi-GPU: pattern shards over `devices` inside libphyhip.so (one RCCL all-reduce per evaluation)
         self.devices = None if devices is None else [int(x) for x in devices]
         self.force_sharded = bool(force_sharded)
+        self.class_axis = bool(class_axis)  # categories = classes of a mixture (PHYHIP_FLAG_CLASS_AXIS)
         self._made = False
         self.inst = None
 
@@ -135,9 +136,11 @@ class LkTree:
         w = np.ascontiguousarray(wght, dtype=np.float64); assert w.size == self.P
         iv = None if invar is None else np.ascontiguousarray(invar, dtype=np.int16)
         ivp = None if iv is None else iv.ctypes.data_as(C.c_void_p)
-        if self.devices is not None:
-            dv = (C.c_int * len(self.devices))(*self.devices)
-            self.L.Make_Tree_For_Lk_On_Devices(self.tree, self.P, _dp(w), ivp, dv, len(self.devices), int(self.force_sharded))
+        if self.devices is not None or self.class_axis:
+            devs = self.devices if self.devices is not None else ([self.device] if self.device >= 0 else [])
+            dv = (C.c_int * max(1, len(devs)))(*devs)
+            self.L.Make_Tree_For_Lk_On_Devices(self.tree, self.P, _dp(w), ivp, dv, len(devs),
+                                               (1 if self.force_sharded else 0) | (2 if self.class_axis else 0))
         else:
             self.L.Make_Tree_For_Lk(self.tree, self.P, _dp(w), ivp, self.device)
         _raise_if_error()

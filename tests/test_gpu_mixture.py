@@ -85,3 +85,91 @@ def test_lg4x_mixture_dlk_on_device(host_pmat):
     finally:
         for t in trees:
             t.close()
+
+
+def _class_axis_tree(d, models, tv, host_matrices):
+    """ONE instance whose four categories are the four LG4X classes (PHYHIP_FLAG_CLASS_AXIS): class rates as category
+    rates, per-class frequencies / eigen systems pushed by index, matrices built on the device per class -- or computed per
+    class by the oracle's PMat and uploaded (the bit-exact route)."""
+    import orc
+    n, P, S, K = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0]), len(models)
+    t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, K, host_pmat=False, class_axis=True)
+    t.tip_root = 0
+    m0 = models[0]
+    rates = np.array([float(md["gamma_rr"][0]) for md in models])
+    t.set_model(m0["pi"], rates, np.full(K, 1.0 / K), m0["e_val"], m0["r_e_vect"], m0["l_e_vect"], float(m0["l_min"][0]),
+                float(m0["l_max"][0]), float(m0["br_len_mult"][0]), 1, 0, 0.0)
+    t.Make_Tree_For_Lk(d["wght"], None)
+    for k, md in enumerate(models):
+        t.inst.set_state_frequencies(md["pi"], index=k)
+        t.inst.set_eigen_decomposition(md["r_e_vect"], md["l_e_vect"], md["e_val"], index=k)
+    t.set_tips(tip_partials=tv)
+    if host_matrices:
+        for e in range(t.ne):
+            pm = np.concatenate([orc.pmat_edge(float(d["edge_len"][e]), S, 1, md["gamma_rr"], float(md["br_len_mult"][0]),
+                                               float(md["l_min"][0]), float(md["l_max"][0]), md["r_e_vect"], md["l_e_vect"], md["e_val"])
+                                 for md in models])
+            t.inst.set_transition_matrix(t.edge(e).contents.Pij_rr_idx, pm)
+    else:
+        for e in range(t.ne):
+            t.Update_PMat_At_Given_Edge(e)
+    return t
+
+
+@pytest.mark.parametrize("host_matrices", [True, False])
+def test_lg4x_mixture_on_the_class_axis(host_matrices):
+    """The same evaluation as test_lg4x_mixture_on_device with the four classes on the category axis of ONE instance:
+    one traversal launch for all classes + the combination, against the reference's dump -- mixture lnL, per-site
+    log-likelihoods, per-class likelihoods and per-class scale exponents."""
+    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x.phyg"))
+    models, factors = replay.mixture_classes(d)
+    S, K = int(d["ns"][0]), len(models)
+    tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
+    t = _class_axis_tree(d, models, tv, host_matrices)
+    try:
+        root = t.node(0).contents.v[0].contents.num
+        t.Post_Order_Lk(0, root)     # queues every update once; all classes run in the one launch below
+        e = int(d["eval_edge"][0])
+        lnl = t.inst.class_mixture_log_likelihood(t.side_buffer(e, 0), t.side_buffer(e, 1), t.edge(e).contents.Pij_rr_idx,
+                                                  [f[0] for f in factors], [f[1] for f in factors], [f[2] for f in factors],
+                                                  float(d["r_mat_weight_sum"][0]), float(d["e_frq_weight_sum"][0]),
+                                                  float(d["sum_probas"][0]))
+        ref = float(d["lnL"][0])
+        assert abs(lnl - ref) <= (1e-13 if host_matrices else 1e-11) * abs(ref), (lnl, ref)
+        logs = t.inst.site_log_likelihoods()
+        assert np.max(np.abs(logs - d["c_lnL_sorted"])) < (1e-11 if host_matrices else 1e-9)
+        _, _, u, f = t.inst.site_outputs(n_fact=K)
+        u = np.asarray(u).reshape(-1, K); f = np.asarray(f).reshape(K, -1)
+        for k in range(K):
+            assert np.array_equal(f[k], d[f"class{k}_fact"])
+            ref_u = d[f"class{k}_unscaled_site_lk_cat"]
+            assert np.max(np.abs(u[:, k] - ref_u) / ref_u) < (1e-13 if host_matrices else 1e-10)
+    finally:
+        t.close()
+
+
+@pytest.mark.parametrize("host_matrices", [True, False])
+def test_lg4x_mixture_dlk_on_the_class_axis(host_matrices):
+    """MIXT_dLk on the class axis: both sides of every edge for all classes in two launches, per-class eigen products in
+    one, the combination in one."""
+    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
+    models, factors = replay.mixture_classes(d)
+    S = int(d["ns"][0])
+    tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
+    e = int(d["eval_edge"][0])
+    t = _class_axis_tree(d, models, tv, host_matrices)
+    try:
+        root = t.node(0).contents.v[0].contents.num
+        t.Post_Order_Lk(0, root)
+        t.Pre_Order_Lk(0, root)
+        t.Update_Eigen_Lr(e)
+        lv, lnl, dlnl = t.inst.class_mixture_eigen_lnl_dlnl(t.side_buffer(e, 0), t.side_buffer(e, 1), float(d["dlk_l"][0]),
+                                                          [f[0] for f in factors], [f[1] for f in factors], [f[2] for f in factors],
+                                                          float(d["r_mat_weight_sum"][0]), float(d["e_frq_weight_sum"][0]),
+                                                          float(d["sum_probas"][0]))
+        ref_lnl, ref_dlnl = float(d["lnL"][0]), float(d["dlnL"][0])
+        tol = 1e-12 if host_matrices else 1e-10
+        assert abs(lnl - ref_lnl) <= tol * abs(ref_lnl), (lnl, ref_lnl)
+        assert abs(dlnl - ref_dlnl) <= 1e-8 * max(1.0, abs(ref_dlnl)), (dlnl, ref_dlnl)
+    finally:
+        t.close()
