@@ -135,7 +135,28 @@ typedef struct
   const void *bufptr[MAXID]; int nbuf, bufcap;
   int        *scaleptr[MAXID]; /* host sum_scale vector of each partials buffer (known once it was a destination) */
   const void *matptr[MAXID]; int nmat, matcap;
+  /* GLUE_CLASS_AXIS=1: the class trees of a mixture share ONE instance whose categories are the classes
+     (PHYHIP_FLAG_CLASS_AXIS).  Every class tree keeps its own pointer tables, but ids are handed out by class 0 only:
+     the reference loops over the class trees for every surface call (MIXT_Update_Partial_Lk, src/mixt.c:1191-1250), so
+     class k > 0 sees exactly the call class 0 just made and registers its pointers under the same ids. */
+  int         cls, K;          /* class index / class count (K = 0: ordinary context) */
 } ctx_t;
+static int g_class_axis = 0;
+/* The partial updates class 0 queued since the last mixture evaluation.  The reference walks the class trees one after
+   the other for a whole traversal (MIXT_Post_Order_Lk, src/mixt.c:656-688: a full post-order per class tree) or one
+   operation at a time (MIXT_Update_Partial_Lk), so class k's j-th call of the batch is class 0's j-th operation. */
+#define MAXCLSOPS 8192
+static phyhip_operation g_cls_ops[MAXCLSOPS];
+static int g_cls_nops = 0, g_cls_pos[kMaxClasses];
+static void cls_batch_done(int K)
+{
+  for (int k = 1; k < K; ++k)
+    if (g_cls_pos[k] != g_cls_nops)
+    { fprintf(stderr, "glue_driver: class tree %d made %d of class 0's %d partial updates before the evaluation\n", k, g_cls_pos[k], g_cls_nops); exit(6); }
+  g_cls_nops = 0;
+  for (int k = 0; k < kMaxClasses; ++k) g_cls_pos[k] = 0;
+}
+static int g_cls_mat = -1;          /* the matrix id class 0 refreshed last */
 static ctx_t g_ctx[MAXCTX];
 static int   g_nctx = 0;
 #define g_inst (g_ctx[0].inst)
@@ -156,6 +177,36 @@ static int mat_id(ctx_t *c, const void *pij)
   c->matptr[c->nmat] = pij;
   return c->nmat++;
 }
+/* class k > 0: the pointer must stand for the id class 0 just used */
+static void mirror_buf(ctx_t *c, const void *p_lk, int id)
+{
+  const int i = id - c->tree->n_otu;
+  if (i < 0) return; /* tip */
+  for (int j = 0; j < c->nbuf; ++j)
+    if (c->bufptr[j] == p_lk)
+    {
+      if (j == i) return;
+      fprintf(stderr, "glue_driver: class tree %d diverged from class 0 (its buffer has id %d, class 0 used %d)\n", c->cls,
+              j + c->tree->n_otu, id);
+      exit(6);
+    }
+  if (c->bufptr[i] != NULL)
+  { fprintf(stderr, "glue_driver: class tree %d diverged from class 0 (partials buffer id %d already taken)\n", c->cls, id); exit(6); }
+  c->bufptr[i] = p_lk;
+  if (i >= c->nbuf) c->nbuf = i + 1;
+}
+static void mirror_mat(ctx_t *c, const void *pij, int id)
+{
+  if (c->matptr[id] == NULL) { c->matptr[id] = pij; if (id >= c->nmat) c->nmat = id + 1; return; }
+  if (c->matptr[id] != pij)
+  {
+    int at = -1;
+    for (int j = 0; j < c->nmat; ++j) if (c->matptr[j] == pij) at = j;
+    fprintf(stderr, "glue_driver: class tree %d diverged from class 0 (matrix id %d holds %p, call has %p which is id %d; nmat %d)\n",
+            c->cls, id, c->matptr[id], pij, at, c->nmat);
+    exit(6);
+  }
+}
 static void edge_sides(ctx_t *c, const t_edge *b, int *left, int *right)
 { /* src/lk.c:605-606 */
   *left  = buf_id(c, b->p_lk_left);
@@ -166,6 +217,20 @@ static void push_model(ctx_t *c)
 { /* update_beagle_ras / _efrqs / _eigen, src/beagle_utils.c:273-395 */
   t_tree *tree = c->tree;
   t_mod  *m = tree->mod;
+  if (c->K > 0)
+  { /* class axis: this class tree's rate, frequencies and eigen system go to class slot c->cls of the shared instance */
+    static double rates[kMaxClasses];
+    rates[c->cls] = m->ras->gamma_rr->v[0] * tree->mixt_tree->mod->ras->gamma_rr->v[m->ras->parent_class_number];
+    if (c->cls == c->K - 1) OK(phyhip_set_category_rates(c->inst, rates)); /* (callers push the classes in order) */
+    OK(phyhip_set_state_frequencies(c->inst, c->cls, m->e_frq->pi->v));
+    OK(phyhip_set_eigen_decomposition(c->inst, c->cls, m->eigen->r_e_vect, m->eigen->l_e_vect, m->eigen->e_val));
+    if (c->cls == 0)
+    {
+      OK(phyhip_set_phyml_options(c->inst, m->l_min, m->l_max, m->br_len_mult->v, tree->apply_lk_scaling));
+      OK(phyhip_set_invariant_sites(c->inst, m->ras->invar, m->ras->pinvar->v, tree->data->invar));
+    }
+    return;
+  }
   if (tree->mixt_tree)
   { /* class tree: one category whose rate is the class rate of the mixture (src/lk.c:2298) */
     const double rate = m->ras->gamma_rr->v[0] * tree->mixt_tree->mod->ras->gamma_rr->v[m->ras->parent_class_number], one = 1.0;
@@ -196,6 +261,37 @@ static ctx_t *ensure_instance(t_tree *tree)
     g_nctx = 0;
   }
   if (g_nctx == MAXCTX) { fprintf(stderr, "glue_driver: too many class trees\n"); exit(5); }
+  if (g_class_axis && tree->mixt_tree && tree->mod->ns == 20)
+  { /* all class trees of the mixture at once: contexts in class order, one instance */
+    int K = 0;
+    for (t_tree *t = tree->mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) ++K;
+    if (K >= 1 && K <= 4 && g_nctx + K <= MAXCTX)
+    {
+      ctx_t *first = NULL, *mine = NULL;
+      int    k = 0;
+      for (t_tree *t = tree->mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, ++k)
+      {
+        ctx_t *c = &g_ctx[g_nctx++];
+        memset(c, 0, sizeof *c);
+        c->tree = t; c->cls = k; c->K = K;
+        c->bufcap = 3 * t->n_otu - 2; c->matcap = 2 * t->n_otu - 1;
+        if (k == 0)
+        {
+          first = c;
+          ++g_n_created;
+          c->inst = phyhip_create_instance(t->n_otu, t->n_otu + c->bufcap, 0, 20, t->data->n_pattern, K, c->matcap, K, 0, NULL, 0,
+                                           0, PHYHIP_FLAG_CLASS_AXIS, NULL);
+          if (c->inst < 0) die("phyhip_create_instance (class axis)");
+          OK(phyhip_set_pattern_weights(c->inst, t->data->wght));
+          for (int i = 0; i < t->n_otu; ++i) OK(phyhip_set_tip_partials(c->inst, t->a_nodes[i]->num, t->a_nodes[i]->b[0]->p_lk_tip_r));
+        }
+        else c->inst = first->inst;
+        if (t == tree) mine = c;
+      }
+      for (ctx_t *c = first; c < first + K; ++c) push_model(c);
+      return mine;
+    }
+  }
   ctx_t *c = &g_ctx[g_nctx++];
   memset(c, 0, sizeof *c);
   ++g_n_created;
@@ -263,6 +359,33 @@ void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
   if (g_host || tree->is_mixt_tree) { real(b_fcus, tree); return; } /* mixture tree: the original loops over the class trees */
   ctx_t *c = ensure_instance(tree);
   if (b_fcus->has_zero_br_len == YES) { fprintf(stderr, "glue_driver: zero-length edge flag not supported\n"); exit(5); }
+  if (c->K > 0)
+  { /* class axis: class 0 names the matrix; the K class blocks are uploaded together when the last class has built its own
+       (or built on the device, per class, from one call: the class trees share the edge length) */
+    int id = -1;
+    if (c->cls == 0) id = g_cls_mat = mat_id(c, b_fcus->Pij_rr);
+    else
+    { /* known pointer: its id (some flows walk one class tree edge by edge); new pointer: the id class 0 just named */
+      for (int j = 0; j < c->nmat; ++j) if (c->matptr[j] == b_fcus->Pij_rr) id = j;
+      if (id < 0) { mirror_mat(c, b_fcus->Pij_rr, g_cls_mat); id = g_cls_mat; }
+    }
+    if (g_device_pmat && !g_check)
+    {
+      const double len = b_fcus->l->v; /* the class trees share the edge length: any class's call rebuilds all classes */
+      OK(phyhip_update_transition_matrices(c->inst, 0, &id, NULL, NULL, &len, 1));
+      return;
+    }
+    real(b_fcus, tree);
+    {
+      const int ss = tree->mod->ns * tree->mod->ns;
+      static double blk[4 * 400];
+      ctx_t *c0 = c - c->cls;
+      for (int k = 0; k < c->K; ++k) if (!(c0 + k)->matptr[id]) return; /* not every class has named this matrix yet */
+      for (int k = 0; k < c->K; ++k) memcpy(blk + (size_t)k * ss, (c0 + k)->matptr[id], sizeof(double) * ss);
+      OK(phyhip_set_transition_matrix(c->inst, id, blk, -1.0)); /* (queued; the last upload of a matrix wins) */
+    }
+    return;
+  }
   const int m = mat_id(c, b_fcus->Pij_rr);
   if (g_device_pmat && !g_check)
   { /* src/lk.c:2344: matrices built on the device from (U, lambda, U^-1, length) */
@@ -291,6 +414,20 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   int    *sum_scale = NULL, *sum_scale_v1 = NULL, *sum_scale_v2 = NULL, *p_lk_loc = NULL;
   Set_All_Partial_Lk(&n_v1, &n_v2, &p_lk, &sum_scale, &p_lk_loc, &Pij1, &tPij1, &p_lk_v1, &sum_scale_v1, &Pij2, &tPij2,
                      &p_lk_v2, &sum_scale_v2, d, b, tree);
+  if (c->K > 0 && c->cls > 0)
+  { /* class axis, class k > 0: the operation class 0 queued covers this class; only register / verify the pointers */
+    if (g_cls_pos[c->cls] >= g_cls_nops) { fprintf(stderr, "glue_driver: class tree %d is ahead of class 0\n", c->cls); exit(6); }
+    const phyhip_operation *o = &g_cls_ops[g_cls_pos[c->cls]++];
+    mirror_buf(c, p_lk, o->destinationPartials);
+    c->scaleptr[o->destinationPartials - tree->n_otu] = sum_scale;
+    if (!n_v1->tax) mirror_buf(c, p_lk_v1, o->child1Partials);
+    if (!n_v2->tax) mirror_buf(c, p_lk_v2, o->child2Partials);
+    if ((n_v1->tax ? n_v1->num : -1) != (o->child1Partials < tree->n_otu ? o->child1Partials : -1) ||
+        (n_v2->tax ? n_v2->num : -1) != (o->child2Partials < tree->n_otu ? o->child2Partials : -1))
+    { fprintf(stderr, "glue_driver: class tree %d diverged from class 0 (tip child)\n", c->cls); exit(6); }
+    if (g_check) real(tree, b, d);
+    return;
+  }
   phyhip_operation op;
   op.destinationPartials = buf_id(c, p_lk);
   c->scaleptr[op.destinationPartials - tree->n_otu] = sum_scale;
@@ -300,6 +437,11 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   op.child2Partials = n_v2->tax ? n_v2->num : buf_id(c, p_lk_v2);
   op.child2TransitionMatrix = mat_id(c, Pij2);
   OK(phyhip_update_partials(c->inst, &op, 1, PHYHIP_OP_NONE));
+  if (c->K > 0)
+  {
+    if (g_cls_nops == MAXCLSOPS) { fprintf(stderr, "glue_driver: too many partial updates between two mixture evaluations\n"); exit(5); }
+    g_cls_ops[g_cls_nops++] = op;
+  }
   if (g_check) real(tree, b, d);
 }
 
@@ -310,6 +452,7 @@ void Update_Eigen_Lr(t_edge *b, t_tree *tree)
   ++g_n_eig;
   if (g_host || tree->is_mixt_tree) { real(b, tree); return; }
   ctx_t *c = ensure_instance(tree);
+  if (c->K > 0 && c->cls > 0) { if (g_check) real(b, tree); return; } /* class axis: class 0's call covered every class */
   int l, r;
   edge_sides(c, b, &l, &r);
   OK(phyhip_update_eigen_lr(c->inst, l, r));
@@ -370,8 +513,12 @@ static int gather_classes(t_edge *e, t_tree *mixt_tree, mix_t *m)
     ctx_t *c = ensure_instance(t);
     push_model(c);
     m->ids[m->K] = c->inst;
-    edge_sides(c, b, &m->lft[m->K], &m->rgt[m->K]);
-    m->pms[m->K] = mat_id(c, b->Pij_rr);
+    if (c->K > 0 && c->cls > 0) m->lft[m->K] = m->rgt[m->K] = m->pms[m->K] = 0; /* class axis: class 0's ids stand for all */
+    else
+    {
+      edge_sides(c, b, &m->lft[m->K], &m->rgt[m->K]);
+      m->pms[m->K] = mat_id(c, b->Pij_rr);
+    }
     m->proba[m->K] = mixt_tree->mod->ras->gamma_r_proba->v[t->mod->ras->parent_class_number];
     m->rw[m->K] = t->mod->r_mat_weight->v; m->ew[m->K] = t->mod->e_frq_weight->v;
     ++m->K;
@@ -380,6 +527,33 @@ static int gather_classes(t_edge *e, t_tree *mixt_tree, mix_t *m)
   m->e_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->e_frq_weight);
   m->sum_p = MIXT_Get_Sum_Of_Probas_Across_Mixtures(m->r_sum, m->e_sum, mixt_tree);
   return 1;
+}
+/* the two mixture evaluations, over class instances or on the class axis of one instance */
+static void mixture_lnl(const mix_t *m, t_tree *mixt_tree, double *lnl)
+{
+  ctx_t *c0 = ensure_instance(mixt_tree->next);
+  if (c0->K > 0)
+  {
+    cls_batch_done(c0->K);
+    OK(phyhip_calculate_class_mixture_log_likelihood(c0->inst, m->lft[0], m->rgt[0], m->pms[0], m->proba, m->rw, m->ew, m->r_sum,
+                                                     m->e_sum, m->sum_p, lnl));
+  }
+  else
+    OK(phyhip_calculate_mixture_log_likelihood(m->ids, m->K, m->lft, m->rgt, m->pms, m->proba, m->rw, m->ew, m->r_sum, m->e_sum,
+                                               m->sum_p, lnl));
+}
+static void mixture_dlnl(const mix_t *m, t_tree *mixt_tree, double *l, double *lnl, double *dlnl)
+{
+  ctx_t *c0 = ensure_instance(mixt_tree->next);
+  if (c0->K > 0)
+  {
+    cls_batch_done(c0->K);
+    OK(phyhip_calculate_class_mixture_eigen_lnl_dlnl(c0->inst, m->lft[0], m->rgt[0], l, m->proba, m->rw, m->ew, m->r_sum, m->e_sum,
+                                                     m->sum_p, lnl, dlnl));
+  }
+  else
+    OK(phyhip_calculate_mixture_eigen_lnl_dlnl(m->ids, m->K, m->lft, m->rgt, l, m->proba, m->rw, m->ew, m->r_sum, m->e_sum, m->sum_p,
+                                               lnl, dlnl));
 }
 static int mixture_supported(const t_tree *mixt_tree)
 {
@@ -419,7 +593,7 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
     if (!mixture_supported(mixt_tree) || mixt_tree->next->use_eigen_lr == YES || !gather_classes(e, mixt_tree, &m))
     { ++g_n_mixt_skipped; return ref; } /* eigen-basis Lk, partitions and +I mixtures: not on the device */
     double lnl = 0.0;
-    OK(phyhip_calculate_mixture_log_likelihood(m.ids, m.K, m.lft, m.rgt, m.pms, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl));
+    mixture_lnl(&m, mixt_tree, &lnl);
     track(&g_worst_mixt, lnl, ref, 1.0);
     if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
     return ref;
@@ -455,7 +629,7 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
   }
   if (!gather_classes(e, mixt_tree, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
   double lnl = 0.0;
-  OK(phyhip_calculate_mixture_log_likelihood(m.ids, m.K, m.lft, m.rgt, m.pms, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl));
+  mixture_lnl(&m, mixt_tree, &lnl);
   mixt_tree->numerical_warning = NO;
   {
     int w = 0;
@@ -485,7 +659,7 @@ phydbl MIXT_dLk(phydbl *l, t_edge *mixt_b, t_tree *mixt_tree)
     const phydbl ref = real(l, mixt_b, mixt_tree);
     if (!mixture_supported(mixt_tree) || !gather_classes(mixt_b, mixt_tree, &m)) { ++g_n_mixt_skipped; return ref; }
     double lnl = 0.0, dlnl = 0.0;
-    OK(phyhip_calculate_mixture_eigen_lnl_dlnl(m.ids, m.K, m.lft, m.rgt, &x, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl, &dlnl));
+    mixture_dlnl(&m, mixt_tree, &x, &lnl, &dlnl);
     track(&g_worst_mixt, lnl, ref, 1.0);
     track(&g_worst_mixt_dlnl, dlnl, mixt_tree->c_dlnL, 1.0);
     if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
@@ -500,7 +674,7 @@ phydbl MIXT_dLk(phydbl *l, t_edge *mixt_b, t_tree *mixt_tree)
   }
   if (!gather_classes(mixt_b, mixt_tree, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
   double lnl = 0.0, dlnl = 0.0;
-  OK(phyhip_calculate_mixture_eigen_lnl_dlnl(m.ids, m.K, m.lft, m.rgt, l, m.proba, m.rw, m.ew, m.r_sum, m.e_sum, m.sum_p, &lnl, &dlnl));
+  mixture_dlnl(&m, mixt_tree, l, &lnl, &dlnl);
   for (t_tree *t = mixt_tree; t; t = t->next) { t->c_lnL = .0; t->c_dlnL = .0; } /* :3026-3032 */
   mixt_tree->c_lnL  = lnl;
   mixt_tree->c_dlnL = dlnl;
@@ -643,6 +817,7 @@ int main(int argc, char **argv)
   g_check = mode && !strcmp(mode, "check");
   g_host  = mode && !strcmp(mode, "host");
   g_device_pmat = getenv("GLUE_DEVICE_PMAT") && atoi(getenv("GLUE_DEVICE_PMAT"));
+  g_class_axis  = getenv("GLUE_CLASS_AXIS") && atoi(getenv("GLUE_CLASS_AXIS"));
 
   const double t0 = now_s();
   g_t0 = t0;

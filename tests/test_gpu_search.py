@@ -111,8 +111,11 @@ def test_real_search_with_device_built_matrices(tmp_path):
     assert info["lnL_final"] > info["lnL_init"] + 10.0
 
 
-def test_lg4x_mixture_analysis_check_mode(tmp_path):
-    """The reference's LG4X mixture analysis (examples/lg4x: four class trees, free rates, SPR + parameter optimisation,
+@pytest.mark.parametrize("class_axis", [False, True], ids=["instance_per_class", "class_axis"])
+def test_lg4x_mixture_analysis_check_mode(class_axis, tmp_path):
+    """(class_axis: the four class trees on the category axis of ONE instance -- PHYHIP_FLAG_CLASS_AXIS, GLUE_CLASS_AXIS=1 --
+    one traversal launch per mixture evaluation instead of four.)
+    The reference's LG4X mixture analysis (examples/lg4x: four class trees, free rates, SPR + parameter optimisation,
     XML mode) with the class trees mirrored on the device: every MIXT_Lk evaluation at the P-matrix level is repeated by
     phyhip_calculate_mixture_log_likelihood, every MIXT_dLk by phyhip_calculate_mixture_eigen_lnl_dlnl, over the four class
     instances, and compared (first 6000 evaluations)."""
@@ -123,7 +126,7 @@ def test_lg4x_mixture_analysis_check_mode(tmp_path):
     for f in os.listdir(os.path.join(GOLDEN, "lg4x")):
         shutil.copy(os.path.join(GOLDEN, "lg4x", f), os.path.join(base, "examples", "lg4x", f))
     shutil.copy(os.path.join(GOLDEN, "examples_proteic.phy"), os.path.join(base, "examples", "proteic"))
-    env = dict(os.environ, GLUE_MODE="check", GLUE_MAX_MIXT="6000")
+    env = dict(os.environ, GLUE_MODE="check", GLUE_MAX_MIXT="6000", GLUE_CLASS_AXIS="1" if class_axis else "0")
     r = subprocess.run([GLUE, "--", "--xml=../examples/lg4x/lg4x_check.xml"], cwd=os.path.join(base, "run"), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
@@ -136,7 +139,9 @@ def test_lg4x_mixture_analysis_check_mode(tmp_path):
     assert info["worst_rel_mixture_dlnL"] < 1e-6, info
 
 
-def test_lg4x_mixture_analysis_driven_by_the_device(tmp_path):
+@pytest.mark.parametrize("class_axis,device_pmat", [(False, False), (True, False), (True, True)],
+                         ids=["instance_per_class", "class_axis", "class_axis_device_matrices"])
+def test_lg4x_mixture_analysis_driven_by_the_device(class_axis, device_pmat, tmp_path):
     """The same analysis with MIXT_Lk / MIXT_dLk SERVED by the device (class partials never computed on the host): the
     first 8000 evaluations of the run; the optimiser must be climbing from the initial -12496.58 like the reference does."""
     if not os.path.exists(GLUE):
@@ -146,7 +151,8 @@ def test_lg4x_mixture_analysis_driven_by_the_device(tmp_path):
     for f in os.listdir(os.path.join(GOLDEN, "lg4x")):
         shutil.copy(os.path.join(GOLDEN, "lg4x", f), os.path.join(base, "examples", "lg4x", f))
     shutil.copy(os.path.join(GOLDEN, "examples_proteic.phy"), os.path.join(base, "examples", "proteic"))
-    env = dict(os.environ, GLUE_MODE="device", GLUE_MAX_MIXT="8000")
+    env = dict(os.environ, GLUE_MODE="device", GLUE_MAX_MIXT="8000", GLUE_CLASS_AXIS="1" if class_axis else "0",
+               GLUE_DEVICE_PMAT="1" if device_pmat else "0")
     r = subprocess.run([GLUE, "--", "--xml=../examples/lg4x/lg4x_check.xml"], cwd=os.path.join(base, "run"), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
