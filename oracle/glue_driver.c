@@ -140,21 +140,25 @@ typedef struct
      the reference loops over the class trees for every surface call (MIXT_Update_Partial_Lk, src/mixt.c:1191-1250), so
      class k > 0 sees exactly the call class 0 just made and registers its pointers under the same ids. */
   int         cls, K;          /* class index / class count (K = 0: ordinary context) */
+  void       *batch;           /* clsbatch_t of the element (class-0 context only) */
 } ctx_t;
 static int g_class_axis = 0;
 /* The partial updates class 0 queued since the last mixture evaluation.  The reference walks the class trees one after
    the other for a whole traversal (MIXT_Post_Order_Lk, src/mixt.c:656-688: a full post-order per class tree) or one
    operation at a time (MIXT_Update_Partial_Lk), so class k's j-th call of the batch is class 0's j-th operation. */
 #define MAXCLSOPS 8192
-static phyhip_operation g_cls_ops[MAXCLSOPS];
-static int g_cls_nops = 0, g_cls_pos[kMaxClasses];
-static void cls_batch_done(int K)
+typedef struct
+{ /* one per partition element (= per class-axis instance), hung on the class-0 context */
+  phyhip_operation ops[MAXCLSOPS];
+  int              nops, pos[kMaxClasses];
+} clsbatch_t;
+static void cls_batch_done(clsbatch_t *q, int K)
 {
   for (int k = 1; k < K; ++k)
-    if (g_cls_pos[k] != g_cls_nops)
-    { fprintf(stderr, "glue_driver: class tree %d made %d of class 0's %d partial updates before the evaluation\n", k, g_cls_pos[k], g_cls_nops); exit(6); }
-  g_cls_nops = 0;
-  for (int k = 0; k < kMaxClasses; ++k) g_cls_pos[k] = 0;
+    if (q->pos[k] != q->nops)
+    { fprintf(stderr, "glue_driver: class tree %d made %d of class 0's %d partial updates before the evaluation\n", k, q->pos[k], q->nops); exit(6); }
+  q->nops = 0;
+  for (int k = 0; k < kMaxClasses; ++k) q->pos[k] = 0;
 }
 static int g_cls_mat = -1;          /* the matrix id class 0 refreshed last */
 static ctx_t g_ctx[MAXCTX];
@@ -278,6 +282,7 @@ static ctx_t *ensure_instance(t_tree *tree)
         if (k == 0)
         {
           first = c;
+          c->batch = calloc(1, sizeof(clsbatch_t));
           ++g_n_created;
           c->inst = phyhip_create_instance(t->n_otu, t->n_otu + c->bufcap, 0, 20, t->data->n_pattern, K, c->matcap, K, 0, NULL, 0,
                                            0, PHYHIP_FLAG_CLASS_AXIS, NULL);
@@ -416,8 +421,9 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
                      &p_lk_v2, &sum_scale_v2, d, b, tree);
   if (c->K > 0 && c->cls > 0)
   { /* class axis, class k > 0: the operation class 0 queued covers this class; only register / verify the pointers */
-    if (g_cls_pos[c->cls] >= g_cls_nops) { fprintf(stderr, "glue_driver: class tree %d is ahead of class 0\n", c->cls); exit(6); }
-    const phyhip_operation *o = &g_cls_ops[g_cls_pos[c->cls]++];
+    clsbatch_t *q = (clsbatch_t *)(c - c->cls)->batch;
+    if (q->pos[c->cls] >= q->nops) { fprintf(stderr, "glue_driver: class tree %d is ahead of class 0\n", c->cls); exit(6); }
+    const phyhip_operation *o = &q->ops[q->pos[c->cls]++];
     mirror_buf(c, p_lk, o->destinationPartials);
     c->scaleptr[o->destinationPartials - tree->n_otu] = sum_scale;
     if (!n_v1->tax) mirror_buf(c, p_lk_v1, o->child1Partials);
@@ -439,8 +445,9 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   OK(phyhip_update_partials(c->inst, &op, 1, PHYHIP_OP_NONE));
   if (c->K > 0)
   {
-    if (g_cls_nops == MAXCLSOPS) { fprintf(stderr, "glue_driver: too many partial updates between two mixture evaluations\n"); exit(5); }
-    g_cls_ops[g_cls_nops++] = op;
+    clsbatch_t *q = (clsbatch_t *)c->batch;
+    if (q->nops == MAXCLSOPS) { fprintf(stderr, "glue_driver: too many partial updates between two mixture evaluations\n"); exit(5); }
+    q->ops[q->nops++] = op;
   }
   if (g_check) real(tree, b, d);
 }
@@ -534,7 +541,7 @@ static void mixture_lnl(const mix_t *m, t_tree *mixt_tree, double *lnl)
   ctx_t *c0 = ensure_instance(mixt_tree->next);
   if (c0->K > 0)
   {
-    cls_batch_done(c0->K);
+    cls_batch_done((clsbatch_t *)c0->batch, c0->K);
     OK(phyhip_calculate_class_mixture_log_likelihood(c0->inst, m->lft[0], m->rgt[0], m->pms[0], m->proba, m->rw, m->ew, m->r_sum,
                                                      m->e_sum, m->sum_p, lnl));
   }
@@ -547,7 +554,7 @@ static void mixture_dlnl(const mix_t *m, t_tree *mixt_tree, double *l, double *l
   ctx_t *c0 = ensure_instance(mixt_tree->next);
   if (c0->K > 0)
   {
-    cls_batch_done(c0->K);
+    cls_batch_done((clsbatch_t *)c0->batch, c0->K);
     OK(phyhip_calculate_class_mixture_eigen_lnl_dlnl(c0->inst, m->lft[0], m->rgt[0], l, m->proba, m->rw, m->ew, m->r_sum, m->e_sum,
                                                      m->sum_p, lnl, dlnl));
   }
@@ -557,7 +564,9 @@ static void mixture_dlnl(const mix_t *m, t_tree *mixt_tree, double *l, double *l
 }
 static int mixture_supported(const t_tree *mixt_tree)
 {
-  return !(mixt_tree->n_root || mixt_tree->next_mixt || mixt_tree->mod->ras->invar == YES || mixt_tree->mod->gamma_mgf_bl == YES);
+  for (const t_tree *mt = mixt_tree; mt; mt = mt->next_mixt) /* every element of the data partition (src/mixt.c:862) */
+    if (mt->n_root || mt->mod->ras->invar == YES || mt->mod->gamma_mgf_bl == YES) return 0;
+  return 1;
 }
 
 static double g_t0 = 0.0;
@@ -589,11 +598,20 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
   {
     const phydbl ref = real(mixt_b, mixt_tree);
     g_last_mixt_lnl = ref;
-    t_edge *e = mixt_b ? mixt_b : mixt_tree->a_nodes[0]->b[0]; /* src/mixt.c:889 */
-    if (!mixture_supported(mixt_tree) || mixt_tree->next->use_eigen_lr == YES || !gather_classes(e, mixt_tree, &m))
-    { ++g_n_mixt_skipped; return ref; } /* eigen-basis Lk, partitions and +I mixtures: not on the device */
+    if (!mixture_supported(mixt_tree) || mixt_tree->next->use_eigen_lr == YES)
+    { ++g_n_mixt_skipped; return ref; } /* eigen-basis Lk and +I mixtures: not on the device */
     double lnl = 0.0;
-    mixture_lnl(&m, mixt_tree, &lnl);
+    {
+      t_edge *mb = mixt_b;
+      for (t_tree *mt = mixt_tree; mt; mt = mt->next_mixt, mb = mb ? mb->next_mixt : NULL)
+      { /* the elements of the data partition: c_lnL is their sum (src/mixt.c:862,1161-1176) */
+        t_edge *e = mb ? mb : mt->a_nodes[0]->b[0]; /* src/mixt.c:889 */
+        double  x = 0.0;
+        if (!gather_classes(e, mt, &m)) { ++g_n_mixt_skipped; return ref; }
+        mixture_lnl(&m, mt, &x);
+        lnl += x;
+      }
+    }
     track(&g_worst_mixt, lnl, ref, 1.0);
     if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
     return ref;
@@ -602,12 +620,13 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
   if (!mixture_supported(mixt_tree) || mixt_tree->next->use_eigen_lr == YES)
   { fprintf(stderr, "glue_driver: this mixture (rooted / partitioned / +I / eigen-basis Lk) runs in check mode only\n"); exit(5); }
   if (!mixt_b)
-  { /* src/mixt.c:754-782 */
-    Update_RAS(mixt_tree->mod);
-    for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next)
-      if (!Update_Boundaries(t->mod) || !Update_Efrq(t->mod) || !Update_Eigen(t->mod)) { fprintf(stderr, "glue_driver: model update failed\n"); exit(5); }
+  { /* src/mixt.c:754-782: every element of the partition, every class tree of the chain */
+    for (t_tree *mt = mixt_tree; mt; mt = mt->next_mixt) Update_RAS(mt->mod);
+    for (t_tree *t = mixt_tree->next; t; t = t->next)
+      if (t->is_mixt_tree == NO && (!Update_Boundaries(t->mod) || !Update_Efrq(t->mod) || !Update_Eigen(t->mod)))
+      { fprintf(stderr, "glue_driver: model update failed\n"); exit(5); }
     if (g_device_pmat) /* device-built matrices need the refreshed class rates / eigen systems on the device first */
-      for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) push_model(ensure_instance(t));
+      for (t_tree *t = mixt_tree->next; t; t = t->next) if (t->is_mixt_tree == NO) push_model(ensure_instance(t));
     for (int br = 0; br < 2 * mixt_tree->n_otu - 3; ++br) MIXT_Update_PMat_At_Given_Edge(mixt_tree->a_edges[br], mixt_tree); /* :784-787 */
     MIXT_Post_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);                                    /* :850-857 */
     if (mixt_tree->both_sides == YES) MIXT_Pre_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);
@@ -615,28 +634,32 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
   else
   {
     if (g_device_pmat)
-      for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) push_model(ensure_instance(t));
+      for (t_tree *t = mixt_tree->next; t; t = t->next) if (t->is_mixt_tree == NO) push_model(ensure_instance(t));
     MIXT_Update_PMat_At_Given_Edge(mixt_b, mixt_tree); /* :806 */
   }
-  t_edge *e = mixt_b ? mixt_b : mixt_tree->a_nodes[0]->b[0];
+  double lnl = 0.0;
   {
-    t_edge *b = e->next;
-    for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
-    {
-      t->c_lnL = 0.0; t->numerical_warning = NO;
-      if (t->update_eigen_lr == YES) Update_Eigen_Lr(b, t); /* :929 */
+    t_edge *mb = mixt_b;
+    for (t_tree *mt = mixt_tree; mt; mt = mt->next_mixt, mb = mb ? mb->next_mixt : NULL)
+    { /* the elements of the data partition (src/mixt.c:862-1159), their sum (:1161-1176) */
+      t_edge *e = mb ? mb : mt->a_nodes[0]->b[0];
+      t_edge *b = e->next;
+      for (t_tree *t = mt->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
+      {
+        t->c_lnL = 0.0; t->numerical_warning = NO;
+        if (t->update_eigen_lr == YES) Update_Eigen_Lr(b, t); /* :929 */
+      }
+      if (!gather_classes(e, mt, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
+      double x = 0.0;
+      mixture_lnl(&m, mt, &x);
+      lnl += x;
+      mt->numerical_warning = NO;
+      int w = 0;
+      OK(phyhip_get_numerical_warning(m.ids[0], &w));
+      if (w) mt->numerical_warning = YES;
     }
   }
-  if (!gather_classes(e, mixt_tree, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
-  double lnl = 0.0;
-  mixture_lnl(&m, mixt_tree, &lnl);
-  mixt_tree->numerical_warning = NO;
-  {
-    int w = 0;
-    OK(phyhip_get_numerical_warning(m.ids[0], &w));
-    if (w) mixt_tree->numerical_warning = YES;
-  }
-  mixt_tree->c_lnL = lnl;
+  for (t_tree *mt = mixt_tree; mt; mt = mt->next_mixt) mt->c_lnL = lnl;
   g_last_mixt_lnl = lnl;
   if (!mixt_b && lnl > g_best_full_lnl) g_best_full_lnl = lnl;
   if (g_max_mixt && g_n_mixt + g_n_mixt_dlk >= g_max_mixt) report_xml_and_exit();
@@ -657,9 +680,18 @@ phydbl MIXT_dLk(phydbl *l, t_edge *mixt_b, t_tree *mixt_tree)
   {
     double       x = *l;
     const phydbl ref = real(l, mixt_b, mixt_tree);
-    if (!mixture_supported(mixt_tree) || !gather_classes(mixt_b, mixt_tree, &m)) { ++g_n_mixt_skipped; return ref; }
+    if (!mixture_supported(mixt_tree)) { ++g_n_mixt_skipped; return ref; }
     double lnl = 0.0, dlnl = 0.0;
-    mixture_dlnl(&m, mixt_tree, &x, &lnl, &dlnl);
+    {
+      t_edge *mb = mixt_b;
+      for (t_tree *mt = mixt_tree; mt; mt = mt->next_mixt, mb = mb->next_mixt)
+      { /* every element with the same length (src/mixt.c:3009-3030), sums at :3325-3360 */
+        double a = 0.0, d = 0.0, xl = x;
+        if (!gather_classes(mb, mt, &m)) { ++g_n_mixt_skipped; return ref; }
+        mixture_dlnl(&m, mt, &xl, &a, &d);
+        lnl += a; dlnl += d;
+      }
+    }
     track(&g_worst_mixt, lnl, ref, 1.0);
     track(&g_worst_mixt_dlnl, dlnl, mixt_tree->c_dlnL, 1.0);
     if (g_max_mixt && g_n_mixt + g_n_mixt_dlk - g_n_mixt_skipped >= g_max_mixt) report_xml_and_exit();
@@ -672,12 +704,20 @@ phydbl MIXT_dLk(phydbl *l, t_edge *mixt_b, t_tree *mixt_tree)
     while (b && &(b->l->v) != l) b = b->next;
     if (!b) { fprintf(stderr, "glue_driver: MIXT_dLk with a length that is not the edge's own\n"); exit(5); }
   }
-  if (!gather_classes(mixt_b, mixt_tree, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
   double lnl = 0.0, dlnl = 0.0;
-  mixture_dlnl(&m, mixt_tree, l, &lnl, &dlnl);
+  {
+    t_edge *mb = mixt_b;
+    const double l_in = *l;
+    for (t_tree *mt = mixt_tree; mt; mt = mt->next_mixt, mb = mb->next_mixt)
+    {
+      double a = 0.0, d = 0.0, xl = l_in;
+      if (!gather_classes(mb, mt, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
+      mixture_dlnl(&m, mt, mt == mixt_tree ? l : &xl, &a, &d);
+      lnl += a; dlnl += d;
+    }
+  }
   for (t_tree *t = mixt_tree; t; t = t->next) { t->c_lnL = .0; t->c_dlnL = .0; } /* :3026-3032 */
-  mixt_tree->c_lnL  = lnl;
-  mixt_tree->c_dlnL = dlnl;
+  for (t_tree *mt = mixt_tree; mt; mt = mt->next_mixt) { mt->c_lnL = lnl; mt->c_dlnL = dlnl; } /* :3325-3360 */
   return mixt_tree->c_lnL;
 }
 

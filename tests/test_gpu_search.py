@@ -21,6 +21,7 @@ import re
 import shutil
 import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
@@ -161,6 +162,55 @@ def test_lg4x_mixture_analysis_driven_by_the_device(class_axis, device_pmat, tmp
     assert info["mode"] == "device" and info["class_instances"] == 4
     assert info["calls"]["MIXT_Lk"] + info["calls"]["MIXT_dLk"] >= 8000
     assert -12496.6 < info["best_full_lnL"] < -12300.0 and info["best_full_lnL"] > -12490.0, info
+
+
+def _read_interleaved(path):
+    """PHYLIP interleaved alignment (the reference's examples/proteic as shipped) -> (names, sequences)."""
+    lines = [l.rstrip("\n") for l in open(path)]
+    n, L = (int(x) for x in lines[0].split())
+    names, seqs, row = [], [], 0
+    for l in lines[1:]:
+        if not l.strip():
+            continue
+        if len(names) < n:
+            names.append(l.split()[0]); seqs.append("".join(l.split()[1:]))
+        else:
+            seqs[row % n] += "".join(l.split()); row += 1
+    assert all(len(s) == L for s in seqs), [len(s) for s in seqs][:3]
+    return names, seqs
+
+
+@pytest.mark.parametrize("mode,class_axis", [("check", False), ("check", True), ("device", True)],
+                         ids=["check_instances", "check_class_axis", "device_class_axis"])
+def test_partitioned_mixture_analysis(mode, class_axis, tmp_path):
+    """A data partition with TWO elements (the two halves of the example alignment under a four-class and a two-class
+    mixture, shared topology and branch lengths; tests/golden/lg4x/part2_check.xml): MIXT_Lk / MIXT_dLk are sums over the
+    elements (src/mixt.c:862, 1161-1176, 3325-3360), every element being one instance group on the device.  Check mode:
+    every evaluation of the reference's analysis against the device; device mode: the device serves them."""
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
+    base = str(tmp_path)
+    os.makedirs(os.path.join(base, "examples", "lg4x")); os.makedirs(os.path.join(base, "run"))
+    for f in os.listdir(os.path.join(GOLDEN, "lg4x")):
+        shutil.copy(os.path.join(GOLDEN, "lg4x", f), os.path.join(base, "examples", "lg4x", f))
+    names, seqs = _read_interleaved(os.path.join(GOLDEN, "examples_proteic.phy"))
+    for tag, (lo, hi) in (("part_a", (0, 270)), ("part_b", (270, 547))):
+        with open(os.path.join(base, "examples", tag), "w") as f:
+            f.write(f"{len(names)} {hi - lo}\n")
+            for nm, sq in zip(names, seqs):
+                f.write(f"{nm}  {sq[lo:hi]}\n")
+    env = dict(os.environ, GLUE_MODE=mode, GLUE_MAX_MIXT="5000", GLUE_CLASS_AXIS="1" if class_axis else "0", GLUE_DEVICE_PMAT="0")
+    r = subprocess.run([GLUE, "--", "--xml=../examples/lg4x/part2_check.xml"], cwd=os.path.join(base, "run"), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2500:]
+    info = json.loads(m.group(1))
+    assert info["class_instances"] == 6          # four + two class trees
+    assert info["calls"]["MIXT_Lk"] + info["calls"]["MIXT_dLk"] >= 5000 and info["calls"]["MIXT_skipped"] == 0, info
+    if mode == "check":
+        assert info["worst_rel_mixture_lnL"] < 1e-10 and info["worst_rel_mixture_dlnL"] < 1e-6, info
+    else:
+        assert info["best_full_lnL"] > -13000.0 and np.isfinite(info["last_mixture_lnL"]), info
 
 
 # ---- fast branch supports (src/alrt.c) on device-resident state: the download hooks of SURVEY 8(f) rank 3 -------------
