@@ -235,6 +235,13 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
                                             const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
                                             double eFrqWeightSum, double sumProbas, double *outLnL, double *outDLnL);
 
+/* +I mixtures (src/mixt.c:1079-1112, 3212-3275): the invariant class of the mixture is not a class tree of the device (PhyML
+   skips it in every per-class loop); its share -- pi_inv[invar[pattern]] x pinvar mixed into the site likelihood, the
+   derivative scaled by (1 - pinvar) -- enters the combination.  Set on the FIRST instance of the class list (or on the
+   class-axis instance); invar_model == 0 switches it off.  The class instances themselves keep invar_model = 0. */
+int phyhip_set_mixture_invariant_sites(int instance, int invar_model, double pinvar, const short *invar,
+                                       const double *piInvariantClass);
+
 /* The same two evaluations on ONE instance created with PHYHIP_FLAG_CLASS_AXIS (class c = category c): the queued
    partial updates of ALL classes and their edge evaluations are one traversal launch (one per class instance above),
    followed by the combination.  The class trees of PhyML's mixture share their topology and their call sequence

@@ -267,14 +267,15 @@ static ctx_t *ensure_instance(t_tree *tree)
   if (g_nctx == MAXCTX) { fprintf(stderr, "glue_driver: too many class trees\n"); exit(5); }
   if (g_class_axis && tree->mixt_tree && tree->mod->ns == 20)
   { /* all class trees of the mixture at once: contexts in class order, one instance */
-    int K = 0;
-    for (t_tree *t = tree->mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) ++K;
-    if (K >= 1 && K <= 4 && g_nctx + K <= MAXCTX)
+    int K = 0; /* class trees that compute (the invariant class of a +I mixture never reaches the surface) */
+    for (t_tree *t = tree->mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) if (t->mod->ras->invar == NO) ++K;
+    if (K >= 1 && K <= 4 && g_nctx + K <= MAXCTX && tree->mod->ras->invar == NO)
     {
       ctx_t *first = NULL, *mine = NULL;
       int    k = 0;
-      for (t_tree *t = tree->mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, ++k)
+      for (t_tree *t = tree->mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next)
       {
+        if (t->mod->ras->invar == YES) continue;
         ctx_t *c = &g_ctx[g_nctx++];
         memset(c, 0, sizeof *c);
         c->tree = t; c->cls = k; c->K = K;
@@ -292,6 +293,7 @@ static ctx_t *ensure_instance(t_tree *tree)
         }
         else c->inst = first->inst;
         if (t == tree) mine = c;
+        ++k;
       }
       for (ctx_t *c = first; c < first + K; ++c) push_model(c);
       return mine;
@@ -362,6 +364,7 @@ void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
   if (!real) real = (void (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "Update_PMat_At_Given_Edge");
   ++g_n_pmat;
   if (g_host || tree->is_mixt_tree) { real(b_fcus, tree); return; } /* mixture tree: the original loops over the class trees */
+  if (tree->mixt_tree && tree->mod->ras->invar == YES) { real(b_fcus, tree); return; } /* invariant class: not on the device */
   ctx_t *c = ensure_instance(tree);
   if (b_fcus->has_zero_br_len == YES) { fprintf(stderr, "glue_driver: zero-length edge flag not supported\n"); exit(5); }
   if (c->K > 0)
@@ -412,7 +415,7 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   if (tree->is_mixt_tree) { real(tree, b, d); return; } /* MIXT_Update_Partial_Lk: per class tree, back through this wrapper */
   if (d->tax) return;
   ++g_n_upd;
-  if (g_host) { real(tree, b, d); return; }
+  if (g_host || (tree->mixt_tree && tree->mod->ras->invar == YES)) { real(tree, b, d); return; }
   ctx_t *c = ensure_instance(tree);
   t_node *n_v1 = NULL, *n_v2 = NULL;
   phydbl *p_lk = NULL, *p_lk_v1 = NULL, *p_lk_v2 = NULL, *Pij1 = NULL, *Pij2 = NULL, *tPij1 = NULL, *tPij2 = NULL;
@@ -457,7 +460,7 @@ void Update_Eigen_Lr(t_edge *b, t_tree *tree)
   static void (*real)(t_edge *, t_tree *) = NULL;
   if (!real) real = (void (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "Update_Eigen_Lr");
   ++g_n_eig;
-  if (g_host || tree->is_mixt_tree) { real(b, tree); return; }
+  if (g_host || tree->is_mixt_tree || (tree->mixt_tree && tree->mod->ras->invar == YES)) { real(b, tree); return; }
   ctx_t *c = ensure_instance(tree);
   if (c->K > 0 && c->cls > 0) { if (g_check) real(b, tree); return; } /* class axis: class 0's call covered every class */
   int l, r;
@@ -514,9 +517,11 @@ static int gather_classes(t_edge *e, t_tree *mixt_tree, mix_t *m)
 {
   m->K = 0;
   t_edge *b = e->next;
+  t_tree *inv_tree = NULL;
   for (t_tree *t = mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
   {
-    if (m->K == kMaxClasses || t->mod->ras->invar == YES) return 0;
+    if (t->mod->ras->invar == YES) { inv_tree = t; continue; } /* the invariant class: no class tree on the device (src/mixt.c:899) */
+    if (m->K == kMaxClasses) return 0;
     ctx_t *c = ensure_instance(t);
     push_model(c);
     m->ids[m->K] = c->inst;
@@ -533,12 +538,24 @@ static int gather_classes(t_edge *e, t_tree *mixt_tree, mix_t *m)
   m->r_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->r_mat_weight);
   m->e_sum = MIXT_Get_Sum_Chained_Scalar_Dbl(mixt_tree->next->mod->e_frq_weight);
   m->sum_p = MIXT_Get_Sum_Of_Probas_Across_Mixtures(m->r_sum, m->e_sum, mixt_tree);
+  if (m->K == 0) return 0;
+  /* +I mixture (src/mixt.c:1079-1112): pinvar of the mixture, the constant-state table of the element, the invariant
+     class tree's frequencies */
+  if (mixt_tree->mod->ras->invar == YES && !inv_tree) return 0;
+  OK(phyhip_set_mixture_invariant_sites(m->ids[0], mixt_tree->mod->ras->invar == YES, mixt_tree->mod->ras->pinvar->v,
+                                        mixt_tree->data->invar, inv_tree ? inv_tree->mod->e_frq->pi->v : NULL));
   return 1;
+}
+static t_tree *first_class_tree(t_tree *mixt_tree)
+{ /* the first class tree that computes: the invariant class of a +I mixture comes first in the chain (src/xml.c) */
+  t_tree *t = mixt_tree->next;
+  while (t && t->is_mixt_tree == NO && t->mod->ras->invar == YES) t = t->next;
+  return t;
 }
 /* the two mixture evaluations, over class instances or on the class axis of one instance */
 static void mixture_lnl(const mix_t *m, t_tree *mixt_tree, double *lnl)
 {
-  ctx_t *c0 = ensure_instance(mixt_tree->next);
+  ctx_t *c0 = ensure_instance(first_class_tree(mixt_tree));
   if (c0->K > 0)
   {
     cls_batch_done((clsbatch_t *)c0->batch, c0->K);
@@ -551,7 +568,7 @@ static void mixture_lnl(const mix_t *m, t_tree *mixt_tree, double *lnl)
 }
 static void mixture_dlnl(const mix_t *m, t_tree *mixt_tree, double *l, double *lnl, double *dlnl)
 {
-  ctx_t *c0 = ensure_instance(mixt_tree->next);
+  ctx_t *c0 = ensure_instance(first_class_tree(mixt_tree));
   if (c0->K > 0)
   {
     cls_batch_done((clsbatch_t *)c0->batch, c0->K);
@@ -565,7 +582,7 @@ static void mixture_dlnl(const mix_t *m, t_tree *mixt_tree, double *l, double *l
 static int mixture_supported(const t_tree *mixt_tree)
 {
   for (const t_tree *mt = mixt_tree; mt; mt = mt->next_mixt) /* every element of the data partition (src/mixt.c:862) */
-    if (mt->n_root || mt->mod->ras->invar == YES || mt->mod->gamma_mgf_bl == YES) return 0;
+    if (mt->n_root || mt->mod->gamma_mgf_bl == YES) return 0;
   return 1;
 }
 
@@ -626,7 +643,7 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
       if (t->is_mixt_tree == NO && (!Update_Boundaries(t->mod) || !Update_Efrq(t->mod) || !Update_Eigen(t->mod)))
       { fprintf(stderr, "glue_driver: model update failed\n"); exit(5); }
     if (g_device_pmat) /* device-built matrices need the refreshed class rates / eigen systems on the device first */
-      for (t_tree *t = mixt_tree->next; t; t = t->next) if (t->is_mixt_tree == NO) push_model(ensure_instance(t));
+      for (t_tree *t = mixt_tree->next; t; t = t->next) if (t->is_mixt_tree == NO && t->mod->ras->invar == NO) push_model(ensure_instance(t));
     for (int br = 0; br < 2 * mixt_tree->n_otu - 3; ++br) MIXT_Update_PMat_At_Given_Edge(mixt_tree->a_edges[br], mixt_tree); /* :784-787 */
     MIXT_Post_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);                                    /* :850-857 */
     if (mixt_tree->both_sides == YES) MIXT_Pre_Order_Lk(mixt_tree->a_nodes[0], mixt_tree->a_nodes[0]->v[0], mixt_tree);
@@ -634,7 +651,7 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
   else
   {
     if (g_device_pmat)
-      for (t_tree *t = mixt_tree->next; t; t = t->next) if (t->is_mixt_tree == NO) push_model(ensure_instance(t));
+      for (t_tree *t = mixt_tree->next; t; t = t->next) if (t->is_mixt_tree == NO && t->mod->ras->invar == NO) push_model(ensure_instance(t));
     MIXT_Update_PMat_At_Given_Edge(mixt_b, mixt_tree); /* :806 */
   }
   double lnl = 0.0;
@@ -647,6 +664,7 @@ phydbl MIXT_Lk(t_edge *mixt_b, t_tree *mixt_tree)
       for (t_tree *t = mt->next; t && t->is_mixt_tree == NO; t = t->next, b = b->next)
       {
         t->c_lnL = 0.0; t->numerical_warning = NO;
+        if (t->mod->ras->invar == YES) continue;              /* :899 */
         if (t->update_eigen_lr == YES) Update_Eigen_Lr(b, t); /* :929 */
       }
       if (!gather_classes(e, mt, &m)) { fprintf(stderr, "glue_driver: unsupported class tree in the mixture\n"); exit(5); }
@@ -728,6 +746,7 @@ phydbl Lk(t_edge *b, t_tree *tree)
   ++g_n_lk;
   if (!b) ++g_n_lk_full;
   if (g_host || tree->is_mixt_tree) return real(b, tree); /* mixture: src/lk.c:465-472 diverts to MIXT_Lk (above) */
+  if (tree->mixt_tree && tree->mod->ras->invar == YES) return real(b, tree); /* the invariant class of a +I mixture: host only */
   if (tree->mixt_tree && !g_check) { fprintf(stderr, "glue_driver: Lk() on a class tree outside MIXT_Lk is served in check mode only\n"); exit(5); }
   if (g_check)
   {

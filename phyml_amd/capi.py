@@ -46,7 +46,7 @@ SYMBOLS = [
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
     "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
     "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_calculate_class_mixture_log_likelihood",
-    "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors",
+    "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors", "phyhip_set_mixture_invariant_sites",
 ]
 
 FLAG_SHARDED = 1 << 40  # PHYHIP_FLAG_SHARDED

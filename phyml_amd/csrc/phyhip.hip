@@ -167,6 +167,8 @@ struct Instance
   bool      warn_current = false; // *h_warn belongs to the evaluation the host last waited for (none launched since)
   int      *d_warn     = nullptr;
   int      *h_warn     = nullptr;
+  int       mix_invar_model = 0;  // +I mixture (phyhip_set_mixture_invariant_sites): carried by the first / class-axis instance
+  double    mix_pinvar = 0.0, mix_pi_inv[20] = {0};
   HostBlock *h_blocks  = nullptr; // host-mapped {block sum, tag} records of the host-side final sum
   int       host_sum_n = 0;       // > 0: the evaluation in flight is finished by the host from this many records
   bool      host_sum   = true;    // PHYHIP_HOST_SUM=0: large grids use final_reduce_kernel instead
@@ -937,6 +939,13 @@ int collect_profile(Instance *I)
   return 0;
 }
 
+// the +I share of a mixture evaluation (phyhip_set_mixture_invariant_sites) into the combination kernel's parameters
+template <typename Q> void fill_mixture_invariant(const Instance *I, Q &q)
+{
+  q.invar_model = I->mix_invar_model; q.pinvar = I->mix_pinvar; q.invar = I->d_invar;
+  for (int s = 0; s < 20; ++s) q.pi_inv[s] = I->mix_pi_inv[s];
+}
+
 #include "phyhip_shard.hpp"
 
 } // namespace
@@ -1615,6 +1624,7 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
   }
   q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
   q.wght = I0->d_wght; q.site_lnl = I0->d_site_lnl; q.cat_stride = 1;
+  fill_mixture_invariant(I0, q);
   const int grid = (int)((I0->P + 255) / 256);
   q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
   q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
@@ -1692,6 +1702,7 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
     }
     q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
     q.expl = I0->d_mixexpl; q.wght = I0->d_wght; q.dot_stride = S_;
+    fill_mixture_invariant(I0, q);
     const int grid = (int)((I0->P + 255) / 256);
     q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
     q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
@@ -1707,6 +1718,25 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
   if ((rc = wait_result(I0))) return rc;
   *outLnL = I0->h_result[0];
   if (outDLnL) *outDLnL = I0->h_result[1];
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_set_mixture_invariant_sites(int instance, int invar_model, double pinvar, const short *invar, const double *piInvariantClass)
+{
+  GET_INST(I, instance);
+  if (invar_model && (!invar || !piInvariantClass)) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "invar_model set but invar / frequencies missing");
+  const bool same_sites = !invar_model || (I->h_invar_set && !memcmp(I->h_invar.data(), invar, I->P * sizeof(short)));
+  if (!same_sites)
+  { // the per-pattern table shares the slot of phyhip_set_invariant_sites: a mixture's class instances run without +I
+    int rc = flush_sync(I);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(I->d_invar, invar, I->P * sizeof(short), hipMemcpyHostToDevice));
+    I->h_invar.assign(invar, invar + I->P);
+    I->h_invar_set = true;
+  }
+  I->mix_invar_model = invar_model ? 1 : 0;
+  I->mix_pinvar      = pinvar;
+  if (invar_model) for (int s = 0; s < I->S; ++s) I->mix_pi_inv[s] = piInvariantClass[s];
   return PHYHIP_SUCCESS;
 }
 
@@ -1735,6 +1765,7 @@ int phyhip_calculate_class_mixture_log_likelihood(int instance, int parent, int 
   }
   q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
   q.wght = I->d_wght; q.site_lnl = I->d_site_lnl; q.cat_stride = I->C;
+  fill_mixture_invariant(I, q);
   const int grid = (int)((I->P + 255) / 256);
   q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
   q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
@@ -1789,6 +1820,7 @@ int phyhip_calculate_class_mixture_eigen_lnl_dlnl(int instance, int left, int ri
   }
   q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
   q.expl = I->d_mixexpl; q.wght = I->d_wght; q.dot_stride = I->C * I->S;
+  fill_mixture_invariant(I, q);
   const int grid = (int)((I->P + 255) / 256);
   q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
   q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;

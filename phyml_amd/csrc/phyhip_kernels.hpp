@@ -1225,6 +1225,11 @@ struct MixParams
   const double *site_cat[kMaxMixClasses]; // per class: [P] (C = 1), or base + class with cat_stride = C (class axis)
   const int    *fact[kMaxMixClasses];
   int           cat_stride;
+  // +I mixture (src/mixt.c:1079-1112): the invariant class is not a class tree of the device; its share enters here
+  int           invar_model;
+  double        pinvar;
+  const short  *invar;   // data->invar[pattern]: the constant state or -1
+  double        pi_inv[20]; // frequencies of the invariant class tree's model
   double        proba[kMaxMixClasses], r_w[kMaxMixClasses], e_w[kMaxMixClasses];
   double        r_sum, e_sum, sum_probas;
   const double *wght;
@@ -1245,6 +1250,12 @@ __global__ __launch_bounds__(256) void mixture_combine_kernel(const MixParams q)
       if (s > 1024) { s = 1023; raise_warn(q.fin.warn); }
       const double x = ldexp(q.site_cat[k][(size_t)p * q.cat_stride], -s); // == site_lk_cat / pow(2, sum): exact power-of-two scaling
       site_lk += x * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
+    }
+    if (q.invar_model)
+    { // Invariant_Lk(0, site, ..) of the invariant class: pi[state] at scale 2^0 (src/lk.c:1226-1273), then the mixing
+      const int    iv  = q.invar[p];
+      const double inv = iv >= 0 ? q.pi_inv[iv] : 0.0;
+      site_lk = site_lk * (1. - q.pinvar) + inv * q.pinvar;
     }
     if (site_lk < kSmall) { site_lk = kSmall; raise_warn(q.fin.warn); }
     const double lsl = log(site_lk);
@@ -1280,6 +1291,10 @@ template <int S> struct MixDlkParams
   double        r_sum, e_sum, sum_probas;
   const double *expl;                                // device: [count][2*S] (value, derivative) pairs
   const double *wght;
+  int           invar_model;                         // +I mixture: src/mixt.c:3212-3275
+  double        pinvar;
+  const short  *invar;
+  double        pi_inv[20];
   FinishParams  fin;
 };
 
@@ -1290,6 +1305,7 @@ template <int S> __global__ __launch_bounds__(256) void mixture_dlk_kernel(const
   if (p < q.P)
   {
     const double wt = q.wght[p];
+    const double one_m_pinv = q.invar_model ? 1. - q.pinvar : 1.; // src/mixt.c:3212-3215
     double       site_lk = 0.0, site_dlk = 0.0;
     for (int k = 0; k < q.count; ++k)
     {
@@ -1312,8 +1328,14 @@ template <int S> __global__ __launch_bounds__(256) void mixture_dlk_kernel(const
       if (wt > kSmall)
       {
         site_lk  += lk * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
-        site_dlk += dlk * 1.0 * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
+        site_dlk += dlk * one_m_pinv * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
       }
+    }
+    if (q.invar_model)
+    { // src/mixt.c:3250-3275
+      const int    iv  = q.invar[p];
+      const double inv = iv >= 0 ? q.pi_inv[iv] : 0.0;
+      site_lk = site_lk * (1. - q.pinvar) + inv * q.pinvar;
     }
     if (wt > kSmall)
     {

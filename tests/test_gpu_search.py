@@ -213,6 +213,33 @@ def test_partitioned_mixture_analysis(mode, class_axis, tmp_path):
         assert info["best_full_lnL"] > -13000.0 and np.isfinite(info["last_mixture_lnL"]), info
 
 
+@pytest.mark.parametrize("mode,class_axis", [("check", False), ("check", True), ("device", True)],
+                         ids=["check_instances", "check_class_axis", "device_class_axis"])
+def test_invariant_mixture_analysis(mode, class_axis, tmp_path):
+    """A +I mixture (tests/golden/lg4x/inv_check.xml: three classes + the invariant class): the invariant class has no
+    class tree on the device; its share enters the combination (phyhip_set_mixture_invariant_sites, src/mixt.c:1079-1112,
+    3212-3275).  Check mode compares every MIXT_Lk / MIXT_dLk of the reference's analysis, device mode serves them."""
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
+    base = str(tmp_path)
+    os.makedirs(os.path.join(base, "examples", "lg4x")); os.makedirs(os.path.join(base, "run"))
+    for f in os.listdir(os.path.join(GOLDEN, "lg4x")):
+        shutil.copy(os.path.join(GOLDEN, "lg4x", f), os.path.join(base, "examples", "lg4x", f))
+    shutil.copy(os.path.join(GOLDEN, "examples_proteic.phy"), os.path.join(base, "examples", "proteic"))
+    env = dict(os.environ, GLUE_MODE=mode, GLUE_MAX_MIXT="5000", GLUE_CLASS_AXIS="1" if class_axis else "0", GLUE_DEVICE_PMAT="0")
+    r = subprocess.run([GLUE, "--", "--xml=../examples/lg4x/inv_check.xml"], cwd=os.path.join(base, "run"), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2500:]
+    info = json.loads(m.group(1))
+    assert 3 <= info["class_instances"] <= 4     # the computing class trees of the chain
+    assert info["calls"]["MIXT_Lk"] + info["calls"]["MIXT_dLk"] >= 5000 and info["calls"]["MIXT_skipped"] == 0, info
+    if mode == "check":
+        assert info["worst_rel_mixture_lnL"] < 1e-10 and info["worst_rel_mixture_dlnL"] < 1e-6, info
+    else:
+        assert info["best_full_lnL"] > -13000.0 and np.isfinite(info["last_mixture_lnL"]), info
+
+
 # ---- fast branch supports (src/alrt.c) on device-resident state: the download hooks of SURVEY 8(f) rank 3 -------------
 
 SUPPORT_ARGS = ["-d", "nt", "-m", "GTR", "-f", "0.3,0.2,0.2,0.3", "-c", "4", "-a", "0.8", "-o", "n", "-b", "-4", "--r_seed", "1"]
