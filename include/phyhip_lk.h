@@ -18,8 +18,8 @@
  *   Br_Len_Opt(&l,b,tree)           src/optimiz.c:607 (call pattern of the eigen path; Newton on dLk)
  *
  * The structs are this repo's own minimal versions of t_tree/t_edge/t_node/t_mod: only the fields the
- * hot path reads, with the reference's field names (src/utilities.h:640-1010).  Unrooted trees only
- * (n_root == NULL), which is what every BASELINE config uses.  Errors follow the reference's
+ * hot path reads, with the reference's field names (src/utilities.h:640-1010).  Unrooted trees, and rooted
+ * input trees the way the `phyml` program evaluates them (root ignored: tree->e_root).  Errors follow the reference's
  * convention: message on stderr, then Exit() (src/utilities.c:1105) -- replaceable via Set_Exit_Handler.
  */
 #ifndef PHYHIP_LK_H
@@ -84,6 +84,10 @@ typedef struct __Tree
   int      n_edges_traversed; /* counter like src/utilities.h:1018 */
   int      spare_p_lk_idx;    /* first of PHL_N_SPARE spare partials buffers (extra SPR edges, src/make.c:750) */
   int      spare_Pij_idx;     /* first of PHL_N_SPARE spare transition-matrix buffers */
+  t_edge  *e_root;            /* rooted input tree with the root ignored (tree->n_root != NULL, ignore_root == YES, the only
+                                 rooted form the `phyml` program evaluates): the edge the root sits on, else NULL.  The
+                                 ignore_root == NO special cases of src/lk.c:2988-3146 are not built: the reference's own AVX
+                                 path cannot run them (oracle/probe_rooted.sh) */
 } t_tree;
 
 #define PHL_N_SPARE 4

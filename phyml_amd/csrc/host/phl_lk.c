@@ -463,7 +463,21 @@ void Pre_Order_Lk(t_node *a, t_node *d, t_tree *tree)
 }
 
 void Update_All_Partial_Lk(t_tree *tree)
-{ /* src/lk.c:432-437 */
+{
+  if (tree->e_root)
+  { /* a rooted input tree whose root is ignored (tree->n_root != NULL, ignore_root == YES -- the only rooted form the
+       `phyml` program evaluates, src/init.c:145): the two subtrees of the root edge (src/lk.c:420-429) */
+    t_edge *e = tree->e_root;
+    Post_Order_Lk(e->rght, e->left, tree);
+    Post_Order_Lk(e->left, e->rght, tree);
+    if (tree->both_sides == YES)
+    {
+      Pre_Order_Lk(e->rght, e->left, tree);
+      Pre_Order_Lk(e->left, e->rght, tree);
+    }
+    return;
+  }
+  /* src/lk.c:432-437 */
   t_node *r = tree->a_nodes[tree->tip_root];
   Post_Order_Lk(r, r->v[0], tree);
   if (tree->both_sides == YES) Pre_Order_Lk(r, r->v[0], tree);
@@ -502,7 +516,8 @@ void Update_Eigen_Lr(t_edge *b, t_tree *tree)
 static t_edge *Traverse_For_Lk(t_tree *tree)
 {
   Update_All_PMat(tree);          /* src/lk.c:500-512 */
-  Update_All_Partial_Lk(tree);    /* src/lk.c:562-564 */
+  Update_All_Partial_Lk(tree);    /* src/lk.c:545-564 */
+  if (tree->e_root) return tree->e_root;      /* src/lk.c:573-576 (ignore_root == YES) */
   return tree->a_nodes[tree->tip_root]->b[0]; /* src/lk.c:578-579 */
 }
 

@@ -48,7 +48,8 @@ class t_tree(C.Structure):
                 ("tip_root", C.c_int), ("both_sides", C.c_short), ("use_eigen_lr", C.c_short),
                 ("update_eigen_lr", C.c_short), ("apply_lk_scaling", C.c_short), ("numerical_warning", C.c_short),
                 ("host_pmat", C.c_short), ("c_lnL", C.c_double), ("old_lnL", C.c_double), ("c_dlnL", C.c_double),
-                ("n_edges_traversed", C.c_int), ("spare_p_lk_idx", C.c_int), ("spare_Pij_idx", C.c_int)]
+                ("n_edges_traversed", C.c_int), ("spare_p_lk_idx", C.c_int), ("spare_Pij_idx", C.c_int),
+                ("e_root", C.POINTER(t_edge))]
 
 
 _lib = None
@@ -205,6 +206,10 @@ class LkTree:
 
     def Update_Partial_Lk(self, b, d):
         self.L.Update_Partial_Lk(self.tree, self.edge(b), self.node(d)); _raise_if_error()
+
+    def set_root_edge(self, b):
+        """Rooted input tree with the root ignored (tree->e_root; None: unrooted)."""
+        self.tree.contents.e_root = self.edge(b) if b is not None else C.POINTER(t_edge)()
 
     def Update_Lk_At_Given_Edge(self, b):
         v = self.L.Update_Lk_At_Given_Edge(self.edge(b), self.tree); _raise_if_error()

@@ -263,3 +263,24 @@ def test_update_lk_at_given_edge(golden):
         assert abs(t.Update_Lk_At_Given_Edge(e) - lnl) / abs(lnl) < 1e-12
     finally:
         t.close()
+
+
+def test_rooted_input_tree_with_the_root_ignored(golden):
+    """tree->n_root != NULL with ignore_root == YES (src/lk.c:420-429, 545-556, 573-576): the traversal starts from the two
+    ends of the root edge and the likelihood is evaluated there; by the pulley principle it is the unrooted tree's value,
+    on every choice of root edge, with one or both sides computed.  (The `phyml` program itself un-roots every input tree,
+    src/main.c:215-216; ignore_root == NO cannot run on the reference's AVX path at all, oracle/probe_rooted.sh.)"""
+    d = golden("nucleic_gtr_g4_inv")
+    t, ot = gpu_common.device_tree_from_golden(d)
+    try:
+        ref = float(d["lnL"][0])
+        for both in (False, True):
+            t.Set_Both_Sides(both)
+            for e in (0, 5, t.ne // 2, t.ne - 1):
+                t.set_root_edge(e)
+                assert abs(t.Lk(None) - ref) / abs(ref) < 1e-12, (both, e)
+        t.set_root_edge(None)
+        t.Set_Both_Sides(False)
+        assert abs(t.Lk(None) - ref) / abs(ref) < 1e-12
+    finally:
+        t.close()
