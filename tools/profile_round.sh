@@ -32,6 +32,7 @@ for wl in ('cfg2_nt_100x50k','cfg3_aa_200x10k'):
     json.dump(res,open(f'{prof}/{tag}_pmc_{wl}.json','w'),indent=1)
     print(wl,res)
 for f in glob.glob(f'{out}/stats_default/*/*kernel_stats.csv'):
-    shutil.copy(f,f'{prof}/{tag}_stats_default_kernel_stats.csv'); print(open(f).read()[:1800])
+    if 'traverse' in open(f).read():  # (the membench child process writes a stats file of its own)
+        shutil.copy(f,f'{prof}/{tag}_stats_default_kernel_stats.csv'); print(open(f).read()[:1800])
 shutil.copy(f'{out}/bench_default.json',f'{prof}/{tag}_bench_default.json')
 PY
