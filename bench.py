@@ -267,10 +267,14 @@ def run_sharded(args, torch):
         n_gpus, mode = world, "one process per GPU: phyhip_comm_init_rank + ncclAllReduce inside libphyhip.so"
     else:
         ndev = torch.cuda.device_count()
-        if ndev < args.gpus:
+        devs = list(range(args.gpus))
+        if os.environ.get("PHYHIP_BENCH_DEVICES"):  # e.g. "0,0": exercise this path on a box with fewer devices than shards
+            devs = [int(x) for x in os.environ["PHYHIP_BENCH_DEVICES"].split(",")]
+            assert len(devs) == args.gpus
+        if ndev <= max(devs):
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) visible")
         wl = workloads.make(name, n_pattern=total)
-        t = build_tree(wl, devices=list(range(args.gpus)))
+        t = build_tree(wl, devices=devs)
         ranks_seen = t.inst.comm_size()
         barrier = None
         n_gpus, mode = args.gpus, "one process, sharded instance: ncclCommInitAll + ncclAllReduce inside libphyhip.so"
@@ -317,7 +321,7 @@ def run_sharded(args, torch):
     if multiproc:
         dist.barrier()
         dist.destroy_process_group()
-    return out, multiproc
+    return out, True   # RCCL was used in this process (either form): see the exit note in main()
 
 
 def main():
@@ -337,11 +341,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    multiproc = False
+    used_rccl = False
     if args.gpus == 1 and os.environ.get("PHYHIP_BENCH_FORCE_DIST") != "1":
         out = run_single(args, torch)
     else:
-        out, multiproc = run_sharded(args, torch)
+        out, used_rccl = run_sharded(args, torch)
     if out is not None:
         # the ONE JSON line goes out last, after RCCL has finished any chatter of its own on stdout
         sys.stdout.flush()
@@ -349,8 +353,8 @@ def main():
     # RCCL prints a version banner on stdout while the interpreter shuts down; leave before that so the JSON
     # line stays the last (and, single-GPU, the only) line on stdout
     sys.stdout.flush(); sys.stderr.flush()
-    if multiproc:
-        os._exit(0)  # (not when single-process: profilers such as rocprofv3 flush their traces at normal exit)
+    if used_rccl:
+        os._exit(0)  # (not for the single-GPU line: profilers such as rocprofv3 flush their traces at normal exit)
 
 
 if __name__ == "__main__":
