@@ -15,7 +15,10 @@
  *   Update_Eigen_Lr(b,tree)         src/lk.c:1038
  *   Set_Both_Sides / Set_Use_Eigen_Lr / Set_Update_Eigen_Lr   src/utilities.c:11614-11640
  *   Make_Tree_For_Lk / Free_Tree_Lk src/make.c:17 / src/free.c:387   (device instance instead of the host slab)
- *   Br_Len_Opt(&l,b,tree)           src/optimiz.c:607 (call pattern of the eigen path; Newton on dLk)
+ *   Br_Len_Newton(&l,b,tree)        NOT a reference function: a harness that drives the surface the way the caller
+ *                                   Br_Len_Opt (src/optimiz.c:607-663) does -- Lk(b) with update_eigen_lr, then dLk alone,
+ *                                   then the matrix refresh -- with a safeguarded Newton search on dlnL in place of the
+ *                                   reference's Br_Len_Spline (src/optimiz.c:2244); optimiz.c itself stays a caller
  *
  * The structs are this repo's own minimal versions of t_tree/t_edge/t_node/t_mod: only the fields the
  * hot path reads, with the reference's field names (src/utilities.h:640-1010).  Unrooted trees, and rooted
@@ -134,7 +137,7 @@ void   Update_Eigen_Lr(t_edge *b, t_tree *tree);
 void   Set_Both_Sides(int yesno, t_tree *tree);
 void   Set_Use_Eigen_Lr(int yesno, t_tree *tree);
 void   Set_Update_Eigen_Lr(int yesno, t_tree *tree);
-phydbl Br_Len_Opt(phydbl *l, t_edge *b, t_tree *tree);
+phydbl Br_Len_Newton(phydbl *l, t_edge *b, t_tree *tree);
 /* host P-matrix (src/models.c:257-326, 353-373) -- used when tree->host_pmat == YES */
 void   PMat(phydbl l, const t_mod *mod, int pos, phydbl *Pij);
 

@@ -572,10 +572,10 @@ phydbl dLk(phydbl *l, t_edge *b, t_tree *tree)
   return tree->c_lnL;
 }
 
-/* Br_Len_Opt keeps the reference's call pattern (src/optimiz.c:607-663): Lk(b) fills dot_prod, then the
+/* Br_Len_Newton (a harness, not a reference function) keeps the call pattern of the caller Br_Len_Opt (src/optimiz.c:607-663): Lk(b) fills dot_prod, then the
    length is optimised on dLk alone, then b's matrices are refreshed.  The 1-D search here is a safeguarded
    Newton/bisection on dlnL (the reference uses a spline search on the same two quantities). */
-phydbl Br_Len_Opt(phydbl *l, t_edge *b, t_tree *tree)
+phydbl Br_Len_Newton(phydbl *l, t_edge *b, t_tree *tree)
 {
   const t_mod *m = tree->mod;
   Set_Update_Eigen_Lr(YES, tree);
@@ -606,7 +606,7 @@ phydbl Br_Len_Opt(phydbl *l, t_edge *b, t_tree *tree)
   Set_Use_Eigen_Lr(NO, tree);
   if (tree->c_lnL < lk_begin - 1.E-6 * fabs(lk_begin))
   { /* src/optimiz.c:656-661 */
-    Lk_Exit("Br_Len_Opt", "likelihood decreased");
+    Lk_Exit("Br_Len_Newton", "likelihood decreased");
     return tree->c_lnL;
   }
   return tree->c_lnL;

@@ -1338,9 +1338,15 @@ static int small_upload(Instance *I, double *dst, const double *src, size_t n)
 {
   const size_t off = (size_t)(dst - I->d_model);
   if (I->h_model_set[off] && !memcmp(I->h_model.data() + off, src, n * sizeof(double))) return PHYHIP_SUCCESS;
-  int rc = flush_sync(I); // model blocks change rarely; keep it simple and ordered
+  // A real change (every step of Round_Optimize's model optimisation): the queued work that still belongs to the old
+  // values is launched, then the new block follows it IN STREAM ORDER through the pinned staging ring -- no host
+  // synchronisation (round 1 drained the stream here).
+  int rc = flush(I, nullptr);
   if (rc) return rc;
-  HIPCHK(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+  void *st = nullptr;
+  if ((rc = I->ring.alloc(n * sizeof(double), I->stream, &st))) return rc;
+  memcpy(st, src, n * sizeof(double));
+  HIPCHK(hipMemcpyAsync(dst, st, n * sizeof(double), hipMemcpyHostToDevice, I->stream));
   memcpy(I->h_model.data() + off, src, n * sizeof(double));
   I->h_model_set[off] = 1;
   return PHYHIP_SUCCESS;

@@ -70,7 +70,7 @@ def load():
         L = C.CDLL(LK_LIB_PATH)
         L.Make_Tree_From_Edges.restype = C.POINTER(t_tree)
         L.Make_Model_Basic.restype = C.POINTER(t_mod)
-        for f in ("Lk", "dLk", "Br_Len_Opt", "Update_Lk_At_Given_Edge"):
+        for f in ("Lk", "dLk", "Br_Len_Newton", "Update_Lk_At_Given_Edge"):
             getattr(L, f).restype = C.c_double
         # tests must survive the reference's print-and-Exit() convention
         L.Set_Exit_Handler(_exit_handler)
@@ -239,9 +239,9 @@ class LkTree:
     def Set_Update_Eigen_Lr(self, yesno):
         self.L.Set_Update_Eigen_Lr(int(bool(yesno)), self.tree)
 
-    def Br_Len_Opt(self, b):
+    def Br_Len_Newton(self, b):
         lv = C.c_double(self.edge(b).contents.l)
-        v = self.L.Br_Len_Opt(C.byref(lv), self.edge(b), self.tree)
+        v = self.L.Br_Len_Newton(C.byref(lv), self.edge(b), self.tree)
         _raise_if_error()
         return lv.value, v
 

@@ -34,7 +34,7 @@ def test_host_layer_exports():
     body = hdr[hdr.index("/* ---- construction"):]
     names = set(re.findall(r"^[A-Za-z_ \*]*?\b([A-Za-z_]+)\(", body, flags=re.M)) - {"void", "handler"}
     assert {"Lk", "dLk", "Update_Partial_Lk", "Update_PMat_At_Given_Edge", "Post_Order_Lk", "Pre_Order_Lk",
-            "Update_Eigen_Lr", "Set_Both_Sides", "Br_Len_Opt", "Make_Tree_For_Lk", "Free_Tree_Lk", "PMat"} <= names, names
+            "Update_Eigen_Lr", "Set_Both_Sides", "Br_Len_Newton", "Make_Tree_For_Lk", "Free_Tree_Lk", "PMat"} <= names, names
     for s in names:
         assert hasattr(H, s), s
 

@@ -127,7 +127,7 @@ def test_br_len_opt_increases_lnl():
         t.Update_PMat_At_Given_Edge(e)
         l1 = t.Lk(e)
         assert l1 < l0
-        lopt, l2 = t.Br_Len_Opt(e)
+        lopt, l2 = t.Br_Len_Newton(e)
         assert l2 >= l1 and l2 >= l0 - 1e-6 * abs(l0)
         assert abs(t.c_dlnL) < 1e-3 * abs(l2) * 1e-3 or abs(t.c_dlnL) < 1e-2
     finally:
