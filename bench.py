@@ -91,12 +91,13 @@ def measured_roofline():
 
 
 def kernel_source_hash():
-    """Identity of the kernels a counter profile belongs to: hash of every source under phyml_amd/csrc."""
+    """Identity of the kernels a counter profile belongs to: hash of the device code, i.e. every header under
+    phyml_amd/csrc (all kernels live in *.hpp; phyhip.hip is the host side)."""
     h = hashlib.sha256()
     base = os.path.join(ROOT, "phyml_amd", "csrc")
     for f in sorted(os.listdir(base)):
         p = os.path.join(base, f)
-        if os.path.isfile(p) and not f.startswith("membench"):
+        if os.path.isfile(p) and f.endswith(".hpp"):
             h.update(f.encode()); h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
