@@ -144,6 +144,10 @@ def test_lg4x_mixture_on_the_class_axis(host_matrices):
             assert np.array_equal(f[k], d[f"class{k}_fact"])
             ref_u = d[f"class{k}_unscaled_site_lk_cat"]
             assert np.max(np.abs(u[:, k] - ref_u) / ref_u) < (1e-13 if host_matrices else 1e-10)
+            # the class's own scale vectors of the two edge sides (phyhip_get_class_scale_factors) add up to its exponent
+            sides = [t.side_buffer(e, 0), t.side_buffer(e, 1)]
+            tot = sum(t.inst.get_class_scale_factors(b, k) for b in sides if b >= t.n)
+            assert np.array_equal(tot, f[k])
     finally:
         t.close()
 
