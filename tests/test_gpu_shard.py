@@ -278,3 +278,21 @@ def test_device_output_path_on_the_callers_stream(golden):
         assert abs(t.Lk(None) - ref) / abs(ref) < 1e-12   # and the host-returning form still works on that stream
     finally:
         t.close()
+
+
+def test_sharded_instances_come_and_go(monkeypatch):
+    """Create / evaluate / finalize sharded instances repeatedly (communicators, helper threads, shared streams and
+    reduction buffers are torn down with them), interleaved with a plain instance that must keep working."""
+    monkeypatch.setenv("PHYHIP_SHARD_THREADS", "1")
+    t0, ot, *_ = synthetic_pair(12, 500, 4, 4, seed=3)
+    try:
+        ref = ot.lk(None)
+        for rep in range(4):
+            t, _, *_ = synthetic_pair(12, 500, 4, 4, seed=3, devices=[0] * (1 + rep % 3), force_sharded=True)
+            try:
+                assert abs(t.Lk(None) - ref) / abs(ref) < 1e-12
+            finally:
+                t.close()
+            assert abs(t0.Lk(None) - ref) / abs(ref) < 1e-12
+    finally:
+        t0.close()

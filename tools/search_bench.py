@@ -25,7 +25,8 @@ else:
 out = {"taxa": n, "patterns": P, "states": ns}
 for mode in (["device"] if skip_host else ["device", "host"]):
     t0 = time.time()
-    r = subprocess.run([GLUE] + args, cwd=tmp, env=dict(os.environ, GLUE_MODE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    wrap = os.environ.get("SEARCH_BENCH_WRAP", "").split()  # e.g. "rocprofv3 --kernel-trace --stats -d /x --": profile the driver itself
+    r = subprocess.run(wrap + [GLUE] + args, cwd=tmp, env=dict(os.environ, GLUE_MODE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
     if not m:
         print(r.stdout[-1500:]); raise SystemExit(1)
