@@ -170,7 +170,9 @@ struct Instance
   int       mix_invar_model = 0;  // +I mixture (phyhip_set_mixture_invariant_sites): carried by the first / class-axis instance
   double    mix_pinvar = 0.0, mix_pi_inv[20] = {0};
   HostBlock *h_blocks  = nullptr; // host-mapped {block sum, tag} records of the host-side final sum
-  int       host_sum_n = 0;       // > 0: the evaluation in flight is finished by the host from this many records
+  int       host_sum_n = 0;       // > 0: the evaluation in flight is finished by the host from this many records per sum
+  int       host_sum_ns = 1;      // ... and this many sums (1: lnL; 2: lnL and dlnL)
+  size_t    h_blocks_cap = 0;
   bool      host_sum   = true;    // PHYHIP_HOST_SUM=0: large grids use final_reduce_kernel instead
   void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
   int       pm_scratch_cap = 0;
@@ -561,7 +563,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
     const int nblk = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     // (fusing on large grids was measured for one-operation launches too: 61.6 vs 41.9 us per SPR candidate at cfg5)
-    fused_sum = !I->class_axis && fuse_reduce(I, nblk);
+    fused_sum = !I->class_axis && fuse_reduce(I, nblk) && !(I->host_sum && ee->to_host && !ee->dev_out);
     if (fused_sum)
     { // the traversal kernel's last workgroup finishes the sum and reports to the host
       q.tickets = I->d_tickets; q.result = ee->dev_out ? ee->dev_out : I->d_result;
@@ -570,7 +572,9 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       q.warn_out = ee->warn_out;
     }
     if (!fused_sum && ee->to_host && !ee->dev_out && I->host_sum && !I->class_axis)
-    { // large grid: the workgroups post their sums to the host, which adds them (wait_result)
+    { // the workgroups post their sums to the host, which adds them (wait_result) -- at every grid size: on small grids
+      // this replaces the ticket draw of the fused sum (block sum written through, atomic, fence, re-read: ~3 us of
+      // dependent memory round trips inside a ~10 us kernel), on large ones the second launch
       q.host_blocks = I->h_blocks; q.host_tag = ++I->seq;
       q.warn        = I->h_warn;   // raised straight in host-mapped memory
       *I->h_warn    = 0;
@@ -788,7 +792,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     }
   }
   HIPCHK(hipGetLastError());
-  I->host_sum_n = host_sum_n;
+  I->host_sum_n = host_sum_n; I->host_sum_ns = 1;
   if (ee && !fused_sum && !host_sum_n && !I->class_axis) // (class axis: the combination kernel follows, no sum here)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
@@ -844,7 +848,7 @@ int check_partial_index(const Instance *I, int idx, bool allow_tip)
 // that the value does not depend on which path produced it.
 int wait_host_sum(Instance *I)
 {
-  const int                n   = I->host_sum_n;
+  const int                n   = I->host_sum_n * I->host_sum_ns, per = I->host_sum_n;
   const unsigned long long tag = I->seq;
   volatile HostBlock      *hb  = I->h_blocks;
   struct timespec t0;
@@ -872,16 +876,20 @@ int wait_host_sum(Instance *I)
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  double acc[256];
-  for (int t = 0; t < 256; ++t)
+  for (int k = 0; k < I->host_sum_ns; ++k)
   {
-    double a = 0.0;
-    for (int i = t; i < n; i += 256) a += I->h_blocks[i].sum;
-    acc[t] = a;
+    const HostBlock *in = I->h_blocks + (size_t)k * per;
+    double           acc[256];
+    for (int t = 0; t < 256; ++t)
+    {
+      double a = 0.0;
+      for (int i = t; i < per; i += 256) a += in[i].sum;
+      acc[t] = a;
+    }
+    for (int off = 128; off > 0; off >>= 1)
+      for (int t = 0; t < off; ++t) acc[t] += acc[t + off];
+    I->h_result[k] = acc[0];
   }
-  for (int off = 128; off > 0; off >>= 1)
-    for (int t = 0; t < off; ++t) acc[t] += acc[t + off];
-  I->h_result[0]   = acc[0];
   I->host_sum_n    = 0;
   I->warn_current  = true;
   *reinterpret_cast<volatile unsigned long long *>(I->h_result + 2) = tag;
@@ -937,6 +945,15 @@ int collect_profile(Instance *I)
   }
   I->prof_pairs.clear();
   return 0;
+}
+
+// A combination / dLk kernel's sums go to the host as posted records (host-side final sum) when the instance allows it
+void host_sum_finish(Instance *I, FinishParams &f, int grid, int ns)
+{
+  if (!I->host_sum || (size_t)grid * ns > I->h_blocks_cap) return; // (keeps the ticket path set up by the caller)
+  f.host_blocks = I->h_blocks; f.host_tag = f.seq; f.stride = grid; f.warn = I->h_warn;
+  *I->h_warn     = 0;
+  I->host_sum_n  = grid; I->host_sum_ns = ns;
 }
 
 // the +I share of a mixture evaluation (phyhip_set_mixture_invariant_sites) into the combination kernel's parameters
@@ -1145,9 +1162,11 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipHostMalloc((void **)&I->h_warn, sizeof(int), hipHostMallocMapped));
   *I->h_warn = 0;
   {
-    const size_t nb = (size_t)std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2));
+    // traversal grids (one sum), dLk grids (two sums, <= 2048 workgroups), mixture combination grids ((P + 255) / 256)
+    const size_t nb = std::max<size_t>((size_t)std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2)), 2 * 2048);
     HIPCHK(hipHostMalloc((void **)&I->h_blocks, nb * sizeof(HostBlock), hipHostMallocMapped));
     memset(I->h_blocks, 0, nb * sizeof(HostBlock));
+    I->h_blocks_cap = nb;
   }
   if (const char *e = getenv("PHYHIP_HOST_SUM")) I->host_sum = atoi(e) != 0;
 
@@ -1635,6 +1654,7 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
   q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
   q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
   q.fin.seq = ++I0->seq;
+  host_sum_finish(I0, q.fin, grid, 1);
   hipLaunchKernelGGL(mixture_combine_kernel, dim3(grid), dim3(256), 0, I0->stream, q);
   HIPCHK(hipGetLastError());
   int rc = wait_result(I0);
@@ -1713,6 +1733,7 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
     q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
     q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
     q.fin.seq = ++I0->seq;
+    host_sum_finish(I0, q.fin, grid, 2);
     hipLaunchKernelGGL((mixture_dlk_kernel<S_>), dim3(grid), dim3(256), 0, I0->stream, q);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1776,6 +1797,7 @@ int phyhip_calculate_class_mixture_log_likelihood(int instance, int parent, int 
   q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
   q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
   q.fin.seq = ++I->seq;
+  host_sum_finish(I, q.fin, grid, 1);
   hipLaunchKernelGGL(mixture_combine_kernel, dim3(grid), dim3(256), 0, I->stream, q);
   HIPCHK(hipGetLastError());
   if ((rc = wait_result(I))) return rc;
@@ -1831,6 +1853,7 @@ int phyhip_calculate_class_mixture_eigen_lnl_dlnl(int instance, int left, int ri
   q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
   q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
   q.fin.seq = ++I->seq;
+  host_sum_finish(I, q.fin, grid, 2);
   hipLaunchKernelGGL((mixture_dlk_kernel<20>), dim3(grid), dim3(256), 0, I->stream, q);
   HIPCHK(hipGetLastError());
   if ((rc = wait_result(I))) return rc;
@@ -1985,7 +2008,13 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   const size_t dot_bytes = (size_t)I->P * I->C * I->S * sizeof(double);
   const int    dgrid = std::min(I->grid, dot_bytes > (size_t)100 << 20 ? 2048 : 512);
   q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = dgrid; q.fin.warn = I->d_warn;
-  const bool fused = fuse_reduce(I, dgrid);
+  const bool hsum  = !dev_out && I->host_sum;
+  const bool fused = !hsum && fuse_reduce(I, dgrid);
+  if (hsum)
+  { // both sums posted to the host per workgroup (see flush_impl)
+    q.fin.host_blocks = I->h_blocks; q.fin.host_tag = ++I->seq; q.fin.warn = I->h_warn;
+    *I->h_warn = 0;
+  }
   if (fused)
   {
     q.fin.tickets = I->d_tickets; q.fin.result = dev_out ? dev_out : I->d_result;
@@ -2023,7 +2052,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   });
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  if (!fused)
+  if (hsum) { I->host_sum_n = dgrid; I->host_sum_ns = 2; }
+  if (!fused && !hsum)
   {
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, dgrid, 2, dgrid,
                        dev_out ? dev_out : I->d_result, dev_out ? (double *)nullptr : I->h_result, I->d_warn, I->h_warn,

@@ -310,6 +310,11 @@ struct FinishParams
   int                *warn, *warn_host;
   unsigned long long  seq;
   double             *warn_out;    // device double that receives the warning flag (sharded evaluation) or nullptr
+  // Scalar wanted on the host: every workgroup posts {sum k, tag} for each of its NS sums straight into host-mapped memory
+  // (record k * stride + workgroup) and retires; the host polls the tags and adds the sums in final_reduce_kernel's order.
+  // No ticket draw, no second launch: the shortest path from a workgroup's sum to the caller, at every grid size.
+  HostBlock          *host_blocks;
+  unsigned long long  host_tag;
 };
 
 __device__ __forceinline__ void raise_warn(int *warn)
@@ -318,13 +323,29 @@ __device__ __forceinline__ void raise_warn(int *warn)
   __hip_atomic_store(warn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Called by every lane of ONE wave per workgroup with the workgroup's sums in lane 0.  Without f.result the sums are
+__device__ __forceinline__ void post_host_block(HostBlock *dst, double sum, unsigned long long tag)
+{
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  u64x2 rec;
+  __builtin_memcpy(&rec, &sum, 8);
+  rec.y = tag;
+  __builtin_nontemporal_store(rec, reinterpret_cast<u64x2 *>(dst)); // one 16-byte write: sum and tag arrive together
+}
+
+// Called by every lane of ONE wave per workgroup with the workgroup's sums in lane 0.  With f.host_blocks each sum is posted to the host and the workgroup retires.  Without f.result the sums are
 // only recorded (final_reduce_kernel follows).  With it, they are stored through to memory (agent scope), a ticket is
 // drawn, and the workgroup that draws the last ticket adds all block sums -- same grouping and order as
 // final_reduce_kernel, so the result does not depend on which workgroup finishes last -- and publishes it: one kernel
 // launch and one inter-kernel gap less per scalar-returning call.
 template <int NS> __device__ __forceinline__ void finish_sums(const FinishParams &f, const double (&s)[NS], int lane)
 {
+  if (f.host_blocks)
+  {
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) post_host_block(f.host_blocks + (size_t)k * f.stride + blockIdx.x, s[k], f.host_tag);
+    return;
+  }
   if (!f.result)
   {
     if (lane == 0)
@@ -404,17 +425,11 @@ __device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s,
 {
   if (q.host_blocks)
   {
-    if (lane == 0)
-    {
-      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-      u64x2 rec;
-      __builtin_memcpy(&rec, &s, 8);
-      rec.y = q.host_tag;
-      __builtin_nontemporal_store(rec, reinterpret_cast<u64x2 *>(q.host_blocks + blockIdx.x)); // one 16-byte write
-    }
+    if (lane == 0) post_host_block(q.host_blocks + blockIdx.x, s, q.host_tag);
     return;
   }
   FinishParams f;
+  f.host_blocks = nullptr; f.host_tag = 0;
   f.tickets = q.tickets; f.block_sums = q.block_sums; f.stride = 0; f.result = q.result; f.result_host = q.result_host;
   f.warn = q.warn; f.warn_host = q.warn_host; f.seq = q.seq; f.warn_out = q.warn_out;
   const double v[1] = {s};

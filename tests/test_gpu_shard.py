@@ -212,12 +212,12 @@ def test_cfg4_one_million_patterns_against_the_reference():
         os.environ.pop("PHYHIP_SHARD_THREADS", None)
 
 
-@pytest.mark.parametrize("split,host_sum", [("0", "1"), ("1", "0"), ("1", "1")])
+@pytest.mark.parametrize("split,host_sum", [("0", "0"), ("1", "0"), ("0", "1")])
 @pytest.mark.parametrize("name", ["nucleic_gtr_g4", "proteic_lg_g4"])
 def test_the_three_final_sums_agree(name, split, host_sum, golden, monkeypatch):
-    """The three ways an evaluation's block sums become the scalar -- fused into the traversal kernel's last workgroup
-    (PHYHIP_SPLIT_REDUCE=0), a separate final_reduce_kernel (=1, PHYHIP_HOST_SUM=0), posted to the host and added there
-    (=1, PHYHIP_HOST_SUM=1: what large grids use) -- all give the golden lnL, dLk and warning flag."""
+    """The three ways an evaluation's block sums become the scalar -- fused into the kernel's last workgroup
+    (PHYHIP_HOST_SUM=0, PHYHIP_SPLIT_REDUCE=0), a separate final_reduce_kernel (PHYHIP_SPLIT_REDUCE=1), posted to the host
+    and added there (PHYHIP_HOST_SUM=1, the default for host-returning calls at every grid size) -- all give the golden lnL, dLk and warning flag."""
     monkeypatch.setenv("PHYHIP_SPLIT_REDUCE", split)
     monkeypatch.setenv("PHYHIP_HOST_SUM", host_sum)
     d = golden(name)
@@ -237,7 +237,7 @@ def test_the_three_final_sums_agree(name, split, host_sum, golden, monkeypatch):
 
 
 def test_host_side_final_sum_is_bit_identical_to_the_device_one(monkeypatch):
-    """Large grid (more than 512 workgroups): the host adds the posted block sums in final_reduce_kernel's order, so the
+    """Large grid (more than 512 workgroups, several host-side partial sums): the host adds the posted block sums in final_reduce_kernel's order, so the
     scalar is the same double whichever path produced it; the numerical-warning flag arrives through host-mapped memory."""
     vals = []
     for hs in ("0", "1"):
