@@ -39,6 +39,10 @@ constexpr bool kDiag = true;
 #else
 constexpr bool kDiag = false;
 #endif
+// PHYHIP_DIAG + PHYHIP_HOSTPROF=1: where the host's time per scalar-returning call goes (cycle counter, printed at finalize)
+struct HostProf { unsigned long long prep = 0, launch = 0, wait = 0, n_launch = 0, n_wait = 0, t_first = 0, t_last = 0; };
+static HostProf g_hp;
+static inline unsigned long long hp_now() { return kDiag ? __builtin_ia32_rdtsc() : 0ull; }
 
 namespace
 {
@@ -194,7 +198,7 @@ struct Instance
   std::vector<uint32_t>                  masks;
   std::unordered_map<uint32_t, int>      mask_code;
   bool                                   masks_dirty = false;
-  std::vector<double>                    h_rates, h_eval;
+  std::vector<double>                    h_rates, h_eval, h_evec, h_ivec;
   std::vector<double>                    h_model;      // host shadow of d_model: a setter called with unchanged values
   std::vector<unsigned char>             h_model_set;  // ... (callers re-push the model before every evaluation) costs nothing
   std::vector<short>                     h_invar;
@@ -409,13 +413,14 @@ static bool fuse_reduce(const Instance *I, int nblocks)
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush_impl(Instance *I, const EdgeEval *ee)
 {
+  const unsigned long long hp0 = hp_now();
   const int n_ops = (int)I->pending.size();
   int rc = 0;
   // a short list of device-built matrices is folded into the lane-per-pattern nucleotide kernel's prologue when the grid
   // is small (measured: 16.7 vs 17.8 us per scalar-returning call on a 382-pattern search prefix; at 100 000 patterns
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
   const bool fold_pm = I->soa && I->fold_pmats && I->grid_nt2 <= 512 && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
-                       I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !(I->ablate & 8);
+                       I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
   if (!fold_pm && (!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
   if (n_ops == 0 && !ee) return 0;
   rc = upload_masks(I);
@@ -428,7 +433,10 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   {
     q.n_fresh = (int)I->pm_idx.size();
     for (int k = 0; k < q.n_fresh; ++k) { q.fresh_idx[k] = I->pm_idx[k]; q.fresh_len[k] = I->pm_len[k]; }
-    q.m_evec = I->d_evec; q.m_ivec = I->d_ivec; q.m_eval = I->d_eval; q.m_rates = I->d_catr;
+    // (4 states, one eigen system, <= 4 categories: see fold_pm) the eigen system rides in the arguments as well
+    memcpy(q.m_evec, I->h_evec.data(), 16 * sizeof(double)); memcpy(q.m_ivec, I->h_ivec.data(), 16 * sizeof(double));
+    memcpy(q.m_eval, I->h_eval.data(), 4 * sizeof(double));
+    for (int c = 0; c < 4; ++c) q.m_rates[c] = c < I->C ? I->h_rates[c] : 0.0;
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats_rw = I->d_pmats;
     // (the matrix queue is cleared only after the launch that rebuilds it has been issued, see below)
   }
@@ -537,7 +545,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       // (reading short lists straight from the pinned staging memory instead was measured: no gain)
       if (in_args)
       {
-        q.recs_in_args = 1;
+        q.recs_in_args = 1; q.n_real_ops = n_ops;
         q.arg_ir[0] = ir[0]; q.arg_ir[1] = ir[1];
         q.arg_xr[0] = xr[0]; q.arg_xr[1] = xr[1];
       }
@@ -561,6 +569,17 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   {
     I->warn_current = false;
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
+    if (n_ops == 0 && fat && I->soa && I->args_recs) { q.recs_in_args = 1; q.n_real_ops = 0; } // (evaluation-only short launch)
+    if (q.recs_in_args)
+    { // short launch: the kernel fetches the sides of the evaluation edge that no queued operation writes up front
+      auto untouched = [&](int idx) {
+        if (idx < I->tips) return false;
+        for (const DevOp &o : I->pending)
+          if (o.dest == idx) return false;
+        return true;
+      };
+      q.e_prefetch = (untouched(ee->parent) ? 1 : 0) | (untouched(ee->child) ? 2 : 0);
+    }
     const int nblk = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     // (fusing on large grids was measured for one-operation launches too: 61.6 vs 41.9 us per SPR candidate at cfg5)
     fused_sum = !I->class_axis && fuse_reduce(I, nblk) && !(I->host_sum && ee->to_host && !ee->dev_out);
@@ -589,6 +608,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, I->stream));
   }
+  const unsigned long long hp1 = hp_now();
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     if constexpr (S_ == 4 && CP_ <= 4)
@@ -622,13 +642,14 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           return 0;
         }
 #endif
+#define NT2LAUNCH(c_, g_, a_)                                                                                               \
+  hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, a_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec,  \
+                     ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);
 #define NT2CASE(c_, g_)                                                                                                     \
-  if (q.recs_in_args)                                                                                                       \
-    hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, true>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
-                       ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
-  else                                                                                                                      \
-    hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, \
-                       ro.tip_codes, (unsigned long long *)nullptr);                                                        \
+  if (!q.recs_in_args) { NT2LAUNCH(c_, g_, 0) }                                                                             \
+  else if (q.n_real_ops == 1) { NT2LAUNCH(c_, g_, 1) }                                                                      \
+  else if (q.n_real_ops == 2) { NT2LAUNCH(c_, g_, 2) }                                                                      \
+  else { NT2LAUNCH(c_, g_, 3) }                                                                                             \
   return 0;
         switch (I->C * 8 + I->nt_groups)
         {
@@ -642,6 +663,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           default: break;
         }
 #undef NT2CASE
+#undef NT2LAUNCH
       }
     }
     if constexpr (S_ == 4 && (CP_ == 8 || kDiag))
@@ -791,6 +813,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       I->prof_wr_bytes += wr * (double)I->P;
     }
   }
+  if (kDiag) { const unsigned long long hp2 = hp_now(); g_hp.prep += hp1 - hp0; g_hp.launch += hp2 - hp1; ++g_hp.n_launch; }
   HIPCHK(hipGetLastError());
   I->host_sum_n = host_sum_n; I->host_sum_ns = 1;
   if (ee && !fused_sum && !host_sum_n && !I->class_axis) // (class axis: the combination kernel follows, no sum here)
@@ -896,7 +919,15 @@ int wait_host_sum(Instance *I)
   return 0;
 }
 
+int wait_result_impl(Instance *I);
 int wait_result(Instance *I)
+{
+  const unsigned long long t0 = hp_now();
+  const int rc = wait_result_impl(I);
+  if (kDiag) { const unsigned long long t1 = hp_now(); g_hp.wait += t1 - t0; ++g_hp.n_wait; if (!g_hp.t_first) g_hp.t_first = t0; g_hp.t_last = t1; }
+  return rc;
+}
+int wait_result_impl(Instance *I)
 {
   if (I->host_sum_n > 0) return wait_host_sum(I);
   if (I->spin_wait)
@@ -1128,6 +1159,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->h_model.assign(model_doubles, 0.0);
   I->h_model_set.assign(model_doubles, 0);
   I->h_eval.assign(NE * I->S, 0.0);
+  I->h_evec.assign(NE * (size_t)I->S * I->S, 0.0); I->h_ivec.assign(NE * (size_t)I->S * I->S, 0.0);
   HIPCHK(hipMalloc((void **)&I->d_site_lnl, I->P * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_site_lk, I->P * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_site_cat, (size_t)I->P * I->C * sizeof(double)));
@@ -1218,6 +1250,18 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
 
 int phyhip_finalize_instance(int instance)
 {
+  if (kDiag && getenv("PHYHIP_HOSTPROF") && g_hp.n_wait)
+  {
+    struct timespec c0, c1;
+    clock_gettime(CLOCK_MONOTONIC, &c0);
+    const unsigned long long r0 = hp_now();
+    do clock_gettime(CLOCK_MONOTONIC, &c1); while ((c1.tv_sec - c0.tv_sec) * 1000000000L + (c1.tv_nsec - c0.tv_nsec) < 5000000L);
+    fprintf(stderr, "hostprof: %.3f cycles per ns\n", (double)(hp_now() - r0) / 5e6);
+    fprintf(stderr, "hostprof (cycles): launches %llu waits %llu | per launch: prep %.0f launch %.0f | per wait: %.0f | span per wait %.0f\n",
+            g_hp.n_launch, g_hp.n_wait, (double)g_hp.prep / g_hp.n_launch, (double)g_hp.launch / g_hp.n_launch,
+            (double)g_hp.wait / g_hp.n_wait, (double)(g_hp.t_last - g_hp.t_first) / g_hp.n_wait);
+    g_hp = HostProf();
+  }
   if (Group *G = get_group(instance))
   {
     {
@@ -1404,6 +1448,8 @@ int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, co
   if (idx < 0 || idx >= I->NE) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex %d (0..%d)", idx, I->NE - 1);
   std::copy(eval, eval + I->S, I->h_eval.begin() + (size_t)idx * I->S);
   const size_t SS = (size_t)I->S * I->S;
+  std::copy(evec, evec + SS, I->h_evec.begin() + idx * SS);
+  std::copy(ivec, ivec + SS, I->h_ivec.begin() + idx * SS);
   int rc = small_upload(I, I->d_evec + idx * SS, evec, SS);
   if (rc) return rc;
   rc = small_upload(I, I->d_ivec + idx * SS, ivec, SS);
@@ -2047,7 +2093,9 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   }
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    const unsigned long long h1 = hp_now();
     hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, I->stream, q);
+    if (kDiag) { g_hp.launch += hp_now() - h1; ++g_hp.n_launch; }
     return 0;
   });
   if (rc) return rc;

@@ -114,13 +114,15 @@ struct TreeParams
   int             n_fresh;
   int             fresh_idx[8];
   double          fresh_len[8];
-  const double   *m_evec, *m_ivec, *m_eval, *m_rates; // U, U^-1, eigenvalues, category rates
+  double          m_evec[16], m_ivec[16], m_eval[4], m_rates[4]; // U, U^-1, eigenvalues, category rates (4 states, <= 4 categories)
   double          br_len_mult, l_min, l_max;
   double         *pmats_rw;
   // One- and two-operation launches (an SPR regraft candidate is ONE update + the edge evaluation, src/spr.c:643-646)
   // carry their operation records here, in the kernel arguments, instead of a staged copy into the device slot ring: one
   // copy command less in front of the launch.
   int             recs_in_args;
+  int             n_real_ops;   // operations before padding (records in the arguments: an odd list is NOT re-executed)
+  int             e_prefetch;   // bit 0 / 1: the evaluation edge's parent / child side is an internal buffer no queued operation writes
   IssueRec        arg_ir[2];
   ExecRec         arg_xr[2];
   // Large grids, scalar wanted on the host: every workgroup posts {block sum, tag} straight into host-mapped memory and
@@ -1096,6 +1098,10 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
     const bool      act = (p0 < q.P) && (c0 < q.C);
     const long long p   = (p0 < q.P) ? p0 : (q.P - 1);
     const int       c   = (c0 < q.C) ? c0 : 0;
+    // (weight, scale exponent, invariant state: fetched with the products, not after the arithmetic)
+    const double    wt_pre = q.wght[p];
+    const int       f_pre  = q.fact[p];
+    const int       iv_pre = q.invar_model ? (int)q.invar[p] : -1;
 
     double dp[S];
     {
@@ -1151,13 +1157,13 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
     double c_lnl = 0.0, c_dlnl = 0.0;
     if (act && c == 0)
     {
-      const double wt = q.wght[p];
+      const double wt = wt_pre;
       if (wt > kSmall)
       {
-        int f = q.fact[p];
+        int f = f_pre;
         if (q.invar_model)
         { // src/lk.c:1005-1025 (dLk) / :910-931 (Lk in the eigen basis)
-          const int iv  = q.invar[p];
+          const int iv  = iv_pre;
           double    inv = 0.0;
           bool      issue = false;
           if (iv >= 0)

@@ -36,9 +36,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // arithmetic and half the registers, two or three per SIMD.  The only cross-lane traffic is one 32-bit exchange per
 // operation (the rescaling maximum) and the category mixture of the edge evaluation.  G = 1 stays the choice for
 // large alignments, where the kernel is HBM-bound and fewer, fatter waves issue fewer instructions per pattern.
-// ARGS: the (one or two) operation records are read from the kernel arguments (TreeParams::arg_ir / arg_xr) instead of
+// ARGS != 0 (short launches): the operation records are read from the kernel arguments (TreeParams::arg_ir / arg_xr) --
+// ARGS = 1: one operation, 2: two, 3: none (evaluation only) -- with the count known at compile time, instead of
 // the device slot ring -- a separate instantiation, so that the long-list kernel carries no trace of it.
-template <int C, int G = 1, bool DBG = false, bool ARGS = false>
+template <int C, int G = 1, bool DBG = false, int ARGS = 0>
 __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec,
                                                              const double *pmats, // (not restrict: the prologue may rewrite entries)
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
   auto first_d = [](const u32x4 &v) { double d; __builtin_memcpy(&d, &v, 8); return d; };
 
   // issue every load an operation needs (which ones are live was decided by the host)
-  auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc) {
+  auto issue_data = [&](const IssueRec &o, Raw &r) {
     // one auxiliary dword per child: a tip child has no scale vector and an internal child no tip byte, so the host
     // points the same descriptor at whichever row exists (spare word x = 1: tip row, addressed by aligned dword)
     const __amdgpu_buffer_rsrc_t d1r = rsrc(o.c1_data), d2r = rsrc(o.c2_data), g1r = rsrc(o.c1_scale), g2r = rsrc(o.c2_scale);
@@ -89,11 +90,17 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     for (int e = 0; e < HP; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b128(d2r, voff16, (unsigned)e * rowb, 0);
     r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, o.c1_scale.x ? (p & ~3u) : voff4, 0, 0);
     r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, o.c2_scale.x ? (p & ~3u) : voff4, 0, 0);
+  };
+  auto issue_pm = [&](const IssueRec &o, u32x4 &pc) {
     // this lane's 16-byte piece of [matrix 1 | matrix 2] (C*16 doubles each)
     int ch = (lane < 16 * C) ? lane : 0;
     const int      mat = ch / (8 * C), within = ch - mat * 8 * C;
     const unsigned off = (mat ? o.c2_data.x : o.c1_data.x) + (unsigned)within * 16u;
     pc = __builtin_amdgcn_raw_buffer_load_b128(pm_rsrc, off, 0, 0);
+  };
+  auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc) {
+    issue_data(o, r);
+    issue_pm(o, pc);
   };
 
   // u[c*4+i] = sum_j P[c][i][j] * x[c*4+j]: first product, then the FMA chain (src/avx.c:593-616);
@@ -148,31 +155,99 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     }
   };
 
-  if (q.n_fresh > 0)
-  { // rebuild the queued matrices (see TreeParams::n_fresh): entry (c, i, j) = lane (and lane + 64 ...), exactly as
-    // pmat_kernel computes it; every workgroup writes the same values, and reads them only after its own writes landed
-    for (int m = 0; m < q.n_fresh; ++m)
+  // records: device slot ring, or the kernel arguments for launches of one or two operations (last <= 1)
+  auto IR = [&](int i) -> IssueRec {
+    if constexpr (ARGS) return i ? q.arg_ir[1] : q.arg_ir[0];
+    else return irec[i];
+  };
+  auto XR = [&](int i) -> ExecRec {
+    if constexpr (ARGS) return i ? q.arg_xr[1] : q.arg_xr[0];
+    else return xrec[i];
+  };
+  const int last = ARGS ? 1 : q.n_ops - 1; // host pads the list to an even length
+  Raw       RA, RB;
+  u32x4     PA, PB;
+  // The children of the first two operations do not depend on the matrices rebuilt below: their loads go out first and
+  // travel while the prologue computes (a launch of one or two operations is a chain of dependent round trips --
+  // kernel arguments, matrices, children, evaluation edge -- and every one taken off the chain is ~1 us of ~9).
+  constexpr bool single  = ARGS == 1; // one operation, records in the arguments: no padded second step
+  const bool     has_ops = ARGS == 0 ? q.n_ops > 0 : ARGS != 3;
+  if (has_ops)
+  {
+    issue_data(IR(0), RA);
+    if constexpr (!single) issue_data(IR((1 < last) ? 1 : last), RB);
+  }
+  // Short launches: the evaluation edge's far side(s) too, when no queued operation writes them (host's call)
+  u32x4    EX[HP], EY[HP];
+  unsigned esl = 0, esr = 0;
+  if constexpr (ARGS)
+  {
+    if (q.edge_eval)
     {
-      double *out = q.pmats_rw + (size_t)q.fresh_idx[m] * (C * 16);
-      for (int e = lane; e < C * 16; e += 64)
+      const size_t bufsz = (size_t)q.Ppad * C * S;
+      auto pre = [&](int idx, u32x4 (&v)[HP], unsigned &sc) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(q.partials + (size_t)(idx - q.tip_count) * bufsz) + (size_t)(c0 * 2) * q.Ppad + p;
+#pragma unroll
+        for (int e = 0; e < HP; ++e) v[e] = src[(size_t)e * q.Ppad];
+        sc = (unsigned)q.scales[(size_t)(idx - q.tip_count) * q.Ppad + p];
+      };
+      if (q.e_prefetch & 1) pre(q.e_parent, EX, esl);
+      if (q.e_prefetch & 2) pre(q.e_child, EY, esr);
+    }
+  }
+
+  if (q.n_fresh > 0)
+  { // rebuild the queued matrices (see TreeParams::n_fresh) with pmat_kernel's arithmetic; every workgroup writes the same
+    // values.  The double-precision exp() is the expensive part (four per entry when every lane builds its own entry: 2 us
+    // of a 8 us launch, measured): a matrix needs only 4 C distinct ones, so lane (mm, c, k) computes exp(eval[k] * len(m0 +
+    // mm, c)) for 64 / (4 C) matrices at once and the entries pick theirs up by shuffle -- one exp deep instead of 4 n_fresh.
+    constexpr int PER = 4 * C, MPR = 64 / PER; // exps per matrix, matrices per round
+    // lane-indexed reads of argument arrays go to the argument segment itself (indexing the by-value struct would make
+    // the compiler copy it to scratch first)
+    typedef const __attribute__((address_space(4))) double karg_double;
+    typedef const __attribute__((address_space(4))) char   karg_char;
+    karg_char   *ka      = (karg_char *)__builtin_amdgcn_kernarg_segment_ptr();
+    karg_double *k_evec  = (karg_double *)(ka + offsetof(TreeParams, m_evec));
+    karg_double *k_ivec  = (karg_double *)(ka + offsetof(TreeParams, m_ivec));
+    karg_double *k_eval  = (karg_double *)(ka + offsetof(TreeParams, m_eval));
+    karg_double *k_rates = (karg_double *)(ka + offsetof(TreeParams, m_rates));
+    karg_double *k_len   = (karg_double *)(ka + offsetof(TreeParams, fresh_len));
+    for (int m0 = 0; m0 < q.n_fresh; m0 += MPR)
+    {
+      const int mm = lane / PER, r = lane % PER, ec = r >> 2, ek = r & 3;
+      double    ex = 0.0;
+      if (mm < MPR && m0 + mm < q.n_fresh)
       {
-        const int c = e >> 4, i = (e >> 2) & 3, j = e & 3;
-        double    len = (q.fresh_len[m] > 0.0 ? q.fresh_len[m] : 0.0) * q.m_rates[c]; // src/lk.c:2296
+        const double fl = k_len[m0 + mm];
+        double       len = (fl > 0.0 ? fl : 0.0) * k_rates[ec]; // src/lk.c:2296
         len *= q.br_len_mult;
         if (len < q.l_min) len = q.l_min;
         else if (len > q.l_max) len = q.l_max;
-        double acc = 0.0;
+        ex = exp(k_eval[ek] * len);
+      }
+      // entry (c, i, j) of a matrix = lane (C <= 4: one pass); idle lanes compute entry 0 and store nothing, so that every
+      // shuffle below runs with the whole wave active
+      const bool live = lane < C * 16;
+      const int  e = live ? lane : 0, c = e >> 4, i = (e >> 2) & 3, j = e & 3;
+      double     u[4], v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc = __builtin_fma(q.m_evec[i * 4 + k] * exp(q.m_eval[k] * len), q.m_ivec[k * 4 + j], acc);
+      for (int k = 0; k < 4; ++k) { u[k] = k_evec[i * 4 + k]; v[k] = k_ivec[k * 4 + j]; }
+      for (int m2 = 0; m2 < MPR && m0 + m2 < q.n_fresh; ++m2)
+      {
+        double *out = q.pmats_rw + (size_t)q.fresh_idx[m0 + m2] * (C * 16);
+        double  acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_fma(u[k] * __shfl(ex, m2 * PER + c * 4 + k, 64), v[k], acc);
         acc = (acc < kSmallPij) ? kSmallPij : acc; // src/models.c:293
         // row sum in ascending j over the four lanes of the row (src/models.c:296-297)
         const double t0 = __shfl(acc, (lane & ~3) + 0, 64), t1 = __shfl(acc, (lane & ~3) + 1, 64),
                      t2 = __shfl(acc, (lane & ~3) + 2, 64), t3 = __shfl(acc, (lane & ~3) + 3, 64);
         const double sum = (((0.0 + t0) + t1) + t2) + t3;
-        out[e] = acc / sum;
+        if (live) out[e] = acc / sum;
       }
     }
-    __builtin_amdgcn_s_waitcnt(0);
+    // No wait for the stores: the loads below come from this same wave, and a wave's vector-memory instructions reach
+    // the cache in program order -- a load issued after a store to the same address returns the stored value.
     asm volatile("" ::: "memory"); // nothing that reads the matrices moves above this point
     __builtin_amdgcn_wave_barrier();
   }
@@ -182,22 +257,10 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
 #pragma unroll
   for (int e = 0; e < CS; ++e) FA[e] = FB[e] = 0.0;
 
-  if (q.n_ops > 0)
+  if (has_ops)
   {
-    const int last = q.n_ops - 1; // host pads the list to an even length
-    Raw       RA, RB;
-    u32x4     PA, PB;
-    // records: device slot ring, or the kernel arguments for launches of one or two operations (last <= 1)
-    auto IR = [&](int i) -> IssueRec {
-      if constexpr (ARGS) return i ? q.arg_ir[1] : q.arg_ir[0];
-      else return irec[i];
-    };
-    auto XR = [&](int i) -> ExecRec {
-      if constexpr (ARGS) return i ? q.arg_xr[1] : q.arg_xr[0];
-      else return xrec[i];
-    };
-    issue(IR(0), RA, PA);
-    issue(IR((1 < last) ? 1 : last), RB, PB);
+    issue_pm(IR(0), PA);
+    if constexpr (!single) issue_pm(IR((1 < last) ? 1 : last), PB);
     ExecRec  cur = XR(0);
     IssueRec nx2 = IR((2 < last) ? 2 : last);
 
@@ -279,7 +342,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
 
       PHY_STAMP(k, 3)
       // prefetch operation k+2 into the registers just freed; then the scalar records of the next step
-      issue(nx2, R, PC);
+      if constexpr (!ARGS) issue(nx2, R, PC); // (records in the arguments: at most two operations, nothing to prefetch)
       PHY_STAMP(k, 7)
       const IssueRec nx3 = IR((k + 3 < last) ? k + 3 : last);
       __builtin_amdgcn_wave_barrier();
@@ -323,11 +386,23 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       nx2 = nx3;
     };
 
-    for (int k = 0; k < q.n_ops; k += 2)
+    if constexpr (ARGS != 0)
     {
-      step(k, 0, RA, PA, FA, scA, FB, scB);
-      step(k + 1, 1, RB, PB, FB, scB, FA, scA);
+      step(0, 0, RA, PA, FA, scA, FB, scB);
+      if constexpr (single)
+      { // the evaluation below expects the last result in the second register set
+#pragma unroll
+        for (int e = 0; e < CS; ++e) FB[e] = FA[e];
+        scB = scA;
+      }
+      else step(1, 1, RB, PB, FB, scB, FA, scA);
     }
+    else
+      for (int k = 0; k < q.n_ops; k += 2)
+      {
+        step(k, 0, RA, PA, FA, scA, FB, scB);
+        step(k + 1, 1, RB, PB, FB, scB, FA, scA);
+      }
   }
 
   if (DBG && stamper && dbg)
@@ -342,8 +417,13 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     const size_t bufsz = (size_t)q.Ppad * C * S;
     double       x[CS], y[CS];
     unsigned     sl, sr;
-    auto side = [&](int idx, double (&v)[CS], unsigned &sc) {
-      if (idx < tips)
+    auto side = [&](int idx, double (&v)[CS], unsigned &sc, const int bit, const u32x4 (&ev)[HP], const unsigned esc) {
+      if (ARGS && (q.e_prefetch & bit))
+      {
+        unpack(ev, v);
+        sc = esc;
+      }
+      else if (idx < tips)
       {
         const unsigned m = tip_codes[(size_t)idx * q.Ppad + p];
 #pragma unroll
@@ -368,8 +448,12 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
         sc = (unsigned)q.scales[(size_t)(idx - tips) * q.Ppad + p];
       }
     };
-    side(q.e_parent, x, sl);
-    side(q.e_child, y, sr);
+    // this pattern's weight (and invariant state) are fetched with the partials, not after the arithmetic
+    const unsigned pc_ = p < (unsigned)q.P ? p : 0u;
+    const double   w_pre = q.wght[pc_];
+    const int      iv_pre = q.invar_model ? (int)q.invar[pc_] : -1;
+    side(q.e_parent, x, sl, 1, EX, esl);
+    side(q.e_child, y, sr, 2, EY, esr);
     const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16) + c0 * 16; // rows: right-side state
     double prod[CL];
 #pragma unroll
@@ -398,13 +482,13 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     }
     if ((G == 1 || grp == 0) && p < (unsigned)q.P) // the group-0 lane of a pattern reports
     {
-      const double w = q.wght[p];
+      const double w = w_pre;
       int          f = q.apply_scaling ? (int)(sl + sr) : 0;
       if (w > kSmall)
       {
         if (q.invar_model)
         {
-          const int iv = q.invar[p];
+          const int iv = iv_pre;
           double    inv = 0.0;
           bool      issue_ = false;
           if (iv >= 0)
