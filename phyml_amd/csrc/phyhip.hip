@@ -177,6 +177,31 @@ struct Instance
   int       host_sum_n = 0;       // > 0: the evaluation in flight is finished by the host from this many records per sum
   int       host_sum_ns = 1;      // ... and this many sums (1: lnL; 2: lnL and dlnL)
   size_t    h_blocks_cap = 0;
+  // resident evaluator (resident_dlk_kernel): dLk / eigen-basis Lk of small alignments without a launch per call
+  bool         resident = true;       // PHYHIP_RESIDENT=0: every evaluation is a kernel launch
+  double       resident_idle_us = 400.0; // PHYHIP_RESIDENT_IDLE_US: the workgroups leave after this long without a command
+  ResidentCmd *r_cmd = nullptr;       // host-mapped command record
+  unsigned long long *d_rmail = nullptr; // device mailbox (larger grids: workgroup 0 relays the commands)
+  hipStream_t  r_stream[2] = {nullptr, nullptr};
+  unsigned long long r_api_no = 0;    // entry-point call of the last command
+  unsigned long long r_gen = 0, r_seq = 0; // launch generation; commands issued
+  bool         r_launched = false, r_inflight = false;
+  DlkParams    r_static;              // what the resident workgroups were launched with
+  int          r_grid = 0;
+  unsigned long long r_n_cmd = 0, r_n_launch = 0, r_n_silent = 0, r_n_busy = 0; // PHYHIP_RESIDENT_STATS=1: printed at finalize
+  // Is everything queued on the stream known to be finished?  The resident workgroups are not ordered with the stream, so
+  // they may only be used when it is.  Conservative bookkeeping: every entry point marks the stream dirty (GET_INST); the
+  // ones that queue nothing put the previous state back; Update_Eigen_Lr -- what precedes a chain of dLk calls -- ends with
+  // a report to the host (stamp) after which the stream is clean; a stream synchronisation cleans it at once.
+  bool               stream_dirty = true, dirty_prev = true;
+  unsigned long long stamp_seq = 0, clean_after = 0;
+  // Lk(b) with update_eigen_lr (src/lk.c: Update_Eigen_Lr, then Lk_Core on the same edge) opens a chain of dLk calls: the
+  // edge evaluation that directly follows an Update_Eigen_Lr makes its workgroups complete their stores before they post
+  // their sums (TreeParams::fence_post), so that once the host has the scalar the whole stream is known to be finished.
+  unsigned long long api_no = 0, eig_api_no = 0; // entry-point calls so far; the call that queued the last eigen_lr kernel
+  bool               fenced_eval = false;        // the evaluation in flight posts behind fences // stamps issued; the stamp whose arrival makes a non-dirty stream clean
+  int          wall_khz = 0;          // rate of the device's wall_clock64()
+  struct timespec r_t_launch = {0, 0}, r_t_cmd = {0, 0};
   bool      host_sum   = true;    // PHYHIP_HOST_SUM=0: large grids use final_reduce_kernel instead
   void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
   int       pm_scratch_cap = 0;
@@ -251,7 +276,10 @@ thread_local int g_cur_dev = -1;
   {                                                                                                          \
     HIPCHK(hipSetDevice(I->dev));                                                                            \
     g_cur_dev = I->dev;                                                                                      \
-  }
+  }                                                                                                          \
+  I->dirty_prev = I->stream_dirty; /* any entry point may queue work on the stream (see Instance::stream_dirty) */ \
+  I->stream_dirty = true;                                                                                    \
+  ++I->api_no;
 
 int next_pow2(int x)
 {
@@ -416,6 +444,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   const unsigned long long hp0 = hp_now();
   const int n_ops = (int)I->pending.size();
   int rc = 0;
+  if (n_ops > 0 || ee || !I->pm_idx.empty() || !I->up_idx.empty()) I->stream_dirty = true;
+  if (ee) I->fenced_eval = false;
   // a short list of device-built matrices is folded into the lane-per-pattern nucleotide kernel's prologue when the grid
   // is small (measured: 16.7 vs 17.8 us per scalar-returning call on a 382-pattern search prefix; at 100 000 patterns
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
@@ -598,6 +628,11 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       q.warn        = I->h_warn;   // raised straight in host-mapped memory
       *I->h_warn    = 0;
       host_sum_n    = nblk;
+      if (I->eig_api_no && I->api_no == I->eig_api_no + 1 && (I->soa || I->perm))
+      { // (the kernels that honour it; eig_api_no is only set for small alignments with the resident evaluator enabled)
+        q.fence_post   = 1;
+        I->fenced_eval = true;
+      }
     }
     if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
   }
@@ -869,6 +904,67 @@ int check_partial_index(const Instance *I, int idx, bool allow_tip)
 // The host's side of the final sum on large grids: poll the {sum, tag} records the workgroups posted (they arrive roughly in
 // launch order), then add them exactly as final_reduce_kernel does -- 256 strided accumulators, then a binary tree -- so
 // that the value does not depend on which path produced it.
+constexpr int kResidentDirect = 8;     // ... up to this many poll the host themselves, above that workgroup 0 relays
+constexpr int kResidentMaxGrid = 64;   // resident evaluator: alignments of up to this many dLk workgroups
+constexpr int kResidentSilent = -4242; // wait_host_sum: the resident workgroups did not answer (not an error)
+static double ns_since(const struct timespec &t0)
+{
+  struct timespec t1;
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+// Tell the resident workgroups (if any) to leave and wait until they have.
+static void resident_stop(Instance *I)
+{
+  if (!I->r_cmd || !I->r_launched) return;
+  __atomic_store_n(&I->r_cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
+  for (hipStream_t st : I->r_stream)
+    if (st) (void)hipStreamSynchronize(st);
+  __atomic_store_n(&I->r_cmd->ctl.w[1], 0ull, __ATOMIC_RELEASE);
+  I->r_launched = false;
+}
+
+// (Re)launch the resident workgroups: generation r_gen + 1 supersedes whatever is left of the previous one (its workgroups
+// see the new generation number at their next poll and leave); commands up to `served` count as done.
+static int resident_launch(Instance *I, const DlkParams &qs, int dgrid, unsigned long long served)
+{
+  if (!I->r_cmd)
+  {
+    HIPCHK(hipHostMalloc((void **)&I->r_cmd, sizeof(ResidentCmd), hipHostMallocMapped | hipHostMallocCoherent)); // (polled from the device while it changes)
+    memset(I->r_cmd, 0, sizeof(ResidentCmd));
+    HIPCHK(hipMalloc((void **)&I->d_rmail, sizeof(ResidentCmd)));
+    HIPCHK(hipMemset(I->d_rmail, 0, sizeof(ResidentCmd)));
+    for (hipStream_t &st : I->r_stream) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  }
+  ++I->r_n_launch;
+  ++I->r_gen;
+  __atomic_store_n(&I->r_cmd->ctl.w[0], I->r_gen, __ATOMIC_RELEASE);
+  ResidentCtl r;
+  r.cmd = I->r_cmd; r.gen = I->r_gen; r.start_seq = served;
+  r.n_lines = (3 + I->C * 2 * I->S + 6) / 7;
+  r.mail = dgrid > kResidentDirect ? I->d_rmail : nullptr;
+  if (I->wall_khz <= 0)
+  {
+    int dev = 0, khz = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    I->wall_khz = khz;
+  }
+  r.idle_ticks = (unsigned long long)(I->resident_idle_us * 1e-3 * (double)I->wall_khz); // wall_clock64 ticks
+  hipStream_t st = I->r_stream[I->r_gen & 1];
+  int rc = dispatch_shape(I, [&](auto s, auto cp) {
+    constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    hipLaunchKernelGGL((resident_dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, st, qs, r);
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  I->r_static = qs; I->r_grid = dgrid; I->r_launched = true;
+  clock_gettime(CLOCK_MONOTONIC, &I->r_t_launch);
+  return 0;
+}
+
 int wait_host_sum(Instance *I)
 {
   const int                n   = I->host_sum_n * I->host_sum_ns, per = I->host_sum_n;
@@ -887,7 +983,14 @@ int wait_host_sum(Instance *I)
       {
         struct timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L || !I->spin_wait)
+        const long waited = (t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec);
+        if (I->r_inflight)
+        { // no answer from the resident workgroups (they may have left just before the command arrived): the caller
+          // retires them and launches the evaluation the ordinary way
+          if (waited > 100000L && ns_since(I->r_t_launch) > 20e6) return kResidentSilent; // (a first launch loads code: ms)
+          continue;
+        }
+        if (waited > 2000000L || !I->spin_wait)
         {
           HIPCHK(hipStreamSynchronize(I->stream));
           synced = true;
@@ -914,6 +1017,7 @@ int wait_host_sum(Instance *I)
     I->h_result[k] = acc[0];
   }
   I->host_sum_n    = 0;
+  I->r_inflight    = false;
   I->warn_current  = true;
   *reinterpret_cast<volatile unsigned long long *>(I->h_result + 2) = tag;
   return 0;
@@ -1005,6 +1109,14 @@ const char *phyhip_get_last_error(void) { return g_err.c_str(); }
 // Frees everything an instance owns (also a partially built one: every pointer starts as nullptr).
 static void release_instance(Instance *I)
 {
+  if (getenv("PHYHIP_RESIDENT_STATS") && (I->r_n_cmd || I->r_n_busy))
+    fprintf(stderr, "resident evaluator: %llu commands, %llu launches, %llu unanswered, %llu evaluations launched because the stream was busy (clock %d kHz)\n",
+            I->r_n_cmd, I->r_n_launch, I->r_n_silent, I->r_n_busy, I->wall_khz);
+  resident_stop(I);
+  if (I->r_cmd) (void)hipHostFree(I->r_cmd);
+  if (I->d_rmail) (void)hipFree(I->d_rmail);
+  for (hipStream_t st : I->r_stream)
+    if (st) (void)hipStreamDestroy(st);
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
@@ -1201,6 +1313,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     I->h_blocks_cap = nb;
   }
   if (const char *e = getenv("PHYHIP_HOST_SUM")) I->host_sum = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_RESIDENT")) I->resident = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_RESIDENT_IDLE_US")) I->resident_idle_us = atof(e);
 
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
@@ -1648,6 +1762,10 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
   if (rc) return rc;
   if ((rc = wait_result(I))) return rc;
   *outSum = I->h_result[0];
+  if (I->fenced_eval)
+  { // every store of this evaluation -- and so everything queued before it -- is in memory
+    I->fenced_eval = false; I->stream_dirty = false; I->clean_after = 0;
+  }
   return PHYHIP_SUCCESS;
 }
 
@@ -2026,6 +2144,9 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   if ((rc = flush(I, nullptr))) return rc;
   EigenParams e;
   e.t = base_params(I); e.ro = base_ro(I, nullptr); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;
+  const bool report = I->resident && I->S == 4 && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co; // (see eigen_eval)
+  e.tickets = report ? I->d_tickets : nullptr;
+  e.stamp_host = reinterpret_cast<unsigned long long *>(I->h_result + 3); e.stamp = report ? ++I->stamp_seq : 0ull;
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     hipLaunchKernelGGL((eigen_lr_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, e);
@@ -2033,6 +2154,8 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   });
   if (rc) return rc;
   HIPCHK(hipGetLastError());
+  if (report) { I->stream_dirty = false; I->clean_after = e.stamp; }
+  I->eig_api_no = report ? I->api_no : 0;
   return PHYHIP_SUCCESS;
 }
 
@@ -2089,6 +2212,82 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       if (len < I->l_min) len = I->l_min;
       else if (len > I->l_max) len = I->l_max;
       for (int s = 0; s < I->S; ++s) q.expl[c * I->S + s] = exp(I->h_eval[s] * len);
+    }
+  }
+  // Small alignment, scalar wanted on the host: hand the evaluation to the resident workgroups (resident_dlk_kernel) when
+  // nothing of this instance is still running on its stream -- they are not ordered with it.  Right after Update_Eigen_Lr
+  // the products are a few microseconds away: poll the stream that long, else launch as usual.
+  // (4 states only: a 20-state command is 24 lines instead of 5 and the round trip loses to the launch, 14.1-14.9 against
+  // 12.4-12.5 us at 2 000 patterns -- measured, tools/gpu_resident_ab2.sh)
+  if (hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait)
+  {
+    bool idle = !I->stream_dirty;
+    if (idle && I->clean_after)
+    { // the report of the last Update_Eigen_Lr: a few microseconds away at most (bounded wait, then the ordinary launch)
+      volatile unsigned long long *stamp = reinterpret_cast<volatile unsigned long long *>(I->h_result + 3);
+      struct timespec t0;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (long it = 1; *stamp < I->clean_after && idle; ++it)
+      {
+        __builtin_ia32_pause();
+        if ((it & 255) == 0 && ns_since(t0) > 200000.0) idle = false;
+      }
+      if (idle) { __atomic_thread_fence(__ATOMIC_ACQUIRE); I->clean_after = 0; }
+    }
+    if (!idle) ++I->r_n_busy;
+    if (idle)
+    {
+      DlkParams qs = q; // what stays the same from call to call
+      qs.with_derivative = 0; qs.invar_model = 0; qs.apply_scaling = 0; qs.pinvar = 0.0; qs.fin.host_tag = 0;
+      memset(qs.expl, 0, sizeof qs.expl);
+      const DlkParams &o = I->r_static;
+      const bool same = I->r_launched && I->r_grid == dgrid && o.dot_prod == qs.dot_prod && o.wght == qs.wght && o.fact == qs.fact &&
+                        o.cat_w == qs.cat_w && o.pi == qs.pi && o.invar == qs.invar && o.P == qs.P && o.C == qs.C &&
+                        o.fin.host_blocks == qs.fin.host_blocks && o.fin.stride == qs.fin.stride && o.fin.warn == qs.fin.warn;
+      static const bool rdbg = getenv("PHYHIP_RESIDENT_DEBUG") != nullptr;
+      if (rdbg) fprintf(stderr, "resident: same %d launched %d since cmd %.1f us since launch %.1f us\n", (int)same, (int)I->r_launched, ns_since(I->r_t_cmd) * 1e-3, ns_since(I->r_t_launch) * 1e-3);
+      if (!same)
+      {
+        resident_stop(I);
+        if ((rc = resident_launch(I, qs, dgrid, I->r_seq))) return rc;
+      }
+      else if (ns_since(I->r_t_cmd) > 500.0 * I->resident_idle_us && ns_since(I->r_t_launch) > 500.0 * I->resident_idle_us)
+      { // idle for more than half the time after which the workgroups leave: assume they have
+        if ((rc = resident_launch(I, qs, dgrid, I->r_seq))) return rc;
+      }
+      // the command: payload words into their lines, each line's number last (see ResidentCmd)
+      unsigned long long words[kResidentWords];
+      const int          n_words = 3 + I->C * 2 * I->S;
+      const bool         changed = I->api_no != I->r_api_no + 1; // something else was called since the last command
+      words[0] = q.fin.host_tag;
+      words[1] = (q.with_derivative ? 1u : 0u) | (q.invar_model ? 2u : 0u) | (q.apply_scaling ? 4u : 0u) | (changed ? 8u : 0u);
+      memcpy(&words[2], &q.pinvar, 8);
+      memcpy(&words[3], q.expl, sizeof(double) * (size_t)(n_words - 3));
+      ++I->r_seq;
+      for (int l = 0; l * 7 < n_words; ++l)
+      {
+        ResidentLine &ln = I->r_cmd->line[l];
+        for (int k = 0; k < 7 && l * 7 + k < n_words; ++k) ln.w[k] = words[l * 7 + k];
+        __atomic_store_n(&ln.seq, I->r_seq, __ATOMIC_RELEASE);
+      }
+      I->r_api_no = I->api_no;
+      ++I->r_n_cmd;
+      clock_gettime(CLOCK_MONOTONIC, &I->r_t_cmd);
+      I->host_sum_n = dgrid; I->host_sum_ns = 2; I->r_inflight = true;
+      rc = wait_result(I);
+      if (rdbg) fprintf(stderr, "resident: answered rc %d after %.1f us\n", rc, ns_since(I->r_t_cmd) * 1e-3);
+      if (rc == 0)
+      {
+        *lnl = I->h_result[0];
+        if (dlnl) *dlnl = I->h_result[1];
+        return PHYHIP_SUCCESS;
+      }
+      if (rc != kResidentSilent) return rc;
+      // nobody there: make sure of it (after this no resident workgroup can still write a record), then the ordinary
+      // launch below repeats the evaluation under the same tag
+      ++I->r_n_silent;
+      resident_stop(I);
+      I->r_inflight = false; I->host_sum_n = 0;
     }
   }
   rc = dispatch_shape(I, [&](auto s, auto cp) {
@@ -2150,6 +2349,7 @@ int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, dou
 {
   Group *G = get_group(instance);
   GET_INST(I, G ? G->sub_id[0] : instance);
+  I->stream_dirty = I->dirty_prev; // (queues nothing by itself; flush() says so if it does)
   if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN"); // src/lk.c:671
   if (*l < I->l_min) *l = I->l_min;                                                     // src/lk.c:673-674
   else if (*l > I->l_max) *l = I->l_max;
@@ -2162,6 +2362,7 @@ int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL)
 {
   if (Group *G = get_group(instance)) return group_eigen_eval(G, l, false, outLnL, nullptr);
   GET_INST(I, instance);
+  I->stream_dirty = I->dirty_prev;
   if (I->co) return rank_eigen_eval(I, l, false, outLnL, nullptr);
   return eigen_eval(I, l, false, outLnL, nullptr);
 }
@@ -2259,7 +2460,9 @@ int phyhip_synchronize(int instance)
 {
   if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_synchronize(id); });
   GET_INST(I, instance);
-  return flush_sync(I);
+  const int rc = flush_sync(I);
+  if (rc == 0) { I->stream_dirty = false; I->clean_after = 0; } // nothing queued is left
+  return rc;
 }
 
 int phyhip_profile(int instance, int enable)

@@ -470,6 +470,7 @@ __global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParam
       return;
     }
     if (kk == 0) xchl[c][pp] = lkc;
+    if (q.fence_post) __threadfence(); // every wave's stores are in memory before wave 0 posts the workgroup's sum
     __syncthreads();
     if (c == 0 && kk == 0 && pact)
     {

@@ -122,6 +122,7 @@ struct TreeParams
   // copy command less in front of the launch.
   int             recs_in_args;
   int             n_real_ops;   // operations before padding (records in the arguments: an odd list is NOT re-executed)
+  int             fence_post;   // a workgroup's stores are complete and written back before it posts its sum (see flush_impl)
   int             e_prefetch;   // bit 0 / 1: the evaluation edge's parent / child side is an internal buffer no queued operation writes
   IssueRec        arg_ir[2];
   ExecRec         arg_xr[2];
@@ -331,7 +332,10 @@ __device__ __forceinline__ void post_host_block(HostBlock *dst, double sum, unsi
   u64x2 rec;
   __builtin_memcpy(&rec, &sum, 8);
   rec.y = tag;
-  __builtin_nontemporal_store(rec, reinterpret_cast<u64x2 *>(dst)); // one 16-byte write: sum and tag arrive together
+  // one 16-byte write: sum and tag arrive together.  System scope (sc0 sc1): written through at once -- a plain or
+  // non-temporal store may sit in the L2 until the kernel ends, which a resident workgroup never does (measured: the host
+  // saw the records of resident_dlk_kernel only when it left, an idle time-out later).
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(rec) : "memory");
 }
 
 // Called by every lane of ONE wave per workgroup with the workgroup's sums in lane 0.  With f.host_blocks each sum is posted to the host and the workgroup retires.  Without f.result the sums are
@@ -427,6 +431,7 @@ __device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s,
 {
   if (q.host_blocks)
   {
+    if (q.fence_post) __threadfence(); // (this wave's stores; kernels with several waves per workgroup fence before their last barrier)
     if (lane == 0) post_host_block(q.host_blocks + blockIdx.x, s, q.host_tag);
     return;
   }
@@ -1020,6 +1025,11 @@ struct EigenParams
   int           left, rght;
   const double *r_e_vect, *l_e_vect;
   double       *dot_prod;
+  // small grids: the workgroup that finishes last reports to the host that the products (and everything queued on the
+  // stream before this kernel) are in memory -- what the resident evaluator waits for before it reads them
+  unsigned           *tickets;    // one counter, zero between launches (nullptr: no report)
+  unsigned long long *stamp_host; // host-mapped
+  unsigned long long  stamp;
 };
 
 template <int S, int CP>
@@ -1060,6 +1070,17 @@ __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
 #pragma unroll
     for (int j = 0; j < S / 2; ++j) dst[j] = make_double2(d[2 * j], d[2 * j + 1]);
   }
+  if (e.tickets)
+  {
+    __threadfence(); // this thread's stores are complete and written back (agent scope) ...
+    __syncthreads(); // ... for every thread of the workgroup, before its ticket is drawn
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(e.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+    {
+      __hip_atomic_store(e.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(e.stamp_host, e.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1084,8 +1105,16 @@ struct DlkParams
   double        expl[kMaxExpl];
 };
 
+// What varies from one evaluation to the next on one edge (the rest of DlkParams is fixed while the instance lives)
+struct DlkCall
+{
+  int    with_derivative, invar_model, apply_scaling;
+  double pinvar;
+};
+
+// One workgroup's share of an evaluation: on return wave 0 holds the workgroup's two sums (every lane of it).
 template <int S, int CP>
-__global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
+__device__ __forceinline__ bool dlk_block(const DlkParams &q, const DlkCall k, const double *expl, int *warn, double (&v)[2])
 {
   // grid-stride over (pattern, category) lanes: a bounded number of workgroups streams dot_prod, each thread
   // accumulating its patterns, so that the per-workgroup sums stay few enough for the fused final sum
@@ -1101,7 +1130,7 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
     // (weight, scale exponent, invariant state: fetched with the products, not after the arithmetic)
     const double    wt_pre = q.wght[p];
     const int       f_pre  = q.fact[p];
-    const int       iv_pre = q.invar_model ? (int)q.invar[p] : -1;
+    const int       iv_pre = k.invar_model ? (int)q.invar[p] : -1;
 
     double dp[S];
     {
@@ -1115,9 +1144,9 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
       }
     }
     double lkc, dlkc = 0.0;
-    if (q.with_derivative)
+    if (k.with_derivative)
     { // four lanes (lk,dlk,lk,dlk) over pairs of states, then lane0+lane2 / lane1+lane3 (src/avx.c:257-274)
-      const double *ex = q.expl + c * 2 * S;
+      const double *ex = expl + c * 2 * S;
       double        z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
 #pragma unroll
       for (int i = 0; i < S / 2; ++i)
@@ -1132,7 +1161,7 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
     }
     else
     { // elementwise product, blockwise lane sums, horizontal norm (src/avx.c:227-244)
-      const double *ex = q.expl + c * S;
+      const double *ex = expl + c * S;
       double        l4[4] = {0., 0., 0., 0.};
 #pragma unroll
       for (int b4 = 0; b4 < S / 4; ++b4)
@@ -1161,7 +1190,7 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
       if (wt > kSmall)
       {
         int f = f_pre;
-        if (q.invar_model)
+        if (k.invar_model)
         { // src/lk.c:1005-1025 (dLk) / :910-931 (Lk in the eigen basis)
           const int iv  = iv_pre;
           double    inv = 0.0;
@@ -1169,7 +1198,7 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
           if (iv >= 0)
           {
             inv = q.pi[iv];
-            if (q.apply_scaling)
+            if (k.apply_scaling)
             {
               int e = f;
               do
@@ -1183,19 +1212,19 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
           }
           if (issue)
           {
-            if (q.with_derivative) { lk = inv * q.pinvar; dlk = 0.0; }
-            else { f = 0; lk = q.pi[iv] * q.pinvar; }
+            if (k.with_derivative) { lk = inv * k.pinvar; dlk = 0.0; }
+            else { f = 0; lk = q.pi[iv] * k.pinvar; }
           }
           else
           {
-            lk  = lk * (1. - q.pinvar) + inv * q.pinvar;
-            dlk = dlk * (1. - q.pinvar);
+            lk  = lk * (1. - k.pinvar) + inv * k.pinvar;
+            dlk = dlk * (1. - k.pinvar);
           }
         }
         if (lk < kSmall)
         {
           lk = kSmall;
-          raise_warn(q.fin.warn);
+          raise_warn(warn);
         }
         c_dlnl = wt * (dlk / lk);                          // src/lk.c:742-744
         c_lnl  = wt * (log(lk) - kLog2 * (double)f);       // src/lk.c:745
@@ -1219,15 +1248,164 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
     ws[1][wid] = c_dlnl;
   }
   __syncthreads();
+  v[0] = v[1] = 0.0;
   if (wid == 0)
-  {
-    double v[2] = {0.0, 0.0};
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w)
     {
-      v[0] += ws[0][k];
-      v[1] += ws[1][k];
+      v[0] += ws[0][w];
+      v[1] += ws[1][w];
     }
-    finish_sums<2>(q.fin, v, lane);
+  __syncthreads(); // (ws may be rewritten by the next evaluation of a resident workgroup)
+  return wid == 0;
+}
+
+template <int S, int CP>
+__global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
+{
+  const DlkCall k = {q.with_derivative, q.invar_model, q.apply_scaling, q.pinvar};
+  double        v[2];
+  if (dlk_block<S, CP>(q, k, q.expl, q.fin.warn, v)) finish_sums<2>(q.fin, v, (int)(threadIdx.x & 63));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident evaluator.  A branch-length Newton step (src/optimiz.c: Br_Len_Opt) is a chain of dLk calls on ONE edge, each
+// waiting for the previous scalar: per call the host pays a kernel launch (~3 us of CPU time), the command processor's
+// dispatch and the kernel's start and end -- more than the ~2 us of work in it.  While such a chain runs, the workgroups of
+// this kernel stay on the device and take their evaluations from a host-mapped command record instead: the host writes
+// {expl table, tag} and bumps the sequence word; every workgroup polls it, evaluates its share exactly as dlk_kernel does
+// (same grid, same block sums, so the host-side final sum gives the same double) and posts {sum, tag}.  A workgroup leaves
+// when told to (seq = ~0), when a newer launch has superseded it (gen), or after idle_ticks without a command -- so a
+// device-wide synchronisation never waits longer than that, and a host that died leaves nothing behind.
+// ---------------------------------------------------------------------------------------------
+// The command record is made of 64-byte lines, each carrying seven payload words and, LAST, the number of the command it
+// belongs to: the host fills a line's payload and then its number, the device reads whole lines (one aligned 64-byte read
+// each) and takes a command when every line carries the number it expects -- payload and "go" arrive in ONE trip over the
+// link instead of two (a poll of a sequence word, then a dependent read of the body: ~2 us each).  Only the first wave of
+// a workgroup reads host memory (every reader costs the others: 24 polling workgroups answered in 8.5 us, 6 in 4.3 --
+// tools/probes/resident_probe.hip); the rest get the payload through LDS.
+// Payload words: 0 tag of the {sum, tag} records, 1 flags (bit 0 derivative, 1 invariant-site model, 2 scaling, 3 device
+// data changed since the last command), 2 pinvar, 3.. the expl table.  Line 0 is control: word 0 generation in charge, word 1
+// != 0: leave.
+struct ResidentLine
+{
+  unsigned long long w[7];
+  unsigned long long seq;
+};
+constexpr int kResidentWords = 3 + kMaxExpl;
+constexpr int kResidentLines = (kResidentWords + 6) / 7;
+struct ResidentCmd
+{
+  ResidentLine ctl;
+  ResidentLine line[kResidentLines];
+};
+struct ResidentCtl
+{
+  const ResidentCmd *cmd;        // host-mapped
+  unsigned long long gen;        // this launch
+  unsigned long long start_seq;  // commands up to here have been served
+  unsigned long long idle_ticks; // wall_clock64 ticks
+  int                n_lines;    // command lines in use (3 + C * 2 * S words)
+  // More than a handful of workgroups: only workgroup 0 polls the host (every reader of host memory slows the others down);
+  // it copies each command into a mailbox in device memory -- same line format, payload before numbers -- which the others poll.
+  unsigned long long *mail;      // device, (1 + kResidentLines) * 8 words; nullptr: every workgroup polls the host
+};
+
+template <int S, int CP>
+__global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, const ResidentCtl r)
+{
+  __shared__ unsigned long long sh_raw[(1 + kResidentLines + 7) / 8 * 64];
+  __shared__ double             sh_expl[kMaxExpl];
+  __shared__ unsigned long long sh_ctl[1];
+  unsigned long long last = r.start_seq, t_last = wall_clock64();
+  const int          n_loads = (1 + r.n_lines + 7) / 8;
+  bool               mail_open = false; // workgroup 0: the mailbox carries this generation's control line
+  for (;;)
+  {
+    if (threadIdx.x < 64)
+    { // one aligned 8-byte word per lane and load: 512 contiguous bytes = 8 lines per instruction
+      const bool                leader = !r.mail || blockIdx.x == 0;
+      const unsigned long long *base = leader ? reinterpret_cast<const unsigned long long *>(r.cmd) : r.mail;
+      const int                 lane = threadIdx.x;
+      bool                      good = true;
+      unsigned long long        first = 0;
+      for (int j = 0; j < n_loads; ++j)
+      {
+        const unsigned long long v = leader ? __hip_atomic_load(base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                            : __hip_atomic_load(base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_raw[j * 64 + lane] = v;
+        if (j == 0) first = v;
+        const int line = j * 8 + (lane >> 3);
+        if ((lane & 7) == 7 && line >= 1 && line <= r.n_lines) good = good && (v == last + 1);
+      }
+      const bool               all_good = __builtin_amdgcn_ballot_w64(!good) == 0;
+      // control: the host's line 0 holds {generation, leave}; the mailbox packs both into its word 0 (generation * 2 + leave)
+      // so that a leaving workgroup 0 can say so with ONE compare-and-swap that fails if a newer generation took over
+      const unsigned long long w0 = __shfl(first, 0, 64), w1 = __shfl(first, 1, 64);
+      const unsigned long long gen = leader ? w0 : (w0 >> 1), stop = leader ? w1 : (w0 & 1);
+      unsigned long long       act = 0; // 0: poll again, 1: evaluate, 2: leave
+      if (leader ? (stop != 0 || gen != r.gen) : (gen > r.gen || (gen == r.gen && stop != 0))) act = 2;
+      else if (all_good && gen == r.gen) act = 1;
+      else if (wall_clock64() - t_last > r.idle_ticks) act = 2;
+      if (leader && r.mail)
+      { // pass it on
+        if (act == 2)
+        { // (a workgroup of an older generation that is still around sees the newer number and leaves by itself)
+          if (lane == 0 && mail_open)
+          {
+            unsigned long long expect = r.gen << 1;
+            __hip_atomic_compare_exchange_strong(r.mail, &expect, (r.gen << 1) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        else if (act == 1 || !mail_open)
+        {
+          for (int j = 0; j < n_loads; ++j)
+            if ((lane & 7) != 7 && !(j == 0 && lane < 8 && lane > 0))
+              __hip_atomic_store(r.mail + j * 64 + lane, (j == 0 && lane == 0) ? (r.gen << 1) : sh_raw[j * 64 + lane],
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control line) before the line numbers
+          if (act == 1)
+            for (int j = 0; j < n_loads; ++j)
+              if ((lane & 7) == 7 && j * 8 + (lane >> 3) != 0)
+                __hip_atomic_store(r.mail + j * 64 + lane, sh_raw[j * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          mail_open = true;
+        }
+      }
+      if (lane == 0) sh_ctl[0] = act;
+    }
+    __syncthreads();
+    const unsigned long long act = sh_ctl[0];
+    if (act == 2) return;
+    if (act == 0)
+    {
+      __syncthreads();
+      continue;
+    }
+    auto word = [&](int k) { return sh_raw[(1 + k / 7) * 8 + k % 7]; };
+    const unsigned long long tag = word(0), flags = word(1);
+    double                   pinvar;
+    {
+      const unsigned long long b = word(2);
+      __builtin_memcpy(&pinvar, &b, 8);
+    }
+    const DlkCall k = {(int)(flags & 1), (int)((flags >> 1) & 1), (int)((flags >> 2) & 1), pinvar};
+    const int     ne = q.C * (k.with_derivative ? 2 : 1) * S;
+    for (int e = threadIdx.x; e < ne; e += blockDim.x)
+    {
+      const unsigned long long b = word(3 + e);
+      __builtin_memcpy(&sh_expl[e], &b, 8);
+    }
+    // what other kernels wrote since the last command (the host says whether anything was) is re-read from memory
+    if (flags & 8) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    double v[2];
+    if (dlk_block<S, CP>(q, k, sh_expl, q.fin.warn, v))
+    {
+      FinishParams f = q.fin;
+      f.host_tag = tag;
+      finish_sums<2>(f, v, (int)(threadIdx.x & 63));
+    }
+    last = last + 1; t_last = wall_clock64();
   }
 }
 
