@@ -304,6 +304,14 @@ int phyhip_profile_read(int instance, double *outTraversalMs, int *outLaunches, 
    SURVEY 8(d), which also charges the forwarded reads. */
 int phyhip_profile_read_traffic(int instance, double *outReadBytes, double *outWriteBytes);
 
+/* The resident evaluator (small nucleotide alignments, scalar wanted on the host): a chain of dLk calls on one edge
+   (src/optimiz.c: Br_Len_Opt) is served by workgroups that stay on the device and take each evaluation from a host-mapped
+   command record instead of a kernel launch per call.  Counters since the instance was created:
+   out[0] evaluations served that way, out[1] launches of the resident workgroups, out[2] commands nobody answered (the
+   evaluation was then launched the ordinary way), out[3] evaluations launched the ordinary way because work queued on the
+   instance's stream was not known to have finished.  Switched off by PHYHIP_RESIDENT=0 in the environment. */
+int phyhip_get_resident_stats(int instance, long long out[4]);
+
 #ifdef __cplusplus
 }
 #endif

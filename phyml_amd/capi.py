@@ -45,7 +45,7 @@ SYMBOLS = [
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
     "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
-    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_calculate_class_mixture_log_likelihood",
+    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_get_resident_stats", "phyhip_calculate_class_mixture_log_likelihood",
     "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors", "phyhip_set_mixture_invariant_sites",
 ]
 
@@ -294,6 +294,12 @@ class Instance:
         ms = C.c_double(0); n = C.c_int(0); u = C.c_double(0)
         _chk(self.L.phyhip_profile_read(self.id, C.byref(ms), C.byref(n), C.byref(u)))
         return ms.value, n.value, u.value
+
+    def resident_stats(self):
+        """(evaluations served by the resident workgroups, their launches, unanswered commands, evaluations launched instead)"""
+        out = (C.c_longlong * 4)()
+        _chk(self.L.phyhip_get_resident_stats(self.id, out))
+        return tuple(int(v) for v in out)
 
     def profile_read_traffic(self):
         r = C.c_double(0); w = C.c_double(0)

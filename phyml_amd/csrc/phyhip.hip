@@ -2506,6 +2506,20 @@ int phyhip_profile_read(int instance, double *ms, int *launches, double *updates
   return PHYHIP_SUCCESS;
 }
 
+int phyhip_get_resident_stats(int instance, long long out[4])
+{
+  if (Group *G = get_group(instance))
+  { // (sharded instances hand their sums to the collective on the device: never resident)
+    out[0] = out[1] = out[2] = out[3] = 0;
+    return PHYHIP_SUCCESS;
+  }
+  GET_INST(I, instance);
+  I->stream_dirty = I->dirty_prev;
+  --I->api_no; // (a query: not a step in the call sequence the evaluator watches)
+  out[0] = (long long)I->r_n_cmd; out[1] = (long long)I->r_n_launch; out[2] = (long long)I->r_n_silent; out[3] = (long long)I->r_n_busy;
+  return PHYHIP_SUCCESS;
+}
+
 int phyhip_profile_read_traffic(int instance, double *outReadBytes, double *outWriteBytes)
 {
   if (Group *G = get_group(instance))

@@ -1,0 +1,123 @@
+"""The resident evaluator (phyhip_kernels.hpp: resident_dlk_kernel): chains of dLk / eigen-basis Lk calls on small nucleotide
+alignments are served by workgroups that stay on the device.  It must be invisible in the numbers -- the same doubles as
+the kernel-launch path, the oracle's values to 1e-12 -- and must actually be the path that ran."""
+import time
+
+import numpy as np
+import pytest
+
+import orc  # noqa: F401
+from gpu_common import device_tree_from_golden, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain(t, ot, edges, pause=0.0):
+    """Br_Len_Opt's call pattern (src/optimiz.c:607-663) on each edge: Lk(b) with update_eigen_lr, dLk at several lengths,
+    Lk(b) in the eigen basis; device values and the oracle's."""
+    dev, ref = [], []
+    for e in edges:
+        t.Set_Update_Eigen_Lr(True); t.Set_Use_Eigen_Lr(False)
+        dev.append(t.Lk(e))
+        ot.lk(e); ot.update_eigen_lr(e); ref.append(ot.lk(e, refresh_pmat=False))
+        t.Set_Update_Eigen_Lr(False); t.Set_Use_Eigen_Lr(True)
+        for i in range(6):
+            l = 0.003 * (i + 1) * (1 + e % 3)
+            _, lnl = t.dLk(l, e)
+            dev += [lnl, t.c_dlnL]
+            _, rl, rd = ot.dlk(l)
+            ref += [rl, rd]
+            if pause and i == 2:
+                time.sleep(pause)  # longer than the idle time: the workgroups have left and are launched again
+        dev.append(t.Lk(e))
+        ref.append(ot.lk_eigen(float(ot.len[e])))
+        t.Set_Use_Eigen_Lr(False)
+    return dev, ref
+
+
+@pytest.mark.parametrize("patterns", [60, 382, 1500, 4000])
+def test_resident_evaluator_matches_the_launch_path_and_the_oracle(patterns, monkeypatch):
+    """382 patterns: every workgroup polls the host; 1500 / 4000: workgroup 0 relays the commands through device memory."""
+    vals = {}
+    for res in ("0", "1"):
+        monkeypatch.setenv("PHYHIP_RESIDENT", res)
+        t, ot, *_ = synthetic_pair(14, patterns, 4, 4, seed=23, ambiguous_every=17)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            ot.lk(None, both_sides=True)
+            dev, ref = _chain(t, ot, [3, 11, 20, 3])
+            served, launches, silent, busy = t.inst.resident_stats()
+            if res == "1":
+                assert served >= 4 * 7 - 4 and silent == 0, (served, launches, silent, busy)
+                assert launches <= 5  # (the oracle runs between the chains: the workgroups may have left meanwhile)
+            else:
+                assert served == 0 and launches == 0
+            for a, b in zip(dev, ref):
+                assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (a, b)
+            assert t.inst.numerical_warning() == 0
+            vals[res] = dev
+        finally:
+            t.close()
+    assert vals["0"] == vals["1"]  # the same doubles, whichever way they were computed
+
+
+def test_resident_workgroups_leave_when_idle_and_come_back(monkeypatch):
+    monkeypatch.setenv("PHYHIP_RESIDENT_IDLE_US", "200")
+    t, ot, *_ = synthetic_pair(10, 300, 4, 4, seed=4)
+    try:
+        t.Set_Both_Sides(True)
+        t.Lk(None)
+        ot.lk(None, both_sides=True)
+        dev, ref = _chain(t, ot, [2, 9, 5], pause=0.003)
+        served, launches, silent, busy = t.inst.resident_stats()
+        assert served > 0 and launches >= 3 and silent == 0
+        for a, b in zip(dev, ref):
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (a, b)
+    finally:
+        t.close()
+
+
+def test_resident_evaluator_sees_what_the_stream_wrote_in_between(golden):
+    """Weights, the invariant-site model and branch lengths change between chains (uploads and kernels on the instance's
+    stream, which the resident workgroups are not ordered with): every chain still reproduces the golden triples."""
+    d = golden("nucleic_gtr_g4_inv")
+    t, ot = device_tree_from_golden(d)
+    try:
+        t.Set_Both_Sides(True)
+        lnl0 = t.Lk(None)
+        assert abs(lnl0 - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-12
+        for rep in range(3):
+            for k, e in enumerate(d["eigen_edges"]):
+                e = int(e)
+                t.Set_Update_Eigen_Lr(True); t.Set_Use_Eigen_Lr(False)
+                t.Lk(e)
+                t.Set_Update_Eigen_Lr(False); t.Set_Use_Eigen_Lr(True)
+                for j in range(3):
+                    l_in, lnl_ref, dlnl_ref = d["dlk_triples"][k, j]
+                    _, lnl = t.dLk(l_in, e)
+                    assert abs(lnl - lnl_ref) / abs(lnl_ref) < 1e-12
+                    assert abs(t.c_dlnL - dlnl_ref) <= 1e-8 * max(1.0, abs(dlnl_ref))
+                t.Set_Use_Eigen_Lr(False)
+            t.Lk(None)  # a full traversal on the stream between the chains
+        served, launches, silent, busy = t.inst.resident_stats()
+        assert served > 0 and silent == 0
+    finally:
+        t.close()
+
+
+def test_two_instances_each_with_resident_workgroups():
+    pairs = [synthetic_pair(9, 200 + 90 * k, 4, 4, seed=40 + k) for k in range(2)]
+    try:
+        for t, ot, *_ in pairs:
+            t.Set_Both_Sides(True); t.Lk(None); ot.lk(None, both_sides=True)
+        for rep in range(2):
+            for t, ot, *_ in pairs:
+                dev, ref = _chain(t, ot, [1 + rep, 6])
+                for a, b in zip(dev, ref):
+                    assert abs(a - b) <= 1e-12 * max(1.0, abs(b)), (a, b)
+        for t, *_ in pairs:
+            assert t.inst.resident_stats()[0] > 0
+    finally:
+        for t, *_ in pairs:
+            t.close()
