@@ -304,13 +304,17 @@ int phyhip_profile_read(int instance, double *outTraversalMs, int *outLaunches, 
    SURVEY 8(d), which also charges the forwarded reads. */
 int phyhip_profile_read_traffic(int instance, double *outReadBytes, double *outWriteBytes);
 
-/* The resident evaluator (small nucleotide alignments, scalar wanted on the host): a chain of dLk calls on one edge
-   (src/optimiz.c: Br_Len_Opt) is served by workgroups that stay on the device and take each evaluation from a host-mapped
-   command record instead of a kernel launch per call.  Counters since the instance was created:
-   out[0] evaluations served that way, out[1] launches of the resident workgroups, out[2] commands nobody answered (the
-   evaluation was then launched the ordinary way), out[3] evaluations launched the ordinary way because work queued on the
-   instance's stream was not known to have finished.  Switched off by PHYHIP_RESIDENT=0 in the environment. */
-int phyhip_get_resident_stats(int instance, long long out[4]);
+/* The resident evaluators (small nucleotide alignments, scalar wanted on the host): the launch-bound calls of a search --
+   the chain of dLk calls of a branch-length optimisation (src/optimiz.c: Br_Len_Opt) and the short evaluations of SPR
+   (src/spr.c:643-646: up to four matrices rebuilt, one or two partial updates, the edge likelihood) -- are served by
+   workgroups that stay on the device and take each evaluation from a host-mapped command record instead of a kernel
+   launch per call, whenever nothing else of the instance is known to be running on its stream.  Counters since the
+   instance was created, out[0..3] for the dLk evaluator and out[4..7] for the short-evaluation one: evaluations served that
+   way, launches of the resident workgroups, commands nobody answered (the evaluation was then launched the ordinary way),
+   evaluations launched the ordinary way because work queued on the stream was not known to have finished.
+   PHYHIP_RESIDENT=0 in the environment switches both off; PHYHIP_RESIDENT_IDLE_US (default 1000) is how long the workgroups
+   wait for a command before they leave. */
+int phyhip_get_resident_stats(int instance, long long out[8]);
 
 #ifdef __cplusplus
 }

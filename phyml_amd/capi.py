@@ -295,11 +295,12 @@ class Instance:
         _chk(self.L.phyhip_profile_read(self.id, C.byref(ms), C.byref(n), C.byref(u)))
         return ms.value, n.value, u.value
 
-    def resident_stats(self):
-        """(evaluations served by the resident workgroups, their launches, unanswered commands, evaluations launched instead)"""
-        out = (C.c_longlong * 4)()
+    def resident_stats(self, which=0):
+        """(evaluations served by the resident workgroups, their launches, unanswered commands, evaluations launched instead)
+        of the dLk evaluator; resident_stats(1): of the short-evaluation one"""
+        out = (C.c_longlong * 8)()
         _chk(self.L.phyhip_get_resident_stats(self.id, out))
-        return tuple(int(v) for v in out)
+        return tuple(int(v) for v in out[4 * which:4 * which + 4])
 
     def profile_read_traffic(self):
         r = C.c_double(0); w = C.c_double(0)

@@ -132,6 +132,20 @@ struct StagingRing
 
 struct Collective;
 
+// Host side of one set of resident workgroups (see resident_dlk_kernel / resident_nt2_kernel)
+struct Resident
+{
+  ResidentCmd        *cmd = nullptr;   // host-mapped command record
+  unsigned long long *mail = nullptr;  // device mailbox (larger grids: workgroup 0 relays the commands)
+  hipStream_t         stream[2] = {nullptr, nullptr};
+  unsigned long long  gen = 0, seq = 0; // launch generation; commands issued
+  unsigned long long  api_no = 0;       // entry-point call of the last command
+  bool                launched = false;
+  int                 grid = 0;
+  struct timespec     t_launch = {0, 0}, t_cmd = {0, 0};
+  unsigned long long  n_cmd = 0, n_launch = 0, n_silent = 0, n_busy = 0; // phyhip_get_resident_stats
+};
+
 struct Instance
 {
   Collective *co         = nullptr; // one-process-per-GPU mode: communicator attached by phyhip_comm_init_rank
@@ -179,16 +193,18 @@ struct Instance
   size_t    h_blocks_cap = 0;
   // resident evaluator (resident_dlk_kernel): dLk / eigen-basis Lk of small alignments without a launch per call
   bool         resident = true;       // PHYHIP_RESIDENT=0: every evaluation is a kernel launch
-  double       resident_idle_us = 400.0; // PHYHIP_RESIDENT_IDLE_US: the workgroups leave after this long without a command
-  ResidentCmd *r_cmd = nullptr;       // host-mapped command record
-  unsigned long long *d_rmail = nullptr; // device mailbox (larger grids: workgroup 0 relays the commands)
-  hipStream_t  r_stream[2] = {nullptr, nullptr};
-  unsigned long long r_api_no = 0;    // entry-point call of the last command
-  unsigned long long r_gen = 0, r_seq = 0; // launch generation; commands issued
-  bool         r_launched = false, r_inflight = false;
+  double       resident_idle_us = 1000.0; // PHYHIP_RESIDENT_IDLE_US: the workgroups leave after this long without a command
+  Resident     rd, rt;                // the dLk evaluator (resident_dlk_kernel) and the short-launch one (resident_nt2_kernel)
+  Resident    *r_inflight = nullptr;  // whose command the evaluation in flight is
   DlkParams    r_static;              // what the resident workgroups were launched with
-  int          r_grid = 0;
-  unsigned long long r_n_cmd = 0, r_n_launch = 0, r_n_silent = 0, r_n_busy = 0; // PHYHIP_RESIDENT_STATS=1: printed at finalize
+  TreeParams   rt_static;
+  // the evaluation last handed to resident_nt2_kernel, kept until it is answered (unanswered: it is launched instead)
+  std::vector<DevOp>  rt_ops;
+  std::vector<int>    rt_pm_idx;
+  std::vector<double> rt_pm_len;
+  bool         rt_skip = false;       // the evaluation being repeated after an unanswered command goes the ordinary way
+  unsigned long long clean_epoch = 0, rt_epoch = 0; // times the stream was found finished after having run something; at the last command
+  bool         touched_call = false;  // this entry-point call has put something on the stream
   // Is everything queued on the stream known to be finished?  The resident workgroups are not ordered with the stream, so
   // they may only be used when it is.  Conservative bookkeeping: every entry point marks the stream dirty (GET_INST); the
   // ones that queue nothing put the previous state back; Update_Eigen_Lr -- what precedes a chain of dLk calls -- ends with
@@ -201,7 +217,6 @@ struct Instance
   unsigned long long api_no = 0, eig_api_no = 0; // entry-point calls so far; the call that queued the last eigen_lr kernel
   bool               fenced_eval = false;        // the evaluation in flight posts behind fences // stamps issued; the stamp whose arrival makes a non-dirty stream clean
   int          wall_khz = 0;          // rate of the device's wall_clock64()
-  struct timespec r_t_launch = {0, 0}, r_t_cmd = {0, 0};
   bool      host_sum   = true;    // PHYHIP_HOST_SUM=0: large grids use final_reduce_kernel instead
   void     *d_pmscratch = nullptr; // [pm_scratch_cap] ints + doubles for phyhip_update_transition_matrices
   int       pm_scratch_cap = 0;
@@ -279,6 +294,7 @@ thread_local int g_cur_dev = -1;
   }                                                                                                          \
   I->dirty_prev = I->stream_dirty; /* any entry point may queue work on the stream (see Instance::stream_dirty) */ \
   I->stream_dirty = true;                                                                                    \
+  I->touched_call = false;                                                                                   \
   ++I->api_no;
 
 int next_pow2(int x)
@@ -349,6 +365,7 @@ struct EdgeEval
 // Host-computed matrices queued by phyhip_set_transition_matrix: one launch per kUploadBatch of them.
 int flush_uploads(Instance *I)
 {
+  if (!I->up_idx.empty()) I->touched_call = true;
   size_t done = 0;
   while (done < I->up_idx.size())
   {
@@ -370,6 +387,7 @@ int flush_uploads(Instance *I)
 // Rebuild every queued transition matrix on the device: one staged copy of (index, length) pairs, one launch.
 int flush_pmats(Instance *I)
 {
+  I->touched_call = true;
   int done = 0, rc = 0;
   if (!I->up_idx.empty() && (rc = flush_uploads(I))) return rc;
   const int count = (int)I->pm_idx.size();
@@ -437,6 +455,114 @@ static bool fuse_reduce(const Instance *I, int nblocks)
   if (I->split_reduce_forced) return !I->split_reduce;
   return nblocks <= 512;
 }
+
+// ---- resident evaluators: host side -----------------------------------------------------------------------------
+constexpr int kResidentDirect = 8;     // ... up to this many poll the host themselves, above that workgroup 0 relays
+constexpr int kResidentMaxGrid = 64;   // resident evaluator: alignments of up to this many dLk workgroups
+constexpr int kResidentSilent = -4242; // wait_host_sum: the resident workgroups did not answer (not an error)
+static double ns_since(const struct timespec &t0)
+{
+  struct timespec t1;
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+// Tell the resident workgroups (if any) to leave and wait until they have.
+static void resident_stop(Resident &R)
+{
+  if (!R.cmd || !R.launched) return;
+  __atomic_store_n(&R.cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
+  for (hipStream_t st : R.stream)
+    if (st) (void)hipStreamSynchronize(st);
+  __atomic_store_n(&R.cmd->ctl.w[1], 0ull, __ATOMIC_RELEASE);
+  R.launched = false;
+}
+
+static void resident_free(Resident &R)
+{
+  resident_stop(R);
+  if (R.cmd) (void)hipHostFree(R.cmd);
+  if (R.mail) (void)hipFree(R.mail);
+  for (hipStream_t st : R.stream)
+    if (st) (void)hipStreamDestroy(st);
+  R = Resident();
+}
+
+// First half of a (re)launch: generation gen + 1 supersedes whatever is left of the previous one (its workgroups see the
+// new number at their next poll and leave); commands up to `served` count as done.  The caller launches its kernel with `r`
+// on `*st`, then calls resident_launched().
+static int resident_prepare(Instance *I, Resident &R, int grid, int n_lines, unsigned long long served, ResidentCtl &r, hipStream_t *st)
+{
+  if (!R.cmd)
+  {
+    HIPCHK(hipHostMalloc((void **)&R.cmd, sizeof(ResidentCmd), hipHostMallocMapped | hipHostMallocCoherent)); // (polled from the device while it changes)
+    memset(R.cmd, 0, sizeof(ResidentCmd));
+    HIPCHK(hipMalloc((void **)&R.mail, sizeof(ResidentCmd)));
+    HIPCHK(hipMemset(R.mail, 0, sizeof(ResidentCmd)));
+    for (hipStream_t &s2 : R.stream) HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  }
+  ++R.n_launch;
+  ++R.gen;
+  __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
+  r.cmd = R.cmd; r.gen = R.gen; r.start_seq = served; r.n_lines = n_lines;
+  r.mail = R.mail; r.relay = grid > kResidentDirect ? 1 : 0;
+  if (I->wall_khz <= 0)
+  {
+    int dev = 0, khz = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    I->wall_khz = khz;
+  }
+  r.idle_ticks = (unsigned long long)(I->resident_idle_us * 1e-3 * (double)I->wall_khz); // wall_clock64 ticks
+  *st = R.stream[R.gen & 1];
+  return 0;
+}
+static void resident_launched(Resident &R, int grid)
+{
+  R.grid = grid; R.launched = true;
+  clock_gettime(CLOCK_MONOTONIC, &R.t_launch);
+}
+
+// Have the workgroups of the current generation left?  (Workgroup 0 reports it, see ResidentCmd::report.)
+static bool resident_gone(const Resident &R)
+{
+  return R.cmd && __atomic_load_n(&R.cmd->report.w[0], __ATOMIC_ACQUIRE) == R.gen;
+}
+
+// The command: payload words into their lines, each line's number last (see ResidentCmd)
+static void resident_send(Instance *I, Resident &R, const unsigned long long *words, int n_words)
+{
+  ++R.seq;
+  for (int l = 0; l * 7 < n_words; ++l)
+  {
+    ResidentLine &ln = R.cmd->line[l];
+    for (int k = 0; k < 7 && l * 7 + k < n_words; ++k) ln.w[k] = words[l * 7 + k];
+    __atomic_store_n(&ln.seq, R.seq, __ATOMIC_RELEASE);
+  }
+  R.api_no = I->api_no;
+  ++R.n_cmd;
+  clock_gettime(CLOCK_MONOTONIC, &R.t_cmd);
+  I->r_inflight = &R;
+}
+
+static int resident_launch_dlk(Instance *I, const DlkParams &qs, int dgrid, unsigned long long served)
+{
+  ResidentCtl r;
+  hipStream_t st;
+  int rc = resident_prepare(I, I->rd, dgrid, (3 + I->C * 2 * I->S + 6) / 7, served, r, &st);
+  if (rc) return rc;
+  rc = dispatch_shape(I, [&](auto s, auto cp) {
+    constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    hipLaunchKernelGGL((resident_dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, st, qs, r);
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  I->r_static = qs;
+  resident_launched(I->rd, dgrid);
+  return 0;
+}
+
 
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush_impl(Instance *I, const EdgeEval *ee)
@@ -636,6 +762,107 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     }
     if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
   }
+  // ---- small nucleotide alignments: the resident short-launch evaluator (resident_nt2_kernel) ------------------------
+  const bool rt_grid = I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis &&
+                       I->grid_nt2 <= kResidentMaxGrid && !I->ablate && I->nt_groups <= 2;
+  static const bool rtdbg = getenv("PHYHIP_RESIDENT_DEBUG") != nullptr;
+  if (rtdbg && ee)
+    fprintf(stderr, "rt: grid_ok %d (res %d spin %d hs %d soa %d co %d cls %d g2 %d abl %d grp %d) hsn %d args %d fresh %d site %d prof %d skip %d dirty_prev %d touched %d\n",
+            (int)rt_grid, (int)I->resident, (int)I->spin_wait, (int)I->host_sum, (int)I->soa, I->co != nullptr, (int)I->class_axis, I->grid_nt2,
+            I->ablate, I->nt_groups, host_sum_n, q.recs_in_args, q.n_fresh, (int)I->want_site_outputs, (int)I->prof, (int)I->rt_skip,
+            (int)I->dirty_prev, (int)I->touched_call);
+  if (rt_grid && host_sum_n > 0)
+  { // every evaluation of such an instance completes its stores before it posts: the stream is clean once the scalar is back
+    q.fence_post   = 1;
+    I->fenced_eval = true;
+  }
+  if (rt_grid && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && !I->prof && !I->rt_skip)
+  {
+    bool clean = !I->dirty_prev && !I->touched_call;
+    if (clean && I->clean_after)
+    { // the report of the last Update_Eigen_Lr (bounded wait, else the ordinary launch)
+      volatile unsigned long long *stamp = reinterpret_cast<volatile unsigned long long *>(I->h_result + 3);
+      struct timespec t0;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (long it = 1; *stamp < I->clean_after && clean; ++it)
+      {
+        __builtin_ia32_pause();
+        if ((it & 255) == 0 && ns_since(t0) > 200000.0) clean = false;
+      }
+      if (clean) { __atomic_thread_fence(__ATOMIC_ACQUIRE); I->clean_after = 0; ++I->clean_epoch; }
+    }
+    if (!clean) ++I->rt.n_busy;
+    else
+    {
+      Resident  &R = I->rt;
+      // what the workgroups are launched with: everything of the launch form's arguments that does not change per call
+      TreeParams sq = base_params(I);
+      sq.host_blocks = I->h_blocks; sq.warn = I->h_warn; sq.fence_post = 1; sq.recs_in_args = 1; sq.edge_eval = 1;
+      sq.br_len_mult = I->br_len_mult; sq.l_min = I->l_min; sq.l_max = I->l_max; sq.pmats_rw = I->d_pmats;
+      if (I->want_site_outputs) { sq.site_lnl = I->d_site_lnl; sq.site_lk = I->d_site_lk; sq.site_cat = I->d_site_cat; }
+      if (!R.launched || R.grid != I->grid_nt2 || memcmp(&I->rt_static, &sq, sizeof sq) != 0 || resident_gone(R))
+      {
+        if (R.launched && (R.grid != I->grid_nt2 || memcmp(&I->rt_static, &sq, sizeof sq) != 0)) resident_stop(R);
+        ResidentCtl r;
+        hipStream_t st;
+        if ((rc = resident_prepare(I, R, I->grid_nt2, (kResidentNtWords + 6) / 7, R.seq, r, &st))) return rc;
+#define NT2RES(c_, g_)                                                                                                      \
+  hipLaunchKernelGGL((resident_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, st, sq, r, (const double *)I->d_pmats,   \
+                     (const uint8_t *)I->d_tipcodes, (const double *)I->d_evec, (const double *)I->d_ivec,                    \
+                     (const double *)I->d_eval, (const double *)I->d_catr);                                                   \
+  break;
+        switch (I->C * 8 + I->nt_groups)
+        {
+          case 1 * 8 + 1: NT2RES(1, 1)
+          case 2 * 8 + 1: NT2RES(2, 1)
+          case 2 * 8 + 2: NT2RES(2, 2)
+          case 3 * 8 + 1: NT2RES(3, 1)
+          case 4 * 8 + 1: NT2RES(4, 1)
+          case 4 * 8 + 2: NT2RES(4, 2)
+          default: return fail(PHYHIP_ERROR_GENERAL, "resident evaluator: no kernel for %d categories in %d groups", I->C, I->nt_groups);
+        }
+#undef NT2RES
+        HIPCHK(hipGetLastError());
+        memcpy(&I->rt_static, &sq, sizeof sq);
+        resident_launched(R, I->grid_nt2);
+      }
+      unsigned long long words[kResidentNtWords];
+      memset(words, 0, sizeof words);
+      const bool changed = I->clean_epoch != I->rt_epoch; // the stream ran something since the last command
+      words[0] = q.host_tag;
+      words[1] = (unsigned long long)q.n_real_ops | (changed ? 4ull : 0ull) | ((unsigned long long)q.n_fresh << 4) |
+                 ((unsigned long long)q.e_prefetch << 8);
+      words[2] = (unsigned long long)(unsigned)q.e_parent | ((unsigned long long)(unsigned)q.e_child << 32);
+      words[3] = (unsigned long long)(unsigned)q.e_pm | ((unsigned long long)(unsigned)q.last_dest << 32);
+      for (int k = 0; k < q.n_fresh; ++k)
+      {
+        words[4 + k / 2] |= (unsigned long long)(unsigned)q.fresh_idx[k] << (32 * (k & 1));
+        memcpy(&words[6 + k], &q.fresh_len[k], 8);
+      }
+      auto put = [&](int k, const Desc &d) { words[k] = d.base; words[k + 1] = (unsigned long long)d.bytes | ((unsigned long long)d.x << 32); };
+      for (int o = 0; o < q.n_real_ops; ++o)
+      {
+        put(10 + o * 12, q.arg_ir[o].c1_data); put(12 + o * 12, q.arg_ir[o].c2_data);
+        put(14 + o * 12, q.arg_ir[o].c1_scale); put(16 + o * 12, q.arg_ir[o].c2_scale);
+        put(18 + o * 12, q.arg_xr[o].dst_data); put(20 + o * 12, q.arg_xr[o].dst_scale);
+      }
+      // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (phyhip_calculate_edge_log_likelihoods)
+      I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
+      resident_send(I, R, words, kResidentNtWords); // (every line the workgroups wait for carries the command's number)
+      I->rt_epoch = I->clean_epoch;
+      I->host_sum_n = host_sum_n; I->host_sum_ns = 1;
+      if (fold_pm)
+      {
+        for (int m : I->pm_idx) I->pm_slot[m] = -1;
+        I->pm_idx.clear();
+        I->pm_len.clear();
+      }
+      I->pending.clear();
+      std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
+      return 0;
+    }
+  }
+  I->touched_call = true; // (everything below goes onto the stream)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (I->prof)
   {
@@ -904,67 +1131,6 @@ int check_partial_index(const Instance *I, int idx, bool allow_tip)
 // The host's side of the final sum on large grids: poll the {sum, tag} records the workgroups posted (they arrive roughly in
 // launch order), then add them exactly as final_reduce_kernel does -- 256 strided accumulators, then a binary tree -- so
 // that the value does not depend on which path produced it.
-constexpr int kResidentDirect = 8;     // ... up to this many poll the host themselves, above that workgroup 0 relays
-constexpr int kResidentMaxGrid = 64;   // resident evaluator: alignments of up to this many dLk workgroups
-constexpr int kResidentSilent = -4242; // wait_host_sum: the resident workgroups did not answer (not an error)
-static double ns_since(const struct timespec &t0)
-{
-  struct timespec t1;
-  clock_gettime(CLOCK_MONOTONIC, &t1);
-  return (double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec);
-}
-
-// Tell the resident workgroups (if any) to leave and wait until they have.
-static void resident_stop(Instance *I)
-{
-  if (!I->r_cmd || !I->r_launched) return;
-  __atomic_store_n(&I->r_cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
-  for (hipStream_t st : I->r_stream)
-    if (st) (void)hipStreamSynchronize(st);
-  __atomic_store_n(&I->r_cmd->ctl.w[1], 0ull, __ATOMIC_RELEASE);
-  I->r_launched = false;
-}
-
-// (Re)launch the resident workgroups: generation r_gen + 1 supersedes whatever is left of the previous one (its workgroups
-// see the new generation number at their next poll and leave); commands up to `served` count as done.
-static int resident_launch(Instance *I, const DlkParams &qs, int dgrid, unsigned long long served)
-{
-  if (!I->r_cmd)
-  {
-    HIPCHK(hipHostMalloc((void **)&I->r_cmd, sizeof(ResidentCmd), hipHostMallocMapped | hipHostMallocCoherent)); // (polled from the device while it changes)
-    memset(I->r_cmd, 0, sizeof(ResidentCmd));
-    HIPCHK(hipMalloc((void **)&I->d_rmail, sizeof(ResidentCmd)));
-    HIPCHK(hipMemset(I->d_rmail, 0, sizeof(ResidentCmd)));
-    for (hipStream_t &st : I->r_stream) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  }
-  ++I->r_n_launch;
-  ++I->r_gen;
-  __atomic_store_n(&I->r_cmd->ctl.w[0], I->r_gen, __ATOMIC_RELEASE);
-  ResidentCtl r;
-  r.cmd = I->r_cmd; r.gen = I->r_gen; r.start_seq = served;
-  r.n_lines = (3 + I->C * 2 * I->S + 6) / 7;
-  r.mail = dgrid > kResidentDirect ? I->d_rmail : nullptr;
-  if (I->wall_khz <= 0)
-  {
-    int dev = 0, khz = 0;
-    HIPCHK(hipGetDevice(&dev));
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
-    I->wall_khz = khz;
-  }
-  r.idle_ticks = (unsigned long long)(I->resident_idle_us * 1e-3 * (double)I->wall_khz); // wall_clock64 ticks
-  hipStream_t st = I->r_stream[I->r_gen & 1];
-  int rc = dispatch_shape(I, [&](auto s, auto cp) {
-    constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
-    hipLaunchKernelGGL((resident_dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, st, qs, r);
-    return 0;
-  });
-  if (rc) return rc;
-  HIPCHK(hipGetLastError());
-  I->r_static = qs; I->r_grid = dgrid; I->r_launched = true;
-  clock_gettime(CLOCK_MONOTONIC, &I->r_t_launch);
-  return 0;
-}
-
 int wait_host_sum(Instance *I)
 {
   const int                n   = I->host_sum_n * I->host_sum_ns, per = I->host_sum_n;
@@ -987,7 +1153,8 @@ int wait_host_sum(Instance *I)
         if (I->r_inflight)
         { // no answer from the resident workgroups (they may have left just before the command arrived): the caller
           // retires them and launches the evaluation the ordinary way
-          if (waited > 100000L && ns_since(I->r_t_launch) > 20e6) return kResidentSilent; // (a first launch loads code: ms)
+          if (waited > 30000L && resident_gone(*I->r_inflight)) return kResidentSilent; // they left as the command arrived
+          if (waited > 100000L && ns_since(I->r_inflight->t_launch) > 20e6) return kResidentSilent; // (a first launch loads code: ms)
           continue;
         }
         if (waited > 2000000L || !I->spin_wait)
@@ -1017,7 +1184,7 @@ int wait_host_sum(Instance *I)
     I->h_result[k] = acc[0];
   }
   I->host_sum_n    = 0;
-  I->r_inflight    = false;
+  I->r_inflight    = nullptr;
   I->warn_current  = true;
   *reinterpret_cast<volatile unsigned long long *>(I->h_result + 2) = tag;
   return 0;
@@ -1109,14 +1276,13 @@ const char *phyhip_get_last_error(void) { return g_err.c_str(); }
 // Frees everything an instance owns (also a partially built one: every pointer starts as nullptr).
 static void release_instance(Instance *I)
 {
-  if (getenv("PHYHIP_RESIDENT_STATS") && (I->r_n_cmd || I->r_n_busy))
-    fprintf(stderr, "resident evaluator: %llu commands, %llu launches, %llu unanswered, %llu evaluations launched because the stream was busy (clock %d kHz)\n",
-            I->r_n_cmd, I->r_n_launch, I->r_n_silent, I->r_n_busy, I->wall_khz);
-  resident_stop(I);
-  if (I->r_cmd) (void)hipHostFree(I->r_cmd);
-  if (I->d_rmail) (void)hipFree(I->d_rmail);
-  for (hipStream_t st : I->r_stream)
-    if (st) (void)hipStreamDestroy(st);
+  if (getenv("PHYHIP_RESIDENT_STATS"))
+    for (const Resident *R : {&I->rd, &I->rt})
+      if (R->n_cmd || R->n_busy)
+        fprintf(stderr, "resident %s: %llu commands, %llu launches, %llu unanswered, %llu evaluations launched because the stream was busy\n",
+                R == &I->rd ? "dLk evaluator" : "short-launch evaluator", R->n_cmd, R->n_launch, R->n_silent, R->n_busy);
+  resident_free(I->rd);
+  resident_free(I->rt);
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
@@ -1660,6 +1826,7 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
   // A whole-tree batch (Update_All_PMat, src/lk.c:500-512) is launched now rather than with the traversal: the device
   // rebuilds the matrices while the host walks the tree and fills the operation list.
   if (count >= kEagerPmBatch && I->eager_pmats) return flush_pmats(I);
+  if (!I->touched_call) I->stream_dirty = I->dirty_prev; // only queued
   return PHYHIP_SUCCESS;
 }
 
@@ -1729,6 +1896,7 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
     I->mat_in_queue[o.child1TransitionMatrix] = 1;
     I->mat_in_queue[o.child2TransitionMatrix] = 1;
   }
+  if (!I->touched_call) I->stream_dirty = I->dirty_prev; // only queued
   return PHYHIP_SUCCESS;
 }
 
@@ -1760,11 +1928,35 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
   EdgeEval ee{parent[0], child[0], pm[0], nullptr, true, nullptr};
   rc = flush(I, &ee);
   if (rc) return rc;
-  if ((rc = wait_result(I))) return rc;
+  const bool by_resident = I->r_inflight != nullptr;
+  rc = wait_result(I);
+  if (rc == kResidentSilent)
+  { // the resident workgroups had left: retire them for good (no late record can arrive after this), put the evaluation
+    // back in the queue and launch it
+    ++I->rt.n_silent;
+    resident_stop(I->rt);
+    I->r_inflight = nullptr; I->host_sum_n = 0;
+    I->pending = I->rt_ops;
+    for (const DevOp &o : I->pending) { I->mat_in_queue[o.pm1] = 1; I->mat_in_queue[o.pm2] = 1; }
+    for (size_t k = 0; k < I->rt_pm_idx.size(); ++k)
+      if (I->pm_slot[I->rt_pm_idx[k]] < 0)
+      {
+        I->pm_slot[I->rt_pm_idx[k]] = (int)I->pm_idx.size();
+        I->pm_idx.push_back(I->rt_pm_idx[k]);
+        I->pm_len.push_back(I->rt_pm_len[k]);
+      }
+    I->rt_skip = true;
+    rc = flush(I, &ee);
+    I->rt_skip = false;
+    if (rc) return rc;
+    rc = wait_result(I);
+  }
+  if (rc) return rc;
   *outSum = I->h_result[0];
   if (I->fenced_eval)
   { // every store of this evaluation -- and so everything queued before it -- is in memory
     I->fenced_eval = false; I->stream_dirty = false; I->clean_after = 0;
+    if (!by_resident) ++I->clean_epoch; // (a kernel ran: the resident workgroups re-read what it wrote)
   }
   return PHYHIP_SUCCESS;
 }
@@ -2232,50 +2424,38 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
         __builtin_ia32_pause();
         if ((it & 255) == 0 && ns_since(t0) > 200000.0) idle = false;
       }
-      if (idle) { __atomic_thread_fence(__ATOMIC_ACQUIRE); I->clean_after = 0; }
+      if (idle) { __atomic_thread_fence(__ATOMIC_ACQUIRE); I->clean_after = 0; ++I->clean_epoch; }
     }
-    if (!idle) ++I->r_n_busy;
+    if (!idle) ++I->rd.n_busy;
     if (idle)
     {
       DlkParams qs = q; // what stays the same from call to call
       qs.with_derivative = 0; qs.invar_model = 0; qs.apply_scaling = 0; qs.pinvar = 0.0; qs.fin.host_tag = 0;
       memset(qs.expl, 0, sizeof qs.expl);
       const DlkParams &o = I->r_static;
-      const bool same = I->r_launched && I->r_grid == dgrid && o.dot_prod == qs.dot_prod && o.wght == qs.wght && o.fact == qs.fact &&
+      Resident  &R = I->rd;
+      const bool same = R.launched && R.grid == dgrid && o.dot_prod == qs.dot_prod && o.wght == qs.wght && o.fact == qs.fact &&
                         o.cat_w == qs.cat_w && o.pi == qs.pi && o.invar == qs.invar && o.P == qs.P && o.C == qs.C &&
                         o.fin.host_blocks == qs.fin.host_blocks && o.fin.stride == qs.fin.stride && o.fin.warn == qs.fin.warn;
-      static const bool rdbg = getenv("PHYHIP_RESIDENT_DEBUG") != nullptr;
-      if (rdbg) fprintf(stderr, "resident: same %d launched %d since cmd %.1f us since launch %.1f us\n", (int)same, (int)I->r_launched, ns_since(I->r_t_cmd) * 1e-3, ns_since(I->r_t_launch) * 1e-3);
       if (!same)
       {
-        resident_stop(I);
-        if ((rc = resident_launch(I, qs, dgrid, I->r_seq))) return rc;
+        resident_stop(R);
+        if ((rc = resident_launch_dlk(I, qs, dgrid, R.seq))) return rc;
       }
-      else if (ns_since(I->r_t_cmd) > 500.0 * I->resident_idle_us && ns_since(I->r_t_launch) > 500.0 * I->resident_idle_us)
-      { // idle for more than half the time after which the workgroups leave: assume they have
-        if ((rc = resident_launch(I, qs, dgrid, I->r_seq))) return rc;
+      else if (resident_gone(R))
+      { // the workgroups have left (idle)
+        if ((rc = resident_launch_dlk(I, qs, dgrid, R.seq))) return rc;
       }
-      // the command: payload words into their lines, each line's number last (see ResidentCmd)
       unsigned long long words[kResidentWords];
       const int          n_words = 3 + I->C * 2 * I->S;
-      const bool         changed = I->api_no != I->r_api_no + 1; // something else was called since the last command
+      const bool         changed = I->api_no != R.api_no + 1; // something else was called since the last command
       words[0] = q.fin.host_tag;
       words[1] = (q.with_derivative ? 1u : 0u) | (q.invar_model ? 2u : 0u) | (q.apply_scaling ? 4u : 0u) | (changed ? 8u : 0u);
       memcpy(&words[2], &q.pinvar, 8);
       memcpy(&words[3], q.expl, sizeof(double) * (size_t)(n_words - 3));
-      ++I->r_seq;
-      for (int l = 0; l * 7 < n_words; ++l)
-      {
-        ResidentLine &ln = I->r_cmd->line[l];
-        for (int k = 0; k < 7 && l * 7 + k < n_words; ++k) ln.w[k] = words[l * 7 + k];
-        __atomic_store_n(&ln.seq, I->r_seq, __ATOMIC_RELEASE);
-      }
-      I->r_api_no = I->api_no;
-      ++I->r_n_cmd;
-      clock_gettime(CLOCK_MONOTONIC, &I->r_t_cmd);
-      I->host_sum_n = dgrid; I->host_sum_ns = 2; I->r_inflight = true;
+      resident_send(I, R, words, n_words);
+      I->host_sum_n = dgrid; I->host_sum_ns = 2;
       rc = wait_result(I);
-      if (rdbg) fprintf(stderr, "resident: answered rc %d after %.1f us\n", rc, ns_since(I->r_t_cmd) * 1e-3);
       if (rc == 0)
       {
         *lnl = I->h_result[0];
@@ -2285,9 +2465,9 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       if (rc != kResidentSilent) return rc;
       // nobody there: make sure of it (after this no resident workgroup can still write a record), then the ordinary
       // launch below repeats the evaluation under the same tag
-      ++I->r_n_silent;
-      resident_stop(I);
-      I->r_inflight = false; I->host_sum_n = 0;
+      ++R.n_silent;
+      resident_stop(R);
+      I->r_inflight = nullptr; I->host_sum_n = 0;
     }
   }
   rc = dispatch_shape(I, [&](auto s, auto cp) {
@@ -2461,7 +2641,7 @@ int phyhip_synchronize(int instance)
   if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_synchronize(id); });
   GET_INST(I, instance);
   const int rc = flush_sync(I);
-  if (rc == 0) { I->stream_dirty = false; I->clean_after = 0; } // nothing queued is left
+  if (rc == 0) { I->stream_dirty = false; I->clean_after = 0; ++I->clean_epoch; } // nothing queued is left
   return rc;
 }
 
@@ -2506,17 +2686,22 @@ int phyhip_profile_read(int instance, double *ms, int *launches, double *updates
   return PHYHIP_SUCCESS;
 }
 
-int phyhip_get_resident_stats(int instance, long long out[4])
+int phyhip_get_resident_stats(int instance, long long out[8])
 {
   if (Group *G = get_group(instance))
   { // (sharded instances hand their sums to the collective on the device: never resident)
-    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int k = 0; k < 8; ++k) out[k] = 0;
     return PHYHIP_SUCCESS;
   }
   GET_INST(I, instance);
   I->stream_dirty = I->dirty_prev;
   --I->api_no; // (a query: not a step in the call sequence the evaluator watches)
-  out[0] = (long long)I->r_n_cmd; out[1] = (long long)I->r_n_launch; out[2] = (long long)I->r_n_silent; out[3] = (long long)I->r_n_busy;
+  for (int k = 0; k < 8; ++k) out[k] = 0;
+  int k = 0;
+  for (const Resident *R : {&I->rd, &I->rt})
+  {
+    out[k++] = (long long)R->n_cmd; out[k++] = (long long)R->n_launch; out[k++] = (long long)R->n_silent; out[k++] = (long long)R->n_busy;
+  }
   return PHYHIP_SUCCESS;
 }
 

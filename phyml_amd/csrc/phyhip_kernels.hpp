@@ -1297,6 +1297,7 @@ struct ResidentCmd
 {
   ResidentLine ctl;
   ResidentLine line[kResidentLines];
+  ResidentLine report; // written by the DEVICE: word 0 = the generation whose workgroups have left (idle, told to, superseded)
 };
 struct ResidentCtl
 {
@@ -1307,8 +1308,79 @@ struct ResidentCtl
   int                n_lines;    // command lines in use (3 + C * 2 * S words)
   // More than a handful of workgroups: only workgroup 0 polls the host (every reader of host memory slows the others down);
   // it copies each command into a mailbox in device memory -- same line format, payload before numbers -- which the others poll.
-  unsigned long long *mail;      // device, (1 + kResidentLines) * 8 words; nullptr: every workgroup polls the host
+  unsigned long long *mail;      // device, (1 + kResidentLines) * 8 words
+  int                 relay;     // != 0: the other workgroups take their commands from the mailbox instead of the host
+  // Workgroup 0 alone decides when a generation leaves (idle time-out): it says so in the mailbox's word 0, which the others
+  // watch, and reports to the host -- which therefore KNOWS whether anybody is there instead of guessing from elapsed time.
 };
+
+// One poll by one (whole) wave: the record's lines go to sh_raw ([n_loads * 64] words); returns 0: nothing yet, 1: command
+// last + 1 is complete in sh_raw, 2: leave.  Workgroup 0 of a relaying launch also keeps the mailbox up to date.
+__device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const unsigned long long last, const unsigned long long t_last,
+                                                  bool &mail_open, unsigned long long *sh_raw, const int n_loads, const int lane)
+{
+  // one aligned 8-byte word per lane and load: 512 contiguous bytes = 8 lines per instruction
+  const bool                decider = blockIdx.x == 0, from_host = decider || !r.relay;
+  const unsigned long long *base = from_host ? reinterpret_cast<const unsigned long long *>(r.cmd) : r.mail;
+  bool                      good = true;
+  unsigned long long        first = 0;
+  for (int j = 0; j < n_loads; ++j)
+  {
+    const unsigned long long v = from_host ? __hip_atomic_load(base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                           : __hip_atomic_load(base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_raw[j * 64 + lane] = v;
+    if (j == 0) first = v;
+    const int line = j * 8 + (lane >> 3);
+    if ((lane & 7) == 7 && line >= 1 && line <= r.n_lines) good = good && (v == last + 1);
+  }
+  // the mailbox's word 0 (generation * 2 + leave): what workgroup 0 has decided
+  unsigned long long m0 = 0;
+  if (!decider && from_host) m0 = __hip_atomic_load(r.mail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool all_good = __builtin_amdgcn_ballot_w64(!good) == 0;
+  // control: the host's line 0 holds {generation, leave}; the mailbox packs both into one word so that a leaving workgroup 0
+  // can say so with ONE compare-and-swap that fails if a newer generation took over
+  const unsigned long long w0 = __shfl(first, 0, 64), w1 = __shfl(first, 1, 64);
+  const unsigned long long gen = from_host ? w0 : (w0 >> 1), stop = from_host ? w1 : (w0 & 1);
+  if (!from_host) m0 = w0;
+  int act = 0;
+  if (from_host && (stop != 0 || gen != r.gen)) act = 2;                                   // the host says so
+  else if (!decider && ((m0 >> 1) > r.gen || ((m0 >> 1) == r.gen && (m0 & 1)))) act = 2; // workgroup 0 (or a newer one) says so
+  else if (all_good && gen == r.gen) act = 1;
+  else if (wall_clock64() - t_last > (decider ? r.idle_ticks : 16 * r.idle_ticks)) act = 2; // (the others: a safety net only)
+  if (decider)
+  {
+    if (act == 2)
+    { // (a workgroup of an older generation that is still around sees the newer number and leaves by itself)
+      if (lane == 0)
+      {
+        if (mail_open)
+        {
+          unsigned long long expect = r.gen << 1;
+          __hip_atomic_compare_exchange_strong(r.mail, &expect, (r.gen << 1) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(const_cast<unsigned long long *>(&r.cmd->report.w[0]), r.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    else if (r.relay ? (act == 1 || !mail_open) : !mail_open)
+    { // pass it on (relay), or just open the mailbox for this generation
+      for (int j = 0; j < (r.relay ? n_loads : 1); ++j)
+        if ((lane & 7) != 7 && !(j == 0 && lane < 8 && lane > 0) && (r.relay || (j == 0 && lane == 0)))
+          __hip_atomic_store(r.mail + j * 64 + lane, (j == 0 && lane == 0) ? (r.gen << 1) : sh_raw[j * 64 + lane], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      if (r.relay)
+      {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control word) before the line numbers
+        if (act == 1)
+          for (int j = 0; j < n_loads; ++j)
+            if ((lane & 7) == 7 && j * 8 + (lane >> 3) != 0)
+              __hip_atomic_store(r.mail + j * 64 + lane, sh_raw[j * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      mail_open = true;
+    }
+  }
+  return act;
+}
 
 template <int S, int CP>
 __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, const ResidentCtl r)
@@ -1322,56 +1394,9 @@ __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, co
   for (;;)
   {
     if (threadIdx.x < 64)
-    { // one aligned 8-byte word per lane and load: 512 contiguous bytes = 8 lines per instruction
-      const bool                leader = !r.mail || blockIdx.x == 0;
-      const unsigned long long *base = leader ? reinterpret_cast<const unsigned long long *>(r.cmd) : r.mail;
-      const int                 lane = threadIdx.x;
-      bool                      good = true;
-      unsigned long long        first = 0;
-      for (int j = 0; j < n_loads; ++j)
-      {
-        const unsigned long long v = leader ? __hip_atomic_load(base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                            : __hip_atomic_load(base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_raw[j * 64 + lane] = v;
-        if (j == 0) first = v;
-        const int line = j * 8 + (lane >> 3);
-        if ((lane & 7) == 7 && line >= 1 && line <= r.n_lines) good = good && (v == last + 1);
-      }
-      const bool               all_good = __builtin_amdgcn_ballot_w64(!good) == 0;
-      // control: the host's line 0 holds {generation, leave}; the mailbox packs both into its word 0 (generation * 2 + leave)
-      // so that a leaving workgroup 0 can say so with ONE compare-and-swap that fails if a newer generation took over
-      const unsigned long long w0 = __shfl(first, 0, 64), w1 = __shfl(first, 1, 64);
-      const unsigned long long gen = leader ? w0 : (w0 >> 1), stop = leader ? w1 : (w0 & 1);
-      unsigned long long       act = 0; // 0: poll again, 1: evaluate, 2: leave
-      if (leader ? (stop != 0 || gen != r.gen) : (gen > r.gen || (gen == r.gen && stop != 0))) act = 2;
-      else if (all_good && gen == r.gen) act = 1;
-      else if (wall_clock64() - t_last > r.idle_ticks) act = 2;
-      if (leader && r.mail)
-      { // pass it on
-        if (act == 2)
-        { // (a workgroup of an older generation that is still around sees the newer number and leaves by itself)
-          if (lane == 0 && mail_open)
-          {
-            unsigned long long expect = r.gen << 1;
-            __hip_atomic_compare_exchange_strong(r.mail, &expect, (r.gen << 1) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        else if (act == 1 || !mail_open)
-        {
-          for (int j = 0; j < n_loads; ++j)
-            if ((lane & 7) != 7 && !(j == 0 && lane < 8 && lane > 0))
-              __hip_atomic_store(r.mail + j * 64 + lane, (j == 0 && lane == 0) ? (r.gen << 1) : sh_raw[j * 64 + lane],
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control line) before the line numbers
-          if (act == 1)
-            for (int j = 0; j < n_loads; ++j)
-              if ((lane & 7) == 7 && j * 8 + (lane >> 3) != 0)
-                __hip_atomic_store(r.mail + j * 64 + lane, sh_raw[j * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          mail_open = true;
-        }
-      }
-      if (lane == 0) sh_ctl[0] = act;
+    {
+      const int a = resident_poll_wave(r, last, t_last, mail_open, sh_raw, n_loads, (int)threadIdx.x);
+      if (threadIdx.x == 0) sh_ctl[0] = (unsigned long long)a;
     }
     __syncthreads();
     const unsigned long long act = sh_ctl[0];

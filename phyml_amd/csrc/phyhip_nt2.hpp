@@ -39,12 +39,21 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // ARGS != 0 (short launches): the operation records are read from the kernel arguments (TreeParams::arg_ir / arg_xr) --
 // ARGS = 1: one operation, 2: two, 3: none (evaluation only) -- with the count known at compile time, instead of
 // the device slot ring -- a separate instantiation, so that the long-list kernel carries no trace of it.
-template <int C, int G = 1, bool DBG = false, int ARGS = 0>
-__global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
-                                                             const ExecRec *__restrict__ xrec,
-                                                             const double *pmats, // (not restrict: the prologue may rewrite entries)
-                                                             const uint8_t *__restrict__ tip_codes,
-                                                             unsigned long long *dbg = nullptr)
+// Where the prologue finds what it needs to rebuild transition matrices (lane-indexed reads: plain loads through these
+// pointers).  traverse_nt2_kernel points them at its own argument segment (indexing the by-value struct would make the
+// compiler copy it to scratch first), the resident kernel at device arrays and the command it received.
+struct NtFresh
+{
+  const int    *idx;                         // [n_fresh] matrix indices
+  const double *len;                         // [n_fresh] edge lengths
+  const double *evec, *ivec, *eval, *rates;  // U, U^-1, eigenvalues, category rates
+};
+
+// One workgroup's (= one wave's) share of a launch: the whole kernel body, callable from a kernel that stays resident.
+template <int C, int G, bool DBG, int ARGS>
+__device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__restrict__ irec, const ExecRec *__restrict__ xrec,
+                                        const double *pmats, // (not restrict: the prologue may rewrite entries)
+                                        const uint8_t *__restrict__ tip_codes, unsigned long long *dbg, const NtFresh fr)
 {
   // DBG: cycle stamps of the first 64 steps of one wave (PHYHIP_ABLATE=8), kept in LDS until the end
   __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
@@ -202,28 +211,18 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
     // of a 8 us launch, measured): a matrix needs only 4 C distinct ones, so lane (mm, c, k) computes exp(eval[k] * len(m0 +
     // mm, c)) for 64 / (4 C) matrices at once and the entries pick theirs up by shuffle -- one exp deep instead of 4 n_fresh.
     constexpr int PER = 4 * C, MPR = 64 / PER; // exps per matrix, matrices per round
-    // lane-indexed reads of argument arrays go to the argument segment itself (indexing the by-value struct would make
-    // the compiler copy it to scratch first)
-    typedef const __attribute__((address_space(4))) double karg_double;
-    typedef const __attribute__((address_space(4))) char   karg_char;
-    karg_char   *ka      = (karg_char *)__builtin_amdgcn_kernarg_segment_ptr();
-    karg_double *k_evec  = (karg_double *)(ka + offsetof(TreeParams, m_evec));
-    karg_double *k_ivec  = (karg_double *)(ka + offsetof(TreeParams, m_ivec));
-    karg_double *k_eval  = (karg_double *)(ka + offsetof(TreeParams, m_eval));
-    karg_double *k_rates = (karg_double *)(ka + offsetof(TreeParams, m_rates));
-    karg_double *k_len   = (karg_double *)(ka + offsetof(TreeParams, fresh_len));
     for (int m0 = 0; m0 < q.n_fresh; m0 += MPR)
     {
       const int mm = lane / PER, r = lane % PER, ec = r >> 2, ek = r & 3;
       double    ex = 0.0;
       if (mm < MPR && m0 + mm < q.n_fresh)
       {
-        const double fl = k_len[m0 + mm];
-        double       len = (fl > 0.0 ? fl : 0.0) * k_rates[ec]; // src/lk.c:2296
+        const double fl = fr.len[m0 + mm];
+        double       len = (fl > 0.0 ? fl : 0.0) * fr.rates[ec]; // src/lk.c:2296
         len *= q.br_len_mult;
         if (len < q.l_min) len = q.l_min;
         else if (len > q.l_max) len = q.l_max;
-        ex = exp(k_eval[ek] * len);
+        ex = exp(fr.eval[ek] * len);
       }
       // entry (c, i, j) of a matrix = lane (C <= 4: one pass); idle lanes compute entry 0 and store nothing, so that every
       // shuffle below runs with the whole wave active
@@ -231,10 +230,10 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
       const int  e = live ? lane : 0, c = e >> 4, i = (e >> 2) & 3, j = e & 3;
       double     u[4], v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { u[k] = k_evec[i * 4 + k]; v[k] = k_ivec[k * 4 + j]; }
+      for (int k = 0; k < 4; ++k) { u[k] = fr.evec[i * 4 + k]; v[k] = fr.ivec[k * 4 + j]; }
       for (int m2 = 0; m2 < MPR && m0 + m2 < q.n_fresh; ++m2)
       {
-        double *out = q.pmats_rw + (size_t)q.fresh_idx[m0 + m2] * (C * 16);
+        double *out = q.pmats_rw + (size_t)fr.idx[m0 + m2] * (C * 16);
         double  acc = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = __builtin_fma(u[k] * __shfl(ex, m2 * PER + c * 4 + k, 64), v[k], acc);
@@ -521,6 +520,100 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
   publish_block_sum(q, contrib, lane);
+}
+
+template <int C, int G = 1, bool DBG = false, int ARGS = 0>
+__global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+                                                             const ExecRec *__restrict__ xrec, const double *pmats,
+                                                             const uint8_t *__restrict__ tip_codes,
+                                                             unsigned long long *dbg = nullptr)
+{
+  typedef const __attribute__((address_space(4))) char karg_char;
+  const char *ka = (const char *)(karg_char *)__builtin_amdgcn_kernarg_segment_ptr(); // q is the first argument
+  NtFresh     fr;
+  fr.idx  = reinterpret_cast<const int *>(ka + offsetof(TreeParams, fresh_idx));
+  fr.len  = reinterpret_cast<const double *>(ka + offsetof(TreeParams, fresh_len));
+  fr.evec = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_evec));
+  fr.ivec = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_ivec));
+  fr.eval = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_eval));
+  fr.rates = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_rates));
+  nt2_run<C, G, DBG, ARGS>(q, irec, xrec, pmats, tip_codes, dbg, fr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident form of the short launches (see resident_dlk_kernel in phyhip_kernels.hpp for the mechanism).  An SPR regraft
+// candidate -- three matrices rebuilt, one partial update, the edge evaluation (src/spr.c:643-646) -- or an Lk(b) is a
+// ~5 us kernel behind a ~3 us launch call, the dispatch, and the kernel's start and end.  While nothing else of the instance
+// is on its stream, the one-wave workgroups of this kernel stay on the device and take those evaluations from the command
+// record: payload words 0 tag, 1 flags (bits 0-1 operations, bit 2 device data changed, bits 4-7 matrices to rebuild, bits
+// 8-9 evaluation sides to fetch early), 2 evaluation edge (parent | child << 32), 3 its matrix | last destination << 32,
+// 4-5 matrix indices, 6-9 their edge lengths, then per operation 12 words: the four child descriptors and the two
+// destination descriptors of the launch form's records.  Everything else is the launch's TreeParams, fixed at launch.
+// A workgroup completes and writes back its stores before it posts its sum (fence_post), so kernels launched afterwards
+// -- on whichever XCD -- find them in memory.
+// ---------------------------------------------------------------------------------------------
+constexpr int kResidentNtWords = 10 + 2 * 12;
+
+template <int C, int G>
+__global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq, const ResidentCtl r, const double *pmats,
+                                                             const uint8_t *__restrict__ tip_codes, const double *evec,
+                                                             const double *ivec, const double *eval, const double *rates)
+{
+  __shared__ unsigned long long sh_raw[64];
+  __shared__ int                sh_idx[4];
+  __shared__ double             sh_len[4];
+  const int          lane = threadIdx.x;
+  unsigned long long last = r.start_seq, t_last = wall_clock64();
+  bool               mail_open = false;
+  for (;;)
+  {
+    const int act = resident_poll_wave(r, last, t_last, mail_open, sh_raw, 1, lane);
+    if (act == 2) return;
+    if (act == 0) continue;
+    __builtin_amdgcn_wave_barrier();
+    // every word is the same for all lanes: make that known (descriptors and loop bounds belong in scalar registers)
+    auto word = [&](int k) {
+      const unsigned long long v = sh_raw[(1 + k / 7) * 8 + k % 7];
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return ((unsigned long long)hi << 32) | lo;
+    };
+    auto desc = [&](int k) {
+      Desc               d;
+      const unsigned long long b = word(k + 1);
+      d.base = word(k); d.bytes = (unsigned)b; d.x = (unsigned)(b >> 32);
+      return d;
+    };
+    const unsigned long long fl = word(1), ed = word(2), pm = word(3);
+    TreeParams               q = sq;
+    q.host_tag = word(0);
+    q.n_fresh = (int)((fl >> 4) & 15); q.e_prefetch = (int)((fl >> 8) & 3);
+    q.edge_eval = 1; q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
+    q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
+    if (lane < 4)
+    {
+      const unsigned long long ix = sh_raw[(1 + (4 + lane / 2) / 7) * 8 + (4 + lane / 2) % 7];
+      sh_idx[lane] = (int)(unsigned)(ix >> (32 * (lane & 1)));
+      const unsigned long long lb = sh_raw[(1 + (6 + lane) / 7) * 8 + (6 + lane) % 7];
+      __builtin_memcpy(&sh_len[lane], &lb, 8);
+    }
+    const int n_ops = (int)(fl & 3);
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+    {
+      q.arg_ir[o].c1_data = desc(10 + o * 12); q.arg_ir[o].c2_data = desc(12 + o * 12);
+      q.arg_ir[o].c1_scale = desc(14 + o * 12); q.arg_ir[o].c2_scale = desc(16 + o * 12);
+      q.arg_xr[o].dst_data = desc(18 + o * 12); q.arg_xr[o].dst_scale = desc(20 + o * 12);
+    }
+    // what kernels on the stream wrote since the last command (the host says whether any did) is re-read from memory
+    if (fl & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    NtFresh fr;
+    fr.idx = sh_idx; fr.len = sh_len; fr.evec = evec; fr.ivec = ivec; fr.eval = eval; fr.rates = rates;
+    if (n_ops == 1) nt2_run<C, G, false, 1>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr);
+    else if (n_ops == 2) nt2_run<C, G, false, 2>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr);
+    else nt2_run<C, G, false, 3>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr);
+    last = last + 1; t_last = wall_clock64();
+  }
 }
 
 } // namespace phyhip

@@ -121,3 +121,33 @@ def test_two_instances_each_with_resident_workgroups():
     finally:
         for t, *_ in pairs:
             t.close()
+
+
+@pytest.mark.parametrize("taxa,patterns,categories", [(40, 382, 4), (30, 1500, 4), (24, 1200, 2), (20, 700, 1)])
+def test_resident_short_evaluations_spr_call_pattern(taxa, patterns, categories, monkeypatch):
+    """A seeded SPR / Br_Len_Opt call stream (phyml_amd/replay.py: matrix refreshes, partial updates, edge likelihoods, eigen
+    products, dLk chains) with both resident evaluators against a kernel launch per call: the same doubles, scalar by
+    scalar, and the oracle's values; device-built matrices (the resident workgroups rebuild them in their prologue)."""
+    from phyml_amd import replay
+    import replay_oracle
+    res, stats = {}, {}
+    for r in ("0", "1"):
+        monkeypatch.setenv("PHYHIP_RESIDENT", r)
+        t, ot, tree, st = synthetic_pair(taxa, patterns, 4, categories, seed=61, host_pmat=False, ambiguous_every=13)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            tr = replay.make_trace(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, 80, seed=8, walk_every=3, opt_every=4, n_dlk=4)
+            res[r] = t.Replay_Surface_Trace(tr)
+            stats[r] = (t.inst.resident_stats(0), t.inst.resident_stats(1))
+            if r == "1":
+                ot.lk(None, both_sides=True)
+                ref, ref2 = replay_oracle.OracleReplayer(ot).run(tr)
+                m = ref != 0
+                assert np.max(np.abs(res[r][0][m] - ref[m]) / np.abs(ref[m])) < 1e-9  # (device exp in the matrices)
+        finally:
+            t.close()
+    assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1])
+    assert stats["0"] == ((0, 0, 0, 0), (0, 0, 0, 0))
+    (d_served, _, d_silent, _), (t_served, t_launches, t_silent, _) = stats["1"]
+    assert d_served > 0 and t_served > 50 and d_silent == 0 and t_silent == 0 and t_launches <= 6
