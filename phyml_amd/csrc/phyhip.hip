@@ -2320,6 +2320,11 @@ int phyhip_get_numerical_warning(int instance, int *out)
     int rc = flush_sync(I);
     if (rc) return rc;
   }
+  else
+  { // a query: it queues nothing and is not a step of the call sequence the resident evaluators watch
+    I->stream_dirty = I->dirty_prev;
+    --I->api_no;
+  }
   *out = *I->h_warn; // written by the final reduction of the last edge evaluation, ahead of its sequence number
   return PHYHIP_SUCCESS;
 }
