@@ -7,7 +7,9 @@ the scalar back on the host -- everything the reference's Lk(NULL) does (src/lk.
 
   --gpus 1            BASELINE configs[1] (cfg2: 100 taxa x 50 000 nt patterns, GTR+G4) on one MI355X; the JSON line
                       also carries `roofline`, `cpu_baseline` (real PhyML AVX, 1 host core, same box, same run) and,
-                      under `extra`, the 20-state configuration (cfg3: 200 taxa x 10 000 aa patterns, LG+G4).
+                      under `extra`, the 20-state configuration (cfg3: 200 taxa x 10 000 aa patterns, LG+G4) and
+                      `call_latency`: microseconds per SPR regraft candidate / per scalar-returning call of a seeded
+                      SPR + Br_Len_Opt call stream at the cfg5 size and at the reference's example-alignment size.
   --gpus N (N > 1)    BASELINE configs[3] (cfg4: 100 taxa x 1 000 000 nt patterns), STRONG scaling: contiguous pattern
                       shards of 1e6/N per GPU, ONE RCCL all-reduce of {warning, lnL} per evaluation inside libphyhip.so.
                       Launched by the driver as N ranks (torch.distributed.run, WORLD_SIZE = N): one process per GPU,
@@ -205,7 +207,7 @@ def run_single(args, torch):
         out["input_checksum_ok"] = bool(synth.states_checksum(st) == exp["checksum"])
     t.close()
     if not args.no_extra and args.workload == "cfg2_nt_100x50k" and args.patterns is None:
-        out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch)}
+        out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch), "call_latency": call_latency()}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample, args.cpu_reps)
     return out
@@ -217,6 +219,41 @@ def mfma_block(P, C, n, kdur):
     flops = float((P + 15) // 16) * C * (n - 2) * (10 * 2048.0 + 10 * 512.0)
     return {"achieved": flops / kdur / 1e12, "peak": 78.6, "unit": "TFLOP/s issued (f64 16x16x4 + 4x4x4_4b)",
             "frac": flops / kdur / 1e12 / 78.6, "useful_frac_of_issued": 1.0}
+
+
+def call_latency():
+    """The launch-bound side of the path, driver-timed in the same run: the seeded SPR / Br_Len_Opt call stream of
+    phyml_amd/replay.py (a regraft candidate = 3 matrix refreshes + 1 partial update + the edge likelihood with the scalar on
+    the host, src/spr.c:643-646; every `opt` candidates a branch-length chain of dLk calls, src/optimiz.c:607-663) at the
+    cfg5 size and at the size of the reference's own example alignment.  Every scalar of this stream is checked
+    against the oracle in tests/test_gpu_cfg5.py / test_gpu_replay.py / test_gpu_resident.py; here it is only timed."""
+    import numpy as np
+    from phyml_amd import lktree, replay, synth, workloads
+    blk = workloads.model_block("model_gtr_g4")
+    rows = {}
+    for name, taxa, P, cand, opt in (("spr_500x100k", 500, 100000, 600, 0), ("spr_54x382", 54, 382, 3000, 0),
+                                     ("spr_and_brlen_54x382", 54, 382, 1500, 4)):
+        tree = synth.random_tree(taxa, 9, 0.02, 0.15)
+        st = synth.simulate_states(tree, P, 4, 9)
+        t = lktree.LkTree(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, P, 4, int(blk["ncatg"][0]))
+        t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"])
+        t.Make_Tree_For_Lk(np.ones(P))
+        t.set_tips(tip_states=st.astype(np.int32))
+        t.Set_Both_Sides(True)
+        t.Lk(None)
+        tr = replay.make_trace(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, cand, seed=3, walk_every=3, opt_every=opt, n_dlk=5)
+        t.Replay_Surface_Trace({k: v[:300] for k, v in tr.items()})  # warm-up (first launches load code)
+        t0 = time.perf_counter()
+        res, _ = t.Replay_Surface_Trace(tr)
+        dt = time.perf_counter() - t0
+        k = tr["kind"]
+        n_scalar = int(np.isin(k, (replay.EDGE_LNL, replay.DLK)).sum())
+        rows[name] = {"us_per_candidate": dt / cand * 1e6, "us_per_scalar_returning_call": dt / n_scalar * 1e6, "candidates": cand,
+                      "scalar_returning_calls": n_scalar, "dlk_calls": int((k == replay.DLK).sum()), "surface_calls": int(len(k)),
+                      "finite": bool(np.isfinite(res).all()),
+                      "served_by_resident_workgroups": {"dlk": t.inst.resident_stats(0)[0], "short_evaluations": t.inst.resident_stats(1)[0]}}
+        t.close()
+    return rows
 
 
 def extra_line(name, args, torch):
