@@ -491,7 +491,7 @@ static void resident_free(Resident &R)
 // First half of a (re)launch: generation gen + 1 supersedes whatever is left of the previous one (its workgroups see the
 // new number at their next poll and leave); commands up to `served` count as done.  The caller launches its kernel with `r`
 // on `*st`, then calls resident_launched().
-static int resident_prepare(Instance *I, Resident &R, int grid, int n_lines, unsigned long long served, ResidentCtl &r, hipStream_t *st)
+static int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned long long served, ResidentCtl &r, hipStream_t *st)
 {
   if (!R.cmd)
   {
@@ -504,7 +504,7 @@ static int resident_prepare(Instance *I, Resident &R, int grid, int n_lines, uns
   ++R.n_launch;
   ++R.gen;
   __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
-  r.cmd = R.cmd; r.gen = R.gen; r.start_seq = served; r.n_lines = n_lines;
+  r.cmd = R.cmd; r.gen = R.gen; r.start_seq = served; r.n_sectors = (n_words + kResidentPay - 1) / kResidentPay;
   r.mail = R.mail; r.relay = grid > kResidentDirect ? 1 : 0;
   if (I->wall_khz <= 0)
   {
@@ -529,15 +529,15 @@ static bool resident_gone(const Resident &R)
   return R.cmd && __atomic_load_n(&R.cmd->report.w[0], __ATOMIC_ACQUIRE) == R.gen;
 }
 
-// The command: payload words into their lines, each line's number last (see ResidentCmd)
+// The command: payload words into their sectors, each sector's number last (see ResidentCmd)
 static void resident_send(Instance *I, Resident &R, const unsigned long long *words, int n_words)
 {
   ++R.seq;
-  for (int l = 0; l * 7 < n_words; ++l)
+  for (int l = 0; l * kResidentPay < n_words; ++l)
   {
-    ResidentLine &ln = R.cmd->line[l];
-    for (int k = 0; k < 7 && l * 7 + k < n_words; ++k) ln.w[k] = words[l * 7 + k];
-    __atomic_store_n(&ln.seq, R.seq, __ATOMIC_RELEASE);
+    ResidentSector &sc = R.cmd->sec[l];
+    for (int k = 0; k < kResidentPay && l * kResidentPay + k < n_words; ++k) sc.w[k] = words[l * kResidentPay + k];
+    __atomic_store_n(&sc.seq, R.seq, __ATOMIC_RELEASE);
   }
   R.api_no = I->api_no;
   ++R.n_cmd;
@@ -549,7 +549,7 @@ static int resident_launch_dlk(Instance *I, const DlkParams &qs, int dgrid, unsi
 {
   ResidentCtl r;
   hipStream_t st;
-  int rc = resident_prepare(I, I->rd, dgrid, (3 + I->C * 2 * I->S + 6) / 7, served, r, &st);
+  int rc = resident_prepare(I, I->rd, dgrid, 3 + I->C * 2 * I->S, served, r, &st);
   if (rc) return rc;
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
@@ -765,7 +765,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // ---- small nucleotide alignments: the resident short-launch evaluator (resident_nt2_kernel) ------------------------
   const bool rt_grid = I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis &&
                        I->grid_nt2 <= kResidentMaxGrid && !I->ablate && I->nt_groups <= 2;
-  static const bool rtdbg = getenv("PHYHIP_RESIDENT_DEBUG") != nullptr;
+  static const bool rtdbg = kDiag && getenv("PHYHIP_RESIDENT_DEBUG") != nullptr; // (diag build: why an evaluation was launched)
   if (rtdbg && ee)
     fprintf(stderr, "rt: grid_ok %d (res %d spin %d hs %d soa %d co %d cls %d g2 %d abl %d grp %d) hsn %d args %d fresh %d site %d prof %d skip %d dirty_prev %d touched %d\n",
             (int)rt_grid, (int)I->resident, (int)I->spin_wait, (int)I->host_sum, (int)I->soa, I->co != nullptr, (int)I->class_axis, I->grid_nt2,
@@ -805,7 +805,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         if (R.launched && (R.grid != I->grid_nt2 || memcmp(&I->rt_static, &sq, sizeof sq) != 0)) resident_stop(R);
         ResidentCtl r;
         hipStream_t st;
-        if ((rc = resident_prepare(I, R, I->grid_nt2, (kResidentNtWords + 6) / 7, R.seq, r, &st))) return rc;
+        if ((rc = resident_prepare(I, R, I->grid_nt2, kResidentNtWords, R.seq, r, &st))) return rc;
 #define NT2RES(c_, g_)                                                                                                      \
   hipLaunchKernelGGL((resident_nt2_kernel<c_, g_>), dim3(I->grid_nt2), dim3(64), 0, st, sq, r, (const double *)I->d_pmats,   \
                      (const uint8_t *)I->d_tipcodes, (const double *)I->d_evec, (const double *)I->d_ivec,                    \
@@ -848,7 +848,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       }
       // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (phyhip_calculate_edge_log_likelihoods)
       I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
-      resident_send(I, R, words, kResidentNtWords); // (every line the workgroups wait for carries the command's number)
+      resident_send(I, R, words, kResidentNtWords); // (every sector the workgroups wait for carries the command's number)
       I->rt_epoch = I->clean_epoch;
       I->host_sum_n = host_sum_n; I->host_sum_ns = 1;
       if (fold_pm)
@@ -2414,7 +2414,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   // Small alignment, scalar wanted on the host: hand the evaluation to the resident workgroups (resident_dlk_kernel) when
   // nothing of this instance is still running on its stream -- they are not ordered with it.  Right after Update_Eigen_Lr
   // the products are a few microseconds away: poll the stream that long, else launch as usual.
-  // (4 states only: a 20-state command is 24 lines instead of 5 and the round trip loses to the launch, 14.1-14.9 against
+  // (4 states only: a 20-state command takes four 512-byte reads per poll instead of one and the round trip loses to the launch, 14.1-14.9 against
   // 12.4-12.5 us at 2 000 patterns -- measured, tools/gpu_resident_ab2.sh)
   if (hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait)
   {

@@ -324,6 +324,9 @@ __device__ __forceinline__ void raise_warn(int *warn)
 { // visible to whichever workgroup ends up doing the final reduction (other XCD, other L2) -- or to the host, when the
   // flag lives in host-mapped memory (host-side final sum)
   __hip_atomic_store(warn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // ... and performed before this wave goes on: the workgroup's {sum, tag} record, which tells the host that the evaluation
+  // is complete, is posted later (program order, or behind the workgroup's barrier) and must not overtake it.  Rare path.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 }
 
 __device__ __forceinline__ void post_host_block(HostBlock *dst, double sum, unsigned long long tag)
@@ -1277,38 +1280,43 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
 // when told to (seq = ~0), when a newer launch has superseded it (gen), or after idle_ticks without a command -- so a
 // device-wide synchronisation never waits longer than that, and a host that died leaves nothing behind.
 // ---------------------------------------------------------------------------------------------
-// The command record is made of 64-byte lines, each carrying seven payload words and, LAST, the number of the command it
-// belongs to: the host fills a line's payload and then its number, the device reads whole lines (one aligned 64-byte read
-// each) and takes a command when every line carries the number it expects -- payload and "go" arrive in ONE trip over the
-// link instead of two (a poll of a sequence word, then a dependent read of the body: ~2 us each).  Only the first wave of
-// a workgroup reads host memory (every reader costs the others: 24 polling workgroups answered in 8.5 us, 6 in 4.3 --
-// tools/probes/resident_probe.hip); the rest get the payload through LDS.
-// Payload words: 0 tag of the {sum, tag} records, 1 flags (bit 0 derivative, 1 invariant-site model, 2 scaling, 3 device
-// data changed since the last command), 2 pinvar, 3.. the expl table.  Line 0 is control: word 0 generation in charge, word 1
-// != 0: leave.
-struct ResidentLine
+// The command record is made of 32-byte sectors, each carrying three payload words and, LAST, the number of the command it
+// belongs to: the host fills a sector's payload and then its number, the device reads whole sectors (aligned 32-byte
+// pieces of one 512-byte wave access -- the smallest unit a read of host memory may be split into, so a sector is never
+// seen half old, half new) and takes a command when every sector carries the number it expects: payload and "go" arrive
+// in ONE trip over the link instead of two (a poll of a sequence word, then a dependent read of the body: ~2 us each).
+// Only the first wave of a workgroup reads host memory (every reader costs the others: 24 polling workgroups answered in
+// 8.5 us, 6 in 4.3 -- tools/probes/resident_probe.hip); the rest get the payload through LDS.
+// dLk payload words: 0 tag of the {sum, tag} records, 1 flags (bit 0 derivative, 1 invariant-site model, 2 scaling, 3 device
+// data changed since the last command), 2 pinvar, 3.. the expl table.  Sector 0 is control: word 0 generation in charge,
+// word 1 != 0: leave.
+constexpr int kResidentPay  = 3;                // payload words per sector
+constexpr int kResidentUnit = kResidentPay + 1; // words per sector
+struct ResidentSector
 {
-  unsigned long long w[7];
+  unsigned long long w[kResidentPay];
   unsigned long long seq;
 };
-constexpr int kResidentWords = 3 + kMaxExpl;
-constexpr int kResidentLines = (kResidentWords + 6) / 7;
+constexpr int kResidentWords   = 3 + kMaxExpl;
+constexpr int kResidentSectors = (kResidentWords + kResidentPay - 1) / kResidentPay;
 struct ResidentCmd
 {
-  ResidentLine ctl;
-  ResidentLine line[kResidentLines];
-  ResidentLine report; // written by the DEVICE: word 0 = the generation whose workgroups have left (idle, told to, superseded)
+  ResidentSector ctl;
+  ResidentSector sec[kResidentSectors];
+  ResidentSector report; // written by the DEVICE: word 0 = the generation whose workgroups have left (idle, told to, superseded)
 };
+// index of payload word k among the record's words (sector 0 is control)
+__host__ __device__ constexpr int resident_slot(int k) { return (1 + k / kResidentPay) * kResidentUnit + k % kResidentPay; }
 struct ResidentCtl
 {
   const ResidentCmd *cmd;        // host-mapped
   unsigned long long gen;        // this launch
   unsigned long long start_seq;  // commands up to here have been served
   unsigned long long idle_ticks; // wall_clock64 ticks
-  int                n_lines;    // command lines in use (3 + C * 2 * S words)
+  int                n_sectors;  // command sectors in use
   // More than a handful of workgroups: only workgroup 0 polls the host (every reader of host memory slows the others down);
   // it copies each command into a mailbox in device memory -- same line format, payload before numbers -- which the others poll.
-  unsigned long long *mail;      // device, (1 + kResidentLines) * 8 words
+  unsigned long long *mail;      // device, a copy of the record's layout
   int                 relay;     // != 0: the other workgroups take their commands from the mailbox instead of the host
   // Workgroup 0 alone decides when a generation leaves (idle time-out): it says so in the mailbox's word 0, which the others
   // watch, and reports to the host -- which therefore KNOWS whether anybody is there instead of guessing from elapsed time.
@@ -1319,7 +1327,7 @@ struct ResidentCtl
 __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const unsigned long long last, const unsigned long long t_last,
                                                   bool &mail_open, unsigned long long *sh_raw, const int n_loads, const int lane)
 {
-  // one aligned 8-byte word per lane and load: 512 contiguous bytes = 8 lines per instruction
+  // one aligned 8-byte word per lane and load: 512 contiguous bytes = 16 sectors per instruction
   const bool                decider = blockIdx.x == 0, from_host = decider || !r.relay;
   const unsigned long long *base = from_host ? reinterpret_cast<const unsigned long long *>(r.cmd) : r.mail;
   bool                      good = true;
@@ -1330,8 +1338,8 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
                                            : __hip_atomic_load(base + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sh_raw[j * 64 + lane] = v;
     if (j == 0) first = v;
-    const int line = j * 8 + (lane >> 3);
-    if ((lane & 7) == 7 && line >= 1 && line <= r.n_lines) good = good && (v == last + 1);
+    const int sector = j * 16 + (lane >> 2);
+    if ((lane & 3) == 3 && sector >= 1 && sector <= r.n_sectors) good = good && (v == last + 1);
   }
   // the mailbox's word 0 (generation * 2 + leave): what workgroup 0 has decided
   unsigned long long m0 = 0;
@@ -1365,7 +1373,7 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
     else if (r.relay ? (act == 1 || !mail_open) : !mail_open)
     { // pass it on (relay), or just open the mailbox for this generation
       for (int j = 0; j < (r.relay ? n_loads : 1); ++j)
-        if ((lane & 7) != 7 && !(j == 0 && lane < 8 && lane > 0) && (r.relay || (j == 0 && lane == 0)))
+        if ((lane & 3) != 3 && !(j == 0 && lane < 4 && lane > 0) && (r.relay || (j == 0 && lane == 0)))
           __hip_atomic_store(r.mail + j * 64 + lane, (j == 0 && lane == 0) ? (r.gen << 1) : sh_raw[j * 64 + lane], __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
       if (r.relay)
@@ -1373,7 +1381,7 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control word) before the line numbers
         if (act == 1)
           for (int j = 0; j < n_loads; ++j)
-            if ((lane & 7) == 7 && j * 8 + (lane >> 3) != 0)
+            if ((lane & 3) == 3 && j * 16 + (lane >> 2) != 0)
               __hip_atomic_store(r.mail + j * 64 + lane, sh_raw[j * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       mail_open = true;
@@ -1385,11 +1393,11 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
 template <int S, int CP>
 __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, const ResidentCtl r)
 {
-  __shared__ unsigned long long sh_raw[(1 + kResidentLines + 7) / 8 * 64];
+  __shared__ unsigned long long sh_raw[(1 + kResidentSectors + 15) / 16 * 64];
   __shared__ double             sh_expl[kMaxExpl];
   __shared__ unsigned long long sh_ctl[1];
   unsigned long long last = r.start_seq, t_last = wall_clock64();
-  const int          n_loads = (1 + r.n_lines + 7) / 8;
+  const int          n_loads = (1 + r.n_sectors + 15) / 16;
   bool               mail_open = false; // workgroup 0: the mailbox carries this generation's control line
   for (;;)
   {
@@ -1406,7 +1414,7 @@ __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, co
       __syncthreads();
       continue;
     }
-    auto word = [&](int k) { return sh_raw[(1 + k / 7) * 8 + k % 7]; };
+    auto word = [&](int k) { return sh_raw[resident_slot(k)]; };
     const unsigned long long tag = word(0), flags = word(1);
     double                   pinvar;
     {

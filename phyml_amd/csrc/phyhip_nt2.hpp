@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     __builtin_amdgcn_wave_barrier();
     // every word is the same for all lanes: make that known (descriptors and loop bounds belong in scalar registers)
     auto word = [&](int k) {
-      const unsigned long long v = sh_raw[(1 + k / 7) * 8 + k % 7];
+      const unsigned long long v = sh_raw[resident_slot(k)];
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
       return ((unsigned long long)hi << 32) | lo;
     };
@@ -591,9 +591,9 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
     if (lane < 4)
     {
-      const unsigned long long ix = sh_raw[(1 + (4 + lane / 2) / 7) * 8 + (4 + lane / 2) % 7];
+      const unsigned long long ix = sh_raw[resident_slot(4 + lane / 2)];
       sh_idx[lane] = (int)(unsigned)(ix >> (32 * (lane & 1)));
-      const unsigned long long lb = sh_raw[(1 + (6 + lane) / 7) * 8 + (6 + lane) % 7];
+      const unsigned long long lb = sh_raw[resident_slot(6 + lane)];
       __builtin_memcpy(&sh_len[lane], &lb, 8);
     }
     const int n_ops = (int)(fl & 3);
