@@ -207,7 +207,9 @@ def run_single(args, torch):
         out["input_checksum_ok"] = bool(synth.states_checksum(st) == exp["checksum"])
     t.close()
     if not args.no_extra and args.workload == "cfg2_nt_100x50k" and args.patterns is None:
-        out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch), "call_latency": call_latency()}
+        out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch)}
+        if not args.no_call_latency:
+            out["extra"]["call_latency"] = call_latency()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample, args.cpu_reps)
     return out
@@ -370,6 +372,8 @@ def main():
     ap.add_argument("--workload", default="cfg2_nt_100x50k", help="N = 1 only")
     ap.add_argument("--patterns", type=int, default=None, help="pattern count override (N = 1: of the workload; N > 1: total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-call-latency", action="store_true",
+                    help="skip the call_latency part of `extra` (kernel-stats profiles: its launches share kernel names with the bench's)")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 line (N = 1) / the single-GPU reference (N > 1)")
     ap.add_argument("--cpu-sample", type=int, default=50000)
     ap.add_argument("--cpu-reps", type=int, default=30)

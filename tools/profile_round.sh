@@ -7,7 +7,7 @@ tag=${1:-r02}
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -- python $repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/stats_default.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -- python $repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-call-latency > $out/stats_default.log 2>&1
 for wl in cfg2_nt_100x50k cfg3_aa_200x10k; do
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
     n=$(echo $c | tr " " "_" | cut -c1-40)

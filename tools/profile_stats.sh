@@ -1,33 +1,13 @@
 #!/bin/bash
-# tools/profile_stats.sh <tag> : the short form of profile_round.sh -- kernel-trace stats of the two bench commands, the HBM
-# byte counters of their traversal kernels in separate counter-only passes, and the bench lines of the same box.
-tag=${1:-r01d}
-out=/root/repo/gpurun_out/$tag; mkdir -p $out
+# tools/profile_stats.sh <tag>: only the `rocprofv3 --kernel-trace --stats` pass of tools/profile_round.sh (the default bench
+# without its call_latency part, whose launches share kernel names with the bench's) -> gpurun_out/<tag>/profiles/
+tag=${1:-r02}
+repo=${GRAFT_REPO_ROOT:-/root/repo}
+out=$repo/gpurun_out/$tag; mkdir -p $out/profiles
 cd /tmp; export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_cfg2 -- python /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/stats_cfg2.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_cfg3 -- python /root/repo/bench.py --workload cfg3_aa_200x10k --steps 10 --warmup 3 --no-cpu-baseline > $out/stats_cfg3.log 2>&1
-for wl in cfg2_nt_100x50k cfg3_aa_200x10k; do
-  for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${wl}_$c -- python /root/repo/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline > $out/pmc_${wl}_$c.log 2>&1 || echo "pass $wl $c failed/timeout"
-  done
+rm -rf $out/stats_default
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_default -- python $repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-call-latency > $out/stats_default.log 2>&1
+for f in $out/stats_default/*/*kernel_stats.csv; do
+  if grep -q traverse $f; then cp $f $out/profiles/${tag}_stats_default_kernel_stats.csv; head -6 $f | cut -c1-70,190-290; fi
 done
-python /root/repo/bench.py --no-cpu-baseline > $out/bench_cfg2.json 2>/dev/null
-python /root/repo/bench.py --no-cpu-baseline --workload cfg3_aa_200x10k > $out/bench_cfg3.json 2>/dev/null
-python3 - <<PY
-import csv,glob,collections,json
-out='$out'
-for wl in ('cfg2_nt_100x50k','cfg3_aa_200x10k'):
-    acc=collections.defaultdict(list)
-    for f in glob.glob(f'{out}/pmc_{wl}_*/*/*counter_collection.csv'):
-        for r in csv.DictReader(open(f)):
-            if 'traverse' in r['Kernel_Name']:
-                acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    res={k:sum(v)/len(v) for k,v in sorted(acc.items())}
-    json.dump(res,open(f'{out}/pmc_{wl}.json','w'),indent=1)
-    print(wl,res)
-for d in ('stats_cfg2','stats_cfg3'):
-    for f in glob.glob(f'{out}/{d}/*/*kernel_stats.csv'):
-        print(d); print(open(f).read()[:900])
-for b in ('bench_cfg2','bench_cfg3'):
-    print(open(f'{out}/{b}.json').read()[:700])
-PY
+grep '^{"metric"' $out/stats_default.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step ms', d['ms_per_step'], 'kernel us', d['roofline']['kernel_avg_us'], 'traffic', d['roofline']['traffic'], 'cfg3 kernel us', d['extra']['cfg3_aa_200x10k']['roofline']['kernel_avg_us'])"
