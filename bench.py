@@ -209,7 +209,10 @@ def run_single(args, torch):
     if not args.no_extra and args.workload == "cfg2_nt_100x50k" and args.patterns is None:
         out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch)}
         if not args.no_call_latency:
-            out["extra"]["call_latency"] = call_latency()
+            try:
+                out["extra"]["call_latency"] = call_latency()
+            except Exception as e:  # (an extra must never cost the run its headline line)
+                out["extra"]["call_latency"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample, args.cpu_reps)
     return out
