@@ -248,6 +248,7 @@ struct Instance
   double l_min = 1.e-8, l_max = 100., br_len_mult = 1.0, pinvar = 0.0; // src/init.c:711-714
   int    apply_scaling = 1, invar_model = 0;
   bool   want_site_outputs = true;
+  int    nt2_dist = 2;       // PHYHIP_NT2_DIST=1: the lane-per-pattern kernel loads one operation ahead instead of two (a wave more per SIMD)
   int    prefetch_dist = 2;  // PHYHIP_DIST: load-stage distance of the nt pipeline (1 or 2)
   bool   fold_pmats = true;    // PHYHIP_FOLD_PMATS=0: always rebuild transition matrices with a separate pmat_kernel launch
   bool   pm_copy = false;      // PHYHIP_PM_COPY=1: copy the P-matrix work list to the device first (measured: +2 us per step at cfg2, +3..6 at cfg3)
@@ -908,7 +909,12 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, a_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec,  \
                      ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);
 #define NT2CASE(c_, g_)                                                                                                     \
-  if (!q.recs_in_args) { NT2LAUNCH(c_, g_, 0) }                                                                             \
+  if (!q.recs_in_args && I->prefetch_dist == 1)                                                                             \
+  {                                                                                                                         \
+    hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, 0, 1>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
+                       ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
+  }                                                                                                                         \
+  else if (!q.recs_in_args) { NT2LAUNCH(c_, g_, 0) }                                                                        \
   else if (q.n_real_ops == 1) { NT2LAUNCH(c_, g_, 1) }                                                                      \
   else if (q.n_real_ops == 2) { NT2LAUNCH(c_, g_, 2) }                                                                      \
   else { NT2LAUNCH(c_, g_, 3) }                                                                                             \
@@ -1450,6 +1456,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   // The pipelined nucleotide kernel is instruction-issue bound per CU, so CU-level balance matters more than
   // workgroup size: one-wave workgroups let the dispatcher spread e.g. 3125 waves as 12-13 per CU instead of
   // 3-4 four-wave groups (measured: 100 taxa x 50 000 patterns, 288 -> 25x us).
+  if (const char *e = getenv("PHYHIP_NT2_DIST")) I->nt2_dist = atoi(e) == 1 ? 1 : 2;
   I->block_nt = 64;
   if (const char *e = getenv("PHYHIP_BLOCK")) { int b = atoi(e); if (b == 64 || b == 128 || b == 256) I->block_nt = b; }
   I->grid_nt = (int)(((long long)I->P * I->CP + I->block_nt - 1) / I->block_nt);
@@ -1458,7 +1465,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     // pipeline unless that would leave a nearly empty second residency round
     const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
     if (!getenv("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
-    if (I->soa) I->prefetch_dist = 2;
+    if (I->soa) I->prefetch_dist = I->nt2_dist;
     if (I->perm) I->prefetch_dist = 1; // the 20-state kernels forward only the previous result
   }
   HIPCHK(hipMalloc((void **)&I->d_block,
@@ -1515,7 +1522,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
   HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups)));
   if (const char *e = getenv("PHYHIP_DIST"))
-    if (!I->perm) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
+    if (!I->perm && !I->soa) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
 
   // codes 0..S-1 are the single states
   for (int s = 0; s < I->S; ++s)

@@ -50,7 +50,9 @@ struct NtFresh
 };
 
 // One workgroup's (= one wave's) share of a launch: the whole kernel body, callable from a kernel that stays resident.
-template <int C, int G, bool DBG, int ARGS>
+// DIST: how many operations ahead the loads run (2: two register sets in flight; 1: one -- 34 registers less per lane,
+// a third wave per SIMD at G = 2; the host then flags forwarding from the previous operation only).
+template <int C, int G, bool DBG, int ARGS, int DIST = 2>
 __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__restrict__ irec, const ExecRec *__restrict__ xrec,
                                         const double *pmats, // (not restrict: the prologue may rewrite entries)
                                         const uint8_t *__restrict__ tip_codes, unsigned long long *dbg, const NtFresh fr)
@@ -184,7 +186,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   if (has_ops)
   {
     issue_data(IR(0), RA);
-    if constexpr (!single) issue_data(IR((1 < last) ? 1 : last), RB);
+    if constexpr (!single && DIST == 2) issue_data(IR((1 < last) ? 1 : last), RB);
   }
   // Short launches: the evaluation edge's far side(s) too, when no queued operation writes them (host's call)
   u32x4    EX[HP], EY[HP];
@@ -259,9 +261,9 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   if (has_ops)
   {
     issue_pm(IR(0), PA);
-    if constexpr (!single) issue_pm(IR((1 < last) ? 1 : last), PB);
+    if constexpr (!single && DIST == 2) issue_pm(IR((1 < last) ? 1 : last), PB);
     ExecRec  cur = XR(0);
-    IssueRec nx2 = IR((2 < last) ? 2 : last);
+    IssueRec nx2 = IR((DIST < last) ? DIST : last); // the next operation whose loads go out
 
     // One pipeline step: operation k; its loads are in (R, PC); Fprev = result of k-1, Fout = result of k-2
     // on entry and the result of k on exit.
@@ -343,7 +345,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
       // prefetch operation k+2 into the registers just freed; then the scalar records of the next step
       if constexpr (!ARGS) issue(nx2, R, PC); // (records in the arguments: at most two operations, nothing to prefetch)
       PHY_STAMP(k, 7)
-      const IssueRec nx3 = IR((k + 3 < last) ? k + 3 : last);
+      const IssueRec nx3 = IR((k + 1 + DIST < last) ? k + 1 + DIST : last);
       __builtin_amdgcn_wave_barrier();
       PHY_STAMP(k, 4)
 
@@ -400,7 +402,8 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
       for (int k = 0; k < q.n_ops; k += 2)
       {
         step(k, 0, RA, PA, FA, scA, FB, scB);
-        step(k + 1, 1, RB, PB, FB, scB, FA, scA);
+        if constexpr (DIST == 2) step(k + 1, 1, RB, PB, FB, scB, FA, scA);
+        else step(k + 1, 1, RA, PA, FB, scB, FA, scA);
       }
   }
 
@@ -522,8 +525,8 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   publish_block_sum(q, contrib, lane);
 }
 
-template <int C, int G = 1, bool DBG = false, int ARGS = 0>
-__global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+template <int C, int G = 1, bool DBG = false, int ARGS = 0, int DIST = 2>
+__global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec, const double *pmats,
                                                              const uint8_t *__restrict__ tip_codes,
                                                              unsigned long long *dbg = nullptr)
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(64, G) void traverse_nt2_kernel(const TreeParams q,
   fr.ivec = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_ivec));
   fr.eval = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_eval));
   fr.rates = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_rates));
-  nt2_run<C, G, DBG, ARGS>(q, irec, xrec, pmats, tip_codes, dbg, fr);
+  nt2_run<C, G, DBG, ARGS, DIST>(q, irec, xrec, pmats, tip_codes, dbg, fr);
 }
 
 // ---------------------------------------------------------------------------------------------
