@@ -132,6 +132,7 @@ struct StagingRing
 
 struct Collective;
 
+constexpr int kResidentDirect = 16;    // up to this many resident workgroups poll the host themselves, above that workgroup 0 relays (measured: 8 / 16 / 32, tools/gpu_direct_ab.sh)
 // Host side of one set of resident workgroups (see resident_dlk_kernel / resident_nt2_kernel)
 struct Resident
 {
@@ -193,6 +194,7 @@ struct Instance
   size_t    h_blocks_cap = 0;
   // resident evaluator (resident_dlk_kernel): dLk / eigen-basis Lk of small alignments without a launch per call
   bool         resident = true;       // PHYHIP_RESIDENT=0: every evaluation is a kernel launch
+  int          resident_direct = kResidentDirect; // PHYHIP_RESIDENT_DIRECT: up to this many workgroups poll the host themselves
   double       resident_idle_us = 1000.0; // PHYHIP_RESIDENT_IDLE_US: the workgroups leave after this long without a command
   Resident     rd, rt;                // the dLk evaluator (resident_dlk_kernel) and the short-launch one (resident_nt2_kernel)
   Resident    *r_inflight = nullptr;  // whose command the evaluation in flight is
@@ -458,7 +460,6 @@ static bool fuse_reduce(const Instance *I, int nblocks)
 }
 
 // ---- resident evaluators: host side -----------------------------------------------------------------------------
-constexpr int kResidentDirect = 8;     // ... up to this many poll the host themselves, above that workgroup 0 relays
 constexpr int kResidentMaxGrid = 64;   // resident evaluator: alignments of up to this many dLk workgroups
 constexpr int kResidentSilent = -4242; // wait_host_sum: the resident workgroups did not answer (not an error)
 static double ns_since(const struct timespec &t0)
@@ -506,7 +507,7 @@ static int resident_prepare(Instance *I, Resident &R, int grid, int n_words, uns
   ++R.gen;
   __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
   r.cmd = R.cmd; r.gen = R.gen; r.start_seq = served; r.n_sectors = (n_words + kResidentPay - 1) / kResidentPay;
-  r.mail = R.mail; r.relay = grid > kResidentDirect ? 1 : 0;
+  r.mail = R.mail; r.relay = grid > I->resident_direct ? 1 : 0;
   if (I->wall_khz <= 0)
   {
     int dev = 0, khz = 0;
@@ -1488,6 +1489,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   if (const char *e = getenv("PHYHIP_HOST_SUM")) I->host_sum = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_RESIDENT")) I->resident = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_RESIDENT_IDLE_US")) I->resident_idle_us = atof(e);
+  if (const char *e = getenv("PHYHIP_RESIDENT_DIRECT")) I->resident_direct = atoi(e);
 
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
