@@ -1035,7 +1035,9 @@ struct EigenParams
   unsigned long long  stamp;
 };
 
-template <int S, int CP>
+// CLS: class-axis instance (per-class frequencies and eigenvectors); a separate instantiation, because only with the offset a
+// compile-time zero are the eigenvector reads provably the same for every lane (scalar loads)
+template <int S, int CP, bool CLS = false>
 __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
 {
   const TreeParams &q  = e.t;
@@ -1047,25 +1049,41 @@ __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
   const int         c   = (c0 < q.C) ? c0 : 0;
   double            x[S], y[S], lp[S];
   int               sl, sr;
+  extern __shared__ double sh_ev[]; // [2][classes or 1][S][S]
   load_side<S, CP>(q, e.ro, e.left, p, c, x, sl);
   load_side<S, CP>(q, e.ro, e.rght, p, c, y, sr);
-  const int co = q.class_axis ? c : 0; // class axis: per-class frequencies and eigenvectors
-  const double *__restrict__ rev = e.r_e_vect + (size_t)co * S * S, *__restrict__ lev = e.l_e_vect + (size_t)co * S * S;
-#pragma unroll
-  for (int i = 0; i < S; ++i) lp[i] = x[i] * q.pi[co * S + i]; // src/avx.c:79
   double d[S];
-#pragma unroll
-  for (int k = 0; k < S; ++k)
-  { // a[k] = sum_i R[i][k] lp[i];  b[k] = sum_i L[k][i] y[i]  (column-wise FMA chains, src/avx.c:81-82)
-    double a = rev[k] * lp[0];
-    double b = lev[k * S] * y[0];
-#pragma unroll
-    for (int i = 1; i < S; ++i)
+  // a[k] = sum_i R[i][k] lp[i];  b[k] = sum_i L[k][i] y[i]  (column-wise FMA chains, src/avx.c:81-82).  Every lane reads the
+  // same 2 S^2 eigenvector entries (per class): straight from memory that was 2 S^2 dependent vector loads per lane (27 us
+  // per call at 20 states, whatever the pattern count; as scalar loads 37 us) -- the workgroup stages them in LDS once and
+  // the lanes read them back as broadcasts.
+  {
+    const int     nsys = CLS ? q.C : 1;
+    const double *sh_r = sh_ev, *sh_l = sh_ev + nsys * S * S;
+    for (int t = threadIdx.x; t < nsys * S * S; t += blockDim.x)
     {
-      a = __builtin_fma(rev[i * S + k], lp[i], a);
-      b = __builtin_fma(lev[k * S + i], y[i], b);
+      sh_ev[t] = e.r_e_vect[t];
+      sh_ev[nsys * S * S + t] = e.l_e_vect[t];
     }
-    d[k] = a * b;
+    __syncthreads();
+    const int     co = CLS ? c : 0;
+    const double *rev = sh_r + co * S * S, *lev = sh_l + co * S * S;
+    const double *__restrict__ pi = q.pi + co * S;
+#pragma unroll
+    for (int i = 0; i < S; ++i) lp[i] = x[i] * pi[i]; // src/avx.c:79
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+    {
+      double a = rev[k] * lp[0];
+      double b = lev[k * S] * y[0];
+#pragma unroll
+      for (int i = 1; i < S; ++i)
+      {
+        a = __builtin_fma(rev[i * S + k], lp[i], a);
+        b = __builtin_fma(lev[k * S + i], y[i], b);
+      }
+      d[k] = a * b;
+    }
   }
   if (act)
   {
