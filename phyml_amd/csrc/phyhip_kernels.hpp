@@ -1378,13 +1378,11 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
     if (act == 2)
     { // (a workgroup of an older generation that is still around sees the newer number and leaves by itself)
       if (lane == 0)
-      {
-        if (mail_open)
-        {
-          unsigned long long expect = r.gen << 1;
-          __hip_atomic_compare_exchange_strong(r.mail, &expect, (r.gen << 1) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+      { // (also when this generation never got to open the mailbox: told to leave at its very first poll)
+        unsigned long long cur = __hip_atomic_load(r.mail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur >> 1) <= r.gen)
+          __hip_atomic_compare_exchange_strong(r.mail, &cur, (r.gen << 1) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-        }
         __hip_atomic_store(const_cast<unsigned long long *>(&r.cmd->report.w[0]), r.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -1396,7 +1394,7 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
                              __HIP_MEMORY_SCOPE_AGENT);
       if (r.relay)
       {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control word) before the line numbers
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control word) before the sector numbers
         if (act == 1)
           for (int j = 0; j < n_loads; ++j)
             if ((lane & 3) == 3 && j * 16 + (lane >> 2) != 0)
