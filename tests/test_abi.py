@@ -125,3 +125,20 @@ def test_host_layer_pmat_matches_reference_matrices():
             assert np.array_equal(out, ref[e]), (name, e)
         H.PMat(C.c_double(-1.0), C.byref(mod), 0, out.ctypes.data_as(C.c_void_p))
         assert np.array_equal(out[0], np.eye(m.ns))
+
+
+def test_every_environment_switch_is_documented():
+    """Each PHYHIP_* variable the library reads is listed where a user looks for it (tools/README.md, include/phyhip.h,
+    INTEGRATION.md or DESIGN.md)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ""
+    for pat in ("phyml_amd/csrc/*.hip", "phyml_amd/csrc/*.hpp", "phyml_amd/csrc/host/*.c"):
+        for f in glob.glob(os.path.join(root, pat)):
+            src += open(f).read()
+    docs = "".join(open(os.path.join(root, f)).read() for f in ("tools/README.md", "include/phyhip.h", "INTEGRATION.md", "DESIGN.md"))
+    names = sorted(set(re.findall(r'getenv\("(PHYHIP_[A-Z0-9_]+)"\)', src)))
+    assert len(names) > 10
+    missing = [n for n in names if n not in docs]
+    assert not missing, missing
