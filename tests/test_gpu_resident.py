@@ -151,3 +151,28 @@ def test_resident_short_evaluations_spr_call_pattern(taxa, patterns, categories,
     assert stats["0"] == ((0, 0, 0, 0), (0, 0, 0, 0))
     (d_served, _, d_silent, _), (t_served, t_launches, t_silent, _) = stats["1"]
     assert d_served > 0 and t_served > 50 and d_silent == 0 and t_silent == 0 and t_launches <= 6
+
+
+def test_resident_protocol_under_stress(monkeypatch):
+    """Idle time far below the time between chains: the workgroups leave and are launched again all the time, commands
+    arrive while they are leaving (unanswered: detected through workgroup 0's exit report, the evaluation is then launched)
+    -- and every scalar is still the launch path's double."""
+    from phyml_amd import replay
+    res = {}
+    for r, idle in (("0", "1000"), ("1", "15"), ("1", "40")):
+        monkeypatch.setenv("PHYHIP_RESIDENT", r)
+        monkeypatch.setenv("PHYHIP_RESIDENT_IDLE_US", idle)
+        t, ot, tree, st = synthetic_pair(30, 500, 4, 4, seed=71, host_pmat=False)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            tr = replay.make_trace(30, tree.edge_left, tree.edge_rght, tree.edge_len, 300, seed=12, walk_every=3, opt_every=3, n_dlk=4)
+            res[(r, idle)] = t.Replay_Surface_Trace(tr)
+            if r == "1":
+                d, s = t.inst.resident_stats(0), t.inst.resident_stats(1)
+                assert d[0] + d[2] > 0 and s[0] + s[2] > 0 and d[1] + s[1] > 4, (d, s)
+        finally:
+            t.close()
+    a, a2 = res[("0", "1000")]
+    for k, (b, b2) in res.items():
+        assert np.array_equal(a, b) and np.array_equal(a2, b2), k
