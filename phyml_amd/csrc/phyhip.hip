@@ -4,10 +4,6 @@
 #include "../../include/phyhip.h"
 #include "phyhip_kernels.hpp"
 #include "phyhip_aa.hpp"
-#ifdef PHYHIP_DIAG
-#include "experimental/phyhip_aa2.hpp" // measured alternatives of the 20-state kernel (slower), A/B only
-#include "experimental/phyhip_aa3.hpp"
-#endif
 #include "phyhip_nt2.hpp"
 
 #include <rccl/rccl.h>
@@ -159,8 +155,7 @@ struct Instance
   bool        class_axis = false; // categories are the classes of a mixture (PHYHIP_FLAG_CLASS_AXIS; TreeParams::class_axis)
   int         NE = 1;          // eigen systems / frequency vectors held: C with the class axis, else 1
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
-  int         aa_tiles = 1;            // -DPHYHIP_DIAG builds: PHYHIP_AA_TILES = 2 | 4 pattern tiles per wave (experimental/phyhip_aa3.hpp)
-  bool        aa_wave_per_tile = false; // -DPHYHIP_DIAG builds: PHYHIP_AA_GEN=2, one wave per tile walks all categories (experimental/phyhip_aa2.hpp)
+  int         aa_nw = 1;               // 20 states: consumer waves (= wave-tiles) per workgroup of traverse_aa_kernel
   bool        soa = false;     // 4-state buffers pattern-minor, lane-per-pattern kernel (phyhip_nt2.hpp)
   int         grid_nt2 = 0;
   int         nt_groups = 1; // lanes per pattern in the lane-per-pattern nucleotide kernel
@@ -307,7 +302,7 @@ int next_pow2(int x)
   return p;
 }
 
-size_t buf_elems(const Instance *I) { return (size_t)I->Ppad * I->C * I->S; }
+size_t buf_elems(const Instance *I) { return I->perm ? aa_buf_elems(I->Ppad, I->C) : (size_t)I->Ppad * I->C * I->S; }
 // ints per partials buffer in the scale table: one exponent per pattern, or per (class, pattern) with the class axis
 size_t scale_elems(const Instance *I) { return (size_t)I->Ppad * (I->class_axis ? I->C : 1); }
 
@@ -663,7 +658,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       const size_t   bufbytes = buf_elems(I) * sizeof(double);
       // spare word of the data descriptors: byte offset of the child's matrix (natural table, or the MFMA
       // A-fragment table for the 20-state kernel)
-      const unsigned matbytes = I->perm ? (unsigned)((size_t)I->C * 2 * kAaT * 64 * sizeof(double))
+      const unsigned matbytes = I->perm ? (unsigned)(kAaMat * sizeof(double))
                                         : (unsigned)((size_t)I->C * I->S * I->S * sizeof(double));
       auto desc = [](const void *base, size_t bytes, unsigned x) {
         Desc d;
@@ -689,10 +684,10 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           data  = desc(I->d_partials + b * buf_elems(I), ld ? bufbytes : 0, pmoff);
           scale = desc(I->d_scales + b * scale_elems(I), ld ? scale_elems(I) * 4 : 0, 0);
           tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->Ppad, t ? (size_t)I->Ppad : 0, 0);
-          // lane-per-pattern nucleotide kernel: ONE auxiliary dword load per child (measured for the 20-state kernel too:
-          // 640 vs 590 us -- slower there) -- the scale descriptor of a tip
-          // child points at its tip row instead (spare word 1: the kernel then reads the aligned dword holding the byte)
-          if (I->soa && t) scale = desc(I->d_tipcodes + (size_t)c * I->Ppad, (size_t)I->Ppad, 1);
+          // lane-per-pattern nucleotide kernel and the 20-state kernel: ONE auxiliary dword load per child -- the scale
+          // descriptor of a tip child points at its tip row instead (spare word 1: the kernel then reads the aligned dword
+          // holding the byte)
+          if ((I->soa || I->perm) && t) scale = desc(I->d_tipcodes + (size_t)c * I->Ppad, (size_t)I->Ppad, 1);
         };
         child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes);
         child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);
@@ -966,85 +961,43 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     {
       if (I->perm)
       {
+        const dim3 blk(64 * (I->aa_nw + 1));
+#define AACASE(c_)                                                                                                          \
+  case c_:                                                                                                                  \
+    hipLaunchKernelGGL((traverse_aa_kernel<c_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,                      \
+                       (const double *)I->d_afrag, I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size(),                \
+                       (unsigned long long *)nullptr);                                                                      \
+    return 0;
 #ifdef PHYHIP_DIAG
-        if (I->aa_wave_per_tile)
-        {
-#ifdef PHYHIP_DIAG
-          if ((I->ablate & 8) && I->C == 4)
-          { // cycle stamps of one wave: phase starts c = 0..3, epilogue start, operation end
-            unsigned long long *&d_dbg = I->d_dbg;
-            if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
-            hipLaunchKernelGGL((traverse_aa2_kernel<4, true>), dim3(I->grid_aa), dim3(64), 0, I->stream, q, d_irec, d_xrec,
-                               (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks,
-                               (int)I->masks.size(), d_dbg);
-            static int printed = 0;
-            if (printed++ == 5)
-            {
-              unsigned long long h[64 * 8];
-              HIPCHK(hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, I->stream));
-              HIPCHK(hipStreamSynchronize(I->stream));
-              for (int k = 0; k < 64 && k < q.n_ops; ++k)
-              {
-                fprintf(stderr, "op %2d: phases", k);
-                for (int i = 1; i < 6; ++i) fprintf(stderr, " %6lld", (long long)(h[k * 8 + i] - h[k * 8 + i - 1]));
-                if (k + 1 < 64) fprintf(stderr, "  | to next %6lld | total %6lld", (long long)(h[(k + 1) * 8] - h[k * 8 + 5]), (long long)(h[(k + 1) * 8] - h[k * 8]));
-                fprintf(stderr, "\n");
-              }
-            }
-            return 0;
-          }
-#endif
-#define AA2CASE(c_) case c_: hipLaunchKernelGGL((traverse_aa2_kernel<c_>), dim3(I->grid_aa), dim3(64), 0, I->stream, q, d_irec, d_xrec, (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size()); return 0;
-          switch (I->C)
+        if ((I->ablate & 8) && I->C == 4)
+        { // PHYHIP_ABLATE=8: cycle stamps of one consumer wave, printed to stderr (diagnostics; costs a sync per launch)
+          unsigned long long *&d_dbg = I->d_dbg;
+          if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
+          hipLaunchKernelGGL((traverse_aa_kernel<4, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,
+                             (const double *)I->d_afrag, I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size(), d_dbg);
+          static int printed = 0;
+          if (printed++ == 5)
           {
-            AA2CASE(1) AA2CASE(2) AA2CASE(3) AA2CASE(4)
-            default: break;
-          }
-#undef AA2CASE
-        }
-#endif
-#ifdef PHYHIP_DIAG
-        if constexpr (CP_ == 4)
-          if (I->ablate & 8)
-          { // PHYHIP_ABLATE=8: cycle stamps of one wave, printed to stderr (diagnostics; costs a sync per launch)
-            unsigned long long *&d_dbg = I->d_dbg;
-            if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
-            hipLaunchKernelGGL((traverse_aa_kernel<CP_, true>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
-                               (const double *)I->d_afrag, I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size(),
-                               I->ablate & 7, d_dbg);
-            static int printed = 0;
-            if (printed++ == 5)
+            unsigned long long h[64 * 8];
+            HIPCHK(hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, I->stream));
+            HIPCHK(hipStreamSynchronize(I->stream));
+            for (int k = 0; k < 64 && k < q.n_ops; ++k)
             {
-              unsigned long long h[64 * 8];
-              HIPCHK(hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, I->stream));
-              HIPCHK(hipStreamSynchronize(I->stream));
-              for (int k = 0; k < 64 && k < q.n_ops; ++k)
-              {
-                fprintf(stderr, "step %2d:", k);
-                for (int i = 1; i < 7; ++i) fprintf(stderr, " %6lld", (long long)(h[k * 8 + i] - h[k * 8 + i - 1]));
-                if (k + 1 < 64) fprintf(stderr, "  | next %6lld", (long long)(h[(k + 1) * 8] - h[k * 8 + 6]));
-                fprintf(stderr, "\n");
-              }
+              fprintf(stderr, "step %2d:", k);
+              for (int i = 1; i < 7; ++i) fprintf(stderr, " %6lld", (long long)(h[k * 8 + i] - h[k * 8 + i - 1]));
+              if (k + 1 < 64) fprintf(stderr, "  | next %6lld", (long long)(h[(k + 1) * 8] - h[k * 8 + 6]));
+              fprintf(stderr, "\n");
             }
-            return 0;
           }
-#endif
-#ifdef PHYHIP_DIAG
-        if (I->aa_tiles == 2 || I->aa_tiles == 4)
-        {
-          if (I->aa_tiles == 2)
-            hipLaunchKernelGGL((traverse_aa3_kernel<CP_, 2>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
-                               (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size());
-          else
-            hipLaunchKernelGGL((traverse_aa3_kernel<CP_, 4>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
-                               (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size());
           return 0;
         }
 #endif
-        hipLaunchKernelGGL((traverse_aa_kernel<CP_>), dim3(I->grid_aa), dim3(64 * I->C), 0, I->stream, q, d_irec, d_xrec,
-                           (const double *)I->d_afrag, (I->ablate & 4) ? 0 : I->nmat, ro.tip_codes, ro.code_masks,
-                           (int)I->masks.size(), I->ablate);
-        return 0;
+        switch (I->C)
+        {
+          AACASE(1) AACASE(2) AACASE(3) AACASE(4)
+          default: break;
+        }
+#undef AACASE
       }
     }
     hipLaunchKernelGGL((traverse_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, ro.ops, ro.pmats, ro.tip_codes,
@@ -1390,7 +1343,6 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
 
   I->perm = (I->S == 20) && (I->C <= 4) && (I->class_axis || !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA"))));
-  if (const char *e = getenv("PHYHIP_AA_GEN")) I->aa_wave_per_tile = kDiag && atoi(e) == 2;
   I->soa  = (I->S == 4) && (I->C <= 4) && !(kDiag && getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
             !(getenv("PHYHIP_GENERIC_NT") && atoi(getenv("PHYHIP_GENERIC_NT")));
   I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
@@ -1413,14 +1365,16 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipMemset(I->d_scales, 0, n_int * scale_elems(I) * sizeof(int)));
   if (I->perm)
   {
-    const size_t fb = (size_t)I->nmat * I->C * 2 * kAaT * 64 * sizeof(double);
+    const size_t fb = (size_t)I->nmat * kAaMat * sizeof(double);
     HIPCHK(hipMalloc((void **)&I->d_afrag, fb));
     HIPCHK(hipMemset(I->d_afrag, 0, fb));
-    // one workgroup (C waves) per aa_tiles tiles of 16 patterns (phyhip_aa3.hpp; 1: phyhip_aa.hpp)
-    if (const char *e = getenv("PHYHIP_AA_TILES")) I->aa_tiles = atoi(e);
-    if (!kDiag || (I->aa_tiles != 2 && I->aa_tiles != 4)) I->aa_tiles = 1;
-    if (I->aa_wave_per_tile) I->aa_tiles = 1;
-    I->grid_aa = (int)((I->Ppad / 16 + I->aa_tiles - 1) / I->aa_tiles);
+    // one consumer wave per wave-tile (16 / aa_cb(C) patterns x all categories) + one loader wave per workgroup; enough
+    // workgroups to give every CU one before any gets a second (the LDS ring allows one workgroup per CU at a time)
+    const long long ntiles = I->Ppad / (16 / aa_cb(I->C));
+    const long long cus    = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    I->aa_nw = (int)std::min<long long>(kAaMaxCons, std::max<long long>(1, (ntiles + cus - 1) / cus));
+    if (const char *e = getenv("PHYHIP_AA_NW")) { const int v = atoi(e); if (v >= 1 && v <= kAaMaxCons) I->aa_nw = v; }
+    I->grid_aa = (int)((ntiles + I->aa_nw - 1) / I->aa_nw);
   }
   HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->Ppad));
   HIPCHK(hipMemset(I->d_tipcodes, 0, (size_t)I->tips * I->Ppad));

@@ -1,37 +1,45 @@
-// phyhip_aa.hpp -- amino-acid (20-state) traversal on the FP64 matrix cores of gfx950.
+// phyhip_aa.hpp -- amino-acid (20-state) traversal on the FP64 matrix cores of gfx950, second generation.
 //
 // Why MFMA here and only here (BASELINE north star): per site-update the 20-state path does
-// 2 x 4 x (20x20) matrix-vector products = 6480 flop against 1289 B of traffic; as a
-// batched product over 16 patterns per wave it is a dense [20 x 20] x [20 x 16] contraction per
-// (child, rate class), which `v_mfma_f64_16x16x4_f64` executes without the per-FMA operand broadcast that
-// limits the VALU form (one LDS/SGPR operand fetch per fused multiply-add).  The 4-state path has a
-// 4x4 contraction per lane and stays on the VALU.
+// 2 x 4 x (20x20) matrix-vector products = 6480 flop against 1289 B of traffic; batched over patterns it is
+// a dense [20 x 20] x [20 x n] contraction per (child, rate class).  The 4-state path has a 4x4 contraction per lane
+// and stays on the VALU.
 //
-// MFMA shapes and data layout
-//   rows 0..15 of the result:  D[16 x 16] += A[16 x 4] * B[4 x 16]      v_mfma_f64_16x16x4_f64
-//   rows 16..19             :  4 blocks of D[4 x 4] += A[4 x 4] * B[4 x 4]   v_mfma_f64_4x4x4_4b_f64
-//   columns     = 16 patterns (one wave owns one tile of 16 patterns; block b of the 4x4x4 form = patterns 4b..4b+3)
-//   k           = 4 consecutive input states (five k-chunks cover the 20 states, ascending, so the
-//                 accumulation order over input states is the reference's: src/avx.c:593-616)
-//   lane l = (kk = l >> 4, pp = l & 15):  B operand (both shapes)  x[pattern pp][c][4t + kk]
-//                                         A operand 16x16x4        P[c][pp][4t + kk]
-//                                         A operand 4x4x4_4b       P[c][16 + (l & 3)][4t + kk]   (same for every block)
-//                                         D 16x16x4 regs r         output states kk + 4r  (r = 0..3)
-//                                         D 4x4x4_4b               output state 16 + kk
-//   (4x4x4_4b lane maps measured with tools/probes/mfma4b.hip: A = 16k + 4b + i, B = 16k + 4b + j, D = 16i + 4b + j.)
-// The 4x4x4 form does the last four rows in a quarter of the matrix-core time of a zero-padded second
-// 16-row tile.  The D fragments of an update are already the B fragment its parent needs: a lane owns states
-// {kk, kk+4, kk+8, kk+12, kk+16} of pattern pp on input and on output, results are forwarded in
-// registers without any shuffle, and the elementwise product of the two children is lane-local.
+// Shape: everything runs on the four-block form  v_mfma_f64_4x4x4_4b_f64  (4 blocks of D[4x4] += A[4x4] * B[4x4],
+// 16 cycles, the same 16 FMA per cycle as the 16x16x4 form), with
+//     block b      = one RATE CATEGORY (C = 4; C = 2: two categories x two pattern groups; C = 1: four pattern groups)
+//     columns j    = 4 patterns
+//     rows i       = 4 output states of row group r (states 4r + i, r = 0..4)
+//     k            = 4 input states of k-chunk t (states 4t + k, t = 0..4, ascending: the accumulation order over
+//                    input states is the reference's FMA chain, src/avx.c:593-616 -- bit-identical results)
+//   lane maps (measured, tools/probes/mfma4b.hip):  A lane = 16k + 4b + i,  B lane = 16k + 4b + j,  D lane = 16i + 4b + j.
+// One wave therefore owns a "wave-tile" of 4 patterns x ALL categories (16 patterns x 1 category for C = 1): 25 MFMAs per
+// child matrix, 20 rows = 5 row groups exactly (no padding), and
+//   * the D fragments of an update ARE the B fragments its parent needs (lane 16i + 4b + j holds states i + 4r of
+//     pattern j, category b, on input and on output): results are forwarded in registers, the product of the two
+//     children is lane-local;
+//   * the maximum over the categories of a pattern (the rescaling rule, src/avx.c:498-510) and the category mixture
+//     of Lk_Core (src/lk.c:816-818) are cross-LANE operations of one wave (DPP row rotations by 4 and 8 lanes): no LDS
+//     exchange, no barrier -- the first generation (one wave per (16-pattern tile, category), 16x16x4 + 4x4x4 MFMAs)
+//     spent a workgroup barrier per operation on them and ran its four waves in lock-step;
+//   * waves are fully independent and small: 10 000 patterns are 2500 wave-tiles, 9.8 per CU (the first generation's
+//     625 four-wave tiles filled 256 CUs as "2 or 3");
+//   * the A operand (the transition matrix: 12.8 KB per matrix with all four categories, natural size, nothing
+//     replicated) is the same for EVERY wave of the launch.  The first generation pulled 10 KB per wave-operation
+//     through the per-CU vector-memory path (5 GB per launch at cfg3, 57 % of that path's bytes); here ONE loader
+//     wave per workgroup stages the two matrices of each operation into an LDS ring (kAaRing operations deep) and
+//     every other wave of the workgroup feeds its MFMAs straight from LDS (ds_read_b128: 256 B/clk/CU): the
+//     vector-memory path carries only children and results.
+// Synchronisation inside a workgroup is two kinds of LDS words and no barrier in the loop: `ready` (operations whose
+// matrices are in the ring; written by the loader) and `done[w]` (operations wave w has finished reading; read by the
+// loader before it overwrites a slot).  LDS executes a wave's instructions in order, so "data, then flag" needs no fence.
 //
 // Device layout of an amino-acid partials buffer ("fragment-major"):
-//   [pattern tile of 16][category c][320 doubles: aa_slot(k-chunk t, lane)]
-// i.e. chunk pairs (0|1), (2|3) as 16 bytes per lane and chunk 4 as 8 bytes per lane: a lane's five values
-// move as 2 x dwordx4 + 1 x dwordx2, each instruction one contiguous 1 KiB / 512 B access.  The per-CU
-// vector-memory path issues ~1 wave-instruction per 12 cycles whatever its width (measured with the cycle
-// stamps of PHYHIP_ABLATE=8), so instruction count, not bytes, is what the layout minimises.  The host-facing
-// layout ([pattern][category][state], t_edge::p_lk_*) is restored by phyhip_get_partials / accepted by
-// phyhip_set_partials.
+//   [wave-tile][320 doubles: aa_slot(k-chunk t, lane)],  lane = 16 (state & 3) + 4 block + (pattern & 3)
+// i.e. chunk pairs (0|1), (2|3) as 16 bytes per lane and chunk 4 as 8 bytes per lane: a lane's five values move as
+// 2 x dwordx4 + 1 x dwordx2, each instruction one contiguous 1 KiB / 512 B access.  The host-facing layout
+// ([pattern][category][state], t_edge::p_lk_*) is restored by phyhip_get_partials / accepted by phyhip_set_partials
+// (aa_off below is the only place that knows the mapping).
 #pragma once
 
 #include "phyhip_kernels.hpp"
@@ -40,19 +48,26 @@
 namespace phyhip
 {
 
-typedef double       v4d __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kAaT     = 5;   // k-chunks of 4 states
-constexpr int kAaBlock = 320; // doubles per (tile, category) block, and per half (rows 0..15 | 16..19) of an A table
+typedef double v2d __attribute__((ext_vector_type(2)));
+constexpr int kAaT      = 5;    // k-chunks of 4 input states = row groups of 4 output states
+constexpr int kAaBlock  = 320;  // doubles per wave-tile block of a partials buffer
+constexpr int kAaRing   = 4;    // operations whose matrices the LDS ring holds (2 x 12.8 KB each)
+constexpr int kAaMaxCons = 11;  // consumer waves per workgroup (+ 1 loader = 12 waves = 3 per SIMD at <= 168 VGPRs)
 
-// element offset of (pattern p, category c, state s) inside a fragment-major buffer
-__host__ __device__ inline size_t aa_off(long long p, int C, int c, int s)
+// Write matrix `mat`'s A-operand table (kAaMat doubles) from its natural [c][i][j] entries: `get(c, i, j)`.
+// Lane (k, b, i) of the A operand holds P[category of block b][4r + i][4t + k]; blocks beyond the category count
+// (C = 3: block 3) get zeros, so their lanes produce zeros.
+template <typename F> __device__ __forceinline__ void aa_fill_atable(double *dst, int C, F get)
 {
-  const long long tile = p >> 4;
-  return (size_t)(tile * C + c) * kAaBlock + (size_t)aa_slot(s >> 2, (s & 3) * 16 + (int)(p & 15));
+  const int cb = aa_cb(C);
+  for (int e = threadIdx.x; e < kAaMat; e += blockDim.x)
+  {
+    const int lane = e & 63, rt = e >> 6, r = rt % kAaT, t = rt / kAaT;
+    const int k = lane >> 4, b = (lane >> 2) & 3, i = lane & 3, c = b % cb;
+    dst[aa_a_slot(t, r, lane)] = (c < C) ? get(c, 4 * r + i, 4 * t + k) : 0.0;
+  }
 }
 
-// A-operand fragments of a set of transition matrices: afrag[m][c][half][aa_slot(t, lane)]
 struct FragParams
 {
   const int    *indices; // nullptr: use small_idx
@@ -75,13 +90,7 @@ __global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
       if ((int)blockIdx.x == k) m = q.small_idx[k];
   }
   const double *src = q.pmats + (size_t)m * q.C * 400;
-  double       *dst = q.afrag + (size_t)m * q.C * (2 * kAaBlock);
-  for (int e = threadIdx.x; e < q.C * 2 * kAaT * 64; e += blockDim.x)
-  {
-    const int lane = e & 63, t = (e >> 6) % kAaT, half = ((e >> 6) / kAaT) & 1, c = (e >> 6) / (2 * kAaT);
-    const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
-    dst[(size_t)c * 2 * kAaBlock + aa_afrag_slot(half, t, lane)] = src[(size_t)c * 400 + i * 20 + j];
-  }
+  aa_fill_atable(q.afrag + (size_t)m * kAaMat, q.C, [&](int c, int i, int j) { return src[(size_t)c * 400 + i * 20 + j]; });
 }
 
 // Host-computed transition matrices (phyhip_set_transition_matrix, the bit-exact route of src/lk.c:2360): up to
@@ -112,414 +121,433 @@ __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadPar
   double *out = q.pmats + (size_t)m * n;
   for (int e = threadIdx.x; e < n; e += blockDim.x) out[e] = mat[e];
   if (q.afrag)
-  {
-    double *dst = q.afrag + (size_t)m * q.C * (2 * kAaBlock);
-    for (int e = threadIdx.x; e < q.C * 2 * kAaT * 64; e += blockDim.x)
-    {
-      const int lane = e & 63, t = (e >> 6) % kAaT, half = ((e >> 6) / kAaT) & 1, c = (e >> 6) / (2 * kAaT);
-      const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
-      dst[(size_t)c * 2 * kAaBlock + aa_afrag_slot(half, t, lane)] = mat[(size_t)c * 400 + i * 20 + j];
-    }
-  }
+    aa_fill_atable(q.afrag + (size_t)m * kAaMat, q.C, [&](int c, int i, int j) { return mat[(size_t)c * 400 + i * 20 + j]; });
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 + K2 for 20 states.  One WAVE owns (tile of 16 patterns, one rate category); the C waves of a
-// workgroup own the C categories of the same tile.  10 000 patterns give only 625 tiles -- fewer than the
-// chip's 1024 SIMDs -- so the category axis is spread over waves (2500 waves for C = 4) to keep every
-// matrix core busy and to have other waves to switch to while one waits for memory.  The only
-// cross-category quantities, the per-pattern maximum of the rescaling rule (src/avx.c:498-510) and the
-// category mixture of Lk_Core (src/lk.c:816-818), go through a few bytes of LDS and one barrier per
-// operation.
-// Pipeline: the host hands every operation over as ready-made buffer descriptors (size 0 = load disabled)
-// plus forwarding flags.  Within step k the children / scale words / tip bytes of operation k+1 are issued
-// before the matrix-core work into the second raw register set, and the A fragments of operation k+1 are
-// issued right after the MFMAs of operation k have consumed theirs, into the same registers (three waves per
-// SIMD need <= 168 VGPRs); the previous result is forwarded in registers.
+// K1 + K2 for 20 states.  Workgroup = 1 loader wave (wave 0) + up to kAaMaxCons consumer waves, one wave-tile each.
+// Pipeline of a consumer: the host hands every operation over as ready-made buffer descriptors (size 0 = load disabled)
+// plus forwarding flags; within step k the children and the auxiliary words of operation k+1 are issued before the
+// matrix-core phase into the second raw register set; the previous result is forwarded in registers.  One auxiliary
+// dword per child: the scale word of an internal child or the aligned four tip codes of a tip child (the host points the
+// descriptor at whichever row exists).
 // ---------------------------------------------------------------------------------------------
-template <int CP, bool DBG = false>
-__global__ __launch_bounds__(64 * CP, 3) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
-                                                                 const ExecRec *__restrict__ xrec,
-                                                                 const double *__restrict__ afrag, int n_frag_mats,
-                                                                 const uint8_t *__restrict__ tip_codes,
-                                                                 const uint32_t *__restrict__ code_masks, int n_masks,
-                                                                 int ablate, unsigned long long *dbg = nullptr)
+template <int C_, bool DBG = false>
+__global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+                                                                            const ExecRec *__restrict__ xrec,
+                                                                            const double *__restrict__ afrag, int n_frag_mats,
+                                                                            const uint8_t *__restrict__ tip_codes,
+                                                                            const uint32_t *__restrict__ code_masks, int n_masks,
+                                                                            unsigned long long *dbg = nullptr)
 {
-  constexpr int   T    = kAaT;
-  // DBG: cycle stamps of the first 64 steps of wave 0 of block 0 (PHYHIP_ABLATE=8), kept in LDS until the end
+  constexpr int T   = kAaT;
+  constexpr int CB  = C_ == 1 ? 1 : (C_ == 2 ? 2 : 4); // blocks (categories) per pattern
+  constexpr int NPW = 16 / CB;                          // patterns per wave-tile
+  static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");
+
+  __shared__ __attribute__((aligned(16))) double ring[kAaRing][2][kAaMat];
+  __shared__ unsigned lmask[256];          // allowed-state masks of the tip codes
+  // (read and written with relaxed workgroup-scope atomics: those stay plain ds_read / ds_write instructions, whereas a
+  // volatile access to LDS is compiled as a flat access behind a vmcnt(0) wait)
+  __shared__ int      s_ready;             // operations (+ the evaluation edge) whose matrices are in the ring
+  __shared__ int      s_done[16];          // per consumer wave: operations whose matrices it has finished reading
+  __shared__ double   s_wsum[16];          // per consumer wave: its share of the workgroup's sum
   __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
-  const bool stamper = DBG && blockIdx.x == 0 && threadIdx.x == 0;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw   = (int)(blockDim.x >> 6) - 1; // consumer waves
+  const int C    = q.C;
+  const size_t ntiles = (size_t)(q.Ppad / NPW);
+  const int n_items = q.n_ops + (q.edge_eval ? 1 : 0);
+
+  for (int i = threadIdx.x; i < n_masks && i < 256; i += blockDim.x) lmask[i] = code_masks[i];
+  if (threadIdx.x < 16)
+  {
+    const size_t tl = (size_t)blockIdx.x * nw + threadIdx.x;
+    s_done[threadIdx.x] = ((int)threadIdx.x < nw && tl < ntiles) ? 0 : 0x7fffffff; // absent waves never hold a slot
+  }
+  if (threadIdx.x == 0) s_ready = 0;
+  __syncthreads();
+  const bool stamper = DBG && blockIdx.x == gridDim.x / 2 && threadIdx.x == 64;
 #define PHY_STAMP(k_, i_)                                                                                              \
   if (DBG)                                                                                                             \
   {                                                                                                                    \
     const unsigned long long t_ = __builtin_readcyclecounter();                                                        \
     if (stamper && (k_) < 64) stamps[(k_) * 8 + (i_)] = t_;                                                            \
   }
-  const int       lane = threadIdx.x & 63;
-  const int       c    = threadIdx.x >> 6;                 // this wave's rate category (blockDim = 64 * C)
-  const long long tile = blockIdx.x;                       // grid = number of tiles: every wave is live
-  const int       pp = lane & 15, kk = lane >> 4;
-  const long long p0   = tile * 16 + pp;                   // < Ppad
-  const bool      pact = p0 < q.P;
-  const int       C    = q.C;
-  const int       tips = q.tip_count;
-  const size_t    ntiles     = (size_t)((q.P + 15) >> 4);
-  const size_t    tile_elems = (size_t)C * kAaBlock;
-  const size_t    buf_elems  = ntiles * tile_elems;
-  const size_t    frag_mat   = (size_t)C * 2 * kAaBlock;   // doubles per matrix in afrag
-  const unsigned  blk_bytes  = (unsigned)(((size_t)tile * tile_elems + (size_t)c * kAaBlock) * 8);
-  const unsigned  voff_d16 = blk_bytes + lane * 16, voff_d8 = blk_bytes + 2048 + lane * 8; // chunk pairs | chunk 4
-  // class axis (mixture classes as categories): every class has its own scale vector, [buffer][class][pattern]
-  const bool      cls    = q.class_axis != 0;
-  const unsigned  voff_s = ((cls ? (unsigned)c * (unsigned)q.Ppad : 0u) + (unsigned)p0) * 4u, voff_t = (unsigned)p0;
-  const unsigned  voff_a16 = (unsigned)c * 2 * kAaBlock * 8 + lane * 16; // this category's A table, this lane's pairs
 
-  __shared__ unsigned xchm[2][CP][16]; // per-pattern maxima (high words), double-buffered by step parity
-  __shared__ double   xchl[CP][16];    // category likelihoods of the edge evaluation
-  __shared__ unsigned lmask[256];      // allowed-state masks of the tip codes
-  for (int i = threadIdx.x; i < n_masks && i < 256; i += blockDim.x) lmask[i] = code_masks[i];
-  __syncthreads();
-
-  struct Frag
-  { // a lane's five k-chunk values as they come from memory
-    u32x4 p01, p23;
-    u32x2 p4;
-  };
-  struct Raw
+  if (wave == 0)
   {
-    Frag     a, b;
-    unsigned sa, sb, ca, cb;
-  };
-  struct AFrag
-  { // one child's matrix for this category: rows 0..15 (five k-chunks) then rows 16..19 (five k-chunks), ten values
-    u32x4 q[5];
-  };
-  const __amdgpu_buffer_rsrc_t af_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<double *>(afrag), 0, (int)((size_t)n_frag_mats * frag_mat * 8), 0x00020000);
-  auto rsrc = [](const Desc &d) {
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
-  };
-  auto load_frag = [](Frag &f, const __amdgpu_buffer_rsrc_t r, unsigned v16, unsigned v8, unsigned soff) {
-    f.p01 = __builtin_amdgcn_raw_buffer_load_b128(r, v16, soff, 0);
-    f.p23 = __builtin_amdgcn_raw_buffer_load_b128(r, v16 + 1024, soff, 0);
-    f.p4  = __builtin_amdgcn_raw_buffer_load_b64(r, v8, soff, 0);
-  };
-  auto unpack = [](const Frag &f, double (&x)[T]) {
-    __builtin_memcpy(&x[0], &f.p01, 16);
-    __builtin_memcpy(&x[2], &f.p23, 16);
-    __builtin_memcpy(&x[4], &f.p4, 8);
-  };
-  auto pack = [](const double (&x)[T], Frag &f) {
-    __builtin_memcpy(&f.p01, &x[0], 16);
-    __builtin_memcpy(&f.p23, &x[2], 16);
-    __builtin_memcpy(&f.p4, &x[4], 8);
-  };
-
-  auto issue_children = [&](const IssueRec &o, Raw &r) {
-    load_frag(r.a, rsrc(o.c1_data), voff_d16, voff_d8, 0);
-    load_frag(r.b, rsrc(o.c2_data), voff_d16, voff_d8, 0);
-    r.sa = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c1_scale), voff_s, 0, 0);
-    r.sb = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_scale), voff_s, 0, 0);
-    r.ca = __builtin_amdgcn_raw_buffer_load_b8(rsrc(o.c1_tip), voff_t, 0, 0);
-    r.cb = __builtin_amdgcn_raw_buffer_load_b8(rsrc(o.c2_tip), voff_t, 0, 0);
-  };
-  auto load_afrag = [&](AFrag &A, unsigned off) {
-#pragma unroll
-    for (int g = 0; g < 5; ++g) A.q[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, voff_a16 + g * 1024, off, 0);
-  };
-  auto issue_matrices = [&](unsigned off1, unsigned off2, AFrag &A1, AFrag &A2) {
-    load_afrag(A1, off1);
-    load_afrag(A2, off2);
-  };
-  auto unpack_afrag = [](const AFrag &A, double (&lo)[T], double (&hi)[T]) {
-    double v[2 * T];
-#pragma unroll
-    for (int g = 0; g < 5; ++g) __builtin_memcpy(&v[2 * g], &A.q[g], 16);
-#pragma unroll
-    for (int t = 0; t < T; ++t) { lo[t] = v[t]; hi[t] = v[T + t]; }
-  };
-  // u[t] = sum over input states of P[c][state kk + 4t][.] * x[.]: rows 0..15 on the 16x16x4 shape, rows 16..19 on
-  // the four-block 4x4x4 shape, five k-chunks each, ascending
-  auto matvec = [&](const AFrag &A, const double (&x)[T], double (&u)[T]) {
-    double alo[T], ahi[T];
-    unpack_afrag(A, alo, ahi);
-    v4d    lo = {0., 0., 0., 0.};
-    double hi = 0.;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
+    // ---- loader: the two A tables of item j (operation j, or the evaluation edge's matrix) -> ring[j % kAaRing] -------
+    const __amdgpu_buffer_rsrc_t af_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(afrag), 0, (int)((size_t)n_frag_mats * kAaMat * 8), 0x00020000);
+    constexpr int      kPieces = 2 * kAaMat * 8 / 1024; // 25 x 1 KiB per item
+    constexpr unsigned kMatB   = kAaMat * 8;            // 12 800 B: piece 12 straddles the two tables
+    static_assert(2 * kAaMat * 8 == kPieces * 1024, "an item is a whole number of 1 KiB pieces");
+    int done_seen = 0;
+    for (int j = 0; j < n_items; ++j)
     {
-      lo = __builtin_amdgcn_mfma_f64_16x16x4f64(alo[t], x[t], lo, 0, 0, 0);
-      hi = __builtin_amdgcn_mfma_f64_4x4x4f64(ahi[t], x[t], hi, 0, 0, 0);
-    }
-    u[0] = lo[0]; u[1] = lo[1]; u[2] = lo[2]; u[3] = lo[3]; u[4] = hi;
-  };
-  auto and4 = [&](int v) { // AND over the four lanes (kk = 0..3) that share a pattern
-    v &= __shfl_xor(v, 16, 64);
-    v &= __shfl_xor(v, 32, 64);
-    return v;
-  };
-  auto maxu4 = [&](unsigned v) {
-    v = max(v, (unsigned)__shfl_xor((int)v, 16, 64));
-    v = max(v, (unsigned)__shfl_xor((int)v, 32, 64));
-    return v;
-  };
-  auto sum4 = [&](double v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-  };
-  auto tip_vec = [&](unsigned code, double (&x)[T]) {
-    const unsigned m = lmask[code & 255u] >> kk;
+      unsigned off1, off2;
+      if (j < q.n_ops) { off1 = irec[j].c1_data.x; off2 = irec[j].c2_data.x; }
+      else off1 = off2 = (unsigned)q.e_pm * kMatB;
+      u32x4 v[kPieces];
 #pragma unroll
-    for (int t = 0; t < T; ++t) x[t] = ((m >> (4 * t)) & 1u) ? 1.0 : 0.0;
-  };
-
-  double   prev[T] = {0., 0., 0., 0., 0.}; // result of the previous operation (this lane's D fragments)
-  unsigned prev_sc = 0;
-
-  if (q.n_ops > 0)
-  {
-    const int last = q.n_ops - 1; // host pads the list to an even length
-    Raw       RA, RB;
-    AFrag     A1, A2;
-    ExecRec   cur = xrec[0];
-    IssueRec  nx1 = irec[(1 < last) ? 1 : last];
-    {
-      const IssueRec first = irec[0];
-      issue_children(first, RA);
-      issue_matrices(first.c1_data.x, first.c2_data.x, A1, A2);
-      // The loop body sees [A loads][4 result stores][children loads] between an A load and its use.  Four
-      // stores through a zero-sized descriptor (dropped by the hardware, but counted) give the loop entry the
-      // same in-flight shape, so the compiler's merged s_waitcnt counts never include the previous step's stores.
-      const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
-      const u32x4                  z4   = {0u, 0u, 0u, 0u};
-      const u32x2                  z2   = {0u, 0u};
-      __builtin_amdgcn_raw_buffer_store_b128(z4, none, 0, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(z4, none, 1024, 0, 0); // distinct offsets: identical stores would be merged
-      __builtin_amdgcn_raw_buffer_store_b64(z2, none, 2048, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(0u, none, 4096, 0, 0);
-    }
-
-    auto step = [&](const int k, const int parity, Raw &R, Raw &Rn) {
-      const unsigned fl = cur.dst_data.x;
-      double         x1[T], x2[T], u1[T], u2[T], o[T];
-      unsigned       s1, s2;
-      PHY_STAMP(k, 0)
-      if (fl & kOpTip1) { tip_vec(R.ca, x1); s1 = 0; }
-      else if (fl & kOpF11)
+      for (int g = 0; g < kPieces; ++g)
       {
-#pragma unroll
-        for (int t = 0; t < T; ++t) x1[t] = prev[t];
-        s1 = prev_sc;
+        const unsigned b = (unsigned)g * 1024u + (unsigned)lane * 16u; // byte inside the item
+        if (g * 1024 + 1024 <= (int)kMatB) v[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, b, off1, 0);
+        else if (g * 1024 >= (int)kMatB) v[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, b - kMatB, off2, 0);
+        else v[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, b < kMatB ? b + off1 : b - kMatB + off2, 0, 0);
       }
-      else { unpack(R.a, x1); s1 = R.sa; }
-      if (fl & kOpTip2) { tip_vec(R.cb, x2); s2 = 0; }
-      else if (fl & kOpF21)
+      // the slot is free once every consumer has finished item j - kAaRing
+      const int need = j - kAaRing + 1;
+      while (done_seen < need)
       {
-#pragma unroll
-        for (int t = 0; t < T; ++t) x2[t] = prev[t];
-        s2 = prev_sc;
+        const int d   = __hip_atomic_load(&s_done[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool ok = d >= need;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) { done_seen = need; break; }
+        __builtin_amdgcn_s_sleep(2);
       }
-      else { unpack(R.b, x2); s2 = R.sb; }
-
-      PHY_STAMP(k, 1)
-      // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587.  Evaluated without a
-      // branch and before the matrix-core phase so that x1 / x2 die with the last MFMA that reads them.
-      int ones = 1;
+      asm volatile("" ::: "memory");
+      u32x4 *dst = reinterpret_cast<u32x4 *>(&ring[j % kAaRing][0][0]) + lane;
 #pragma unroll
-      for (int t = 0; t < T; ++t) ones &= (x1[t] == 1.0) & (x2[t] == 1.0);
-      ones = and4(ones);
-      PHY_STAMP(k, 2)
-      const unsigned nx_off1 = nx1.c1_data.x, nx_off2 = nx1.c2_data.x;
-      {
-        // Matrix-core phase.  The ten 16x16x4 MFMAs occupy the pipe for 64 cycles each; the ten vector-memory
-        // instructions of operation k+1 (children, scale words, tip bytes -> the other raw set) are slotted one
-        // per MFMA so that their issue cost disappears behind the matrix cores (sched_group_barrier pins the
-        // interleave).  Measured alternatives, both slower at 10 000 patterns: all of them before the operand
-        // select (628 vs 589 us), all of them after the MFMA chain (627 vs 576 us).  The A fragments of operation k+1 follow the last MFMA that reads this operation's, into
-        // the same registers.
-        double a1lo[T], a1hi[T], a2lo[T], a2hi[T];
-        unpack_afrag(A1, a1lo, a1hi);
-        unpack_afrag(A2, a2lo, a2hi);
-        v4d    lo1 = {0., 0., 0., 0.}, lo2 = {0., 0., 0., 0.};
-        double hi1 = 0., hi2 = 0.;
-        issue_children(nx1, Rn);
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-        {
-          lo1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1lo[t], x1[t], lo1, 0, 0, 0);
-          lo2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2lo[t], x2[t], lo2, 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-        {
-          hi1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1hi[t], x1[t], hi1, 0, 0, 0);
-          hi2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2hi[t], x2[t], hi2, 0, 0, 0);
-        }
-        issue_matrices(nx_off1, nx_off2, A1, A2);
-#pragma unroll
-        for (int i = 0; i < 2 * T; ++i)
-        {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // one vector-memory read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * T, 0);  // the 4x4x4 chain
-        __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);     // A fragments of operation k+1
-        u1[0] = lo1[0]; u1[1] = lo1[1]; u1[2] = lo1[2]; u1[3] = lo1[3]; u1[4] = hi1;
-        u2[0] = lo2[0]; u2[1] = lo2[1]; u2[2] = lo2[2]; u2[3] = lo2[3]; u2[4] = hi2;
-      }
-      const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
-      const ExecRec  nxe = xrec[(k + 1 < last) ? k + 1 : last];
-
-      PHY_STAMP(k, 3)
-      unsigned mxh = 0;
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-      {
-        o[t] = ones ? 1.0 : u1[t] * u2[t];
-        mxh  = max(mxh, hi32(o[t]));
-      }
-      mxh = maxu4(mxh);
-      PHY_STAMP(k, 4)
-      if (CP > 1 && !(ablate & 2) && !cls)
-      { // maximum over the categories of the pattern: one LDS round trip, one barrier (a mixture class rescales alone)
-        if (kk == 0) xchm[parity][c][pp] = mxh;
-        __syncthreads();
-#pragma unroll
-        for (int cc = 0; cc < CP; ++cc)
-          if (cc < C) mxh = max(mxh, xchm[parity][cc][pp]);
-      }
-      PHY_STAMP(k, 5)
-      unsigned sc = s1 + s2; // src/avx.c:462-464
-      if (mxh < kHiInvTwoToLarge && q.apply_scaling)
-      { // src/avx.c:504-510
-#pragma unroll
-        for (int t = 0; t < T; ++t) o[t] *= kTwoToLarge;
-        sc += kLarge;
-      }
-      {
-        const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
-        Frag w;
-        pack(o, w);
-        __builtin_amdgcn_raw_buffer_store_b128(w.p01, dr, voff_d16, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(w.p23, dr, voff_d16 + 1024, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(w.p4, dr, voff_d8, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_s, 0, 0); // every lane of the pattern stores the same word
-      }
-      PHY_STAMP(k, 6)
-#pragma unroll
-      for (int t = 0; t < T; ++t) prev[t] = o[t];
-      prev_sc = sc;
-      cur     = nxe;
-      nx1     = nx2;
-    };
-    for (int k = 0; k < q.n_ops; k += 2)
-    {
-      step(k, 0, RA, RB);
-      step(k + 1, 1, RB, RA);
+      for (int g = 0; g < kPieces; ++g) dst[g * 64] = v[g];
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_ready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-
-  if (DBG && stamper && dbg)
-    for (int i = 0; i < 64 * 8; ++i) dbg[i] = stamps[i];
-#undef PHY_STAMP
-  if (!q.edge_eval) return;
-
-  // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861) ---------------------
-  double contrib = 0.0;
+  else
   {
-    double   x[T], y[T], u[T];
-    unsigned sl, sr;
-    auto side = [&](int idx, double (&v)[T], unsigned &sc) {
-      if (idx < tips)
-      {
-        tip_vec(tip_codes[(size_t)idx * q.Ppad + p0], v);
-        sc = 0;
-      }
-      else if (idx == q.last_dest)
-      {
-#pragma unroll
-        for (int t = 0; t < T; ++t) v[t] = prev[t];
-        sc = prev_sc;
-      }
-      else
-      {
-        const double *src = q.partials + (size_t)(idx - tips) * buf_elems + (size_t)tile * tile_elems + (size_t)c * kAaBlock;
-#pragma unroll
-        for (int t = 0; t < T; ++t) v[t] = src[aa_slot(t, lane)];
-        sc = (unsigned)q.scales[((size_t)(idx - tips) * (cls ? C : 1) + (cls ? c : 0)) * q.Ppad + p0];
-      }
-    };
-    __syncthreads();
-    side(q.e_parent, x, sl);
-    side(q.e_child, y, sr);
+    // ---- consumers -------------------------------------------------------------------------------------------------
+    const int       w    = wave - 1;
+    const long long tile = (long long)blockIdx.x * nw + w;
+    if (tile < (long long)ntiles)
     {
-      AFrag A;
-      load_afrag(A, (unsigned)((size_t)q.e_pm * frag_mat * 8));
-      matvec(A, x, u); // rows: right-side state
-    }
-    const double *pi_c = q.pi + (cls ? c * 20 : 0);
-    double part = 0.0;
-#pragma unroll
-    for (int t = 0; t < T; ++t) part += u[t] * (y[t] * pi_c[4 * t + kk]);
-    const double lkc = sum4(part);
-    if (pact && kk == 0 && q.site_cat) q.site_cat[(size_t)p0 * C + c] = lkc;
-    if (cls)
-    { // per class: its likelihood (above) and its scale exponent; the mixture is combined by class_combine_kernel
-      if (pact && kk == 0) q.fact[(size_t)c * q.P + p0] = q.apply_scaling ? (int)(sl + sr) : 0;
-      return;
-    }
-    if (kk == 0) xchl[c][pp] = lkc;
-    if (q.fence_post) __threadfence(); // every wave's stores are in memory before wave 0 posts the workgroup's sum
-    __syncthreads();
-    if (c == 0 && kk == 0 && pact)
-    {
-      double site = 0.0;
-#pragma unroll
-      for (int cc = 0; cc < CP; ++cc)
-        if (cc < C) site += xchl[cc][pp] * q.cat_w[cc]; // src/lk.c:816-818
-      const double w = q.wght[p0];
-      int          f = q.apply_scaling ? (int)(sl + sr) : 0;
-      if (w > kSmall)
+      const int kk = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3; // state residue / MFMA block / pattern within the group
+      const int c  = b % CB;                                        // this lane's rate category
+      const bool idle = c >= C_;                                    // C = 3: block 3 carries nothing
+      const long long p0 = tile * NPW + (b / CB) * 4 + jj;          // < Ppad
+      const bool      pact = p0 < q.P && !idle;
+      const int       tips = q.tip_count;
+      const bool      cls  = q.class_axis != 0;
+      const unsigned  blk_bytes = (unsigned)((size_t)tile * kAaBlock * 8);
+      const unsigned  voff_d16 = blk_bytes + lane * 16, voff_d8 = blk_bytes + 2048 + lane * 8; // chunk pairs | chunk 4
+      // class axis (mixture classes as categories): every class has its own scale vector, [buffer][class][pattern]
+      const unsigned  voff_s = ((cls ? (unsigned)(idle ? 0 : c) * (unsigned)q.Ppad : 0u) + (unsigned)p0) * 4u;
+      const unsigned  voff_t = (unsigned)p0 & ~3u, tip_sh = ((unsigned)p0 & 3u) * 8u;
+      // the scale word of a pattern (of a (class, pattern)) is stored by ONE lane; the others aim past the end of the buffer
+      const unsigned  voff_sst = (kk == 0 && !idle && (cls || c == 0)) ? voff_s : 0x7ffffff0u;
+
+      struct Frag
+      { // a lane's five k-chunk values as they come from memory
+        u32x4 p01, p23;
+        u32x2 p4;
+      };
+      struct Raw
       {
-        if (q.invar_model)
-        { // src/lk.c:820-842, 1226-1273
-          const int iv  = q.invar[p0];
-          double    inv = 0.0;
-          bool      issue_ = false;
-          if (iv >= 0)
+        Frag     a, b;
+        unsigned xa, xb; // scale word, or the dword holding the tip code
+      };
+      auto rsrc = [](const Desc &d) {
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
+      };
+      auto load_frag = [](Frag &f, const __amdgpu_buffer_rsrc_t r, unsigned v16, unsigned v8) {
+        f.p01 = __builtin_amdgcn_raw_buffer_load_b128(r, v16, 0, 0);
+        f.p23 = __builtin_amdgcn_raw_buffer_load_b128(r, v16 + 1024, 0, 0);
+        f.p4  = __builtin_amdgcn_raw_buffer_load_b64(r, v8, 0, 0);
+      };
+      auto unpack = [](const Frag &f, double (&x)[T]) {
+        __builtin_memcpy(&x[0], &f.p01, 16);
+        __builtin_memcpy(&x[2], &f.p23, 16);
+        __builtin_memcpy(&x[4], &f.p4, 8);
+      };
+      auto pack = [](const double (&x)[T], Frag &f) {
+        __builtin_memcpy(&f.p01, &x[0], 16);
+        __builtin_memcpy(&f.p23, &x[2], 16);
+        __builtin_memcpy(&f.p4, &x[4], 8);
+      };
+      auto issue_children = [&](const IssueRec &o, Raw &r) {
+        load_frag(r.a, rsrc(o.c1_data), voff_d16, voff_d8);
+        load_frag(r.b, rsrc(o.c2_data), voff_d16, voff_d8);
+        r.xa = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c1_scale), o.c1_scale.x ? voff_t : voff_s, 0, 0);
+        r.xb = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_scale), o.c2_scale.x ? voff_t : voff_s, 0, 0);
+      };
+      // cross-lane helpers.  Lanes that share a (pattern, category) differ in bits 4-5 (the state residue): the two
+      // half-exchange instructions of gfx950 put both partners' values side by side without an LDS round trip.
+      auto xor16_pair = [](unsigned v, unsigned &a, unsigned &bb) {
+        auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        a = r[0]; bb = r[1];
+      };
+      auto xor32_pair = [](unsigned v, unsigned &a, unsigned &bb) {
+        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        a = r[0]; bb = r[1];
+      };
+      auto and_states = [&](unsigned v) { // AND over the four lanes (kk = 0..3) of a (pattern, category)
+        unsigned a, bb;
+        xor16_pair(v, a, bb); v = a & bb;
+        xor32_pair(v, a, bb); return a & bb;
+      };
+      auto max_states = [&](unsigned v) {
+        unsigned a, bb;
+        xor16_pair(v, a, bb); v = max(a, bb);
+        xor32_pair(v, a, bb); return max(a, bb);
+      };
+      auto max_cats = [&](unsigned v) { // maximum over the categories of a pattern: lanes that differ in the block bits
+        if (CB == 4)
+        {
+          v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false)); // row_ror:4
+          v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false)); // row_ror:8
+        }
+        else if (CB == 2) v = max(v, (unsigned)__shfl_xor((int)v, 4, 64));
+        return v;
+      };
+      auto sum_states = [&](double v) { // (kk0 + kk1) + (kk2 + kk3), whichever lane asks
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+      };
+      auto tip_vec = [&](unsigned word, double (&x)[T]) {
+        const unsigned m = lmask[(word >> tip_sh) & 255u] >> kk;
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[t] = ((m >> (4 * t)) & 1u) ? 1.0 : 0.0;
+      };
+      // wait until the ring holds item k; returns the item's first A table
+      int ready_seen = 0;
+      auto wait_item = [&](int k) -> const double * {
+        while (ready_seen <= k)
+        {
+          ready_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (ready_seen <= k) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        return &ring[k % kAaRing][0][0];
+      };
+      auto release_item = [&](int k) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&s_done[w], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      // u[r] = sum over input states of P[c][4r + i][.] * x[.]: five row groups x five k-chunks, k ascending
+      auto mfma_chunk = [&](const double *A, int t, const double xt, double (&u)[T]) {
+        const v2d   *pr = reinterpret_cast<const v2d *>(A + t * kAaBlock) + lane;
+        const v2d    a01 = pr[0], a23 = pr[64];
+        const double a4  = A[t * kAaBlock + 256 + lane];
+        u[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01.x, xt, u[0], 0, 0, 0);
+        u[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01.y, xt, u[1], 0, 0, 0);
+        u[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a23.x, xt, u[2], 0, 0, 0);
+        u[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a23.y, xt, u[3], 0, 0, 0);
+        u[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xt, u[4], 0, 0, 0);
+      };
+
+      double   prev[T] = {0., 0., 0., 0., 0.}; // result of the previous operation (this lane's D fragments)
+      unsigned prev_sc = 0;
+
+      if (q.n_ops > 0)
+      {
+        const int last = q.n_ops - 1; // host pads the list to an even length
+        Raw       RA, RB;
+        ExecRec   cur = xrec[0];
+        IssueRec  nx1 = irec[(1 < last) ? 1 : last];
+        issue_children(irec[0], RA);
+
+        auto step = [&](const int k, Raw &R, Raw &Rn) {
+          const unsigned fl = cur.dst_data.x;
+          double         x1[T], x2[T], o[T];
+          unsigned       s1, s2;
+          PHY_STAMP(k, 0)
+          if (fl & kOpTip1) { tip_vec(R.xa, x1); s1 = 0; }
+          else if (fl & kOpF11)
           {
-            inv = q.pi[iv];
-            if (q.apply_scaling)
-            {
-              int e = f;
-              do
-              {
-                const int piece = e < 63 ? e : 63;
-                inv *= (double)(1ull << piece);
-                e -= piece;
-              } while (e != 0);
-            }
-            issue_ = isinf(inv);
+#pragma unroll
+            for (int t = 0; t < T; ++t) x1[t] = prev[t];
+            s1 = prev_sc;
           }
-          if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
-          else site = site * (1. - q.pinvar) + inv * q.pinvar;
+          else { unpack(R.a, x1); s1 = R.xa; }
+          if (fl & kOpTip2) { tip_vec(R.xb, x2); s2 = 0; }
+          else if (fl & kOpF21)
+          {
+#pragma unroll
+            for (int t = 0; t < T; ++t) x2[t] = prev[t];
+            s2 = prev_sc;
+          }
+          else { unpack(R.b, x2); s2 = R.xb; }
+          PHY_STAMP(k, 1)
+          // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587
+          unsigned ones = 1;
+#pragma unroll
+          for (int t = 0; t < T; ++t) ones &= (unsigned)((x1[t] == 1.0) & (x2[t] == 1.0));
+          ones = and_states(ones);
+          issue_children(nx1, Rn);
+          PHY_STAMP(k, 2)
+          double u1[T] = {0., 0., 0., 0., 0.}, u2[T] = {0., 0., 0., 0., 0.};
+          {
+            const double *A = wait_item(k);
+            PHY_STAMP(k, 3)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+            {
+              mfma_chunk(A, t, x1[t], u1);
+              mfma_chunk(A + kAaMat, t, x2[t], u2);
+            }
+            release_item(k);
+          }
+          const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
+          const ExecRec  nxe = xrec[(k + 1 < last) ? k + 1 : last];
+          PHY_STAMP(k, 4)
+          unsigned mxh = 0;
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+          {
+            o[t] = ones ? 1.0 : u1[t] * u2[t];
+            mxh  = max(mxh, hi32(o[t]));
+          }
+          if (C_ == 3 && idle) mxh = 0;
+          mxh = max_states(mxh);
+          if (!cls) mxh = max_cats(mxh); // a mixture class rescales alone
+          PHY_STAMP(k, 5)
+          unsigned sc = s1 + s2; // src/avx.c:462-464
+          if (mxh < kHiInvTwoToLarge && q.apply_scaling)
+          { // src/avx.c:504-510
+#pragma unroll
+            for (int t = 0; t < T; ++t) o[t] *= kTwoToLarge;
+            sc += kLarge;
+          }
+          {
+            const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
+            Frag wv;
+            pack(o, wv);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p01, dr, voff_d16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p23, dr, voff_d16 + 1024, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(wv.p4, dr, voff_d8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_sst, 0, 0);
+          }
+          PHY_STAMP(k, 6)
+#pragma unroll
+          for (int t = 0; t < T; ++t) prev[t] = o[t];
+          prev_sc = sc;
+          cur     = nxe;
+          nx1     = nx2;
+        };
+        for (int k = 0; k < q.n_ops; k += 2)
+        {
+          step(k, RA, RB);
+          step(k + 1, RB, RA);
         }
-        if (site < kSmall) { site = kSmall; raise_warn(q); }
-        const double lsl = log(site) - kLog2 * (double)f;
-        if (q.site_lnl) q.site_lnl[p0] = lsl;
-        if (q.site_lk) q.site_lk[p0] = exp(lsl);
-        contrib = w * lsl;
       }
-      q.fact[p0] = f;
+
+      if (q.edge_eval)
+      {
+        // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861) -------------------------------
+        double contrib = 0.0;
+        double   x[T], y[T], u[T] = {0., 0., 0., 0., 0.};
+        unsigned sl, sr;
+        auto side = [&](int idx, double (&v)[T], unsigned &sc) {
+          if (idx < tips)
+          {
+            const unsigned word = *reinterpret_cast<const unsigned *>(tip_codes + (size_t)idx * q.Ppad + voff_t);
+            tip_vec(word, v);
+            sc = 0;
+          }
+          else if (idx == q.last_dest)
+          {
+#pragma unroll
+            for (int t = 0; t < T; ++t) v[t] = prev[t];
+            sc = prev_sc;
+          }
+          else
+          {
+            const double *src = q.partials + (size_t)(idx - tips) * (ntiles * kAaBlock) + (size_t)tile * kAaBlock;
+#pragma unroll
+            for (int t = 0; t < T; ++t) v[t] = src[aa_slot(t, lane)];
+            sc = (unsigned)q.scales[(size_t)(idx - tips) * (cls ? C : 1) * q.Ppad + voff_s / 4];
+          }
+        };
+        side(q.e_parent, x, sl);
+        side(q.e_child, y, sr);
+        {
+          const double *A = wait_item(q.n_ops);
+#pragma unroll
+          for (int t = 0; t < T; ++t) mfma_chunk(A, t, x[t], u); // rows: right-side state
+          release_item(q.n_ops);
+        }
+        const double *pi_c = q.pi + ((cls && !idle) ? c * 20 : 0);
+        double part = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) part += u[t] * (y[t] * pi_c[4 * t + kk]);
+        const double lkc = sum_states(part);
+        if (pact && kk == 0 && q.site_cat) q.site_cat[(size_t)p0 * C + c] = lkc;
+        if (cls)
+        { // per class: its likelihood (above) and its scale exponent; the mixture is combined by class_combine_kernel
+          if (pact && kk == 0) q.fact[(size_t)c * q.P + p0] = q.apply_scaling ? (int)(sl + sr) : 0;
+        }
+        else
+        {
+          // the categories of this lane's pattern, in category order (src/lk.c:816-818)
+          double site = 0.0;
+#pragma unroll
+          for (int cc = 0; cc < C_; ++cc) site += __shfl(lkc, (lane & ~(3 << 2)) | (((b / CB) * CB + cc) << 2), 64) * q.cat_w[cc];
+          if (pact && kk == 0 && c == 0)
+          {
+            const double wt = q.wght[p0];
+            int          f  = q.apply_scaling ? (int)(sl + sr) : 0;
+            if (wt > kSmall)
+            {
+              if (q.invar_model)
+              { // src/lk.c:820-842, 1226-1273
+                const int iv  = q.invar[p0];
+                double    inv = 0.0;
+                bool      issue_ = false;
+                if (iv >= 0)
+                {
+                  inv = q.pi[iv];
+                  if (q.apply_scaling)
+                  {
+                    int e = f;
+                    do
+                    {
+                      const int piece = e < 63 ? e : 63;
+                      inv *= (double)(1ull << piece);
+                      e -= piece;
+                    } while (e != 0);
+                  }
+                  issue_ = isinf(inv);
+                }
+                if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
+                else site = site * (1. - q.pinvar) + inv * q.pinvar;
+              }
+              if (site < kSmall) { site = kSmall; raise_warn(q); }
+              const double lsl = log(site) - kLog2 * (double)f;
+              if (q.site_lnl) q.site_lnl[p0] = lsl;
+              if (q.site_lk) q.site_lk[p0] = exp(lsl);
+              contrib = wt * lsl;
+            }
+            q.fact[p0] = f;
+          }
+          // this wave's share: fixed shuffle tree -> deterministic
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+          if (lane == 0) s_wsum[w] = contrib;
+        }
+        if (q.fence_post) __threadfence(); // every wave's stores are in memory before the workgroup's sum is posted
+      }
     }
   }
-  // only wave 0 (category 0) carries contributions; fixed shuffle tree -> deterministic
-  if (c == 0)
+
+  if (DBG && dbg)
   {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
-    publish_block_sum(q, contrib, lane);
+    __syncthreads();
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+      for (int i = 0; i < 64 * 8; ++i) dbg[i] = stamps[i];
+  }
+#undef PHY_STAMP
+  if (!q.edge_eval || q.class_axis) return;
+  __syncthreads();
+  if (wave == 0)
+  { // the consumers' shares in wave order
+    double tot = 0.0;
+    for (int i = 0; i < nw; ++i)
+      if ((size_t)blockIdx.x * nw + i < ntiles) tot += s_wsum[i];
+    publish_block_sum(q, tot, lane);
   }
 }
 

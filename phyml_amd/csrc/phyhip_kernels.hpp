@@ -184,17 +184,30 @@ struct RO
   const uint32_t *__restrict__ code_masks; // allowed-state bit mask per code
 };
 
-// 20-state fragment-major layout (phyhip_aa.hpp): one (tile of 16 patterns, category) block is 320 doubles --
-// the five k-chunk values a lane owns are stored as two 16-byte pairs (chunks 0|1 and 2|3) and one single
-// (chunk 4), each group contiguous over the 64 lanes, so a fragment set moves as 2 x dwordx4 + 1 x dwordx2.
+// 20-state fragment-major layout (phyhip_aa.hpp).  A wave of the amino-acid kernel owns a "wave-tile": the MFMA
+// v_mfma_f64_4x4x4_4b_f64 has four blocks of four columns; a pattern's categories sit in aa_cb(C) consecutive blocks
+// (C = 3 leaves one idle), so a wave-tile is 16 / aa_cb(C) patterns x all categories = one block of 320 doubles.
+// Lane = 16 (state & 3) + 4 block + (pattern & 3) owns the five k-chunk values (states 4t + (state & 3)) of its
+// (pattern, category): stored as two 16-byte pairs (chunks 0|1 and 2|3) and one single (chunk 4), each group contiguous
+// over the 64 lanes, so a fragment set moves as 2 x dwordx4 + 1 x dwordx2.
+__host__ __device__ inline int aa_cb(int C) { return C == 1 ? 1 : (C == 2 ? 2 : 4); }
 __host__ __device__ inline int aa_slot(int t, int lane) { return t < 4 ? (t >> 1) * 128 + lane * 2 + (t & 1) : 256 + lane; }
-// A-operand table of one (matrix, category): 640 doubles -- a lane's ten values (rows 0..15: k-chunks 0..4, then rows
-// 16..19: k-chunks 0..4) as five 16-byte pairs, each pair contiguous over the 64 lanes: five dwordx4 loads per matrix
-__host__ __device__ inline int aa_afrag_slot(int half, int t, int lane)
+// element offset of (pattern p, category c, state s) inside a fragment-major buffer
+__host__ __device__ inline size_t aa_off(long long p, int C, int c, int s)
 {
-  const int v = half * 5 + t;
-  return (v >> 1) * 128 + lane * 2 + (v & 1);
+  const int       cb = aa_cb(C), npw = 16 / cb;
+  const long long w  = p / npw;
+  const int       r  = (int)(p % npw);
+  const int       lane = 16 * (s & 3) + 4 * ((r >> 2) * cb + c) + (r & 3);
+  return (size_t)w * 320 + (size_t)aa_slot(s >> 2, lane);
 }
+// doubles per partials buffer of Ppad patterns (Ppad a multiple of 16)
+__host__ __device__ inline size_t aa_buf_elems(long long Ppad, int C) { return (size_t)Ppad * aa_cb(C) * 20; }
+// A-operand table of one matrix (ALL its categories): 25 values per lane -- row group r (output states 4r + i) x k-chunk t
+// (input states 4t + k), lane = 16k + 4 block + i -- stored per k-chunk as the five row groups in aa_slot order, so the
+// consumer's LDS reads per chunk are 2 x ds_read_b128 + 1 x ds_read_b64, conflict-free
+constexpr int kAaMat = 1600;
+__host__ __device__ inline int aa_a_slot(int t, int r, int lane) { return t * 320 + aa_slot(r, lane); }
 
 // child fetch in two phases so that ALL loads of an operation are in flight before the first wait:
 //   issue_side  -- only issues the loads (tip: one code byte; internal: S doubles + the scale word)
@@ -225,17 +238,14 @@ __device__ __forceinline__ void issue_side(const TreeParams &q, const RO &ro, in
     if (c == 0) r.sc = q.scales[b * q.Ppad + p];
   }
   else if (S == 20 && q.perm)
-  { // fragment-major layout (phyhip_aa.hpp): 320 doubles per (tile, category), slot aa_slot(s / 4, lane)
+  { // fragment-major layout (aa_off)
     const size_t  b    = (size_t)(idx - q.tip_count);
-    const size_t  nt   = (size_t)((q.P + 15) >> 4);
-    const double *base = q.partials + b * nt * (size_t)q.C * 320 + ((size_t)(p >> 4) * q.C + c) * 320;
-    const int     pp   = (int)(p & 15);
+    const double *base = q.partials + b * aa_buf_elems(q.Ppad, q.C);
 #pragma unroll
     for (int j = 0; j < S / 2; ++j)
     {
-      const int s0 = 2 * j, s1 = 2 * j + 1;
-      r.v[j].x = base[aa_slot(s0 >> 2, (s0 & 3) * 16 + pp)];
-      r.v[j].y = base[aa_slot(s1 >> 2, (s1 & 3) * 16 + pp)];
+      r.v[j].x = base[aa_off(p, q.C, c, 2 * j)];
+      r.v[j].y = base[aa_off(p, q.C, c, 2 * j + 1)];
     }
     if (c == 0) r.sc = q.scales[b * q.Ppad + p];
   }
@@ -1690,13 +1700,14 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
   double *out = q.pmats + (size_t)mat * C * S * S;
   for (int e = threadIdx.x; e < C * S * S; e += blockDim.x) out[e] = tmp[e] / rsum[e / S];
   if (q.afrag)
-  { // 20 states: the same entries once more in MFMA A-operand order (phyhip_aa.hpp: afrag[m][c][half][aa_slot(t, lane)])
-    double *dst = q.afrag + (size_t)mat * C * 640;
-    for (int e = threadIdx.x; e < C * 640; e += blockDim.x)
+  { // 20 states: the same entries once more in MFMA A-operand order (phyhip_aa.hpp: aa_a_slot), all categories in one table
+    double   *dst = q.afrag + (size_t)mat * kAaMat;
+    const int cb  = aa_cb(C);
+    for (int e = threadIdx.x; e < kAaMat; e += blockDim.x)
     {
-      const int lane = e & 63, t = (e >> 6) % 5, half = ((e >> 6) / 5) & 1, c = (e >> 6) / 10;
-      const int i = half ? 16 + (lane & 3) : (lane & 15), j = 4 * t + (lane >> 4);
-      dst[(size_t)c * 640 + aa_afrag_slot(half, t, lane)] = tmp[(c * S + i) * S + j] / rsum[c * S + i];
+      const int lane = e & 63, rt = e >> 6, r = rt % 5, t = rt / 5;
+      const int k = lane >> 4, b = (lane >> 2) & 3, i = 4 * r + (lane & 3), j = 4 * t + k, c = b % cb;
+      dst[aa_a_slot(t, r, lane)] = (c < C) ? tmp[(c * S + i) * S + j] / rsum[c * S + i] : 0.0;
     }
   }
 }
