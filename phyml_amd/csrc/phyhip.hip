@@ -165,6 +165,7 @@ struct Instance
   double   *d_partials = nullptr;
   int      *d_scales   = nullptr;
   uint8_t  *d_tipcodes = nullptr;
+  uint32_t *d_tipmasks = nullptr;      // 20-state fragment-major instances: [tip][Ppad] allowed-state masks (traverse_aa_kernel)
   uint32_t *d_masks    = nullptr;
   double   *d_pmats    = nullptr;
   double   *d_wght     = nullptr;
@@ -687,7 +688,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           // lane-per-pattern nucleotide kernel and the 20-state kernel: ONE auxiliary dword load per child -- the scale
           // descriptor of a tip child points at its tip row instead (spare word 1: the kernel then reads the aligned dword
           // holding the byte)
-          if ((I->soa || I->perm) && t) scale = desc(I->d_tipcodes + (size_t)c * I->Ppad, (size_t)I->Ppad, 1);
+          if (I->soa && t) scale = desc(I->d_tipcodes + (size_t)c * I->Ppad, (size_t)I->Ppad, 1);
+          if (I->perm && t) scale = desc(I->d_tipmasks + (size_t)c * I->Ppad, (size_t)I->Ppad * 4, 1); // (the mask itself)
         };
         child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes);
         child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);
@@ -965,16 +967,29 @@ int flush_impl(Instance *I, const EdgeEval *ee)
 #define AACASE(c_)                                                                                                          \
   case c_:                                                                                                                  \
     hipLaunchKernelGGL((traverse_aa_kernel<c_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,                      \
-                       (const double *)I->d_afrag, I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size(),                \
-                       (unsigned long long *)nullptr);                                                                      \
+                       (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
     return 0;
 #ifdef PHYHIP_DIAG
-        if ((I->ablate & 8) && I->C == 4)
+        if (I->C == 4 && I->ablate >= 256)
+        { // PHYHIP_ABLATE = 256 + bits: timing-only ablations of the 20-state kernel (results invalid)
+#define AAABL(a_) case a_: hipLaunchKernelGGL((traverse_aa_kernel<4, false, a_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec, (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); return 0;
+          switch (I->ablate - 256)
+          {
+            AAABL(1) AAABL(2) AAABL(4) AAABL(8) AAABL(9) AAABL(16) AAABL(18) AAABL(5) AAABL(13) AAABL(31) AAABL(27)
+            default: break;
+          }
+#undef AAABL
+        }
+        if ((I->ablate & 8) && I->ablate < 256 && I->C == 4)
         { // PHYHIP_ABLATE=8: cycle stamps of one consumer wave, printed to stderr (diagnostics; costs a sync per launch)
           unsigned long long *&d_dbg = I->d_dbg;
           if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
+          if (I->ablate & 128) // (stamps of the bare skeleton: every ablation on)
+            hipLaunchKernelGGL((traverse_aa_kernel<4, true, 31>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,
+                               (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, d_dbg);
+          else
           hipLaunchKernelGGL((traverse_aa_kernel<4, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,
-                             (const double *)I->d_afrag, I->nmat, ro.tip_codes, ro.code_masks, (int)I->masks.size(), d_dbg);
+                             (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, d_dbg);
           static int printed = 0;
           if (printed++ == 5)
           {
@@ -1246,7 +1261,7 @@ static void release_instance(Instance *I)
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg};
+                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
@@ -1378,6 +1393,11 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   }
   HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->Ppad));
   HIPCHK(hipMemset(I->d_tipcodes, 0, (size_t)I->tips * I->Ppad));
+  if (I->perm)
+  {
+    HIPCHK(hipMalloc((void **)&I->d_tipmasks, (size_t)I->tips * I->Ppad * sizeof(uint32_t)));
+    HIPCHK(hipMemset(I->d_tipmasks, 0, (size_t)I->tips * I->Ppad * sizeof(uint32_t)));
+  }
   HIPCHK(hipMalloc((void **)&I->d_masks, 256 * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void **)&I->d_pmats, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
   HIPCHK(hipMemset(I->d_pmats, 0, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
@@ -1533,6 +1553,12 @@ static int set_tip_codes(Instance *I, int tip, const std::vector<uint8_t> &codes
   int rc = flush_sync(I);
   if (rc) return rc;
   HIPCHK(hipMemcpy(I->d_tipcodes + (size_t)tip * I->Ppad, codes.data(), (size_t)I->P, hipMemcpyHostToDevice));
+  if (I->d_tipmasks)
+  {
+    std::vector<uint32_t> m((size_t)I->P);
+    for (long long p = 0; p < I->P; ++p) m[(size_t)p] = I->masks[codes[(size_t)p]];
+    HIPCHK(hipMemcpy(I->d_tipmasks + (size_t)tip * I->Ppad, m.data(), (size_t)I->P * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   return upload_masks(I);
 }
 

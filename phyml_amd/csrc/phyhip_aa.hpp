@@ -52,7 +52,13 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int kAaT      = 5;    // k-chunks of 4 input states = row groups of 4 output states
 constexpr int kAaBlock  = 320;  // doubles per wave-tile block of a partials buffer
 constexpr int kAaRing   = 4;    // operations whose matrices the LDS ring holds (2 x 12.8 KB each)
-constexpr int kAaMaxCons = 11;  // consumer waves per workgroup (+ 1 loader = 12 waves = 3 per SIMD at <= 168 VGPRs)
+constexpr int kAaMaxCons = 15;  // consumer waves per workgroup (+ 1 loader = 16 waves = 4 per SIMD at <= 128 VGPRs)
+#ifndef AA_LPRIO
+#define AA_LPRIO 3
+#endif
+#ifndef AA_CPRIO
+#define AA_CPRIO 0
+#endif
 
 // Write matrix `mat`'s A-operand table (kAaMat doubles) from its natural [c][i][j] entries: `get(c, i, j)`.
 // Lane (k, b, i) of the A operand holds P[category of block b][4r + i][4t + k]; blocks beyond the category count
@@ -127,17 +133,18 @@ __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadPar
 // ---------------------------------------------------------------------------------------------
 // K1 + K2 for 20 states.  Workgroup = 1 loader wave (wave 0) + up to kAaMaxCons consumer waves, one wave-tile each.
 // Pipeline of a consumer: the host hands every operation over as ready-made buffer descriptors (size 0 = load disabled)
-// plus forwarding flags; within step k the children and the auxiliary words of operation k+1 are issued before the
+// plus forwarding flags (tips: one 32-bit allowed-state mask per pattern); within step k the children and the auxiliary words of operation k+1 are issued before the
 // matrix-core phase into the second raw register set; the previous result is forwarded in registers.  One auxiliary
 // dword per child: the scale word of an internal child or the aligned four tip codes of a tip child (the host points the
 // descriptor at whichever row exists).
 // ---------------------------------------------------------------------------------------------
-template <int C_, bool DBG = false>
+// ABL (diag build only, results INVALID): 1 no matrix phase, 2 no cross-lane maximum, 4 children loads and result stores
+// zero-sized, 8 no ring hand-shake (nothing is loaded), 16 no all-ones test
+template <int C_, bool DBG = false, int ABL = 0>
 __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                                             const ExecRec *__restrict__ xrec,
                                                                             const double *__restrict__ afrag, int n_frag_mats,
-                                                                            const uint8_t *__restrict__ tip_codes,
-                                                                            const uint32_t *__restrict__ code_masks, int n_masks,
+                                                                            const uint32_t *__restrict__ tip_masks,
                                                                             unsigned long long *dbg = nullptr)
 {
   constexpr int T   = kAaT;
@@ -146,7 +153,6 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
   static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");
 
   __shared__ __attribute__((aligned(16))) double ring[kAaRing][2][kAaMat];
-  __shared__ unsigned lmask[256];          // allowed-state masks of the tip codes
   // (read and written with relaxed workgroup-scope atomics: those stay plain ds_read / ds_write instructions, whereas a
   // volatile access to LDS is compiled as a flat access behind a vmcnt(0) wait)
   __shared__ int      s_ready;             // operations (+ the evaluation edge) whose matrices are in the ring
@@ -161,7 +167,6 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
   const size_t ntiles = (size_t)(q.Ppad / NPW);
   const int n_items = q.n_ops + (q.edge_eval ? 1 : 0);
 
-  for (int i = threadIdx.x; i < n_masks && i < 256; i += blockDim.x) lmask[i] = code_masks[i];
   if (threadIdx.x < 16)
   {
     const size_t tl = (size_t)blockIdx.x * nw + threadIdx.x;
@@ -179,43 +184,68 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
 
   if (wave == 0)
   {
+    __builtin_amdgcn_s_setprio(AA_LPRIO); // a late matrix stalls every consumer of the workgroup: the loader issues first
     // ---- loader: the two A tables of item j (operation j, or the evaluation edge's matrix) -> ring[j % kAaRing] -------
     const __amdgpu_buffer_rsrc_t af_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(afrag), 0, (int)((size_t)n_frag_mats * kAaMat * 8), 0x00020000);
     constexpr int      kPieces = 2 * kAaMat * 8 / 1024; // 25 x 1 KiB per item
     constexpr unsigned kMatB   = kAaMat * 8;            // 12 800 B: piece 12 straddles the two tables
-    static_assert(2 * kAaMat * 8 == kPieces * 1024, "an item is a whole number of 1 KiB pieces");
-    int done_seen = 0;
-    for (int j = 0; j < n_items; ++j)
+    static_assert(2 * kAaMat * 8 == kPieces * 1024 && kPieces == 25, "an item is 25 pieces of 1 KiB (the vmcnt(25) below)");
+    // LDS-DMA (buffer_load_dwordx4 ... lds): the pieces go from L2 straight into the ring, no registers, no ds_write; a
+    // wave's pieces land in issue order, so "item j has landed" is vmcnt <= kPieces once item j+1 has been issued -- two
+    // items in flight (the 6-bit vmcnt counter allows 63 pieces).
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    int  done_seen = 0, flagged = 0; // items known to be released by every consumer / items published in s_ready
+    // The loader's own flag accesses are written as instructions: the compiler orders every LDS access it can see behind
+    // ALL pending LDS-DMA of the wave (s_waitcnt vmcnt(0)), which would allow only one item in flight.
+    const unsigned a_ready = (unsigned)(uintptr_t)(lds_ptr)&s_ready, a_done = (unsigned)(uintptr_t)(lds_ptr)&s_done[lane & 15];
+    auto publish   = [&](int n) {
+      if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(a_ready), "v"(n) : "memory");
+      flagged = n;
+    };
+    auto slot_free = [&](int need) { // every consumer has finished item need - 1
+      if (done_seen >= need) return true;
+      int d;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a_done) : "memory");
+      if (__builtin_amdgcn_ballot_w64(d < need) != 0) return false;
+      done_seen = need;
+      return true;
+    };
+    for (int j = 0; j < ((ABL & 8) ? 0 : n_items); ++j)
     {
       unsigned off1, off2;
       if (j < q.n_ops) { off1 = irec[j].c1_data.x; off2 = irec[j].c2_data.x; }
       else off1 = off2 = (unsigned)q.e_pm * kMatB;
-      u32x4 v[kPieces];
+      // the slot is free once every consumer has finished item j - kAaRing
+      const int need = j - kAaRing + 1;
+      if (!slot_free(need))
+      { // the consumers may be waiting for what is still in flight: publish it before waiting for them
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        asm volatile("" ::: "memory");
+        publish(j);
+        while (!slot_free(need)) __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+      char *slot = reinterpret_cast<char *>(&ring[j % kAaRing][0][0]);
 #pragma unroll
       for (int g = 0; g < kPieces; ++g)
       {
         const unsigned b = (unsigned)g * 1024u + (unsigned)lane * 16u; // byte inside the item
-        if (g * 1024 + 1024 <= (int)kMatB) v[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, b, off1, 0);
-        else if (g * 1024 >= (int)kMatB) v[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, b - kMatB, off2, 0);
-        else v[g] = __builtin_amdgcn_raw_buffer_load_b128(af_rsrc, b < kMatB ? b + off1 : b - kMatB + off2, 0, 0);
+        lds_ptr dst = (lds_ptr)(slot + g * 1024);
+        if (g * 1024 + 1024 <= (int)kMatB) __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b, off1, 0, 0);
+        else if (g * 1024 >= (int)kMatB) __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b - kMatB, off2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b < kMatB ? b + off1 : b - kMatB + off2, 0, 0, 0);
       }
-      // the slot is free once every consumer has finished item j - kAaRing
-      const int need = j - kAaRing + 1;
-      while (done_seen < need)
+      if (flagged < j)
       {
-        const int d   = __hip_atomic_load(&s_done[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool ok = d >= need;
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0) { done_seen = need; break; }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_waitcnt(0x4F79); // vmcnt(25): everything but the item just issued has landed
+        asm volatile("" ::: "memory");
+        publish(j);
       }
-      asm volatile("" ::: "memory");
-      u32x4 *dst = reinterpret_cast<u32x4 *>(&ring[j % kAaRing][0][0]) + lane;
-#pragma unroll
-      for (int g = 0; g < kPieces; ++g) dst[g * 64] = v[g];
-      asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&s_ready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    asm volatile("" ::: "memory");
+    publish(n_items);
   }
   else
   {
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
       const unsigned  voff_d16 = blk_bytes + lane * 16, voff_d8 = blk_bytes + 2048 + lane * 8; // chunk pairs | chunk 4
       // class axis (mixture classes as categories): every class has its own scale vector, [buffer][class][pattern]
       const unsigned  voff_s = ((cls ? (unsigned)(idle ? 0 : c) * (unsigned)q.Ppad : 0u) + (unsigned)p0) * 4u;
-      const unsigned  voff_t = (unsigned)p0 & ~3u, tip_sh = ((unsigned)p0 & 3u) * 8u;
+      const unsigned  voff_t = (unsigned)p0 * 4u; // tip rows: one allowed-state mask (32 bits) per pattern
       // the scale word of a pattern (of a (class, pattern)) is stored by ONE lane; the others aim past the end of the buffer
       const unsigned  voff_sst = (kk == 0 && !idle && (cls || c == 0)) ? voff_s : 0x7ffffff0u;
 
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         unsigned xa, xb; // scale word, or the dword holding the tip code
       };
       auto rsrc = [](const Desc &d) {
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (ABL & 4) ? 0 : (int)d.bytes, 0x00020000);
       };
       auto load_frag = [](Frag &f, const __amdgpu_buffer_rsrc_t r, unsigned v16, unsigned v8) {
         f.p01 = __builtin_amdgcn_raw_buffer_load_b128(r, v16, 0, 0);
@@ -308,14 +338,14 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         return v;
       };
       auto tip_vec = [&](unsigned word, double (&x)[T]) {
-        const unsigned m = lmask[(word >> tip_sh) & 255u] >> kk;
+        const unsigned m = word >> kk;
 #pragma unroll
         for (int t = 0; t < T; ++t) x[t] = ((m >> (4 * t)) & 1u) ? 1.0 : 0.0;
       };
       // wait until the ring holds item k; returns the item's first A table
       int ready_seen = 0;
       auto wait_item = [&](int k) -> const double * {
-        while (ready_seen <= k)
+        while (!(ABL & 8) && ready_seen <= k)
         {
           ready_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           if (ready_seen <= k) __builtin_amdgcn_s_sleep(1);
@@ -349,6 +379,18 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         ExecRec   cur = xrec[0];
         IssueRec  nx1 = irec[(1 < last) ? 1 : last];
         issue_children(irec[0], RA);
+        {
+          // The loop body sees [children loads of k+1][4 result stores of k] in flight when step k+1 starts.  Four stores
+          // through a zero-sized descriptor (dropped by the hardware, but counted) give the loop entry the same shape, so
+          // the compiler's merged s_waitcnt counts never make a step wait for the previous step's stores.
+          const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+          const u32x4                  z4   = {0u, 0u, 0u, 0u};
+          const u32x2                  z2   = {0u, 0u};
+          __builtin_amdgcn_raw_buffer_store_b128(z4, none, 0, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(z4, none, 1024, 0, 0); // distinct offsets: identical stores would be merged
+          __builtin_amdgcn_raw_buffer_store_b64(z2, none, 2048, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(0u, none, 4096, 0, 0);
+        }
 
         auto step = [&](const int k, Raw &R, Raw &Rn) {
           const unsigned fl = cur.dst_data.x;
@@ -376,20 +418,30 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           unsigned ones = 1;
 #pragma unroll
           for (int t = 0; t < T; ++t) ones &= (unsigned)((x1[t] == 1.0) & (x2[t] == 1.0));
-          ones = and_states(ones);
+          if (!(ABL & 16)) ones = and_states(ones);
           issue_children(nx1, Rn);
           PHY_STAMP(k, 2)
           double u1[T] = {0., 0., 0., 0., 0.}, u2[T] = {0., 0., 0., 0., 0.};
           {
             const double *A = wait_item(k);
+            if (AA_CPRIO) __builtin_amdgcn_s_setprio(0);
             PHY_STAMP(k, 3)
-#pragma unroll
-            for (int t = 0; t < T; ++t)
+            if (ABL & 1)
             {
-              mfma_chunk(A, t, x1[t], u1);
-              mfma_chunk(A + kAaMat, t, x2[t], u2);
+#pragma unroll
+              for (int t = 0; t < T; ++t) { u1[t] = x1[t]; u2[t] = x2[t]; }
+            }
+            else
+            {
+#pragma unroll
+              for (int t = 0; t < T; ++t)
+              {
+                mfma_chunk(A, t, x1[t], u1);
+                mfma_chunk(A + kAaMat, t, x2[t], u2);
+              }
             }
             release_item(k);
+            if (AA_CPRIO) __builtin_amdgcn_s_setprio(AA_CPRIO);
           }
           const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
           const ExecRec  nxe = xrec[(k + 1 < last) ? k + 1 : last];
@@ -402,8 +454,11 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
             mxh  = max(mxh, hi32(o[t]));
           }
           if (C_ == 3 && idle) mxh = 0;
-          mxh = max_states(mxh);
-          if (!cls) mxh = max_cats(mxh); // a mixture class rescales alone
+          if (!(ABL & 2))
+          {
+            mxh = max_states(mxh);
+            if (!cls) mxh = max_cats(mxh); // a mixture class rescales alone
+          }
           PHY_STAMP(k, 5)
           unsigned sc = s1 + s2; // src/avx.c:462-464
           if (mxh < kHiInvTwoToLarge && q.apply_scaling)
@@ -444,8 +499,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         auto side = [&](int idx, double (&v)[T], unsigned &sc) {
           if (idx < tips)
           {
-            const unsigned word = *reinterpret_cast<const unsigned *>(tip_codes + (size_t)idx * q.Ppad + voff_t);
-            tip_vec(word, v);
+            tip_vec(tip_masks[(size_t)idx * q.Ppad + p0], v);
             sc = 0;
           }
           else if (idx == q.last_dest)
