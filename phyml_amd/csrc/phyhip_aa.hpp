@@ -53,12 +53,7 @@ constexpr int kAaT      = 5;    // k-chunks of 4 input states = row groups of 4 
 constexpr int kAaBlock  = 320;  // doubles per wave-tile block of a partials buffer
 constexpr int kAaRing   = 4;    // operations whose matrices the LDS ring holds (2 x 12.8 KB each)
 constexpr int kAaMaxCons = 15;  // consumer waves per workgroup (+ 1 loader = 16 waves = 4 per SIMD at <= 128 VGPRs)
-#ifndef AA_LPRIO
-#define AA_LPRIO 3
-#endif
-#ifndef AA_CPRIO
-#define AA_CPRIO 0
-#endif
+
 
 // Write matrix `mat`'s A-operand table (kAaMat doubles) from its natural [c][i][j] entries: `get(c, i, j)`.
 // Lane (k, b, i) of the A operand holds P[category of block b][4r + i][4t + k]; blocks beyond the category count
@@ -184,7 +179,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
 
   if (wave == 0)
   {
-    __builtin_amdgcn_s_setprio(AA_LPRIO); // a late matrix stalls every consumer of the workgroup: the loader issues first
+    __builtin_amdgcn_s_setprio(3); // a late matrix stalls every consumer of the workgroup: the loader issues first
     // ---- loader: the two A tables of item j (operation j, or the evaluation edge's matrix) -> ring[j % kAaRing] -------
     const __amdgpu_buffer_rsrc_t af_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(afrag), 0, (int)((size_t)n_frag_mats * kAaMat * 8), 0x00020000);
@@ -338,7 +333,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         return v;
       };
       auto tip_vec = [&](unsigned word, double (&x)[T]) {
-        const unsigned m = word >> kk;
+        const unsigned m = (word ? word : 1u) >> kk;
 #pragma unroll
         for (int t = 0; t < T; ++t) x[t] = ((m >> (4 * t)) & 1u) ? 1.0 : 0.0;
       };
@@ -369,6 +364,16 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         u[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xt, u[4], 0, 0, 0);
       };
 
+      // column `state` of a table, rows 4r + kk of this lane's category: the A lane that holds P[c][4r + i][4t + k] is
+      // 16k + 4b + i, so this (D) lane kk reads lane 16 (state & 3) + 4b + kk of k-chunk state >> 2
+      auto tip_column = [&](const double *A, unsigned mask, double (&u)[T]) {
+        const int st = __builtin_ctz(mask), la = 16 * (st & 3) + 4 * b + kk;
+        const double *At = A + (st >> 2) * kAaBlock;
+        const v2d    *pr = reinterpret_cast<const v2d *>(At) + la;
+        const v2d     a01 = pr[0], a23 = pr[64];
+        u[0] = a01.x; u[1] = a01.y; u[2] = a23.x; u[3] = a23.y; u[4] = At[256 + la];
+      };
+
       double   prev[T] = {0., 0., 0., 0., 0.}; // result of the previous operation (this lane's D fragments)
       unsigned prev_sc = 0;
 
@@ -397,7 +402,27 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           double         x1[T], x2[T], o[T];
           unsigned       s1, s2;
           PHY_STAMP(k, 0)
-          if (fl & kOpTip1) { tip_vec(R.xa, x1); s1 = 0; }
+          // The loads of operation k+1 go out first (their registers were consumed by step k-1), then the records of
+          // k+2 / k+1 are requested into the scalar registers the issue just freed: both have the whole step to arrive.
+          issue_children(nx1, Rn);
+          const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
+          const ExecRec  nxe = xrec[(k + 1 < last) ? k + 1 : last];
+          // A tip child whose patterns all carry ONE state contributes a column of its matrix (the reference's Exex / Exin
+          // kernels, src/avx.c:527-564): five values per lane straight from the ring, no product.  (Through the matrix
+          // cores the result would be the same doubles -- the other 19 products are exact zeros -- at 25 MFMAs.)
+          unsigned m1 = 0, m2 = 0;
+          bool     hot1 = false, hot2 = false;
+          if (fl & kOpTip1)
+          {
+            m1   = R.xa ? R.xa : 1u; // (padding patterns carry no state: any column will do)
+            hot1 = __builtin_amdgcn_ballot_w64((m1 & (m1 - 1u)) != 0u) == 0;
+          }
+          if (fl & kOpTip2)
+          {
+            m2   = R.xb ? R.xb : 1u;
+            hot2 = __builtin_amdgcn_ballot_w64((m2 & (m2 - 1u)) != 0u) == 0;
+          }
+          if (fl & kOpTip1) { if (!hot1) tip_vec(m1, x1); s1 = 0; }
           else if (fl & kOpF11)
           {
 #pragma unroll
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
             s1 = prev_sc;
           }
           else { unpack(R.a, x1); s1 = R.xa; }
-          if (fl & kOpTip2) { tip_vec(R.xb, x2); s2 = 0; }
+          if (fl & kOpTip2) { if (!hot2) tip_vec(m2, x2); s2 = 0; }
           else if (fl & kOpF21)
           {
 #pragma unroll
@@ -414,17 +439,19 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           }
           else { unpack(R.b, x2); s2 = R.xb; }
           PHY_STAMP(k, 1)
-          // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587
-          unsigned ones = 1;
+          // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587 (never with a one-state tip)
+          unsigned ones = 0;
+          if (!hot1 && !hot2)
+          {
+            ones = 1;
 #pragma unroll
-          for (int t = 0; t < T; ++t) ones &= (unsigned)((x1[t] == 1.0) & (x2[t] == 1.0));
-          if (!(ABL & 16)) ones = and_states(ones);
-          issue_children(nx1, Rn);
+            for (int t = 0; t < T; ++t) ones &= (unsigned)((x1[t] == 1.0) & (x2[t] == 1.0));
+            if (!(ABL & 16)) ones = and_states(ones);
+          }
           PHY_STAMP(k, 2)
           double u1[T] = {0., 0., 0., 0., 0.}, u2[T] = {0., 0., 0., 0., 0.};
           {
             const double *A = wait_item(k);
-            if (AA_CPRIO) __builtin_amdgcn_s_setprio(0);
             PHY_STAMP(k, 3)
             if (ABL & 1)
             {
@@ -433,18 +460,21 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
             }
             else
             {
-#pragma unroll
-              for (int t = 0; t < T; ++t)
+              if (hot1) tip_column(A, m1, u1);
+              else
               {
-                mfma_chunk(A, t, x1[t], u1);
-                mfma_chunk(A + kAaMat, t, x2[t], u2);
+#pragma unroll
+                for (int t = 0; t < T; ++t) mfma_chunk(A, t, x1[t], u1);
+              }
+              if (hot2) tip_column(A + kAaMat, m2, u2);
+              else
+              {
+#pragma unroll
+                for (int t = 0; t < T; ++t) mfma_chunk(A + kAaMat, t, x2[t], u2);
               }
             }
             release_item(k);
-            if (AA_CPRIO) __builtin_amdgcn_s_setprio(AA_CPRIO);
           }
-          const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
-          const ExecRec  nxe = xrec[(k + 1 < last) ? k + 1 : last];
           PHY_STAMP(k, 4)
           unsigned mxh = 0;
 #pragma unroll
