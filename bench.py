@@ -13,7 +13,8 @@ the scalar back on the host -- everything the reference's Lk(NULL) does (src/lk.
   --gpus N (N > 1)    BASELINE configs[3] (cfg4: 100 taxa x 1 000 000 nt patterns), STRONG scaling: contiguous pattern
                       shards of 1e6/N per GPU, ONE RCCL all-reduce of {warning, lnL} per evaluation inside libphyhip.so.
                       Launched by the driver as N ranks (torch.distributed.run, WORLD_SIZE = N): one process per GPU,
-                      phyhip_comm_init_rank on an id broadcast through torch.distributed.  Launched bare
+                      phyhip_comm_init_rank on an id broadcast through torch.distributed (gloo: rendezvous, barrier and the
+                      MAX over the ranks' timers are host-side; the only RCCL communicator is the library's own).  Launched bare
                       (`python bench.py --gpus N`): ONE process drives all N devices through the sharded instance of
                       the C ABI (phyhip_create_instance with a resource list of N devices, ncclCommInitAll).
 Prints ONE JSON line (rank 0).
@@ -105,18 +106,19 @@ def kernel_source_hash():
 
 
 def pmc_traffic(workload):
-    """HBM bytes per traversal launch from the rocprofv3 PMC passes of this same command (tools/profile_pmc.sh writes
-    profiles/r02_pmc_<workload>.json with the kernel-source hash it was taken on): 2 x FETCH_SIZE (gfx950 correction,
+    """HBM bytes per traversal launch from the rocprofv3 PMC passes of this same command (tools/profile_round.sh writes
+    profiles/rNN_pmc_<workload>.json with the kernel-source hash it was taken on): 2 x FETCH_SIZE (gfx950 correction,
     MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes.  A profile taken on other kernel sources is refused
     (null): counters do not travel across kernel changes."""
-    f = os.path.join(ROOT, "profiles", f"r02_pmc_{workload}.json")
-    try:
-        d = json.load(open(f))
-        if d.get("kernel_source_hash") != kernel_source_hash():
-            return None
-        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-    except Exception:  # noqa: BLE001
-        return None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{workload}.json")), reverse=True):  # newest round first
+        try:
+            d = json.load(open(f))
+            if d.get("kernel_source_hash") == kernel_source_hash():
+                return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        except Exception:  # noqa: BLE001
+            pass
+    return None
 
 
 def build_tree(wl, device=None, devices=None):
@@ -185,8 +187,9 @@ def run_single(args, torch):
     dt, lnl = timed_steps(t, args.steps, args.warmup, torch.cuda.synchronize)
     value = float(P) * (n - 2) * args.steps / dt / 1e6
     roof, kdur = roofline_block(t, n, P, S, C, args.workload, args.patterns is None)
+    # ("scaling": the N = 1 line is the cfg2 workload on one GPU -- neither weak nor strong; --gpus N > 1 is STRONG scaling of cfg4)
     out = {"metric": METRIC, "value": value, "unit": "M site-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "none", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": f"{args.workload}: {n} taxa x {P} {'nt' if S == 4 else 'aa'} patterns, "
                                   f"{'GTR' if S == 4 else 'LG'}+G{C}, fixed random tree, full post-order Lk(NULL) incl. P-matrix refresh and root-edge reduce",
@@ -219,11 +222,15 @@ def run_single(args, torch):
 
 
 def mfma_block(P, C, n, kdur):
-    # 20-state path: FP64 MFMA work issued per launch, per (tile, category, operation): rows 0..15 as ten 16x16x4
-    # (2048 flop) and rows 16..19 as ten four-block 4x4x4 (512 flop) -- all of it useful
-    flops = float((P + 15) // 16) * C * (n - 2) * (10 * 2048.0 + 10 * 512.0)
-    return {"achieved": flops / kdur / 1e12, "peak": 78.6, "unit": "TFLOP/s issued (f64 16x16x4 + 4x4x4_4b)",
-            "frac": flops / kdur / 1e12 / 78.6, "useful_frac_of_issued": 1.0}
+    # 20-state path: FP64 MFMA work issued per launch.  A wave-tile (16 / blocks-per-pattern patterns x all categories)
+    # spends 25 v_mfma_f64_4x4x4_4b (512 flop each) per INTERNAL child of an operation -- the n - 1 one-state tip children of
+    # this synthetic alignment read a matrix column instead (phyhip_aa.hpp) -- and 25 for the evaluation edge
+    cb = 1 if C == 1 else (2 if C == 2 else 4)
+    tiles = float((P + 15) // 16 * 16) / (16 // cb)
+    flops = tiles * ((n - 3) + 1) * 25 * 512.0
+    return {"achieved": flops / kdur / 1e12, "peak": 78.6, "unit": "TFLOP/s issued (f64 4x4x4_4b)",
+            "frac": flops / kdur / 1e12 / 78.6, "useful_frac_of_issued": C / float(cb),
+            "note": "one-state tip children cost no matrix-core work (column lookup): half of the products of a full post-order"}
 
 
 def call_latency():
@@ -297,7 +304,8 @@ def run_sharded(args, torch):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # rendezvous over gloo (CPU): the ONLY RCCL communicator on a device is the one libphyhip.so builds below
+        dist.init_process_group("gloo")
         lo, hi = shard.shard_range(total, rank, world)
         wl = workloads.make(name, n_pattern=hi - lo, pattern_offset=lo)
         t = build_tree(wl, device=local)
@@ -330,7 +338,7 @@ def run_sharded(args, torch):
     n, S, C = tree.n_otu, cfg["ns"], int(wl["model"]["ncatg"][0])
     dt, lnl = timed_steps(t, args.steps, args.warmup, sync, barrier)
     if multiproc:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     P_local = wl["states"].shape[1] if multiproc else total // n_gpus

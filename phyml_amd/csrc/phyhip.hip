@@ -2573,6 +2573,7 @@ int phyhip_comm_init_rank(int instance, int nranks, int rank, const char *unique
   I->co->ctx.push_back(c);
   I->co->nranks = nranks;
   I->d_red      = c.d_red;
+  if ((rc = warm_up_collective(*I->co))) return rc; // (collective: every rank is inside phyhip_comm_init_rank here)
   return PHYHIP_SUCCESS;
 }
 

@@ -51,7 +51,10 @@ namespace phyhip
 typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int kAaT      = 5;    // k-chunks of 4 input states = row groups of 4 output states
 constexpr int kAaBlock  = 320;  // doubles per wave-tile block of a partials buffer
-constexpr int kAaRing   = 4;    // operations whose matrices the LDS ring holds (2 x 12.8 KB each)
+#ifndef AA_RING
+#define AA_RING 4
+#endif
+constexpr int kAaRing   = AA_RING;    // operations whose matrices the LDS ring holds (2 x 12.8 KB each)
 constexpr int kAaMaxCons = 15;  // consumer waves per workgroup (+ 1 loader = 16 waves = 4 per SIMD at <= 128 VGPRs)
 
 

@@ -108,6 +108,28 @@ static int reduce_and_publish(Collective &co, int count, Instance *I0)
   return wait_result(I0);
 }
 
+// One all-reduce of zeros on every communicator of `co`, waited for: RCCL builds its channels, proxies and kernels on the
+// FIRST collective of a communicator (tens of milliseconds) -- that belongs to communicator creation, not to the caller's
+// first likelihood evaluation.
+static int warm_up_collective(Collective &co)
+{
+  int        rc      = 0;
+  const bool grouped = co.ctx.size() > 1;
+  if (grouped) NCCLCHK(ncclGroupStart());
+  for (auto &c : co.ctx)
+  {
+    if ((rc = set_dev(c.dev))) return rc;
+    NCCLCHK(ncclAllReduce(c.d_red, c.d_red, (size_t)kRedStride, ncclDouble, ncclSum, c.comm, c.stream));
+  }
+  if (grouped) NCCLCHK(ncclGroupEnd());
+  for (auto &c : co.ctx)
+  {
+    if ((rc = set_dev(c.dev))) return rc;
+    HIPCHK(hipStreamSynchronize(c.stream));
+  }
+  return 0;
+}
+
 static void release_collective(Collective *co)
 {
   if (!co) return;
@@ -322,10 +344,10 @@ static int create_group(int tipCount, int partialsBufferCount, int stateCount, i
     }
   }
   G->co->nranks = nctx;
+  for (int k = 0; k < nctx; ++k) G->co->ctx[k].comm = comms[k]; // (all of them first: release_group destroys what ctx holds)
   for (int k = 0; k < nctx; ++k)
   {
     DevCtx &c = G->co->ctx[k];
-    c.comm = comms[k];
     hipError_t e = hipSetDevice(c.dev);
     g_cur_dev = c.dev;
     const size_t bytes = sizeof(double) * kRedStride * (size_t)(1 + c.nsub);
@@ -336,6 +358,11 @@ static int create_group(int tipCount, int partialsBufferCount, int stateCount, i
       release_group(G);
       return fail(PHYHIP_ERROR_OUT_OF_MEMORY, "reduction buffer: %s", hipGetErrorString(e));
     }
+  }
+  if (warm_up_collective(*G->co))
+  {
+    release_group(G);
+    return PHYHIP_ERROR_GENERAL;
   }
   {
     const char *e = getenv("PHYHIP_SHARD_THREADS");
