@@ -256,6 +256,7 @@ struct Instance
   int    ablate = 0;         // PHYHIP_ABLATE (-DPHYHIP_DIAG builds only): timing-only kernel variants (results invalid)
   unsigned long long *d_dbg = nullptr; // cycle stamps of PHYHIP_ABLATE=8
   bool   args_recs = true;   // PHYHIP_ARGS_RECS=0: operation records of 1-2-operation launches go through the slot ring too
+  bool   arg_uploads = true; // PHYHIP_ARG_UPLOADS=0: host-computed matrices always go through upload_matrices_kernel
   bool   eager_pmats = true; // PHYHIP_EAGER_PMAT=0: whole-tree matrix batches wait for the traversal launch too
   bool   no_loads = false;   // PHYHIP_NOLOADS (-DPHYHIP_DIAG builds only): zero-size every child load (timing only)
   bool   generic_nt = false; // PHYHIP_GENERIC_NT=1: run nucleotides through the generic (non-pipelined) kernel
@@ -575,7 +576,11 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
   const bool fold_pm = I->soa && I->fold_pmats && I->grid_nt2 <= 512 && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
                        I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
-  if (!fold_pm && (!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
+  // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
+  // (TreeParams::n_up): no upload kernel in front of the traversal
+  const bool arg_up = I->soa && I->arg_uploads && !I->up_idx.empty() && (int)I->up_idx.size() <= kArgUp && I->pm_idx.empty() &&
+                      (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
+  if (!fold_pm && !arg_up && (!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
   if (n_ops == 0 && !ee) return 0;
   rc = upload_masks(I);
   if (rc) return rc;
@@ -583,6 +588,19 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   TreeParams q = base_params(I);
   RO         ro = base_ro(I, nullptr);
   bool       fused_sum = false;
+  if (arg_up)
+  {
+    q.n_up = (int)I->up_idx.size();
+    for (int k = 0; k < q.n_up; ++k)
+    {
+      q.up_idx[k] = I->up_idx[k];
+      memcpy(q.up_val[k], I->up_src[k], sizeof(double) * 16 * I->C); // (pinned staging memory: an ordinary host read)
+    }
+    q.pmats_rw = I->d_pmats;
+    for (int m : I->up_idx) I->up_slot[m] = -1;
+    I->up_idx.clear();
+    I->up_src.clear();
+  }
   if (fold_pm)
   {
     q.n_fresh = (int)I->pm_idx.size();
@@ -775,7 +793,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     q.fence_post   = 1;
     I->fenced_eval = true;
   }
-  if (rt_grid && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && !I->prof && !I->rt_skip)
+  if (rt_grid && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0 && !I->prof && !I->rt_skip)
   {
     bool clean = !I->dirty_prev && !I->touched_call;
     if (clean && I->clean_after)
@@ -1486,6 +1504,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
 #endif
   if (const char *e = getenv("PHYHIP_EAGER_PMAT")) I->eager_pmats = atoi(e) != 0;
+  if (const char *e = getenv("PHYHIP_ARG_UPLOADS")) I->arg_uploads = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_ARGS_RECS")) I->args_recs = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce()
   {
@@ -1688,6 +1707,13 @@ int phyhip_set_category_rates(int instance, const double *r)
 {
   if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_set_category_rates(id, r); });
   GET_INST(I, instance);
+  // queued matrix rebuilds ride in kernel arguments built from these host shadows (flush_impl): launch what still belongs
+  // to the old model before the shadow changes
+  if (memcmp(I->h_rates.data(), r, sizeof(double) * I->C) != 0)
+  {
+    int rc = flush(I, nullptr);
+    if (rc) return rc;
+  }
   I->h_rates.assign(r, r + I->C);
   return small_upload(I, I->d_catr, r, I->C);
 }
@@ -1715,8 +1741,14 @@ int phyhip_set_eigen_decomposition(int instance, int idx, const double *evec, co
     return group_each(G, [&](int id, long long, long long) { return phyhip_set_eigen_decomposition(id, idx, evec, ivec, eval); });
   GET_INST(I, instance);
   if (idx < 0 || idx >= I->NE) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex %d (0..%d)", idx, I->NE - 1);
-  std::copy(eval, eval + I->S, I->h_eval.begin() + (size_t)idx * I->S);
   const size_t SS = (size_t)I->S * I->S;
+  if (memcmp(I->h_eval.data() + (size_t)idx * I->S, eval, sizeof(double) * I->S) || memcmp(I->h_evec.data() + idx * SS, evec, sizeof(double) * SS) ||
+      memcmp(I->h_ivec.data() + idx * SS, ivec, sizeof(double) * SS))
+  { // (as in phyhip_set_category_rates: queued rebuilds are launched with the model they were queued under)
+    int rc0 = flush(I, nullptr);
+    if (rc0) return rc0;
+  }
+  std::copy(eval, eval + I->S, I->h_eval.begin() + (size_t)idx * I->S);
   std::copy(evec, evec + SS, I->h_evec.begin() + idx * SS);
   std::copy(ivec, ivec + SS, I->h_ivec.begin() + idx * SS);
   int rc = small_upload(I, I->d_evec + idx * SS, evec, SS);

@@ -26,6 +26,7 @@ constexpr double kInvTwoToLarge = 0x1p-256;                    // INV_TWO_TO_THE
 constexpr double kSmall         = 2.2250738585072014e-308;     // SMALL = DBL_MIN, src/utilities.h:476
 constexpr double kLog2          = 0.69314718055994528623;      // LOG2, src/utilities.h:267
 constexpr double kSmallPij      = 1.E-100;                     // SMALL_PIJ, src/utilities.h:478
+constexpr int    kArgUp         = 3;                           // host-computed matrices per launch in the kernel arguments
 constexpr int    kMaxExpl       = 2 * 8 * 20;                  // dLk's expl table: [C<=8][2][S<=20]
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -117,6 +118,13 @@ struct TreeParams
   double          m_evec[16], m_ivec[16], m_eval[4], m_rates[4]; // U, U^-1, eigenvalues, category rates (4 states, <= 4 categories)
   double          br_len_mult, l_min, l_max;
   double         *pmats_rw;
+  // Host-computed matrices (phyhip_set_transition_matrix, the bit-exact route of src/lk.c:2360) queued since the last launch,
+  // up to kArgUp of them (SPR: three per candidate): they ride here, every workgroup of the lane-per-pattern nucleotide
+  // kernel writes them to their slots in its prologue (same values everywhere) and reads them back in program order -- no
+  // upload kernel in front of the traversal, nothing to wait for.
+  int             n_up;
+  int             up_idx[3];
+  double          up_val[3][64]; // [matrix][c * 16 + i * 4 + j], C <= 4
   // One- and two-operation launches (an SPR regraft candidate is ONE update + the edge evaluation, src/spr.c:643-646)
   // carry their operation records here, in the kernel arguments, instead of a staged copy into the device slot ring: one
   // copy command less in front of the launch.

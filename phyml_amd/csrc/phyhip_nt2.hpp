@@ -47,6 +47,8 @@ struct NtFresh
   const int    *idx;                         // [n_fresh] matrix indices
   const double *len;                         // [n_fresh] edge lengths
   const double *evec, *ivec, *eval, *rates;  // U, U^-1, eigenvalues, category rates
+  const int    *up_idx = nullptr;            // [n_up] host-computed matrices of this launch (TreeParams::up_idx / up_val)
+  const double *up_val = nullptr;            // [n_up][64]
 };
 
 // One workgroup's (= one wave's) share of a launch: the whole kernel body, callable from a kernel that stays resident.
@@ -207,6 +209,13 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
     }
   }
 
+  if (q.n_up > 0)
+  { // host-computed matrices from the arguments to their slots (see TreeParams::n_up)
+    for (int m = 0; m < q.n_up; ++m)
+      if (lane < C * 16) q.pmats_rw[(size_t)fr.up_idx[m] * (C * 16) + lane] = fr.up_val[m * 64 + lane];
+    asm volatile("" ::: "memory"); // (as below: this wave's later loads see these stores)
+    __builtin_amdgcn_wave_barrier();
+  }
   if (q.n_fresh > 0)
   { // rebuild the queued matrices (see TreeParams::n_fresh) with pmat_kernel's arithmetic; every workgroup writes the same
     // values.  The double-precision exp() is the expensive part (four per entry when every lane builds its own entry: 2 us
@@ -540,6 +549,8 @@ __global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel
   fr.ivec = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_ivec));
   fr.eval = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_eval));
   fr.rates = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_rates));
+  fr.up_idx = reinterpret_cast<const int *>(ka + offsetof(TreeParams, up_idx));
+  fr.up_val = reinterpret_cast<const double *>(ka + offsetof(TreeParams, up_val));
   nt2_run<C, G, DBG, ARGS, DIST>(q, irec, xrec, pmats, tip_codes, dbg, fr);
 }
 
