@@ -260,12 +260,47 @@ def call_latency():
         dt = time.perf_counter() - t0
         k = tr["kind"]
         n_scalar = int(np.isin(k, (replay.EDGE_LNL, replay.DLK)).sum())
+        if name == "spr_500x100k":
+            brlen = brlen_block(t, taxa, P, 4, int(blk["ncatg"][0]))
         rows[name] = {"us_per_candidate": dt / cand * 1e6, "us_per_scalar_returning_call": dt / n_scalar * 1e6, "candidates": cand,
                       "scalar_returning_calls": n_scalar, "dlk_calls": int((k == replay.DLK).sum()), "surface_calls": int(len(k)),
                       "finite": bool(np.isfinite(res).all()),
                       "served_by_resident_workgroups": {"dlk": t.inst.resident_stats(0)[0], "short_evaluations": t.inst.resident_stats(1)[0]}}
         t.close()
+    rows["brlen_500x100k"] = brlen
     return rows
+
+
+def brlen_block(t, taxa, P, S, C):
+    """K3 / K4 at the cfg5 size: Update_Eigen_Lr's kernel streams two partial vectors in and the eigen-basis
+    products out (3 x P C S 8 B), the dLk kernel streams the products in (P C S 8 B + weights + scale exponents); HIP events
+    around each launch (phyhip_profile_read_eigen), Br_Len_Opt's call pattern: one Update_Eigen_Lr, then a chain of dLk."""
+    e = t.ne // 2
+    t.Lk(e)
+    t.Update_Eigen_Lr(e)
+    t.Set_Update_Eigen_Lr(0); t.Set_Use_Eigen_Lr(1)
+    for i in range(3):
+        t.dLk(0.05, e)
+    t.inst.profile(1)
+    n_chain, n_dlk = 40, 5
+    t0 = time.perf_counter()
+    for k in range(n_chain):
+        t.Set_Update_Eigen_Lr(1); t.Update_Eigen_Lr(e); t.Set_Update_Eigen_Lr(0)
+        for i in range(n_dlk):
+            t.dLk(0.05 + 1e-3 * i + 1e-5 * k, e)
+    wall = time.perf_counter() - t0
+    (k3_ms, k3_n), (k4_ms, k4_n) = t.inst.profile_read_eigen()
+    t.inst.profile(0)
+    t.Set_Use_Eigen_Lr(0)
+    vec = float(P) * C * S * 8.0
+    k3_bytes, k4_bytes = 3.0 * vec + 2.0 * 4.0 * P, vec + 8.0 * P + 4.0 * P
+    k3_us, k4_us = k3_ms / max(k3_n, 1) * 1e3, k4_ms / max(k4_n, 1) * 1e3
+    return {"patterns": P, "taxa": taxa,
+            "eigen_lr_kernel": {"launches": k3_n, "avg_us": k3_us, "bytes": k3_bytes, "GBps": k3_bytes / (k3_us * 1e-6) / 1e9 if k3_us else 0.0,
+                                "frac_of_8TBps": k3_bytes / (k3_us * 1e-6) / 8e12 if k3_us else 0.0},
+            "dlk_kernel": {"launches": k4_n, "avg_us": k4_us, "bytes": k4_bytes, "GBps": k4_bytes / (k4_us * 1e-6) / 1e9 if k4_us else 0.0,
+                           "frac_of_8TBps": k4_bytes / (k4_us * 1e-6) / 8e12 if k4_us else 0.0},
+            "us_per_chain_of_1_eigen_lr_and_5_dlk": wall / n_chain * 1e6}
 
 
 def extra_line(name, args, torch):

@@ -303,6 +303,9 @@ int phyhip_profile_read(int instance, double *outTraversalMs, int *outLaunches, 
    unless it is a tip (1 byte) or one of the two previous results.  The honest floor under the algorithmic byte count of
    SURVEY 8(d), which also charges the forwarded reads. */
 int phyhip_profile_read_traffic(int instance, double *outReadBytes, double *outWriteBytes);
+/* The eigen-basis kernels launched since phyhip_profile(instance, 1): Update_Eigen_Lr's kernel (src/lk.c:1038) and the
+   dLk / eigen-basis Lk kernel (src/lk.c:655-753), milliseconds and launches of each (HIP events on the instance's stream). */
+int phyhip_profile_read_eigen(int instance, double *outEigenLrMs, int *outEigenLrLaunches, double *outDlkMs, int *outDlkLaunches);
 
 /* The resident evaluators (small nucleotide alignments, scalar wanted on the host): the launch-bound calls of a search --
    the chain of dLk calls of a branch-length optimisation (src/optimiz.c: Br_Len_Opt) and the short evaluations of SPR

@@ -45,7 +45,7 @@ SYMBOLS = [
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
     "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
-    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_get_resident_stats", "phyhip_calculate_class_mixture_log_likelihood",
+    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_profile_read_eigen", "phyhip_get_resident_stats", "phyhip_calculate_class_mixture_log_likelihood",
     "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors", "phyhip_set_mixture_invariant_sites",
 ]
 
@@ -301,6 +301,12 @@ class Instance:
         out = (C.c_longlong * 8)()
         _chk(self.L.phyhip_get_resident_stats(self.id, out))
         return tuple(int(v) for v in out[4 * which:4 * which + 4])
+
+    def profile_read_eigen(self):
+        """(ms, launches) of eigen_lr_kernel and of dlk_kernel since profile(1)"""
+        a = C.c_double(0); an = C.c_int(0); b = C.c_double(0); bn = C.c_int(0)
+        _chk(self.L.phyhip_profile_read_eigen(self.id, C.byref(a), C.byref(an), C.byref(b), C.byref(bn)))
+        return (a.value, an.value), (b.value, bn.value)
 
     def profile_read_traffic(self):
         r = C.c_double(0); w = C.c_double(0)

@@ -265,6 +265,10 @@ struct Instance
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   hipEvent_t ev_sync = nullptr; // orders this instance's stream before another instance's (mixture evaluations)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pairs;
+  struct ProfPair { hipEvent_t a, b; int kind; };
+  std::vector<ProfPair> prof_aux;          // eigen-basis kernels while profiling: kind 0 eigen_lr_kernel (K3), 1 dlk_kernel (K4)
+  double     prof_aux_ms[2] = {0.0, 0.0};
+  int        prof_aux_n[2]  = {0, 0};
   double     prof_ms = 0.0, prof_updates = 0.0;
   double     prof_rd_bytes = 0.0, prof_wr_bytes = 0.0; // traffic model of the profiled launches (phyhip_profile_read_traffic)
   int        prof_n = 0;
@@ -1239,8 +1243,39 @@ int collect_profile(Instance *I)
     (void)hipEventDestroy(pr.second);
   }
   I->prof_pairs.clear();
+  for (auto &pr : I->prof_aux)
+  {
+    HIPCHK(hipEventSynchronize(pr.b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, pr.a, pr.b));
+    I->prof_aux_ms[pr.kind] += ms;
+    I->prof_aux_n[pr.kind] += 1;
+    (void)hipEventDestroy(pr.a);
+    (void)hipEventDestroy(pr.b);
+  }
+  I->prof_aux.clear();
   return 0;
 }
+
+// HIP events around one launch of an eigen-basis kernel while the instance is being profiled (bench.py's K3 / K4 lines)
+struct AuxProf
+{
+  Instance  *I;
+  int        kind;
+  hipEvent_t a = nullptr, b = nullptr;
+  AuxProf(Instance *I_, int kind_) : I(I_), kind(kind_)
+  {
+    if (!I->prof) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, I->stream);
+  }
+  ~AuxProf()
+  {
+    if (!a) return;
+    (void)hipEventRecord(b, I->stream);
+    I->prof_aux.push_back({a, b, kind});
+  }
+};
 
 // A combination / dLk kernel's sums go to the host as posted records (host-side final sum) when the instance allows it
 void host_sum_finish(Instance *I, FinishParams &f, int grid, int ns)
@@ -2365,6 +2400,7 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   const bool report = I->resident && I->S == 4 && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co; // (see eigen_eval)
   e.tickets = report ? I->d_tickets : nullptr;
   e.stamp_host = reinterpret_cast<unsigned long long *>(I->h_result + 3); e.stamp = report ? ++I->stamp_seq : 0ull;
+  AuxProf ap(I, 0);
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     const size_t lds = sizeof(double) * 2 * (size_t)(I->class_axis ? I->C : 1) * S_ * S_; // the eigenvectors, staged per workgroup
@@ -2498,6 +2534,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       I->r_inflight = nullptr; I->host_sum_n = 0;
     }
   }
+  {
+  AuxProf ap(I, 1);
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     const unsigned long long h1 = hp_now();
@@ -2505,6 +2543,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
     if (kDiag) { g_hp.launch += hp_now() - h1; ++g_hp.n_launch; }
     return 0;
   });
+  }
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   if (hsum) { I->host_sum_n = dgrid; I->host_sum_ns = 2; }
@@ -2683,6 +2722,21 @@ int phyhip_profile(int instance, int enable)
   collect_profile(I);
   I->prof = enable != 0;
   I->prof_ms = 0.0; I->prof_n = 0; I->prof_updates = 0.0; I->prof_rd_bytes = 0.0; I->prof_wr_bytes = 0.0;
+  I->prof_aux_ms[0] = I->prof_aux_ms[1] = 0.0; I->prof_aux_n[0] = I->prof_aux_n[1] = 0;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_profile_read_eigen(int instance, double *outEigenLrMs, int *outEigenLrLaunches, double *outDlkMs, int *outDlkLaunches)
+{
+  if (get_group(instance)) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "per-kernel profile of a sharded instance");
+  GET_INST(I, instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  if ((rc = collect_profile(I))) return rc;
+  if (outEigenLrMs) *outEigenLrMs = I->prof_aux_ms[0];
+  if (outEigenLrLaunches) *outEigenLrLaunches = I->prof_aux_n[0];
+  if (outDlkMs) *outDlkMs = I->prof_aux_ms[1];
+  if (outDlkLaunches) *outDlkLaunches = I->prof_aux_n[1];
   return PHYHIP_SUCCESS;
 }
 
