@@ -35,6 +35,11 @@ constexpr bool kDiag = true;
 #else
 constexpr bool kDiag = false;
 #endif
+// A/B switches (another kernel or another route to the same numbers: PHYHIP_NT_GROUPS, _NT2_DIST, _DIST, _BLOCK, _GENERIC_NT/AA,
+// _FOLD_PMATS, _PM_COPY, _EAGER_PMAT, _ARGS_RECS, _ARG_UPLOADS, _SPLIT_REDUCE, _SPIN, _RESIDENT_DIRECT, _AA_NW) are read by the
+// diag build only; the product library reads PHYHIP_DEVICE, _RESIDENT, _RESIDENT_IDLE_US, _RESIDENT_STATS, _HOST_SUM and
+// _SHARD_THREADS.  tests/test_gpu_switches.py runs every A/B switch on the diag build and holds it to the default's numbers.
+static inline const char *diag_env(const char *name) { return kDiag ? getenv(name) : nullptr; }
 // PHYHIP_DIAG + PHYHIP_HOSTPROF=1: where the host's time per scalar-returning call goes (cycle counter, printed at finalize)
 struct HostProf { unsigned long long prep = 0, launch = 0, wait = 0, n_launch = 0, n_wait = 0, t_first = 0, t_last = 0; };
 static HostProf g_hp;
@@ -286,6 +291,26 @@ Instance *get(int id)
 
 thread_local int g_cur_dev = -1;
 
+// THE choke point of the resident protocol: resident workgroups are not ordered with the
+// instance's stream, so they may only be used while nothing queued on it is still running.  Every entry point of the C ABI
+// that names an instance comes through here (GET_INST) and thereby declares the stream dirty -- "may have enqueued work" is
+// the default.  The only ways back are the three leave_* helpers below, used by the entry points on the explicit lists of
+// tests/test_abi.py::test_resident_choke_point (a new entry point that touches an instance without GET_INST, or a new use
+// of a leave_* helper, fails that test until it is reviewed and listed).
+static inline void enter_stream_work(Instance *I)
+{
+  I->dirty_prev   = I->stream_dirty;
+  I->stream_dirty = true;
+  I->touched_call = false;
+  ++I->api_no;
+}
+// the call only queued (operations, matrix rebuilds): nothing went onto the stream unless a flush inside it said so
+static inline void leave_queued_only(Instance *I) { if (!I->touched_call) I->stream_dirty = I->dirty_prev; }
+// the call queues nothing by itself; whatever it runs (flush / eigen_eval) marks the stream itself
+static inline void leave_untouched(Instance *I) { I->stream_dirty = I->dirty_prev; }
+// a query: queues nothing and is not a step of the call sequence the resident evaluators watch
+static inline void leave_query(Instance *I) { I->stream_dirty = I->dirty_prev; --I->api_no; }
+
 // hipSetDevice costs about a microsecond; the surface is entered hundreds of thousands of times per tree
 // search, so only switch when the calling thread is actually on another device
 #define GET_INST(I, id)                                                                                      \
@@ -296,10 +321,7 @@ thread_local int g_cur_dev = -1;
     HIPCHK(hipSetDevice(I->dev));                                                                            \
     g_cur_dev = I->dev;                                                                                      \
   }                                                                                                          \
-  I->dirty_prev = I->stream_dirty; /* any entry point may queue work on the stream (see Instance::stream_dirty) */ \
-  I->stream_dirty = true;                                                                                    \
-  I->touched_call = false;                                                                                   \
-  ++I->api_no;
+  enter_stream_work(I);
 
 int next_pow2(int x)
 {
@@ -1410,16 +1432,16 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
 
-  I->perm = (I->S == 20) && (I->C <= 4) && (I->class_axis || !(getenv("PHYHIP_GENERIC_AA") && atoi(getenv("PHYHIP_GENERIC_AA"))));
-  I->soa  = (I->S == 4) && (I->C <= 4) && !(kDiag && getenv("PHYHIP_NT_SOA") && atoi(getenv("PHYHIP_NT_SOA")) == 0) &&
-            !(getenv("PHYHIP_GENERIC_NT") && atoi(getenv("PHYHIP_GENERIC_NT")));
+  I->perm = (I->S == 20) && (I->C <= 4) && (I->class_axis || !(diag_env("PHYHIP_GENERIC_AA") && atoi(diag_env("PHYHIP_GENERIC_AA"))));
+  I->soa  = (I->S == 4) && (I->C <= 4) && !(diag_env("PHYHIP_NT_SOA") && atoi(diag_env("PHYHIP_NT_SOA")) == 0) &&
+            !(diag_env("PHYHIP_GENERIC_NT") && atoi(diag_env("PHYHIP_GENERIC_NT")));
   I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
   // category groups of the lane-per-pattern kernel (phyhip_nt2.hpp): split a pattern over 2 lanes while the
   // alignment is too short to give every SIMD two waves of 64 patterns
   I->nt_groups = 1;
   // measured (us per traversal, G=2 / G=1): 50 k 195 / 206, 75 k 301 / 363, 125 k 444 / 456, 250 k 837 / 848, 1 M 3293 / 3246
   if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 4096) I->nt_groups = 2;
-  if (const char *e = getenv("PHYHIP_NT_GROUPS"))
+  if (const char *e = diag_env("PHYHIP_NT_GROUPS"))
   {
     const int g = atoi(e);
     if (g >= 1 && g <= 4 && I->C % g == 0 && 64 % g == 0 && !(I->C == 2 && g == 4)) I->nt_groups = g;
@@ -1441,7 +1463,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     const long long ntiles = I->Ppad / (16 / aa_cb(I->C));
     const long long cus    = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     I->aa_nw = (int)std::min<long long>(kAaMaxCons, std::max<long long>(1, (ntiles + cus - 1) / cus));
-    if (const char *e = getenv("PHYHIP_AA_NW")) { const int v = atoi(e); if (v >= 1 && v <= kAaMaxCons) I->aa_nw = v; }
+    if (const char *e = diag_env("PHYHIP_AA_NW")) { const int v = atoi(e); if (v >= 1 && v <= kAaMaxCons) I->aa_nw = v; }
     I->grid_aa = (int)((ntiles + I->aa_nw - 1) / I->aa_nw);
   }
   HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->Ppad));
@@ -1484,15 +1506,15 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   // The pipelined nucleotide kernel is instruction-issue bound per CU, so CU-level balance matters more than
   // workgroup size: one-wave workgroups let the dispatcher spread e.g. 3125 waves as 12-13 per CU instead of
   // 3-4 four-wave groups (measured: 100 taxa x 50 000 patterns, 288 -> 25x us).
-  if (const char *e = getenv("PHYHIP_NT2_DIST")) I->nt2_dist = atoi(e) == 1 ? 1 : 2;
+  if (const char *e = diag_env("PHYHIP_NT2_DIST")) I->nt2_dist = atoi(e) == 1 ? 1 : 2;
   I->block_nt = 64;
-  if (const char *e = getenv("PHYHIP_BLOCK")) { int b = atoi(e); if (b == 64 || b == 128 || b == 256) I->block_nt = b; }
+  if (const char *e = diag_env("PHYHIP_BLOCK")) { int b = atoi(e); if (b == 64 || b == 128 || b == 256) I->block_nt = b; }
   I->grid_nt = (int)(((long long)I->P * I->CP + I->block_nt - 1) / I->block_nt);
   {
     // distance-2 prefetch needs 168 VGPRs (3 waves/SIMD), distance-1 fits 4 waves/SIMD: prefer the deeper
     // pipeline unless that would leave a nearly empty second residency round
     const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
-    if (!getenv("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
+    if (!diag_env("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
     if (I->soa) I->prefetch_dist = I->nt2_dist;
     if (I->perm) I->prefetch_dist = 1; // the 20-state kernels forward only the previous result
   }
@@ -1501,7 +1523,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipMalloc((void **)&I->d_result, 2 * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&I->h_result, 4 * sizeof(double), hipHostMallocMapped));
   memset(I->h_result, 0, 4 * sizeof(double));
-  if (const char *e = getenv("PHYHIP_SPIN")) I->spin_wait = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_SPIN")) I->spin_wait = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_warn, sizeof(int)));
   HIPCHK(hipMemset(I->d_warn, 0, sizeof(int)));
   HIPCHK(hipHostMalloc((void **)&I->h_warn, sizeof(int), hipHostMallocMapped));
@@ -1516,7 +1538,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   if (const char *e = getenv("PHYHIP_HOST_SUM")) I->host_sum = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_RESIDENT")) I->resident = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_RESIDENT_IDLE_US")) I->resident_idle_us = atof(e);
-  if (const char *e = getenv("PHYHIP_RESIDENT_DIRECT")) I->resident_direct = atoi(e);
+  if (const char *e = diag_env("PHYHIP_RESIDENT_DIRECT")) I->resident_direct = atoi(e);
 
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
@@ -1533,25 +1555,25 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->pm_slot.assign(I->nmat, -1);
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
   I->slot_kind.assign(I->ops_slots, -1);
-  if (const char *e = getenv("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
 #ifdef PHYHIP_DIAG
-  if (const char *e = getenv("PHYHIP_ABLATE")) I->ablate = atoi(e);
-  if (const char *e = getenv("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_ABLATE")) I->ablate = atoi(e);
+  if (const char *e = diag_env("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
 #endif
-  if (const char *e = getenv("PHYHIP_EAGER_PMAT")) I->eager_pmats = atoi(e) != 0;
-  if (const char *e = getenv("PHYHIP_ARG_UPLOADS")) I->arg_uploads = atoi(e) != 0;
-  if (const char *e = getenv("PHYHIP_ARGS_RECS")) I->args_recs = atoi(e) != 0;
-  if (const char *e = getenv("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce()
+  if (const char *e = diag_env("PHYHIP_EAGER_PMAT")) I->eager_pmats = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_ARG_UPLOADS")) I->arg_uploads = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_ARGS_RECS")) I->args_recs = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce()
   {
     I->split_reduce        = atoi(e) != 0;
     I->split_reduce_forced = true;
   }
-  if (const char *e = getenv("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
-  if (const char *e = getenv("PHYHIP_FOLD_PMATS")) I->fold_pmats = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_PM_COPY")) I->pm_copy = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_FOLD_PMATS")) I->fold_pmats = atoi(e) != 0;
   HIPCHK(hipMalloc((void **)&I->d_mixexpl, sizeof(double) * kMaxMixClasses * 2 * 20));
   HIPCHK(hipMalloc((void **)&I->d_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
   HIPCHK(hipMemset(I->d_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups)));
-  if (const char *e = getenv("PHYHIP_DIST"))
+  if (const char *e = diag_env("PHYHIP_DIST"))
     if (!I->perm && !I->soa) I->prefetch_dist = atoi(e) == 1 ? 1 : 2;
 
   // codes 0..S-1 are the single states
@@ -1882,7 +1904,7 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
   // A whole-tree batch (Update_All_PMat, src/lk.c:500-512) is launched now rather than with the traversal: the device
   // rebuilds the matrices while the host walks the tree and fills the operation list.
   if (count >= kEagerPmBatch && I->eager_pmats) return flush_pmats(I);
-  if (!I->touched_call) I->stream_dirty = I->dirty_prev; // only queued
+  leave_queued_only(I);
   return PHYHIP_SUCCESS;
 }
 
@@ -1952,7 +1974,7 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
     I->mat_in_queue[o.child1TransitionMatrix] = 1;
     I->mat_in_queue[o.child2TransitionMatrix] = 1;
   }
-  if (!I->touched_call) I->stream_dirty = I->dirty_prev; // only queued
+  leave_queued_only(I);
   return PHYHIP_SUCCESS;
 }
 
@@ -2378,8 +2400,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
   }
   else
   { // a query: it queues nothing and is not a step of the call sequence the resident evaluators watch
-    I->stream_dirty = I->dirty_prev;
-    --I->api_no;
+    leave_query(I);
   }
   *out = *I->h_warn; // written by the final reduction of the last edge evaluation, ahead of its sequence number
   return PHYHIP_SUCCESS;
@@ -2596,7 +2617,7 @@ int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, dou
 {
   Group *G = get_group(instance);
   GET_INST(I, G ? G->sub_id[0] : instance);
-  I->stream_dirty = I->dirty_prev; // (queues nothing by itself; flush() says so if it does)
+  leave_untouched(I); // (queues nothing by itself; flush() says so if it does)
   if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN"); // src/lk.c:671
   if (*l < I->l_min) *l = I->l_min;                                                     // src/lk.c:673-674
   else if (*l > I->l_max) *l = I->l_max;
@@ -2609,7 +2630,7 @@ int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL)
 {
   if (Group *G = get_group(instance)) return group_eigen_eval(G, l, false, outLnL, nullptr);
   GET_INST(I, instance);
-  I->stream_dirty = I->dirty_prev;
+  leave_untouched(I);
   if (I->co) return rank_eigen_eval(I, l, false, outLnL, nullptr);
   return eigen_eval(I, l, false, outLnL, nullptr);
 }
@@ -2777,8 +2798,7 @@ int phyhip_get_resident_stats(int instance, long long out[8])
     return PHYHIP_SUCCESS;
   }
   GET_INST(I, instance);
-  I->stream_dirty = I->dirty_prev;
-  --I->api_no; // (a query: not a step in the call sequence the evaluator watches)
+  leave_query(I);
   for (int k = 0; k < 8; ++k) out[k] = 0;
   int k = 0;
   for (const Resident *R : {&I->rd, &I->rt})

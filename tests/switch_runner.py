@@ -1,0 +1,57 @@
+"""Child process of tests/test_gpu_switches.py: loads the DIAG build of the engine (PHYHIP_LIBDIR is set by the parent), runs
+the golden fixture and a seeded SPR / Br_Len_Opt call stream under the environment it was given, and prints one JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import orc  # noqa: E402,F401
+import phyg  # noqa: E402
+from gpu_common import device_tree_from_golden, synthetic_pair  # noqa: E402
+
+
+def main():
+    d = phyg.load(os.path.join(ROOT, "tests", "golden", "nucleic_gtr_g4.phyg"))
+    t, ot = device_tree_from_golden(d)
+    res = {}
+    try:
+        t.Set_Both_Sides(True)
+        lnl = t.Lk(None)
+        res["lnl_rel"] = abs(lnl - d["lnL"][0]) / abs(d["lnL"][0])
+        w = d["wght"] > 0
+        ot.lk(None, both_sides=True)
+        ok = True
+        for (e, side), p in ot.plk.items():
+            ok = ok and np.array_equal(t.partials(e, side)[w], p[w]) and np.array_equal(t.scale_factors(e, side)[w], ot.scale[(e, side)][w])
+        res["vectors_bit_equal"] = bool(ok)
+    finally:
+        t.close()
+    from phyml_amd import replay
+    t, ot, tree, st = synthetic_pair(26, 900, 4, 4, seed=19, host_pmat=False, ambiguous_every=11)
+    try:
+        t.Set_Both_Sides(True)
+        t.Lk(None)
+        tr = replay.make_trace(26, tree.edge_left, tree.edge_rght, tree.edge_len, 40, seed=2, walk_every=3, opt_every=4, n_dlk=3)
+        a, a2 = t.Replay_Surface_Trace(tr)
+    finally:
+        t.close()
+    res["stream"] = [float.hex(float(x)) for x in a]
+    res["stream2"] = [float.hex(float(x)) for x in a2]
+    # 20 states: the golden proteic fixture (generic kernel against the MFMA kernel)
+    d = phyg.load(os.path.join(ROOT, "tests", "golden", "proteic_lg_g4.phyg"))
+    t, ot = device_tree_from_golden(d)
+    try:
+        lnl = t.Lk(None)
+        res["aa_lnl_rel"] = abs(lnl - d["lnL"][0]) / abs(d["lnL"][0])
+    finally:
+        t.close()
+    print("SWITCH_RESULT " + json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

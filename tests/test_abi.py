@@ -138,7 +138,45 @@ def test_every_environment_switch_is_documented():
         for f in glob.glob(os.path.join(root, pat)):
             src += open(f).read()
     docs = "".join(open(os.path.join(root, f)).read() for f in ("tools/README.md", "include/phyhip.h", "INTEGRATION.md", "DESIGN.md"))
-    names = sorted(set(re.findall(r'getenv\("(PHYHIP_[A-Z0-9_]+)"\)', src)))
+    names = sorted(set(re.findall(r'(?:getenv|diag_env)\("(PHYHIP_[A-Z0-9_]+)"\)', src)))
     assert len(names) > 10
+    # the product library reads only these; every other switch goes through diag_env (diag build only)
+    product = set(re.findall(r'[^_a-z]getenv\("(PHYHIP_[A-Z0-9_]+)"\)', src))
+    assert product <= {"PHYHIP_DEVICE", "PHYHIP_RESIDENT", "PHYHIP_RESIDENT_IDLE_US", "PHYHIP_RESIDENT_STATS", "PHYHIP_HOST_SUM",
+                       "PHYHIP_SHARD_THREADS", "PHYHIP_HOSTPROF", "PHYHIP_RESIDENT_DEBUG"}, product  # (the last two: behind kDiag)
     missing = [n for n in names if n not in docs]
     assert not missing, missing
+
+
+def test_resident_choke_point():
+    """The resident evaluators are only safe while every entry point that names an instance declares the stream dirty unless it
+    is KNOWN not to have enqueued anything.  Enforced statically on the source: every exported `phyhip_*` function either goes
+    through GET_INST (= enter_stream_work, the choke point) or is on the reviewed list of functions that never touch an
+    instance's stream themselves; the three `leave_*` helpers (the only ways back to "clean") are used by exactly the reviewed
+    functions; nothing else writes `stream_dirty = ... dirty_prev`."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "phyml_amd", "csrc", "phyhip.hip")).read()
+    ext = src[src.index('extern "C" {'):]
+    heads = [(m.start(), m.group(1)) for m in re.finditer(r'^(?:int|const char \*)\s*(phyhip_[a-z_0-9]+)\(', ext, flags=re.M)]
+    bodies = {}
+    for (a, name), nxt in zip(heads, heads[1:] + [(len(ext), None)]):
+        bodies[name] = ext[a:nxt[0]]
+    from phyml_amd import capi
+    assert set(capi.SYMBOLS) <= set(bodies), sorted(set(capi.SYMBOLS) - set(bodies))
+    # functions that never name ONE instance's stream themselves: no instance at all, creation, or a loop that calls GET_INST
+    # per class instance
+    NO_INSTANCE = {"phyhip_get_last_error", "phyhip_create_instance", "phyhip_comm_get_unique_id"}
+    for name, body in bodies.items():
+        if name in NO_INSTANCE:
+            continue
+        assert "GET_INST(" in body, f"{name}: touches an instance without the choke point (GET_INST / enter_stream_work)"
+    REVIEWED = {"leave_queued_only": {"phyhip_update_transition_matrices", "phyhip_update_partials"},
+                "leave_untouched": {"phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl"},
+                "leave_query": {"phyhip_get_numerical_warning", "phyhip_get_resident_stats"}}
+    for helper, allowed in REVIEWED.items():
+        users = {name for name, body in bodies.items() if helper + "(" in body}
+        assert users == allowed, (helper, sorted(users ^ allowed))
+    # ... and nobody restores the flag by hand
+    assert len(re.findall(r"stream_dirty\s*=\s*I->dirty_prev", src)) == 3  # the three helpers themselves
+    assert src.count("enter_stream_work(I)") == 1  # called from GET_INST and nowhere else

@@ -1,59 +1,67 @@
-"""Every environment switch of the product library that selects another kernel or another route to the same numbers gives the
-same numbers: golden lnL, partial vectors and scale vectors bit-equal to the oracle, and a seeded SPR / Br_Len_Opt call
-stream equal to the default build's, scalar by scalar (tools/README.md lists the switches and what each was measured for)."""
-import numpy as np
-import pytest
+"""Every A/B switch of the engine (another kernel or another route to the same numbers; read by the DIAG build only --
+phyml_amd/lib_diag, built next to the product by __graft_entry__.build()) gives the same numbers: golden lnL, partial vectors
+and scale vectors bit-equal to the oracle, and a seeded SPR / Br_Len_Opt call stream equal to the default's, scalar by
+scalar (tools/README.md lists the switches and what each was measured for).  The switches the PRODUCT library still reads
+(PHYHIP_RESIDENT, PHYHIP_HOST_SUM) are run on the product."""
+import json
+import os
+import subprocess
+import sys
 
-import orc  # noqa: F401
-from gpu_common import device_tree_from_golden, synthetic_pair
+import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = [{}, {"PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_NT_GROUPS": "2"}, {"PHYHIP_NT_GROUPS": "4"}, {"PHYHIP_NT2_DIST": "1"},
-            {"PHYHIP_NT2_DIST": "1", "PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_FOLD_PMATS": "0"}, {"PHYHIP_ARGS_RECS": "0"},
-            {"PHYHIP_RESIDENT": "0"}, {"PHYHIP_HOST_SUM": "0"}, {"PHYHIP_SPIN": "0"}, {"PHYHIP_EAGER_PMAT": "0"},
-            {"PHYHIP_PM_COPY": "1"}, {"PHYHIP_GENERIC_NT": "1"}]
-_stream = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG = [{}, {"PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_NT_GROUPS": "2"}, {"PHYHIP_NT_GROUPS": "4"}, {"PHYHIP_NT2_DIST": "1"},
+        {"PHYHIP_NT2_DIST": "1", "PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_FOLD_PMATS": "0"}, {"PHYHIP_ARGS_RECS": "0"},
+        {"PHYHIP_SPIN": "0"}, {"PHYHIP_EAGER_PMAT": "0"}, {"PHYHIP_PM_COPY": "1"}, {"PHYHIP_GENERIC_NT": "1"},
+        {"PHYHIP_GENERIC_AA": "1"}, {"PHYHIP_AA_NW": "3"}, {"PHYHIP_SPLIT_REDUCE": "1"}, {"PHYHIP_ARG_UPLOADS": "0"}]
+PRODUCT = [{}, {"PHYHIP_RESIDENT": "0"}, {"PHYHIP_HOST_SUM": "0"}]
+_cache = {}
 
 
 def _ids(sw):
     return ",".join(f"{k[7:]}={v}" for k, v in sw.items()) or "default"
 
 
-@pytest.mark.parametrize("sw", SWITCHES, ids=_ids)
-def test_switch_gives_the_same_numbers(sw, golden, monkeypatch):
-    for k, v in sw.items():
-        monkeypatch.setenv(k, v)
-    d = golden("nucleic_gtr_g4")
-    t, ot = device_tree_from_golden(d)
-    try:
-        t.Set_Both_Sides(True)
-        lnl = t.Lk(None)
-        assert abs(lnl - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-12
-        w = d["wght"] > 0
-        ot.lk(None, both_sides=True)
-        for (e, side), p in ot.plk.items():
-            assert np.array_equal(t.partials(e, side)[w], p[w]), (e, side)
-            assert np.array_equal(t.scale_factors(e, side)[w], ot.scale[(e, side)][w]), (e, side)
-    finally:
-        t.close()
-    # the call stream of a search: device-built matrices, partial updates, edge likelihoods, eigen products, dLk chains
-    from phyml_amd import replay
-    t, ot, tree, st = synthetic_pair(26, 900, 4, 4, seed=19, host_pmat=False, ambiguous_every=11)
-    try:
-        t.Set_Both_Sides(True)
-        t.Lk(None)
-        tr = replay.make_trace(26, tree.edge_left, tree.edge_rght, tree.edge_len, 40, seed=2, walk_every=3, opt_every=4, n_dlk=3)
-        out = t.Replay_Surface_Trace(tr)
-    finally:
-        t.close()
-    if not sw:
-        _stream["default"] = out
-    elif "default" in _stream:
-        a, a2 = _stream["default"]
-        if "PHYHIP_GENERIC_NT" in sw or "PHYHIP_HOST_SUM" in sw or sw.get("PHYHIP_NT_GROUPS") in ("1", "4"):
-            # another kernel shape adds the patterns' contributions in another order: the same value to rounding
-            m = a != 0
-            assert np.max(np.abs(out[0][m] - a[m]) / np.abs(a[m])) < 1e-12
-        else:
-            assert np.array_equal(out[0], a) and np.array_equal(out[1], a2)
+def _run(libdir, sw):
+    key = (libdir, tuple(sorted(sw.items())))
+    if key not in _cache:
+        env = dict(os.environ)
+        env.update(sw)
+        env["PHYHIP_LIBDIR"] = os.path.join(ROOT, "phyml_amd", libdir)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_runner.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [x for x in r.stdout.splitlines() if x.startswith("SWITCH_RESULT ")][-1]
+        _cache[key] = json.loads(line[len("SWITCH_RESULT "):])
+    return _cache[key]
+
+
+def _check(libdir, sw):
+    res, base = _run(libdir, sw), _run(libdir, {})
+    assert res["lnl_rel"] < 1e-12 and res["vectors_bit_equal"] and res["aa_lnl_rel"] < 1e-12
+    a, b = [float.fromhex(x) for x in res["stream"]], [float.fromhex(x) for x in base["stream"]]
+    a2, b2 = [float.fromhex(x) for x in res["stream2"]], [float.fromhex(x) for x in base["stream2"]]
+    reorder = ("PHYHIP_GENERIC_NT" in sw or "PHYHIP_HOST_SUM" in sw or "PHYHIP_SPLIT_REDUCE" in sw or
+               sw.get("PHYHIP_NT_GROUPS") in ("1", "4"))
+    if reorder:  # another kernel shape / another final sum adds the patterns' contributions in another order
+        assert max(abs(x - y) / abs(y) for x, y in zip(a, b) if y != 0) < 1e-12
+    else:
+        assert a == b and a2 == b2
+
+
+@pytest.mark.parametrize("sw", DIAG, ids=_ids)
+def test_diag_switch_gives_the_same_numbers(sw):
+    _check("lib_diag", sw)
+
+
+@pytest.mark.parametrize("sw", PRODUCT, ids=_ids)
+def test_product_switch_gives_the_same_numbers(sw):
+    _check("lib", sw)
+
+
+def test_the_diag_build_and_the_product_agree():
+    a, b = _run("lib_diag", {}), _run("lib", {})
+    assert a["stream"] == b["stream"] and a["stream2"] == b["stream2"]
