@@ -141,6 +141,7 @@ typedef struct
      class k > 0 sees exactly the call class 0 just made and registers its pointers under the same ids. */
   int         cls, K;          /* class index / class count (K = 0: ordinary context) */
   void       *batch;           /* clsbatch_t of the element (class-0 context only) */
+  int         is_class_tree;   /* tree->mixt_tree != NULL when the context was made (the tree object may be gone later) */
 } ctx_t;
 static int g_class_axis = 0;
 /* The partial updates class 0 queued since the last mixture evaluation.  The reference walks the class trees one after
@@ -260,7 +261,8 @@ static ctx_t *ensure_instance(t_tree *tree)
   if (!tree->mixt_tree && g_nctx > 0)
   { /* a fresh tree object for the same data (aLRT_From_String rebuilds the tree from its Newick string and calls
        Make_Tree_For_Lk again; under BEAGLE it creates a fresh instance there too, src/utilities.c:9314): the old instance goes */
-    if (g_nctx != 1 || g_ctx[0].tree->mixt_tree) { fprintf(stderr, "glue_driver: an ordinary tree after class trees\n"); exit(5); }
+    /* (the replaced tree object may already be freed -- bootstrap replicates: never look into it) */
+    if (g_nctx != 1 || g_ctx[0].is_class_tree) { fprintf(stderr, "glue_driver: an ordinary tree after class trees\n"); exit(5); }
     OK(phyhip_finalize_instance(g_ctx[0].inst));
     g_nctx = 0;
   }
@@ -278,7 +280,7 @@ static ctx_t *ensure_instance(t_tree *tree)
         if (t->mod->ras->invar == YES) continue;
         ctx_t *c = &g_ctx[g_nctx++];
         memset(c, 0, sizeof *c);
-        c->tree = t; c->cls = k; c->K = K;
+        c->tree = t; c->cls = k; c->K = K; c->is_class_tree = 1;
         c->bufcap = 3 * t->n_otu - 2; c->matcap = 2 * t->n_otu - 1;
         if (k == 0)
         {
@@ -304,6 +306,7 @@ static ctx_t *ensure_instance(t_tree *tree)
   ++g_n_created;
   const int n = tree->n_otu, P = tree->data->n_pattern, S = tree->mod->ns, C = tree->mod->ras->n_catg;
   c->tree = tree;
+  c->is_class_tree = tree->mixt_tree != NULL;
   c->bufcap = 3 * n - 2;  /* internal edge sides + both sides of the two spare SPR edges (src/make.c:96-104) */
   c->matcap = 2 * n - 1;
   if (c->bufcap > MAXID || c->matcap > MAXID) { fprintf(stderr, "glue_driver: tree too large for the index tables\n"); exit(5); }
