@@ -3,7 +3,7 @@
 # default bench command (cfg2, which also runs the cfg3 line under `extra`), then separate counter-only passes (each
 # bounded by `timeout`), summaries under gpurun_out/<tag>/ AND, with the hash of the kernel sources they were taken on,
 # under profiles/<tag>_* (bench.py reports `roofline.traffic` only from a profile whose hash matches the sources it runs).
-tag=${1:-r02}
+tag=${1:-r03}
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
