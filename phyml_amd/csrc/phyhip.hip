@@ -1315,6 +1315,25 @@ template <typename Q> void fill_mixture_invariant(const Instance *I, Q &q)
   for (int s = 0; s < 20; ++s) q.pi_inv[s] = I->mix_pi_inv[s];
 }
 
+// Where a mixture evaluation's sums go: to the host (mo == nullptr: host-side final sum or the ticket path, then the caller
+// waits), or -- one shard of a sharded evaluation -- into device memory next to the warning flag, nobody waiting (the
+// collective follows, phyhip_shard.hpp)
+struct MixOut
+{
+  double *dev_out, *warn_out;
+};
+static void mix_finish_setup(Instance *I0, FinishParams &fin, int grid, int ns, const MixOut *mo)
+{
+  fin.block_sums = I0->d_block; fin.stride = grid; fin.warn = I0->d_warn; fin.tickets = I0->d_tickets; fin.warn_host = I0->h_warn;
+  if (mo)
+  {
+    fin.result = mo->dev_out; fin.result_host = nullptr; fin.seq = 0; fin.warn_out = mo->warn_out;
+    return;
+  }
+  fin.result = I0->d_result; fin.result_host = I0->h_result; fin.seq = ++I0->seq;
+  host_sum_finish(I0, fin, grid, ns);
+}
+
 #include "phyhip_shard.hpp"
 
 } // namespace
@@ -1369,15 +1388,13 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(PHYHIP_ERROR_NO_RESOURCE, "no HIP device visible: libphyhip has no CPU fallback");
-  if ((requirementFlags & PHYHIP_FLAG_CLASS_AXIS) && resourceList && (resourceCount > 1 || (requirementFlags & PHYHIP_FLAG_SHARDED)))
-    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "mixtures are not sharded");
   if (resourceList && (resourceCount > 1 || (resourceCount == 1 && (requirementFlags & PHYHIP_FLAG_SHARDED))))
   { // sharded instance: one per-device instance per entry of the resource list + the RCCL communicators
     for (int g = 0; g < resourceCount; ++g)
       if (resourceList[g] < 0 || resourceList[g] >= ndev)
         return fail(PHYHIP_ERROR_NO_RESOURCE, "device %d not present (%d visible)", resourceList[g], ndev);
     return create_group(tipCount, partialsBufferCount, stateCount, patternCount, matrixBufferCount, categoryCount, resourceList,
-                        resourceCount, returnInfo);
+                        resourceCount, returnInfo, requirementFlags & PHYHIP_FLAG_CLASS_AXIS);
   }
   int dev = 0;
   if (resourceList && resourceCount > 0) dev = resourceList[0];
@@ -2052,9 +2069,9 @@ int phyhip_calculate_edge_log_likelihoods_device(int instance, int parent, int c
   return flush(I, &ee);
 }
 
-int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, const int *parent, const int *child, const int *pm,
-                                            const double *classProba, const double *rMatWeight, const double *eFrqWeight,
-                                            double rMatWeightSum, double eFrqWeightSum, double sumProbas, double *outLnL)
+static int mixture_lnl_impl(const int *instances, int count, const int *parent, const int *child, const int *pm,
+                            const double *classProba, const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
+                            double eFrqWeightSum, double sumProbas, double *outLnL, const MixOut *mo)
 {
   if (count < 1 || count > kMaxMixClasses) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "1..%d mixture classes", kMaxMixClasses);
   Instance *I0 = nullptr;
@@ -2085,22 +2102,48 @@ int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, con
   q.wght = I0->d_wght; q.site_lnl = I0->d_site_lnl; q.cat_stride = 1;
   fill_mixture_invariant(I0, q);
   const int grid = (int)((I0->P + 255) / 256);
-  q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
-  q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
-  q.fin.seq = ++I0->seq;
-  host_sum_finish(I0, q.fin, grid, 1);
+  mix_finish_setup(I0, q.fin, grid, 1, mo);
   hipLaunchKernelGGL(mixture_combine_kernel, dim3(grid), dim3(256), 0, I0->stream, q);
   HIPCHK(hipGetLastError());
+  if (mo) return PHYHIP_SUCCESS;
   int rc = wait_result(I0);
   if (rc) return rc;
   *outLnL = I0->h_result[0];
   return PHYHIP_SUCCESS;
 }
 
-int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, const int *left, const int *right, double *l,
+int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, const int *parent, const int *child, const int *pm,
                                             const double *classProba, const double *rMatWeight, const double *eFrqWeight,
-                                            double rMatWeightSum, double eFrqWeightSum, double sumProbas, double *outLnL,
-                                            double *outDLnL)
+                                            double rMatWeightSum, double eFrqWeightSum, double sumProbas, double *outLnL)
+{
+  if (count >= 1 && get_group(instances[0]))
+  { // class instances that are sharded instances: every shard combines its own patterns, ONE all-reduce of {warning, lnL}
+    std::vector<Group *> Gs;
+    int rc = mixture_groups(instances, count, Gs);
+    if (rc) return rc;
+    Group *G0 = Gs[0];
+    rc = group_parallel(G0, [&](int g) -> int {
+      int ids[kMaxMixClasses];
+      for (int k = 0; k < count; ++k) ids[k] = Gs[k]->sub_id[g];
+      double      *slot = shard_slot(G0->co->ctx[G0->ctx_of[g]], G0->k_of[g]);
+      const MixOut mo{slot + 1, slot};
+      return mixture_lnl_impl(ids, count, parent, child, pm, classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum, sumProbas,
+                              nullptr, &mo);
+    });
+    if (rc) return rc;
+    if ((rc = reduce_and_publish(*G0->co, 2, G0->sub[0]))) return rc;
+    *outLnL        = G0->sub[0]->h_result[0];
+    G0->last_warn  = *G0->sub[0]->h_warn;
+    G0->warn_valid = true;
+    return PHYHIP_SUCCESS;
+  }
+  return mixture_lnl_impl(instances, count, parent, child, pm, classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum, sumProbas,
+                          outLnL, nullptr);
+}
+
+static int mixture_dlnl_impl(const int *instances, int count, const int *left, const int *right, double *l, const double *classProba,
+                             const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum, double eFrqWeightSum,
+                             double sumProbas, double *outLnL, double *outDLnL, const MixOut *mo)
 {
   if (count < 1 || count > kMaxMixClasses) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "1..%d mixture classes", kMaxMixClasses);
   if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN");
@@ -2164,10 +2207,7 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
     q.expl = I0->d_mixexpl; q.wght = I0->d_wght; q.dot_stride = S_;
     fill_mixture_invariant(I0, q);
     const int grid = (int)((I0->P + 255) / 256);
-    q.fin.block_sums = I0->d_block; q.fin.stride = grid; q.fin.warn = I0->d_warn;
-    q.fin.tickets = I0->d_tickets; q.fin.result = I0->d_result; q.fin.result_host = I0->h_result; q.fin.warn_host = I0->h_warn;
-    q.fin.seq = ++I0->seq;
-    host_sum_finish(I0, q.fin, grid, 2);
+    mix_finish_setup(I0, q.fin, grid, 2, mo);
     hipLaunchKernelGGL((mixture_dlk_kernel<S_>), dim3(grid), dim3(256), 0, I0->stream, q);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2176,14 +2216,52 @@ int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, con
   else if (I0->S == 20) rc = launch(std::integral_constant<int, 20>());
   else return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "mixtures: 4 or 20 states");
   if (rc) return rc;
+  if (mo) return PHYHIP_SUCCESS;
   if ((rc = wait_result(I0))) return rc;
   *outLnL = I0->h_result[0];
   if (outDLnL) *outDLnL = I0->h_result[1];
   return PHYHIP_SUCCESS;
 }
 
+int phyhip_calculate_mixture_eigen_lnl_dlnl(const int *instances, int count, const int *left, const int *right, double *l,
+                                            const double *classProba, const double *rMatWeight, const double *eFrqWeight,
+                                            double rMatWeightSum, double eFrqWeightSum, double sumProbas, double *outLnL,
+                                            double *outDLnL)
+{
+  if (count >= 1 && get_group(instances[0]))
+  { // sharded class instances: ONE all-reduce of {warning, lnL, dlnL}
+    std::vector<Group *> Gs;
+    int rc = mixture_groups(instances, count, Gs);
+    if (rc) return rc;
+    Group *G0 = Gs[0];
+    std::vector<double> ls(G0->sub.size(), *l); // every shard clamps its own copy the same way
+    rc = group_parallel(G0, [&](int g) -> int {
+      int ids[kMaxMixClasses];
+      for (int k = 0; k < count; ++k) ids[k] = Gs[k]->sub_id[g];
+      double      *slot = shard_slot(G0->co->ctx[G0->ctx_of[g]], G0->k_of[g]);
+      const MixOut mo{slot + 1, slot};
+      return mixture_dlnl_impl(ids, count, left, right, &ls[g], classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum,
+                               sumProbas, nullptr, nullptr, &mo);
+    });
+    if (rc) return rc;
+    *l = ls[0];
+    if ((rc = reduce_and_publish(*G0->co, 3, G0->sub[0]))) return rc;
+    *outLnL = G0->sub[0]->h_result[0];
+    if (outDLnL) *outDLnL = G0->sub[0]->h_result[1];
+    G0->last_warn  = *G0->sub[0]->h_warn;
+    G0->warn_valid = true;
+    return PHYHIP_SUCCESS;
+  }
+  return mixture_dlnl_impl(instances, count, left, right, l, classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum, sumProbas,
+                           outLnL, outDLnL, nullptr);
+}
+
 int phyhip_set_mixture_invariant_sites(int instance, int invar_model, double pinvar, const short *invar, const double *piInvariantClass)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) {
+      return phyhip_set_mixture_invariant_sites(id, invar_model, pinvar, invar ? invar + lo : nullptr, piInvariantClass);
+    });
   GET_INST(I, instance);
   if (invar_model && (!invar || !piInvariantClass)) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "invar_model set but invar / frequencies missing");
   const bool same_sites = !invar_model || (I->h_invar_set && !memcmp(I->h_invar.data(), invar, I->P * sizeof(short)));
@@ -2203,9 +2281,9 @@ int phyhip_set_mixture_invariant_sites(int instance, int invar_model, double pin
 
 // ---- mixtures on the class axis of ONE instance --------------------------------------------------------------------
 
-int phyhip_calculate_class_mixture_log_likelihood(int instance, int parent, int child, int pm, const double *classProba,
-                                                  const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
-                                                  double eFrqWeightSum, double sumProbas, double *outLnL)
+static int class_mixture_lnl_impl(int instance, int parent, int child, int pm, const double *classProba, const double *rMatWeight,
+                                  const double *eFrqWeight, double rMatWeightSum, double eFrqWeightSum, double sumProbas,
+                                  double *outLnL, const MixOut *mo)
 {
   GET_INST(I, instance);
   if (!I->class_axis) return fail(PHYHIP_ERROR_GENERAL, "instance %d was not created with PHYHIP_FLAG_CLASS_AXIS", instance);
@@ -2228,20 +2306,41 @@ int phyhip_calculate_class_mixture_log_likelihood(int instance, int parent, int 
   q.wght = I->d_wght; q.site_lnl = I->d_site_lnl; q.cat_stride = I->C;
   fill_mixture_invariant(I, q);
   const int grid = (int)((I->P + 255) / 256);
-  q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
-  q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
-  q.fin.seq = ++I->seq;
-  host_sum_finish(I, q.fin, grid, 1);
+  mix_finish_setup(I, q.fin, grid, 1, mo);
   hipLaunchKernelGGL(mixture_combine_kernel, dim3(grid), dim3(256), 0, I->stream, q);
   HIPCHK(hipGetLastError());
+  if (mo) return PHYHIP_SUCCESS;
   if ((rc = wait_result(I))) return rc;
   *outLnL = I->h_result[0];
   return PHYHIP_SUCCESS;
 }
 
-int phyhip_calculate_class_mixture_eigen_lnl_dlnl(int instance, int left, int right, double *l, const double *classProba,
+int phyhip_calculate_class_mixture_log_likelihood(int instance, int parent, int child, int pm, const double *classProba,
                                                   const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
-                                                  double eFrqWeightSum, double sumProbas, double *outLnL, double *outDLnL)
+                                                  double eFrqWeightSum, double sumProbas, double *outLnL)
+{
+  if (Group *G = get_group(instance))
+  {
+    int rc = group_parallel(G, [&](int g) -> int {
+      double      *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
+      const MixOut mo{slot + 1, slot};
+      return class_mixture_lnl_impl(G->sub_id[g], parent, child, pm, classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum,
+                                    sumProbas, nullptr, &mo);
+    });
+    if (rc) return rc;
+    if ((rc = reduce_and_publish(*G->co, 2, G->sub[0]))) return rc;
+    *outLnL       = G->sub[0]->h_result[0];
+    G->last_warn  = *G->sub[0]->h_warn;
+    G->warn_valid = true;
+    return PHYHIP_SUCCESS;
+  }
+  return class_mixture_lnl_impl(instance, parent, child, pm, classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum, sumProbas,
+                                outLnL, nullptr);
+}
+
+static int class_mixture_dlnl_impl(int instance, int left, int right, double *l, const double *classProba, const double *rMatWeight,
+                                   const double *eFrqWeight, double rMatWeightSum, double eFrqWeightSum, double sumProbas,
+                                   double *outLnL, double *outDLnL, const MixOut *mo)
 {
   GET_INST(I, instance);
   if (!I->class_axis) return fail(PHYHIP_ERROR_GENERAL, "instance %d was not created with PHYHIP_FLAG_CLASS_AXIS", instance);
@@ -2284,16 +2383,40 @@ int phyhip_calculate_class_mixture_eigen_lnl_dlnl(int instance, int left, int ri
   q.expl = I->d_mixexpl; q.wght = I->d_wght; q.dot_stride = I->C * I->S;
   fill_mixture_invariant(I, q);
   const int grid = (int)((I->P + 255) / 256);
-  q.fin.block_sums = I->d_block; q.fin.stride = grid; q.fin.warn = I->d_warn;
-  q.fin.tickets = I->d_tickets; q.fin.result = I->d_result; q.fin.result_host = I->h_result; q.fin.warn_host = I->h_warn;
-  q.fin.seq = ++I->seq;
-  host_sum_finish(I, q.fin, grid, 2);
+  mix_finish_setup(I, q.fin, grid, 2, mo);
   hipLaunchKernelGGL((mixture_dlk_kernel<20>), dim3(grid), dim3(256), 0, I->stream, q);
   HIPCHK(hipGetLastError());
+  if (mo) return PHYHIP_SUCCESS;
   if ((rc = wait_result(I))) return rc;
   *outLnL = I->h_result[0];
   if (outDLnL) *outDLnL = I->h_result[1];
   return PHYHIP_SUCCESS;
+}
+
+int phyhip_calculate_class_mixture_eigen_lnl_dlnl(int instance, int left, int right, double *l, const double *classProba,
+                                                  const double *rMatWeight, const double *eFrqWeight, double rMatWeightSum,
+                                                  double eFrqWeightSum, double sumProbas, double *outLnL, double *outDLnL)
+{
+  if (Group *G = get_group(instance))
+  {
+    std::vector<double> ls(G->sub.size(), *l);
+    int rc = group_parallel(G, [&](int g) -> int {
+      double      *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
+      const MixOut mo{slot + 1, slot};
+      return class_mixture_dlnl_impl(G->sub_id[g], left, right, &ls[g], classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum,
+                                     sumProbas, nullptr, nullptr, &mo);
+    });
+    if (rc) return rc;
+    *l = ls[0];
+    if ((rc = reduce_and_publish(*G->co, 3, G->sub[0]))) return rc;
+    *outLnL = G->sub[0]->h_result[0];
+    if (outDLnL) *outDLnL = G->sub[0]->h_result[1];
+    G->last_warn  = *G->sub[0]->h_warn;
+    G->warn_valid = true;
+    return PHYHIP_SUCCESS;
+  }
+  return class_mixture_dlnl_impl(instance, left, right, l, classProba, rMatWeight, eFrqWeight, rMatWeightSum, eFrqWeightSum, sumProbas,
+                                 outLnL, outDLnL, nullptr);
 }
 
 int phyhip_get_site_log_likelihoods(int instance, double *out)
@@ -2310,10 +2433,18 @@ int phyhip_get_site_log_likelihoods(int instance, double *out)
 int phyhip_get_site_outputs(int instance, double *c_lnL_sorted, double *cur_site_lk, double *unscaled, int *fact)
 {
   if (Group *G = get_group(instance))
-    return group_each(G, [&](int id, long long lo, long long) {
-      return phyhip_get_site_outputs(id, c_lnL_sorted ? c_lnL_sorted + lo : nullptr, cur_site_lk ? cur_site_lk + lo : nullptr,
-                                     unscaled ? unscaled + lo * G->C : nullptr, fact ? fact + lo : nullptr);
+  {
+    const bool cls = G->sub[0]->class_axis; // fact_sum_scale of a class-axis instance is [class][pattern]: per-class rows
+    std::vector<int> tmp;
+    return group_each(G, [&](int id, long long lo, long long n) {
+      if (cls && fact) tmp.resize((size_t)n * G->C);
+      const int rc = phyhip_get_site_outputs(id, c_lnL_sorted ? c_lnL_sorted + lo : nullptr, cur_site_lk ? cur_site_lk + lo : nullptr,
+                                             unscaled ? unscaled + lo * G->C : nullptr, !fact ? nullptr : (cls ? tmp.data() : fact + lo));
+      if (rc == PHYHIP_SUCCESS && cls && fact)
+        for (int k = 0; k < G->C; ++k) memcpy(fact + (size_t)k * G->P + lo, tmp.data() + (size_t)k * n, sizeof(int) * (size_t)n);
+      return rc;
     });
+  }
   GET_INST(I, instance);
   int rc = flush_sync(I);
   if (rc) return rc;
@@ -2350,6 +2481,8 @@ int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *o
 
 int phyhip_get_class_scale_factors(int instance, int bufferIndex, int classIndex, int *out)
 {
+  if (Group *G = get_group(instance))
+    return group_each(G, [&](int id, long long lo, long long) { return phyhip_get_class_scale_factors(id, bufferIndex, classIndex, out + lo); });
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;

@@ -288,8 +288,25 @@ static void release_group(Group *G)
   delete G;
 }
 
+// the sharded class instances of one mixture: same shard layout, same devices (mixtures on sharded instances)
+static int mixture_groups(const int *instances, int count, std::vector<Group *> &Gs)
+{
+  if (count > kMaxMixClasses) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "1..%d mixture classes", kMaxMixClasses);
+  Gs.clear();
+  for (int k = 0; k < count; ++k)
+  {
+    Group *G = get_group(instances[k]);
+    if (!G) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture class %d: sharded and plain class instances cannot be mixed", k);
+    if (k > 0 && (G->n != Gs[0]->n || G->ctx_of != Gs[0]->ctx_of || G->k_of != Gs[0]->k_of))
+      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture class %d: another shard layout than class 0", k);
+    Gs.push_back(G);
+  }
+  return 0;
+}
+
 static int create_group(int tipCount, int partialsBufferCount, int stateCount, int patternCount, int matrixBufferCount,
-                        int categoryCount, const int *resourceList, int resourceCount, phyhip_instance_details *returnInfo)
+                        int categoryCount, const int *resourceList, int resourceCount, phyhip_instance_details *returnInfo,
+                        long classAxisFlag = 0)
 {
   if (patternCount < resourceCount)
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "%d patterns cannot be sharded over %d devices", patternCount, resourceCount);
@@ -304,7 +321,7 @@ static int create_group(int tipCount, int partialsBufferCount, int stateCount, i
     const int       dev = resourceList[g];
     phyhip_instance_details det;
     const int id = phyhip_create_instance(tipCount, partialsBufferCount, 0, stateCount, (int)n, 1, matrixBufferCount, categoryCount,
-                                          0, &dev, 1, 0, 0, &det);
+                                          0, &dev, 1, 0, classAxisFlag, &det);
     if (id < 0)
     {
       release_group(G);

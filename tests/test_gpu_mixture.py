@@ -12,8 +12,24 @@ from phyml_amd import capi, lktree, phyg, replay
 pytestmark = pytest.mark.gpu
 
 
+def _layouts():
+    """None: plain instances.  Otherwise the class instances are SHARDED instances (pattern shards inside libphyhip.so, one RCCL
+    all-reduce of {warning, lnL[, dlnL]} per mixture evaluation): one forced shard, three shards on device 0 and -- with two
+    devices visible -- shards on distinct devices."""
+    import torch
+    lay = [("plain", None, False), ("one_shard_forced", [0], True), ("three_shards_dev0", [0, 0, 0], False)]
+    if torch.cuda.device_count() >= 2:
+        lay.append(("two_devices", [0, 1], False))
+    return lay
+
+
+LAYOUTS = _layouts()
+LAY = pytest.mark.parametrize("layout", LAYOUTS, ids=[x[0] for x in LAYOUTS])
+
+
+@LAY
 @pytest.mark.parametrize("host_pmat", [True, False])
-def test_lg4x_mixture_on_device(host_pmat):
+def test_lg4x_mixture_on_device(host_pmat, layout):
     d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x.phyg"))
     models, factors = replay.mixture_classes(d)
     n, P, S = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0])
@@ -21,7 +37,8 @@ def test_lg4x_mixture_on_device(host_pmat):
     trees = []
     try:
         for md in models:
-            t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, 1, host_pmat=host_pmat)
+            t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, 1, host_pmat=host_pmat, devices=layout[1],
+                              force_sharded=layout[2])
             t.tip_root = 0  # src/mixt.c:889
             t.set_model(md["pi"], md["gamma_rr"], md["gamma_r_proba"], md["e_val"], md["r_e_vect"], md["l_e_vect"],
                         float(md["l_min"][0]), float(md["l_max"][0]), float(md["br_len_mult"][0]), 1, 0, 0.0)
@@ -51,8 +68,9 @@ def test_lg4x_mixture_on_device(host_pmat):
             t.close()
 
 
+@LAY
 @pytest.mark.parametrize("host_pmat", [True, False])
-def test_lg4x_mixture_dlk_on_device(host_pmat):
+def test_lg4x_mixture_dlk_on_device(host_pmat, layout):
     """MIXT_dLk (src/mixt.c:2962-3340) through phyhip_calculate_mixture_eigen_lnl_dlnl against a call dumped from the
     reference's own LG4X analysis: class partials recomputed on both sides, Update_Eigen_Lr per class, combination."""
     d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
@@ -63,7 +81,8 @@ def test_lg4x_mixture_dlk_on_device(host_pmat):
     trees = []
     try:
         for md in models:
-            t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, 1, host_pmat=host_pmat)
+            t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, 1, host_pmat=host_pmat, devices=layout[1],
+                              force_sharded=layout[2])
             t.tip_root = 0
             t.set_model(md["pi"], md["gamma_rr"], md["gamma_r_proba"], md["e_val"], md["r_e_vect"], md["l_e_vect"],
                         float(md["l_min"][0]), float(md["l_max"][0]), float(md["br_len_mult"][0]), 1, 0, 0.0)
@@ -87,13 +106,14 @@ def test_lg4x_mixture_dlk_on_device(host_pmat):
             t.close()
 
 
-def _class_axis_tree(d, models, tv, host_matrices):
+def _class_axis_tree(d, models, tv, host_matrices, layout=("plain", None, False)):
     """ONE instance whose four categories are the four LG4X classes (PHYHIP_FLAG_CLASS_AXIS): class rates as category
     rates, per-class frequencies / eigen systems pushed by index, matrices built on the device per class -- or computed per
     class by the oracle's PMat and uploaded (the bit-exact route)."""
     import orc
     n, P, S, K = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0]), len(models)
-    t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, K, host_pmat=False, class_axis=True)
+    t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, K, host_pmat=False, class_axis=True, devices=layout[1],
+                      force_sharded=layout[2])
     t.tip_root = 0
     m0 = models[0]
     rates = np.array([float(md["gamma_rr"][0]) for md in models])
@@ -116,8 +136,9 @@ def _class_axis_tree(d, models, tv, host_matrices):
     return t
 
 
+@LAY
 @pytest.mark.parametrize("host_matrices", [True, False])
-def test_lg4x_mixture_on_the_class_axis(host_matrices):
+def test_lg4x_mixture_on_the_class_axis(host_matrices, layout):
     """The same evaluation as test_lg4x_mixture_on_device with the four classes on the category axis of ONE instance:
     one traversal launch for all classes + the combination, against the reference's dump -- mixture lnL, per-site
     log-likelihoods, per-class likelihoods and per-class scale exponents."""
@@ -125,7 +146,7 @@ def test_lg4x_mixture_on_the_class_axis(host_matrices):
     models, factors = replay.mixture_classes(d)
     S, K = int(d["ns"][0]), len(models)
     tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
-    t = _class_axis_tree(d, models, tv, host_matrices)
+    t = _class_axis_tree(d, models, tv, host_matrices, layout)
     try:
         root = t.node(0).contents.v[0].contents.num
         t.Post_Order_Lk(0, root)     # queues every update once; all classes run in the one launch below
@@ -152,8 +173,9 @@ def test_lg4x_mixture_on_the_class_axis(host_matrices):
         t.close()
 
 
+@LAY
 @pytest.mark.parametrize("host_matrices", [True, False])
-def test_lg4x_mixture_dlk_on_the_class_axis(host_matrices):
+def test_lg4x_mixture_dlk_on_the_class_axis(host_matrices, layout):
     """MIXT_dLk on the class axis: both sides of every edge for all classes in two launches, per-class eigen products in
     one, the combination in one."""
     d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
@@ -161,7 +183,7 @@ def test_lg4x_mixture_dlk_on_the_class_axis(host_matrices):
     S = int(d["ns"][0])
     tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
     e = int(d["eval_edge"][0])
-    t = _class_axis_tree(d, models, tv, host_matrices)
+    t = _class_axis_tree(d, models, tv, host_matrices, layout)
     try:
         root = t.node(0).contents.v[0].contents.num
         t.Post_Order_Lk(0, root)
