@@ -1406,8 +1406,9 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   HIPCHK(hipGetDeviceProperties(&prop, dev));
 
   const bool class_axis = (requirementFlags & PHYHIP_FLAG_CLASS_AXIS) != 0;
-  if (class_axis && (stateCount != 20 || categoryCount > 4))
-    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "the class axis is built for 20 states and up to 4 classes (one instance per class otherwise)");
+  if (class_axis && !((stateCount == 20 && categoryCount <= 4) || (stateCount == 4 && (categoryCount == 1 || categoryCount == 2 || categoryCount == 4))))
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "the class axis is built for 20 states x up to 4 classes and 4 states x 1, 2 or 4 classes "
+                                                "(one instance per class otherwise)");
   Instance *I = new Instance();
   I->class_axis = class_axis; I->NE = class_axis ? categoryCount : 1;
   I->dev = dev; I->tips = tipCount; I->nbuf = partialsBufferCount; I->S = stateCount; I->C = categoryCount;
@@ -1450,8 +1451,9 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
 
   I->perm = (I->S == 20) && (I->C <= 4) && (I->class_axis || !(diag_env("PHYHIP_GENERIC_AA") && atoi(diag_env("PHYHIP_GENERIC_AA"))));
-  I->soa  = (I->S == 4) && (I->C <= 4) && !(diag_env("PHYHIP_NT_SOA") && atoi(diag_env("PHYHIP_NT_SOA")) == 0) &&
-            !(diag_env("PHYHIP_GENERIC_NT") && atoi(diag_env("PHYHIP_GENERIC_NT")));
+  I->soa  = (I->S == 4) && (I->C <= 4) &&
+            (I->class_axis || (!(diag_env("PHYHIP_NT_SOA") && atoi(diag_env("PHYHIP_NT_SOA")) == 0) &&
+                               !(diag_env("PHYHIP_GENERIC_NT") && atoi(diag_env("PHYHIP_GENERIC_NT")))));
   I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
   // category groups of the lane-per-pattern kernel (phyhip_nt2.hpp): split a pattern over 2 lanes while the
   // alignment is too short to give every SIMD two waves of 64 patterns
@@ -1463,6 +1465,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     const int g = atoi(e);
     if (g >= 1 && g <= 4 && I->C % g == 0 && 64 % g == 0 && !(I->C == 2 && g == 4)) I->nt_groups = g;
   }
+  if (I->soa && I->class_axis) I->nt_groups = I->C; // one class per lane: scaling and evaluation are per class
   I->grid_nt2 = (int)(I->Ppad / (64 / I->nt_groups));
   const size_t n_int = (size_t)(I->nbuf - I->tips);
   const size_t be    = buf_elems(I);
@@ -2370,21 +2373,26 @@ static int class_mixture_dlnl_impl(int instance, int left, int right, double *l,
   if ((rc = I->ring.alloc(eb, I->stream, &st))) return rc;
   memcpy(st, expl.data(), eb);
   HIPCHK(hipMemcpyAsync(I->d_mixexpl, st, eb, hipMemcpyHostToDevice, I->stream));
-  MixDlkParams<20> q;
-  memset(&q, 0, sizeof q);
-  for (int k = 0; k < I->C; ++k)
-  {
-    q.dot[k]     = I->d_dot + (size_t)k * I->S;
-    q.scale_l[k] = left < I->tips ? nullptr : I->d_scales + (size_t)(left - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
-    q.scale_r[k] = right < I->tips ? nullptr : I->d_scales + (size_t)(right - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
-    q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
-  }
-  q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
-  q.expl = I->d_mixexpl; q.wght = I->d_wght; q.dot_stride = I->C * I->S;
-  fill_mixture_invariant(I, q);
-  const int grid = (int)((I->P + 255) / 256);
-  mix_finish_setup(I, q.fin, grid, 2, mo);
-  hipLaunchKernelGGL((mixture_dlk_kernel<20>), dim3(grid), dim3(256), 0, I->stream, q);
+  auto launch = [&](auto s_) {
+    constexpr int S_ = decltype(s_)::value;
+    MixDlkParams<S_> q;
+    memset(&q, 0, sizeof q);
+    for (int k = 0; k < I->C; ++k)
+    {
+      q.dot[k]     = I->d_dot + (size_t)k * I->S;
+      q.scale_l[k] = left < I->tips ? nullptr : I->d_scales + (size_t)(left - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
+      q.scale_r[k] = right < I->tips ? nullptr : I->d_scales + (size_t)(right - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
+      q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
+    }
+    q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
+    q.expl = I->d_mixexpl; q.wght = I->d_wght; q.dot_stride = I->C * I->S;
+    fill_mixture_invariant(I, q);
+    const int grid = (int)((I->P + 255) / 256);
+    mix_finish_setup(I, q.fin, grid, 2, mo);
+    hipLaunchKernelGGL((mixture_dlk_kernel<S_>), dim3(grid), dim3(256), 0, I->stream, q);
+  };
+  if (I->S == 4) launch(std::integral_constant<int, 4>());
+  else launch(std::integral_constant<int, 20>());
   HIPCHK(hipGetLastError());
   if (mo) return PHYHIP_SUCCESS;
   if ((rc = wait_result(I))) return rc;
@@ -2585,7 +2593,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   // ~100 MB of dot_prod (20 states x 100 k patterns: 33 vs 48); beyond, filling every wave slot (2048 workgroups, separate
   // final sum) streams better (4 states x 1 M patterns: 45 vs 64; the one-workgroup-per-256-lanes form took 75)
   const size_t dot_bytes = (size_t)I->P * I->C * I->S * sizeof(double);
-  const int    dgrid = std::min(I->grid, dot_bytes > (size_t)100 << 20 ? 2048 : 512);
+  int          dgrid = std::min(I->grid, dot_bytes > (size_t)100 << 20 ? 2048 : 512);
+  if (const char *e = diag_env("PHYHIP_DLK_GRID")) dgrid = std::min(I->grid, std::max(1, atoi(e)));
   q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = dgrid; q.fin.warn = I->d_warn;
   const bool hsum  = !dev_out && I->host_sum;
   const bool fused = !hsum && fuse_reduce(I, dgrid);

@@ -78,7 +78,10 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   const unsigned p    = blockIdx.x * (unsigned)PW + pl;   // < Ppad by construction of the grid
   constexpr int  HP   = CS / 2;                           // 16-byte state pairs per lane
   const unsigned rowb = (unsigned)(q.Ppad * 16);          // bytes between consecutive (c, state pair) rows
-  const unsigned voff16 = p * 16u + (unsigned)(c0 * 2) * rowb, voff4 = p * 4u;
+  // Class axis (mixture classes as categories, TreeParams::class_axis; the host then runs G = C: one class per lane): every
+  // class has its own scale vector, [buffer][class][pattern], rescales alone and goes out of the edge evaluation alone
+  const bool     cls    = (CL == 1) && q.class_axis != 0;
+  const unsigned voff16 = p * 16u + (unsigned)(c0 * 2) * rowb, voff4 = (p + (cls ? (unsigned)c0 * (unsigned)q.Ppad : 0u)) * 4u;
 
   struct Raw
   {
@@ -202,7 +205,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         const u32x4 *src = reinterpret_cast<const u32x4 *>(q.partials + (size_t)(idx - q.tip_count) * bufsz) + (size_t)(c0 * 2) * q.Ppad + p;
 #pragma unroll
         for (int e = 0; e < HP; ++e) v[e] = src[(size_t)e * q.Ppad];
-        sc = (unsigned)q.scales[(size_t)(idx - q.tip_count) * q.Ppad + p];
+        sc = (unsigned)q.scales[(size_t)(idx - q.tip_count) * (cls ? C : 1) * q.Ppad + voff4 / 4];
       };
       if (q.e_prefetch & 1) pre(q.e_parent, EX, esl);
       if (q.e_prefetch & 2) pre(q.e_child, EY, esr);
@@ -368,8 +371,12 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
       }
       if constexpr (G > 1)
       { // the maximum runs over all categories of the pattern (src/avx.c:498-503): combine the category groups
+        // (not for mixture classes: a class tree rescales on its own, src/mixt.c:2603-2640)
+        if (!cls)
+        {
 #pragma unroll
-        for (int d = PW; d < 64; d <<= 1) mxh = max(mxh, (unsigned)__shfl_xor((int)mxh, d, 64));
+          for (int d = PW; d < 64; d <<= 1) mxh = max(mxh, (unsigned)__shfl_xor((int)mxh, d, 64));
+        }
       }
       unsigned sc = s1 + s2; // src/avx.c:462-464
       if (mxh < kHiInvTwoToLarge && q.apply_scaling)
@@ -456,7 +463,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
           const double2 t2 = src[(size_t)e * q.Ppad];
           v[2 * e] = t2.x; v[2 * e + 1] = t2.y;
         }
-        sc = (unsigned)q.scales[(size_t)(idx - tips) * q.Ppad + p];
+        sc = (unsigned)q.scales[(size_t)(idx - tips) * (cls ? C : 1) * q.Ppad + voff4 / 4];
       }
     };
     // this pattern's weight (and invariant state) are fetched with the partials, not after the arithmetic
@@ -477,11 +484,16 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         double a = 0.0;
 #pragma unroll
         for (int i = 0; i < S; ++i) a = __builtin_fma(M[c * 16 + kk * 4 + i], x[c * 4 + i], a);
-        t[kk] = a * (y[c * 4 + kk] * q.pi[kk]);
+        t[kk] = a * (y[c * 4 + kk] * q.pi[(cls ? c0 * 4 : 0) + kk]);
       }
       const double lkc = (t[0] + t[2]) + (t[1] + t[3]);
       if (p < (unsigned)q.P && q.site_cat) q.site_cat[(size_t)p * C + c0 + c] = lkc;
       prod[c] = lkc * q.cat_w[c0 + c];
+    }
+    if (cls)
+    { // per class: its likelihood (above) and its scale exponent; the mixture is combined by the caller's combination kernel
+      if (p < (unsigned)q.P) q.fact[(size_t)c0 * q.P + p] = q.apply_scaling ? (int)(sl + sr) : 0;
+      return;
     }
     double site = 0.0; // src/lk.c:816-818: categories in ascending order, whichever lane holds them
 #pragma unroll

@@ -106,6 +106,24 @@ def main():
         print(r.stdout[-3000:])
         raise SystemExit("mixture driver (dlk) failed")
     print(f"{'mixture_lg4x_dlk':22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
+    # --- the same two dumps for a four-class NUCLEOTIDE mixture (tests/golden/ntmix/nt4_check.xml: this repo's own input) ---
+    os.makedirs(os.path.join(tmp, "examples", "ntmix"), exist_ok=True)
+    shutil.copy(os.path.join(REF, "examples", "nucleic"), os.path.join(tmp, "examples", "nucleic"))
+    os.chmod(os.path.join(tmp, "examples", "nucleic"), 0o644)
+    xml = open(os.path.join(HERE, "ntmix", "nt4_check.xml")).read()
+    open(os.path.join(tmp, "examples", "ntmix", "nt4_check.xml"), "w").write(xml)
+    open(os.path.join(tmp, "examples", "ntmix", "fixed.xml"), "w").write(
+        xml.replace('optimise.freerates="yes"', 'optimise.freerates="no"').replace('optimise.lens="yes"', 'optimise.lens="no"'))
+    for name, argv in (("mixture_nt4", ["0", "--", "--xml=../examples/ntmix/fixed.xml"]),
+                       ("mixture_nt4_dlk", ["40", "dlk", "--", "--xml=../examples/ntmix/nt4_check.xml"])):
+        out = os.path.join(HERE, name + ".phyg")
+        r = subprocess.run([mixt, out] + argv, cwd=os.path.join(tmp, "run"), stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        m = re.search(r"MIXT_DRIVER .*", r.stdout)
+        if r.returncode != 0 or not m:
+            print(r.stdout[-3000:])
+            raise SystemExit(f"mixture driver failed for {name}")
+        print(f"{name:22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
     shutil.rmtree(tmp, ignore_errors=True)
 
 

@@ -25,12 +25,16 @@ def _layouts():
 
 LAYOUTS = _layouts()
 LAY = pytest.mark.parametrize("layout", LAYOUTS, ids=[x[0] for x in LAYOUTS])
+# lg4x: the reference's LG4X example (20 states); nt4: a four-class nucleotide mixture on examples/nucleic (HKY85 + empirical
+# frequencies / K80 + equal frequencies, four free rates; tests/golden/ntmix/nt4_check.xml)
+FIX = pytest.mark.parametrize("fx", ["lg4x", "nt4"])
 
 
+@FIX
 @LAY
 @pytest.mark.parametrize("host_pmat", [True, False])
-def test_lg4x_mixture_on_device(host_pmat, layout):
-    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x.phyg"))
+def test_lg4x_mixture_on_device(host_pmat, layout, fx):
+    d = phyg.load(os.path.join(GOLDEN, f"mixture_{fx}.phyg"))
     models, factors = replay.mixture_classes(d)
     n, P, S = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0])
     tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
@@ -68,12 +72,13 @@ def test_lg4x_mixture_on_device(host_pmat, layout):
             t.close()
 
 
+@FIX
 @LAY
 @pytest.mark.parametrize("host_pmat", [True, False])
-def test_lg4x_mixture_dlk_on_device(host_pmat, layout):
+def test_lg4x_mixture_dlk_on_device(host_pmat, layout, fx):
     """MIXT_dLk (src/mixt.c:2962-3340) through phyhip_calculate_mixture_eigen_lnl_dlnl against a call dumped from the
     reference's own LG4X analysis: class partials recomputed on both sides, Update_Eigen_Lr per class, combination."""
-    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
+    d = phyg.load(os.path.join(GOLDEN, f"mixture_{fx}_dlk.phyg"))
     models, factors = replay.mixture_classes(d)
     n, P, S = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0])
     tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
@@ -136,13 +141,14 @@ def _class_axis_tree(d, models, tv, host_matrices, layout=("plain", None, False)
     return t
 
 
+@FIX
 @LAY
 @pytest.mark.parametrize("host_matrices", [True, False])
-def test_lg4x_mixture_on_the_class_axis(host_matrices, layout):
+def test_lg4x_mixture_on_the_class_axis(host_matrices, layout, fx):
     """The same evaluation as test_lg4x_mixture_on_device with the four classes on the category axis of ONE instance:
     one traversal launch for all classes + the combination, against the reference's dump -- mixture lnL, per-site
     log-likelihoods, per-class likelihoods and per-class scale exponents."""
-    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x.phyg"))
+    d = phyg.load(os.path.join(GOLDEN, f"mixture_{fx}.phyg"))
     models, factors = replay.mixture_classes(d)
     S, K = int(d["ns"][0]), len(models)
     tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
@@ -173,12 +179,13 @@ def test_lg4x_mixture_on_the_class_axis(host_matrices, layout):
         t.close()
 
 
+@FIX
 @LAY
 @pytest.mark.parametrize("host_matrices", [True, False])
-def test_lg4x_mixture_dlk_on_the_class_axis(host_matrices, layout):
+def test_lg4x_mixture_dlk_on_the_class_axis(host_matrices, layout, fx):
     """MIXT_dLk on the class axis: both sides of every edge for all classes in two launches, per-class eigen products in
     one, the combination in one."""
-    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
+    d = phyg.load(os.path.join(GOLDEN, f"mixture_{fx}_dlk.phyg"))
     models, factors = replay.mixture_classes(d)
     S = int(d["ns"][0])
     tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)

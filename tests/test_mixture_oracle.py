@@ -6,6 +6,7 @@ scale exponents, per-site log-likelihoods and lnL."""
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 from phyml_amd import phyg, replay
@@ -21,8 +22,11 @@ def class_tree(d, model_dict):
     return ot
 
 
-def test_lg4x_mixture_matches_reference():
-    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x.phyg"))
+# mixture_nt4: a four-class NUCLEOTIDE mixture (HKY85 + empirical frequencies / K80 + equal frequencies, four free rates) on
+# examples/nucleic, dumped the same way (tests/golden/ntmix/nt4_check.xml, tests/golden/make_traces.py)
+@pytest.mark.parametrize("fixture", ["mixture_lg4x", "mixture_nt4"])
+def test_lg4x_mixture_matches_reference(fixture):
+    d = phyg.load(os.path.join(GOLDEN, fixture + ".phyg"))
     models, factors = replay.mixture_classes(d)
     assert len(models) == 4
     unscaled, fact = [], []
@@ -49,10 +53,11 @@ def test_lg4x_mixture_matches_reference():
     assert np.array_equal(logs2, d["c_lnL_sorted"]) and lnl2 == float(d["lnL"][0])
 
 
-def test_lg4x_mixture_dlk_matches_reference():
+@pytest.mark.parametrize("fixture", ["mixture_lg4x_dlk", "mixture_nt4_dlk"])
+def test_lg4x_mixture_dlk_matches_reference(fixture):
     """A MIXT_dLk call of the reference's own LG4X analysis (41st call of the first branch-length round): per-class
     eigen-basis products from the oracle's Update_Eigen_Lr on freshly computed partials, and the restated combination."""
-    d = phyg.load(os.path.join(GOLDEN, "mixture_lg4x_dlk.phyg"))
+    d = phyg.load(os.path.join(GOLDEN, fixture + ".phyg"))
     models, factors = replay.mixture_classes(d)
     e = int(d["eval_edge"][0])
     dots, facts = [], []
