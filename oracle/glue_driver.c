@@ -267,11 +267,12 @@ static ctx_t *ensure_instance(t_tree *tree)
     g_nctx = 0;
   }
   if (g_nctx == MAXCTX) { fprintf(stderr, "glue_driver: too many class trees\n"); exit(5); }
-  if (g_class_axis && tree->mixt_tree && tree->mod->ns == 20)
+  if (g_class_axis && tree->mixt_tree && (tree->mod->ns == 20 || tree->mod->ns == 4))
   { /* all class trees of the mixture at once: contexts in class order, one instance */
     int K = 0; /* class trees that compute (the invariant class of a +I mixture never reaches the surface) */
     for (t_tree *t = tree->mixt_tree->next; t && t->is_mixt_tree == NO; t = t->next) if (t->mod->ras->invar == NO) ++K;
-    if (K >= 1 && K <= 4 && g_nctx + K <= MAXCTX && tree->mod->ras->invar == NO)
+    /* (what the class axis is built for: 20 states x up to 4 classes, 4 states x 1, 2 or 4 classes) */
+    if (K >= 1 && K <= 4 && !(tree->mod->ns == 4 && K == 3) && g_nctx + K <= MAXCTX && tree->mod->ras->invar == NO)
     {
       ctx_t *first = NULL, *mine = NULL;
       int    k = 0;
@@ -287,7 +288,7 @@ static ctx_t *ensure_instance(t_tree *tree)
           first = c;
           c->batch = calloc(1, sizeof(clsbatch_t));
           ++g_n_created;
-          c->inst = phyhip_create_instance(t->n_otu, t->n_otu + c->bufcap, 0, 20, t->data->n_pattern, K, c->matcap, K, 0, NULL, 0,
+          c->inst = phyhip_create_instance(t->n_otu, t->n_otu + c->bufcap, 0, t->mod->ns, t->data->n_pattern, K, c->matcap, K, 0, NULL, 0,
                                            0, PHYHIP_FLAG_CLASS_AXIS, NULL);
           if (c->inst < 0) die("phyhip_create_instance (class axis)");
           OK(phyhip_set_pattern_weights(c->inst, t->data->wght));

@@ -140,6 +140,29 @@ def test_lg4x_mixture_analysis_check_mode(class_axis, tmp_path):
     assert info["worst_rel_mixture_dlnL"] < 1e-6, info
 
 
+@pytest.mark.parametrize("class_axis", [False, True], ids=["instance_per_class", "class_axis"])
+def test_nucleotide_mixture_analysis_check_mode(class_axis, tmp_path):
+    """The same for a four-class NUCLEOTIDE mixture (tests/golden/ntmix/nt4_check.xml: HKY85 + empirical frequencies / K80 +
+    equal frequencies, four free rates, on examples/nucleic): the reference's own XML analysis, every MIXT_Lk / MIXT_dLk
+    repeated on the device -- four one-category instances, or the four classes on the lanes of ONE class-axis instance."""
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
+    base = str(tmp_path)
+    os.makedirs(os.path.join(base, "examples", "ntmix")); os.makedirs(os.path.join(base, "run"))
+    shutil.copy(os.path.join(GOLDEN, "ntmix", "nt4_check.xml"), os.path.join(base, "examples", "ntmix", "nt4_check.xml"))
+    shutil.copy(os.path.join(GOLDEN, "examples_nucleic.phy"), os.path.join(base, "examples", "nucleic"))
+    env = dict(os.environ, GLUE_MODE="check", GLUE_MAX_MIXT="4000", GLUE_CLASS_AXIS="1" if class_axis else "0")
+    r = subprocess.run([GLUE, "--", "--xml=../examples/ntmix/nt4_check.xml"], cwd=os.path.join(base, "run"), env=env,
+                       stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:]
+    info = json.loads(m.group(1))
+    assert info["class_instances"] == 4
+    assert info["calls"]["MIXT_Lk"] + info["calls"]["MIXT_dLk"] - info["calls"]["MIXT_skipped"] >= 1000, info
+    assert info["worst_rel_mixture_lnL"] < 1e-10, info
+    assert info["worst_rel_mixture_dlnL"] < 1e-6, info
+
+
 @pytest.mark.parametrize("class_axis,device_pmat", [(False, False), (True, False), (True, True)],
                          ids=["instance_per_class", "class_axis", "class_axis_device_matrices"])
 def test_lg4x_mixture_analysis_driven_by_the_device(class_axis, device_pmat, tmp_path):
