@@ -455,11 +455,12 @@ int flush_pmats(Instance *I)
     q.count = n;
     q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
-    const int threads = (I->S == 4) ? 64 : 256;
+    const int threads = (I->S == 4) ? 64 : 1024;
     q.afrag = I->perm ? I->d_afrag : nullptr; // 20 states: the MFMA A-operand fragments come out of the same kernel
     q.class_axis = I->class_axis ? 1 : 0;
-    const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)I->C * I->S * I->S + (size_t)2 * I->NE * I->S * I->S);
-    hipLaunchKernelGGL(pmat_kernel, dim3(n), dim3(threads), lds, I->stream, q);
+    const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)2 * I->C * I->S * I->S + (size_t)2 * I->NE * I->S * I->S);
+    if (I->S == 4) hipLaunchKernelGGL(pmat_kernel<4>, dim3(n), dim3(threads), lds, I->stream, q);
+    else hipLaunchKernelGGL(pmat_kernel<20>, dim3(n), dim3(threads), lds, I->stream, q);
     HIPCHK(hipGetLastError());
     done += n;
   }
@@ -669,7 +670,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     char *dst = I->d_ops + (size_t)I->ops_slot * I->ops_slot_bytes;
     // one or two operations of the lane-per-pattern nucleotide kernel travel in the kernel arguments (phyhip_nt2.hpp):
     // no staging, no copy command, and the device slots keep the long lists they cache
-    const bool in_args = fat && I->soa && I->args_recs && n_ops <= 2;
+    const bool in_args = fat && (I->soa || I->perm) && I->args_recs && n_ops <= 2;
     IssueRec   arg_ir[2];
     ExecRec    arg_xr[2];
     if (!in_args)

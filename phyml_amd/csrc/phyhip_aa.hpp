@@ -139,13 +139,24 @@ __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadPar
 // ABL (diag build only, results INVALID): 1 no matrix phase, 2 no cross-lane maximum, 4 children loads and result stores
 // zero-sized, 8 no ring hand-shake (nothing is loaded), 16 no all-ones test
 template <int C_, bool DBG = false, int ABL = 0>
-__global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
-                                                                            const ExecRec *__restrict__ xrec,
+__global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec_,
+                                                                            const ExecRec *__restrict__ xrec_,
                                                                             const double *__restrict__ afrag, int n_frag_mats,
                                                                             const uint32_t *__restrict__ tip_masks,
                                                                             unsigned long long *dbg = nullptr)
 {
   constexpr int T   = kAaT;
+  // One- and two-operation launches (an SPR regraft candidate) carry their records in the kernel arguments (TreeParams::arg_ir /
+  // arg_xr): no staged copy in front of the launch; the records are read from the argument segment like any others.
+  const IssueRec *__restrict__ irec = irec_;
+  const ExecRec *__restrict__  xrec = xrec_;
+  if (q.recs_in_args)
+  {
+    typedef const __attribute__((address_space(4))) char karg_char;
+    const char *ka = (const char *)(karg_char *)__builtin_amdgcn_kernarg_segment_ptr(); // q is the first argument
+    irec = reinterpret_cast<const IssueRec *>(ka + offsetof(TreeParams, arg_ir));
+    xrec = reinterpret_cast<const ExecRec *>(ka + offsetof(TreeParams, arg_xr));
+  }
   constexpr int CB  = C_ == 1 ? 1 : (C_ == 2 ? 2 : 4); // blocks (categories) per pattern
   constexpr int NPW = 16 / CB;                          // patterns per wave-tile
   static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");

@@ -1649,11 +1649,16 @@ struct PmatParams
   int           class_axis;  // U, V, R are [C] eigen systems: category c is class c of a mixture
 };
 
-__global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
+// ST: the state count at compile time (4 | 20): unrolled 20-term chains, and for 20 states the products U[i][k] e[c][k] formed
+// once per (c, i, k) in LDS instead of once per entry (a third of the LDS reads of the chain), 1024 threads (two entries each).
+// The arithmetic is unchanged: (U[i][k] * e[c][k]) first, then the FMA into the sum over ascending k (src/models.c:278-292).
+template <int ST>
+__global__ __launch_bounds__(ST == 4 ? 64 : 1024) void pmat_kernel(const PmatParams q)
 {
-  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S] | tmp [C][S][S] | row sums [C][S] | U [S][S] | V [S][S]
+  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S] | tmp [C][S][S] | row sums [C][S] | U [S][S] | V [S][S] | W [C][S][S]
   const int    m  = blockIdx.x;
-  const int    S  = q.S, C = q.C;
+  constexpr int S = ST;
+  const int    C = q.C;
   // SPR refreshes three matrices per candidate: such short lists ride in the kernel arguments (no H2D copy)
   double l;
   int    mat;
@@ -1670,6 +1675,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
   const int NE = q.class_axis ? C : 1; // eigen systems
   double *Us   = rsum + C * S;         // eigenvectors staged once per block
   double *Vs   = Us + NE * S * S;
+  double *Ws   = Vs + NE * S * S;      // [C][S][S]: U[i][k] * e[c][k]
   for (int t = threadIdx.x; t < NE * S * S; t += blockDim.x)
   {
     Us[t] = q.U[t];
@@ -1685,13 +1691,20 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
     expt[t] = exp(q.R[(q.class_axis ? c * S : 0) + k] * len); // src/models.c:275
   }
   __syncthreads();
+  for (int e = threadIdx.x; e < C * S * S; e += blockDim.x)
+  {
+    const int c = e / (S * S), ik = e % (S * S), k = e % S;
+    Ws[e] = Us[(q.class_axis ? c * S * S : 0) + ik] * expt[c * S + k];
+  }
+  __syncthreads();
   // one thread per entry: acc = sum_k (U[i][k]*expt[c][k]) * V[k][j], ascending k with FMA (src/models.c:278-292)
   for (int e = threadIdx.x; e < C * S * S; e += blockDim.x)
   {
     const int c = e / (S * S), i = (e / S) % S, j = e % S;
-    const double *Uc = Us + (q.class_axis ? c * S * S : 0), *Vc = Vs + (q.class_axis ? c * S * S : 0);
+    const double *Wc = Ws + (c * S + i) * S, *Vc = Vs + (q.class_axis ? c * S * S : 0) + j;
     double    acc = 0.0;
-    for (int k = 0; k < S; ++k) acc = __builtin_fma(Uc[i * S + k] * expt[c * S + k], Vc[k * S + j], acc);
+#pragma unroll
+    for (int k = 0; k < S; ++k) acc = __builtin_fma(Wc[k], Vc[k * S], acc);
     tmp[e] = (acc < kSmallPij) ? kSmallPij : acc; // :293
   }
   __syncthreads();
@@ -1700,6 +1713,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
   {
     const double *row = tmp + (size_t)t * S;
     double        sum = 0.0;
+#pragma unroll
     for (int j = 0; j < S; ++j) sum += row[j];
     rsum[t] = sum;
   }
@@ -1707,7 +1721,7 @@ __global__ __launch_bounds__(256) void pmat_kernel(const PmatParams q)
   // the division (src/models.c:298), one coalesced pass over the matrix
   double *out = q.pmats + (size_t)mat * C * S * S;
   for (int e = threadIdx.x; e < C * S * S; e += blockDim.x) out[e] = tmp[e] / rsum[e / S];
-  if (q.afrag)
+  if (ST == 20 && q.afrag)
   { // 20 states: the same entries once more in MFMA A-operand order (phyhip_aa.hpp: aa_a_slot), all categories in one table
     double   *dst = q.afrag + (size_t)mat * kAaMat;
     const int cb  = aa_cb(C);
