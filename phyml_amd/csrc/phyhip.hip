@@ -2567,8 +2567,9 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     const size_t lds = sizeof(double) * 2 * (size_t)(I->class_axis ? I->C : 1) * S_ * S_; // the eigenvectors, staged per workgroup
-    if (I->class_axis) hipLaunchKernelGGL((eigen_lr_kernel<S_, CP_, true>), dim3(I->grid), dim3(256), lds, I->stream, e);
-    else hipLaunchKernelGGL((eigen_lr_kernel<S_, CP_, false>), dim3(I->grid), dim3(256), lds, I->stream, e);
+    const int egrid = (int)(((long long)I->P * I->CP * kEigenSplit<S_> + 255) / 256);
+    if (I->class_axis) hipLaunchKernelGGL((eigen_lr_kernel<S_, CP_, true>), dim3(egrid), dim3(256), lds, I->stream, e);
+    else hipLaunchKernelGGL((eigen_lr_kernel<S_, CP_, false>), dim3(egrid), dim3(256), lds, I->stream, e);
     return 0;
   });
   if (rc) return rc;

@@ -1055,11 +1055,18 @@ struct EigenParams
 
 // CLS: class-axis instance (per-class frequencies and eigenvectors); a separate instantiation, because only with the offset a
 // compile-time zero are the eigenvector reads provably the same for every lane (scalar loads)
+// 20 states: the S products of a (pattern, category) are split over kEigenSplit lanes (S / kEigenSplit of them each: every
+// product is its own two FMA chains, so the arithmetic does not change): small alignments -- Br_Len_Opt on a few thousand
+// patterns -- get four times the lanes and a quarter of the serial chain (11 -> ~5 us at 2000 patterns x 4 categories).
+template <int S> constexpr int kEigenSplit = (S == 20) ? 4 : 1;
 template <int S, int CP, bool CLS = false>
 __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
 {
+  constexpr int     KS = kEigenSplit<S>, KN = S / KS; // lanes per (pattern, category), products per lane
   const TreeParams &q  = e.t;
-  const long long   gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long   g0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int         ks = (int)(g0 % KS);
+  const long long   gl = g0 / KS;
   const long long   p0 = gl / CP;
   const int         c0 = (int)(gl % CP);
   const bool        act = (p0 < q.P) && (c0 < q.C);
@@ -1070,7 +1077,7 @@ __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
   extern __shared__ double sh_ev[]; // [2][classes or 1][S][S]
   load_side<S, CP>(q, e.ro, e.left, p, c, x, sl);
   load_side<S, CP>(q, e.ro, e.rght, p, c, y, sr);
-  double d[S];
+  double d[KN];
   // a[k] = sum_i R[i][k] lp[i];  b[k] = sum_i L[k][i] y[i]  (column-wise FMA chains, src/avx.c:81-82).  Every lane reads the
   // same 2 S^2 eigenvector entries (per class): straight from memory that was 2 S^2 dependent vector loads per lane (27 us
   // per call at 20 states, whatever the pattern count; as scalar loads 37 us) -- the workgroup stages them in LDS once and
@@ -1090,8 +1097,9 @@ __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
 #pragma unroll
     for (int i = 0; i < S; ++i) lp[i] = x[i] * pi[i]; // src/avx.c:79
 #pragma unroll
-    for (int k = 0; k < S; ++k)
+    for (int kk = 0; kk < KN; ++kk)
     {
+      const int k = ks * KN + kk;
       double a = rev[k] * lp[0];
       double b = lev[k * S] * y[0];
 #pragma unroll
@@ -1100,14 +1108,22 @@ __global__ __launch_bounds__(256) void eigen_lr_kernel(const EigenParams e)
         a = __builtin_fma(rev[i * S + k], lp[i], a);
         b = __builtin_fma(lev[k * S + i], y[i], b);
       }
-      d[k] = a * b;
+      d[kk] = a * b;
     }
   }
   if (act)
   {
-    double2 *dst = reinterpret_cast<double2 *>(e.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S);
+    double *dst = e.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S + ks * KN;
+    if constexpr (KN % 2 == 0)
+    {
 #pragma unroll
-    for (int j = 0; j < S / 2; ++j) dst[j] = make_double2(d[2 * j], d[2 * j + 1]);
+      for (int j = 0; j < KN / 2; ++j) reinterpret_cast<double2 *>(dst)[j] = make_double2(d[2 * j], d[2 * j + 1]);
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < KN; ++j) dst[j] = d[j];
+    }
   }
   if (e.tickets)
   {
