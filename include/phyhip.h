@@ -57,7 +57,8 @@ extern "C" {
 /* requirementFlags bit: the categoryCount "categories" of the instance are the CLASSES of a mixture of class models
    (src/mixt.c; e.g. the four classes of LG4X): class c has its own eigen system and frequencies (eigenIndex / 
    stateFrequenciesIndex = c), its category rate is the class rate, every partials buffer carries one scale vector per
-   class, and evaluations go through phyhip_calculate_class_mixture_*.  20 states, up to 4 classes, one device. */
+   class, and evaluations go through phyhip_calculate_class_mixture_*.  20 states x up to 4 classes, or 4 states x 1, 2 or 4
+   classes; with a resource list the instance is sharded like any other (one all-reduce per mixture evaluation). */
 #define PHYHIP_FLAG_CLASS_AXIS (1L << 41)
 
 /* BeagleOperation (src/beagle_utils.c:243).  The two scale-index fields are accepted and ignored:
