@@ -96,7 +96,7 @@ typedef struct
    the entry points below, the model and the transition matrices are replicated, and every scalar-returning evaluation
    (phyhip_calculate_edge_log_likelihoods, phyhip_calculate_eigen_lnl[_dlnl]) ends in ONE RCCL all-reduce over the
    communicators of ncclCommInitAll: {warning flag, lnL} for Lk (the sum of src/lk.c:856), {warning, lnL, dlnL} for dLk
-   (src/lk.c:744-745).  The caller sees the same API and the same numbers; mixtures are not sharded.
+   (src/lk.c:744-745).  The caller sees the same API and the same numbers; mixture evaluations (below) accept sharded class instances too.
    Returns the instance id (>= 0) or a negative error. */
 int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
                            int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
