@@ -1011,6 +1011,10 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         const dim3 blk(64 * (I->aa_nw + 1));
 #define AACASE(c_)                                                                                                          \
   case c_:                                                                                                                  \
+    if (q.recs_in_args)                                                                                                     \
+      hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,    \
+                         (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
+    else                                                                                                                    \
     hipLaunchKernelGGL((traverse_aa_kernel<c_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,                      \
                        (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
     return 0;

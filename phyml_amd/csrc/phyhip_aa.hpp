@@ -138,25 +138,26 @@ __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadPar
 // ---------------------------------------------------------------------------------------------
 // ABL (diag build only, results INVALID): 1 no matrix phase, 2 no cross-lane maximum, 4 children loads and result stores
 // zero-sized, 8 no ring hand-shake (nothing is loaded), 16 no all-ones test
-template <int C_, bool DBG = false, int ABL = 0>
-__global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec_,
-                                                                            const ExecRec *__restrict__ xrec_,
+// ARGS: one- and two-operation launches (an SPR regraft candidate) carry their records in the kernel arguments
+// (TreeParams::arg_ir / arg_xr, as the nucleotide kernel's short launches do): no staged copy in front of the launch.  A
+// separate instantiation: the records of the list form must stay provably uniform (scalar loads through the noalias
+// parameters) -- selecting between two pointers at run time turned every record load into a vector load (+35 % kernel time).
+template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false>
+__global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+                                                                            const ExecRec *__restrict__ xrec,
                                                                             const double *__restrict__ afrag, int n_frag_mats,
                                                                             const uint32_t *__restrict__ tip_masks,
                                                                             unsigned long long *dbg = nullptr)
 {
   constexpr int T   = kAaT;
-  // One- and two-operation launches (an SPR regraft candidate) carry their records in the kernel arguments (TreeParams::arg_ir /
-  // arg_xr): no staged copy in front of the launch; the records are read from the argument segment like any others.
-  const IssueRec *__restrict__ irec = irec_;
-  const ExecRec *__restrict__  xrec = xrec_;
-  if (q.recs_in_args)
-  {
-    typedef const __attribute__((address_space(4))) char karg_char;
-    const char *ka = (const char *)(karg_char *)__builtin_amdgcn_kernarg_segment_ptr(); // q is the first argument
-    irec = reinterpret_cast<const IssueRec *>(ka + offsetof(TreeParams, arg_ir));
-    xrec = reinterpret_cast<const ExecRec *>(ka + offsetof(TreeParams, arg_xr));
-  }
+  auto IR = [&](int i) -> IssueRec {
+    if constexpr (ARGS) return i ? q.arg_ir[1] : q.arg_ir[0];
+    else return irec[i];
+  };
+  auto XR = [&](int i) -> ExecRec {
+    if constexpr (ARGS) return i ? q.arg_xr[1] : q.arg_xr[0];
+    else return xrec[i];
+  };
   constexpr int CB  = C_ == 1 ? 1 : (C_ == 2 ? 2 : 4); // blocks (categories) per pattern
   constexpr int NPW = 16 / CB;                          // patterns per wave-tile
   static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
     for (int j = 0; j < ((ABL & 8) ? 0 : n_items); ++j)
     {
       unsigned off1, off2;
-      if (j < q.n_ops) { off1 = irec[j].c1_data.x; off2 = irec[j].c2_data.x; }
+      if (j < q.n_ops) { const IssueRec rj = IR(j); off1 = rj.c1_data.x; off2 = rj.c2_data.x; }
       else off1 = off2 = (unsigned)q.e_pm * kMatB;
       // the slot is free once every consumer has finished item j - kAaRing
       const int need = j - kAaRing + 1;
@@ -395,9 +396,9 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
       {
         const int last = q.n_ops - 1; // host pads the list to an even length
         Raw       RA, RB;
-        ExecRec   cur = xrec[0];
-        IssueRec  nx1 = irec[(1 < last) ? 1 : last];
-        issue_children(irec[0], RA);
+        ExecRec   cur = XR(0);
+        IssueRec  nx1 = IR((1 < last) ? 1 : last);
+        issue_children(IR(0), RA);
         {
           // The loop body sees [children loads of k+1][4 result stores of k] in flight when step k+1 starts.  Four stores
           // through a zero-sized descriptor (dropped by the hardware, but counted) give the loop entry the same shape, so
@@ -419,8 +420,8 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           // The loads of operation k+1 go out first (their registers were consumed by step k-1), then the records of
           // k+2 / k+1 are requested into the scalar registers the issue just freed: both have the whole step to arrive.
           issue_children(nx1, Rn);
-          const IssueRec nx2 = irec[(k + 2 < last) ? k + 2 : last];
-          const ExecRec  nxe = xrec[(k + 1 < last) ? k + 1 : last];
+          const IssueRec nx2 = IR((k + 2 < last) ? k + 2 : last);
+          const ExecRec  nxe = XR((k + 1 < last) ? k + 1 : last);
           // A tip child whose patterns all carry ONE state contributes a column of its matrix (the reference's Exex / Exin
           // kernels, src/avx.c:527-564): five values per lane straight from the ring, no product.  (Through the matrix
           // cores the result would be the same doubles -- the other 19 products are exact zeros -- at 25 MFMAs.)
@@ -515,9 +516,9 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
             const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
             Frag wv;
             pack(o, wv);
-            __builtin_amdgcn_raw_buffer_store_b128(wv.p01, dr, voff_d16, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(wv.p23, dr, voff_d16 + 1024, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(wv.p4, dr, voff_d8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p01, dr, voff_d16, 0, PHYHIP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p23, dr, voff_d16 + 1024, 0, PHYHIP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(wv.p4, dr, voff_d8, 0, PHYHIP_STORE_AUX);
             __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_sst, 0, 0);
           }
           PHY_STAMP(k, 6)

@@ -21,6 +21,9 @@
 // the last two operations forwarded in registers (two alternating register files, no copies), both
 // transition matrices of an operation staged once per wave into LDS and read back as broadcasts.
 #pragma once
+#ifndef PHYHIP_STORE_AUX
+#define PHYHIP_STORE_AUX 2 // cache policy bits of the result stores: 2 = non-temporal (a result is read back at most once, much later: cfg2 kernel 186 -> 166 us, 1 M patterns -2.5 %; tools/gpu_store_ab.sh)
+#endif
 
 #include "phyhip_kernels.hpp"
 
@@ -394,7 +397,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         {
           u32x4 w;
           __builtin_memcpy(&w, &Fout[2 * e], 16);
-          __builtin_amdgcn_raw_buffer_store_b128(w, dr, voff16, (unsigned)e * rowb, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(w, dr, voff16, (unsigned)e * rowb, PHYHIP_STORE_AUX);
         }
         __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff4, 0, 0);
       }
