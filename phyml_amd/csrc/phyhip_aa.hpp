@@ -293,9 +293,9 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (ABL & 4) ? 0 : (int)d.bytes, 0x00020000);
       };
       auto load_frag = [](Frag &f, const __amdgpu_buffer_rsrc_t r, unsigned v16, unsigned v8) {
-        f.p01 = __builtin_amdgcn_raw_buffer_load_b128(r, v16, 0, 0);
-        f.p23 = __builtin_amdgcn_raw_buffer_load_b128(r, v16 + 1024, 0, 0);
-        f.p4  = __builtin_amdgcn_raw_buffer_load_b64(r, v8, 0, 0);
+        f.p01 = __builtin_amdgcn_raw_buffer_load_b128(r, v16, 0, PHYHIP_LOAD_AUX);
+        f.p23 = __builtin_amdgcn_raw_buffer_load_b128(r, v16 + 1024, 0, PHYHIP_LOAD_AUX);
+        f.p4  = __builtin_amdgcn_raw_buffer_load_b64(r, v8, 0, PHYHIP_LOAD_AUX);
       };
       auto unpack = [](const Frag &f, double (&x)[T]) {
         __builtin_memcpy(&x[0], &f.p01, 16);

@@ -21,6 +21,9 @@
 // the last two operations forwarded in registers (two alternating register files, no copies), both
 // transition matrices of an operation staged once per wave into LDS and read back as broadcasts.
 #pragma once
+#ifndef PHYHIP_LOAD_AUX
+#define PHYHIP_LOAD_AUX 2 // cache policy bits of the children loads: non-temporal too (read once: -1 ... -3 % on the large cases)
+#endif
 #ifndef PHYHIP_STORE_AUX
 #define PHYHIP_STORE_AUX 2 // cache policy bits of the result stores: 2 = non-temporal (a result is read back at most once, much later: cfg2 kernel 186 -> 166 us, 1 M patterns -2.5 %; tools/gpu_store_ab.sh)
 #endif
@@ -104,9 +107,9 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
     // points the same descriptor at whichever row exists (spare word x = 1: tip row, addressed by aligned dword)
     const __amdgpu_buffer_rsrc_t d1r = rsrc(o.c1_data), d2r = rsrc(o.c2_data), g1r = rsrc(o.c1_scale), g2r = rsrc(o.c2_scale);
 #pragma unroll
-    for (int e = 0; e < HP; ++e) r.a[e] = __builtin_amdgcn_raw_buffer_load_b128(d1r, voff16, (unsigned)e * rowb, 0);
+    for (int e = 0; e < HP; ++e) r.a[e] = __builtin_amdgcn_raw_buffer_load_b128(d1r, voff16, (unsigned)e * rowb, PHYHIP_LOAD_AUX);
 #pragma unroll
-    for (int e = 0; e < HP; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b128(d2r, voff16, (unsigned)e * rowb, 0);
+    for (int e = 0; e < HP; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b128(d2r, voff16, (unsigned)e * rowb, PHYHIP_LOAD_AUX);
     r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, o.c1_scale.x ? (p & ~3u) : voff4, 0, 0);
     r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, o.c2_scale.x ? (p & ~3u) : voff4, 0, 0);
   };
