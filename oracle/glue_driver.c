@@ -362,6 +362,57 @@ void Init_Partial_Lk_Tips_Double(t_tree *tree)
     }
 }
 
+/* Leave-one-out cross-validation (MIXT_Maxfold_Cv, src/mixt.c:4198-4290): one character of one tip is hidden, the pendant
+   edge optimised, the character restored -- Init_Partial_Lk_Tips_Double_One_Character (src/lk.c:2092) rewrites ONE pattern of
+   the tip vector in place.  The mixture tree's call fans out to the class trees (src/mixt.c:2674-2686) and comes back here. */
+static long g_n_tipchar = 0, g_n_cv_vec = 0, g_n_cv_bad = 0;
+void Init_Partial_Lk_Tips_Double_One_Character(int node_id, int site, t_tree *tree)
+{
+  static void (*real)(int, int, t_tree *) = NULL;
+  if (!real) real = (void (*)(int, int, t_tree *))dlsym(RTLD_NEXT, "Init_Partial_Lk_Tips_Double_One_Character");
+  real(node_id, site, tree);
+  if (g_host || tree->is_mixt_tree == YES) return;
+  for (int i = 0; i < g_nctx; ++i)
+    if (g_ctx[i].tree == tree)
+    {
+      if (g_ctx[i].K > 0 && g_ctx[i].cls > 0) return; /* class axis: the classes share ONE instance, class 0 pushed it */
+      OK(phyhip_set_tip_partials_at_pattern(g_ctx[i].inst, node_id, site, tree->a_nodes[node_id]->b[0]->p_lk_tip_r + (size_t)site * tree->mod->ns));
+      ++g_n_tipchar;
+      return;
+    }
+}
+
+/* ... and what the loop reads afterwards (CV_State_Probs_Core, src/cv.c:294-420): p_lk_left of the pendant edge of every
+   class tree (or of the tree) at the hidden site.  Check mode: the device's vector is downloaded (phyhip_get_partials, the hook
+   of SURVEY 8f rank 3) and compared BIT FOR BIT with the host's at that site. */
+void CV_State_Probs_Core(phydbl **state_probs, short int **truth, phydbl **site_loglk, phydbl **weights, int *n_prob_vectors,
+                         int tax_id, int site, int true_d_state, phydbl patt_weight, t_tree *tree)
+{
+  static void (*real)(phydbl **, short int **, phydbl **, phydbl **, int *, int, int, int, phydbl, t_tree *) = NULL;
+  if (!real) real = (void (*)(phydbl **, short int **, phydbl **, phydbl **, int *, int, int, int, phydbl, t_tree *))dlsym(RTLD_NEXT, "CV_State_Probs_Core");
+  if (!g_host && g_check)
+    for (t_tree *t = tree->is_mixt_tree == YES ? tree->next : tree; t && t->is_mixt_tree == NO; t = (tree->is_mixt_tree == YES) ? t->next : NULL)
+    {
+      if (t->mod->ras->invar == YES) continue;
+      ctx_t *c = NULL;
+      for (int i = 0; i < g_nctx; ++i) if (g_ctx[i].tree == t) c = &g_ctx[i];
+      if (!c) continue;
+      const t_edge *b = t->a_nodes[tax_id]->b[0];
+      int id = -1;
+      for (int i = 0; i < c->nbuf; ++i) if (c->bufptr[i] == (const void *)b->p_lk_left) id = t->n_otu + i;
+      if (id < 0) continue; /* (never a destination on the device: nothing to compare) */
+      const int ns = t->mod->ns, P = t->data->n_pattern, K = c->K > 0 ? c->K : 1, C = K > 1 ? K : t->mod->ras->n_catg;
+      double   *v = (double *)malloc(sizeof(double) * (size_t)P * C * ns);
+      OK(phyhip_get_partials(c->inst, id, PHYHIP_OP_NONE, v));
+      const int     ncat = t->mod->ras->n_catg; /* host layout [site][catg][state]; class axis: the class is the category */
+      const double *dev = v + ((size_t)site * C + (K > 1 ? c->cls : 0)) * ns, *host = b->p_lk_left + (size_t)site * ncat * ns;
+      ++g_n_cv_vec;
+      if (memcmp(dev, host, sizeof(double) * (size_t)(K > 1 ? 1 : ncat) * ns) != 0) ++g_n_cv_bad;
+      free(v);
+    }
+  real(state_probs, truth, site_loglk, weights, n_prob_vectors, tax_id, site, true_d_state, patt_weight, tree);
+}
+
 void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
 {
   static void (*real)(t_edge *, t_tree *) = NULL;
@@ -596,9 +647,10 @@ static void report_xml_and_exit(void)
 {
   printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"xml\": 1, \"seconds\": %.3f, \"calls\": {\"Lk\": %ld, \"MIXT_Lk\": %ld, \"MIXT_dLk\": %ld, \"MIXT_skipped\": %ld, "
          "\"Update_Partial_Lk\": %ld, \"Update_PMat\": %ld, \"Update_Eigen_Lr\": %ld, \"dLk\": %ld}, \"class_instances\": %d, "
-         "\"worst_rel_mixture_lnL\": %.3g, \"worst_rel_mixture_dlnL\": %.3g, \"last_mixture_lnL\": %.17g, \"best_full_lnL\": %.17g}\n",
+         "\"worst_rel_mixture_lnL\": %.3g, \"worst_rel_mixture_dlnL\": %.3g, \"last_mixture_lnL\": %.17g, \"best_full_lnL\": %.17g, "
+         "\"tip_characters_rewritten\": %ld, \"cv_vectors_compared\": %ld, \"cv_vector_mismatches\": %ld}\n",
          g_host ? "host" : (g_check ? "check" : "device"), now_s() - g_t0, g_n_lk, g_n_mixt, g_n_mixt_dlk, g_n_mixt_skipped, g_n_upd, g_n_pmat, g_n_eig, g_n_dlk,
-         g_nctx, g_worst_mixt, g_worst_mixt_dlnl, g_last_mixt_lnl, g_best_full_lnl);
+         g_nctx, g_worst_mixt, g_worst_mixt_dlnl, g_last_mixt_lnl, g_best_full_lnl, g_n_tipchar, g_n_cv_vec, g_n_cv_bad);
   fflush(stdout);
   _exit(0);
 }

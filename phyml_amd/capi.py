@@ -35,7 +35,7 @@ class InstanceDetails(C.Structure):
 # every symbol include/phyhip.h declares (tests check the library exports them all)
 SYMBOLS = [
     "phyhip_create_instance", "phyhip_finalize_instance", "phyhip_get_last_error", "phyhip_set_tip_partials",
-    "phyhip_set_tip_states", "phyhip_set_partials", "phyhip_set_pattern_weights", "phyhip_set_category_rates",
+    "phyhip_set_tip_states", "phyhip_set_tip_partials_at_pattern", "phyhip_set_partials", "phyhip_set_pattern_weights", "phyhip_set_category_rates",
     "phyhip_set_category_weights", "phyhip_set_state_frequencies", "phyhip_set_eigen_decomposition",
     "phyhip_set_phyml_options", "phyhip_set_invariant_sites", "phyhip_update_transition_matrices",
     "phyhip_set_transition_matrix", "phyhip_get_transition_matrix", "phyhip_update_partials",
@@ -122,6 +122,10 @@ class Instance:
     def set_tip_partials(self, tip, partials):
         a = _f64(partials); assert a.size == self.P * self.S
         _chk(self.L.phyhip_set_tip_partials(self.id, tip, _ptr(a)))
+
+    def set_tip_partials_at_pattern(self, tip, pattern, partials):
+        a = _f64(partials); assert a.size == self.S
+        _chk(self.L.phyhip_set_tip_partials_at_pattern(self.id, int(tip), int(pattern), _ptr(a)))
 
     def set_tip_states(self, tip, states):
         a = np.ascontiguousarray(states, dtype=np.int32); assert a.size == self.P

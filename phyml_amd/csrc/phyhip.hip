@@ -603,7 +603,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // a short list of device-built matrices is folded into the lane-per-pattern nucleotide kernel's prologue when the grid
   // is small (measured: 16.7 vs 17.8 us per scalar-returning call on a 382-pattern search prefix; at 100 000 patterns
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
-  const bool fold_pm = I->soa && I->fold_pmats && I->grid_nt2 <= 512 && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
+  static const int fold_grid_max = diag_env("PHYHIP_FOLD_GRID") ? atoi(diag_env("PHYHIP_FOLD_GRID")) : 512;
+  const bool fold_pm = I->soa && I->fold_pmats && I->grid_nt2 <= fold_grid_max && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
                        I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
   // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
   // (TreeParams::n_up): no upload kernel in front of the traversal
@@ -1707,6 +1708,44 @@ int phyhip_set_tip_partials(int instance, int tipIndex, const double *inPartials
     codes[(size_t)p] = (uint8_t)code;
   }
   return set_tip_codes(I, tipIndex, codes);
+}
+
+// One pattern of one tip rewritten in place (leave-one-out cross-validation hides a character, optimises the pendant edge
+// and restores it: src/cv.c:51-118, src/mixt.c:4225-4258 -> Init_Partial_Lk_Tips_Double_One_Character, src/lk.c:2092).  In
+// stream order behind whatever was queued against the old state; no host synchronisation.
+int phyhip_set_tip_partials_at_pattern(int instance, int tipIndex, int pattern, const double *inPartials)
+{
+  if (Group *G = get_group(instance))
+  {
+    for (size_t g = 0; g < G->sub.size(); ++g)
+      if (pattern >= G->lo[g] && pattern < G->lo[g] + G->n[g])
+        return phyhip_set_tip_partials_at_pattern(G->sub_id[g], tipIndex, (int)(pattern - G->lo[g]), inPartials);
+    return fail(PHYHIP_ERROR_OUT_OF_RANGE, "pattern %d", pattern);
+  }
+  GET_INST(I, instance);
+  if (tipIndex < 0 || tipIndex >= I->tips) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip index %d", tipIndex);
+  if (pattern < 0 || pattern >= I->P) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "pattern %d", pattern);
+  uint32_t m = 0;
+  for (int s = 0; s < I->S; ++s)
+  {
+    const double x = inPartials[s];
+    if (x == 1.0) m |= 1u << s;
+    else if (x != 0.0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "tip %d pattern %d state %d: partial %g is not 0 or 1", tipIndex, pattern, s, x);
+  }
+  int code = (int)m; // S <= 8: the byte stored on the device is the allowed-state mask itself
+  int rc   = 0;
+  if (I->S > 8 && (rc = code_for_mask(I, m, &code))) return rc;
+  if ((rc = flush(I, nullptr))) return rc; // queued operations read the old state
+  void *st = nullptr;
+  if ((rc = I->ring.alloc(16, I->stream, &st))) return rc;
+  *reinterpret_cast<uint8_t *>(st) = (uint8_t)code;
+  *(reinterpret_cast<uint32_t *>(st) + 1) = m;
+  I->stream_dirty = true; I->touched_call = true;
+  HIPCHK(hipMemcpyAsync(I->d_tipcodes + (size_t)tipIndex * I->Ppad + pattern, st, 1, hipMemcpyHostToDevice, I->stream));
+  if (I->d_tipmasks)
+    HIPCHK(hipMemcpyAsync(I->d_tipmasks + (size_t)tipIndex * I->Ppad + pattern, reinterpret_cast<uint32_t *>(st) + 1, 4,
+                          hipMemcpyHostToDevice, I->stream));
+  return upload_masks(I);
 }
 
 int phyhip_set_tip_states(int instance, int tipIndex, const int *inStates)

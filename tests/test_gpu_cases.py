@@ -284,3 +284,33 @@ def test_rooted_input_tree_with_the_root_ignored(golden):
         assert abs(t.Lk(None) - ref) / abs(ref) < 1e-12
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("ns,devices", [(4, None), (20, None), (4, [0, 0, 0]), (20, [0, 0])])
+def test_single_character_tip_rewrite(ns, devices):
+    """phyhip_set_tip_partials_at_pattern (Init_Partial_Lk_Tips_Double_One_Character, src/lk.c:2092: the tip rewrite of the
+    leave-one-out cross-validation loops): hide one character, evaluate, restore it, evaluate -- against oracle trees built with
+    the hidden / original character, partial vectors bit-equal; plain and sharded instances."""
+    t, ot, tree, st = synthetic_pair(9, 130, ns, 4, seed=77, devices=devices)
+    try:
+        t.Set_Both_Sides(True)
+        ref0 = ot.lk(None, both_sides=True)
+        assert abs(t.Lk(None) - ref0) / abs(ref0) < 1e-12
+        for tip, pat in ((3, 0), (0, 129), (8, 64)):
+            rows = ot.tip_vec[tip].reshape(-1, ns)   # (a view: the oracle reads the same memory)
+            orig = rows[pat].copy()
+            hidden = np.ones(ns)
+            t.inst.set_tip_partials_at_pattern(tip, pat, hidden)
+            rows[pat] = hidden
+            ot.tip_amb[tip][pat] = 1
+            a, b = t.Lk(None), ot.lk(None, both_sides=True)
+            assert abs(a - b) / abs(b) < 1e-12 and abs(b - ref0) > 1e-9
+            for (e, side), p in ot.plk.items():
+                assert np.array_equal(t.partials(e, side), p), (tip, pat, e, side)
+            t.inst.set_tip_partials_at_pattern(tip, pat, orig)
+            rows[pat] = orig
+            ot.tip_amb[tip][pat] = 0
+            a = t.Lk(None)
+            assert abs(a - ref0) / abs(ref0) < 1e-12
+    finally:
+        t.close()

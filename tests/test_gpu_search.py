@@ -163,6 +163,33 @@ def test_nucleotide_mixture_analysis_check_mode(class_axis, tmp_path):
     assert info["worst_rel_mixture_dlnL"] < 1e-6, info
 
 
+@pytest.mark.parametrize("class_axis", [False, True], ids=["instance_per_class", "class_axis"])
+def test_leave_one_out_cross_validation_check_mode(class_axis, tmp_path):
+    """`cv.type="maxfold"` (MIXT_Maxfold_Cv, src/mixt.c:4198-4290 -> src/cv.c:294-420): every (site, taxon) position is hidden
+    (Init_Partial_Lk_Tips_Double_One_Character -> phyhip_set_tip_partials_at_pattern), the pendant edge optimised (MIXT_dLk /
+    MIXT_Lk, compared call by call as in every check-mode run), the character restored, and the reader's input -- p_lk_left of the
+    pendant edge at the hidden site, per class tree -- downloaded from the device and compared bit for bit (SURVEY 8f rank 3's
+    last reader)."""
+    if not os.path.exists(GLUE):
+        pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
+    base = str(tmp_path)
+    os.makedirs(os.path.join(base, "examples", "ntmix")); os.makedirs(os.path.join(base, "run"))
+    shutil.copy(os.path.join(GOLDEN, "ntmix", "nt4_cv.xml"), os.path.join(base, "examples", "ntmix", "nt4_cv.xml"))
+    shutil.copy(os.path.join(GOLDEN, "examples_nucleic.phy"), os.path.join(base, "examples", "nucleic"))
+    env = dict(os.environ, GLUE_MODE="check", GLUE_MAX_MIXT="4000", GLUE_CLASS_AXIS="1" if class_axis else "0")
+    r = subprocess.run([GLUE, "--", "--xml=../examples/ntmix/nt4_cv.xml"], cwd=os.path.join(base, "run"), env=env,
+                       stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:]
+    info = json.loads(m.group(1))
+    assert info["class_instances"] == 4
+    assert info["tip_characters_rewritten"] > 200, info           # two rewrites per hidden position (hide, restore)
+    assert info["cv_vectors_compared"] > 400 and info["cv_vector_mismatches"] == 0, info
+    assert info["calls"]["MIXT_dLk"] > 1000, info
+    assert info["worst_rel_mixture_lnL"] < 1e-10, info
+    assert info["worst_rel_mixture_dlnL"] < 1e-6, info
+
+
 @pytest.mark.parametrize("class_axis,device_pmat", [(False, False), (True, False), (True, True)],
                          ids=["instance_per_class", "class_axis", "class_axis_device_matrices"])
 def test_lg4x_mixture_analysis_driven_by_the_device(class_axis, device_pmat, tmp_path):
