@@ -1467,7 +1467,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   // alignment is too short to give every SIMD two waves of 64 patterns
   I->nt_groups = 1;
   // measured (us per traversal, G=2 / G=1): 50 k 195 / 206, 75 k 301 / 363, 125 k 444 / 456, 250 k 837 / 848, 1 M 3293 / 3246
-  if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 4096) I->nt_groups = 2;
+  // (round 3, non-temporal result stores: 50 k 165 / 198, 125 k 386 / 377, 1 M 3188 / 3186 -- the crossover moved to ~100 k)
+  if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 1600) I->nt_groups = 2;
   if (const char *e = diag_env("PHYHIP_NT_GROUPS"))
   {
     const int g = atoi(e);
