@@ -455,14 +455,16 @@ int flush_pmats(Instance *I)
     q.count = n;
     q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats = I->d_pmats;
-    // (20 states: a short list is latency -- 1024 threads, two entries each: 7.9 vs 11.5 us for three matrices; a whole
-    // tree's batch is throughput -- 256-thread blocks: 12 vs 15.9 us for 397 matrices)
-    const int threads = (I->S == 4) ? 64 : (n <= 16 ? 1024 : 256);
+    // (20 states: a short list is latency -- 1024 threads, two entries each, products pre-formed: 7.9 vs 11.5 us for three
+    // matrices; a whole tree's 397 matrices: 512 threads without the extra phase 14.7 us; 256 / 1024 threads 16.3-17.4 / 15.5)
+    int threads = (I->S == 4) ? 64 : (n <= 16 ? 1024 : 512);
+    if (const char *e = diag_env("PHYHIP_PMAT_THREADS")) threads = atoi(e);
     q.afrag = I->perm ? I->d_afrag : nullptr; // 20 states: the MFMA A-operand fragments come out of the same kernel
     q.class_axis = I->class_axis ? 1 : 0;
     const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)2 * I->C * I->S * I->S + (size_t)2 * I->NE * I->S * I->S);
-    if (I->S == 4) hipLaunchKernelGGL(pmat_kernel<4>, dim3(n), dim3(threads), lds, I->stream, q);
-    else hipLaunchKernelGGL(pmat_kernel<20>, dim3(n), dim3(threads), lds, I->stream, q);
+    if (I->S == 4) hipLaunchKernelGGL((pmat_kernel<4, true>), dim3(n), dim3(threads), lds, I->stream, q);
+    else if (n <= 16) hipLaunchKernelGGL((pmat_kernel<20, true>), dim3(n), dim3(threads), lds, I->stream, q);
+    else hipLaunchKernelGGL((pmat_kernel<20, false>), dim3(n), dim3(threads), lds, I->stream, q);
     HIPCHK(hipGetLastError());
     done += n;
   }
