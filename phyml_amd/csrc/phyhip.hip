@@ -261,6 +261,8 @@ struct Instance
   int    ablate = 0;         // PHYHIP_ABLATE (-DPHYHIP_DIAG builds only): timing-only kernel variants (results invalid)
   unsigned long long *d_dbg = nullptr; // cycle stamps of PHYHIP_ABLATE=8
   bool   args_recs = true;   // PHYHIP_ARGS_RECS=0: operation records of 1-2-operation launches go through the slot ring too
+  bool   fuse_eigen = true;  // PHYHIP_FUSE_EIGEN=0 (diag): Update_Eigen_Lr always as its own eigen_lr_kernel launch
+  bool   eig_fused_report = false; unsigned long long eig_fused_stamp = 0;
   bool   arg_uploads = true; // PHYHIP_ARG_UPLOADS=0: host-computed matrices always go through upload_matrices_kernel
   bool   eager_pmats = true; // PHYHIP_EAGER_PMAT=0: whole-tree matrix batches wait for the traversal launch too
   bool   no_loads = false;   // PHYHIP_NOLOADS (-DPHYHIP_DIAG builds only): zero-size every child load (timing only)
@@ -386,6 +388,7 @@ struct EdgeEval
   double *dev_out;  // optional user device pointer
   bool    to_host;
   double *warn_out; // sharded evaluation: device double receiving the numerical-warning flag (or nullptr)
+  bool    eigen = false; // not an evaluation: the eigen-basis products of Update_Eigen_Lr for (parent = left, child = right)
 };
 
 // Host-computed matrices queued by phyhip_set_transition_matrix: one launch per kUploadBatch of them.
@@ -770,7 +773,29 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       I->ops_slot = (new_slot + 1) % I->ops_slots;
     }
   }
-  if (ee)
+  if (ee && ee->eigen)
+  { // Update_Eigen_Lr fused behind the queued partial update(s): no sums, the products go to d_dot
+    q.edge_eval = 2; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = 0; q.dot_out = I->d_dot;
+    memcpy(q.m_evec, I->h_evec.data(), 16 * sizeof(double)); memcpy(q.m_ivec, I->h_ivec.data(), 16 * sizeof(double));
+    if (n_ops == 0 && I->args_recs) { q.recs_in_args = 1; q.n_real_ops = 0; }
+    if (q.recs_in_args)
+    {
+      auto untouched = [&](int idx) {
+        if (idx < I->tips) return false;
+        for (const DevOp &o : I->pending)
+          if (o.dest == idx) return false;
+        return true;
+      };
+      q.e_prefetch = (untouched(ee->parent) ? 1 : 0) | (untouched(ee->child) ? 2 : 0);
+    }
+    // (the report is what the resident dLk evaluator waits for: ITS eligibility -- dlk_kernel's grid -- decides, see eigen_eval)
+    const bool report = I->resident && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co;
+    q.eig_tickets = report ? I->d_tickets : nullptr;
+    q.eig_stamp_host = reinterpret_cast<unsigned long long *>(I->h_result + 3);
+    q.eig_stamp = report ? ++I->stamp_seq : 0ull;
+    I->eig_fused_report = report; I->eig_fused_stamp = q.eig_stamp;
+  }
+  else if (ee)
   {
     I->warn_current = false;
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
@@ -1107,7 +1132,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   if (kDiag) { const unsigned long long hp2 = hp_now(); g_hp.prep += hp1 - hp0; g_hp.launch += hp2 - hp1; ++g_hp.n_launch; }
   HIPCHK(hipGetLastError());
   I->host_sum_n = host_sum_n; I->host_sum_ns = 1;
-  if (ee && !fused_sum && !host_sum_n && !I->class_axis) // (class axis: the combination kernel follows, no sum here)
+  if (ee && !ee->eigen && !fused_sum && !host_sum_n && !I->class_axis) // (class axis: the combination kernel follows, no sum here)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
     const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
@@ -1593,6 +1618,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
 #endif
   if (const char *e = diag_env("PHYHIP_EAGER_PMAT")) I->eager_pmats = atoi(e) != 0;
   if (const char *e = diag_env("PHYHIP_ARG_UPLOADS")) I->arg_uploads = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_FUSE_EIGEN")) I->fuse_eigen = atoi(e) != 0;
   if (const char *e = diag_env("PHYHIP_ARGS_RECS")) I->args_recs = atoi(e) != 0;
   if (const char *e = diag_env("PHYHIP_SPLIT_REDUCE")) // see fuse_reduce()
   {
@@ -2605,6 +2631,18 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, rght, true))) return rc;
+  if (I->soa && !I->class_axis && I->NE == 1 && I->C <= 4 && I->fuse_eigen)
+  { // lane-per-pattern nucleotide kernel: the queued partial update(s) and the products are ONE launch (TreeParams::edge_eval 2)
+    {
+      AuxProf  ap(I, 0);
+      EdgeEval ee{left, rght, 0, nullptr, false, nullptr};
+      ee.eigen = true;
+      if ((rc = flush(I, &ee))) return rc;
+    }
+    if (I->eig_fused_report) { I->stream_dirty = false; I->clean_after = I->eig_fused_stamp; }
+    I->eig_api_no = I->eig_fused_report ? I->api_no : 0;
+    return PHYHIP_SUCCESS;
+  }
   if ((rc = flush(I, nullptr))) return rc;
   EigenParams e;
   e.t = base_params(I); e.ro = base_ro(I, nullptr); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;

@@ -478,6 +478,46 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
     const int      iv_pre = q.invar_model ? (int)q.invar[pc_] : -1;
     side(q.e_parent, x, sl, 1, EX, esl);
     side(q.e_child, y, sr, 2, EY, esr);
+    if (q.edge_eval == 2)
+    { // K3 behind the partial update it needs (Update_Eigen_Lr, src/lk.c:1038-1114; arithmetic of src/avx.c:79-82 as in
+      // eigen_lr_kernel): dot_prod[p][c][k] = (sum_i R[i][k] (x_i pi_i)) (sum_i L[k][i] y_i), first product, then the FMA chains
+      if (p < (unsigned)q.P)
+      {
+#pragma unroll
+        for (int c = 0; c < CL; ++c)
+        {
+          double lp[4], d[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lp[i] = x[c * 4 + i] * q.pi[i];
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq)
+          {
+            double a = fr.evec[kq] * lp[0];
+            double b = fr.ivec[kq * 4] * y[c * 4];
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+            {
+              a = __builtin_fma(fr.evec[i * 4 + kq], lp[i], a);
+              b = __builtin_fma(fr.ivec[kq * 4 + i], y[c * 4 + i], b);
+            }
+            d[kq] = a * b;
+          }
+          double2 *dst = reinterpret_cast<double2 *>(q.dot_out + ((size_t)p * C + c0 + c) * 4);
+          dst[0] = make_double2(d[0], d[1]);
+          dst[1] = make_double2(d[2], d[3]);
+        }
+      }
+      if (q.eig_tickets)
+      { // (as eigen_lr_kernel: every workgroup's stores complete and written back before its ticket is drawn)
+        __threadfence();
+        if (lane == 0 && __hip_atomic_fetch_add(q.eig_tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+        {
+          __hip_atomic_store(q.eig_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(q.eig_stamp_host, q.eig_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      return;
+    }
     const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16) + c0 * 16; // rows: right-side state
     double prod[CL];
 #pragma unroll
