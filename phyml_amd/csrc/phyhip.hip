@@ -773,6 +773,9 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       I->ops_slot = (new_slot + 1) % I->ops_slots;
     }
   }
+  // small nucleotide alignments: the resident short-launch evaluator (resident_nt2_kernel) may take the call
+  const bool rt_grid = I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis &&
+                       I->grid_nt2 <= kResidentMaxGrid && !I->ablate && I->nt_groups <= 2;
   if (ee && ee->eigen)
   { // Update_Eigen_Lr fused behind the queued partial update(s): no sums, the products go to d_dot
     q.edge_eval = 2; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = 0; q.dot_out = I->d_dot;
@@ -789,7 +792,14 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       q.e_prefetch = (untouched(ee->parent) ? 1 : 0) | (untouched(ee->child) ? 2 : 0);
     }
     // (the report is what the resident dLk evaluator waits for: ITS eligibility -- dlk_kernel's grid -- decides, see eigen_eval)
-    const bool report = I->resident && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co;
+    bool report = I->resident && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co;
+    if (rt_grid)
+    { // completion as an evaluation's: every workgroup fences its stores and posts an (empty) record the caller waits for --
+      // the stream is clean when phyhip_update_eigen_lr returns, and the resident workgroups can take the call
+      report = false;
+      q.host_blocks = I->h_blocks; q.host_tag = ++I->seq; q.warn = I->h_warn;
+      host_sum_n    = I->grid_nt2;
+    }
     q.eig_tickets = report ? I->d_tickets : nullptr;
     q.eig_stamp_host = reinterpret_cast<unsigned long long *>(I->h_result + 3);
     q.eig_stamp = report ? ++I->stamp_seq : 0ull;
@@ -837,8 +847,6 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     if (I->want_site_outputs) { q.site_lnl = I->d_site_lnl; q.site_lk = I->d_site_lk; q.site_cat = I->d_site_cat; }
   }
   // ---- small nucleotide alignments: the resident short-launch evaluator (resident_nt2_kernel) ------------------------
-  const bool rt_grid = I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis &&
-                       I->grid_nt2 <= kResidentMaxGrid && !I->ablate && I->nt_groups <= 2;
   static const bool rtdbg = kDiag && getenv("PHYHIP_RESIDENT_DEBUG") != nullptr; // (diag build: why an evaluation was launched)
   if (rtdbg && ee)
     fprintf(stderr, "rt: grid_ok %d (res %d spin %d hs %d soa %d co %d cls %d g2 %d abl %d grp %d) hsn %d args %d fresh %d site %d prof %d skip %d dirty_prev %d touched %d\n",
@@ -873,6 +881,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       TreeParams sq = base_params(I);
       sq.host_blocks = I->h_blocks; sq.warn = I->h_warn; sq.fence_post = 1; sq.recs_in_args = 1; sq.edge_eval = 1;
       sq.br_len_mult = I->br_len_mult; sq.l_min = I->l_min; sq.l_max = I->l_max; sq.pmats_rw = I->d_pmats;
+      sq.dot_out = I->d_dot;
       if (I->want_site_outputs) { sq.site_lnl = I->d_site_lnl; sq.site_lk = I->d_site_lk; sq.site_cat = I->d_site_cat; }
       if (!R.launched || R.grid != I->grid_nt2 || memcmp(&I->rt_static, &sq, sizeof sq) != 0 || resident_gone(R))
       {
@@ -905,7 +914,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       const bool changed = I->clean_epoch != I->rt_epoch; // the stream ran something since the last command
       words[0] = q.host_tag;
       words[1] = (unsigned long long)q.n_real_ops | (changed ? 4ull : 0ull) | ((unsigned long long)q.n_fresh << 4) |
-                 ((unsigned long long)q.e_prefetch << 8);
+                 ((unsigned long long)q.e_prefetch << 8) | (q.edge_eval == 2 ? 1ull << 10 : 0ull);
       words[2] = (unsigned long long)(unsigned)q.e_parent | ((unsigned long long)(unsigned)q.e_child << 32);
       words[3] = (unsigned long long)(unsigned)q.e_pm | ((unsigned long long)(unsigned)q.last_dest << 32);
       for (int k = 0; k < q.n_fresh; ++k)
@@ -2073,6 +2082,44 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
   return PHYHIP_SUCCESS;
 }
 
+// An evaluation the host waits for (edge sum, or the empty records of a small alignment's Update_Eigen_Lr): queue, launch or
+// hand to the resident short-launch evaluator, wait.  An evaluation the resident workgroups do not answer is launched.
+static int flush_and_wait(Instance *I, EdgeEval &ee, bool flushed = false)
+{
+  int rc = flushed ? 0 : flush(I, &ee);
+  if (rc) return rc;
+  const bool by_resident = I->r_inflight != nullptr;
+  rc = wait_result(I);
+  if (rc == kResidentSilent)
+  { // the resident workgroups had left: retire them for good (no late record can arrive after this), put the evaluation
+    // back in the queue and launch it
+    ++I->rt.n_silent;
+    resident_stop(I->rt);
+    I->r_inflight = nullptr; I->host_sum_n = 0;
+    I->pending = I->rt_ops;
+    for (const DevOp &o : I->pending) { I->mat_in_queue[o.pm1] = 1; I->mat_in_queue[o.pm2] = 1; }
+    for (size_t k = 0; k < I->rt_pm_idx.size(); ++k)
+      if (I->pm_slot[I->rt_pm_idx[k]] < 0)
+      {
+        I->pm_slot[I->rt_pm_idx[k]] = (int)I->pm_idx.size();
+        I->pm_idx.push_back(I->rt_pm_idx[k]);
+        I->pm_len.push_back(I->rt_pm_len[k]);
+      }
+    I->rt_skip = true;
+    rc = flush(I, &ee);
+    I->rt_skip = false;
+    if (rc) return rc;
+    rc = wait_result(I);
+  }
+  if (rc) return rc;
+  if (I->fenced_eval)
+  { // every store of this evaluation -- and so everything queued before it -- is in memory
+    I->fenced_eval = false; I->stream_dirty = false; I->clean_after = 0;
+    if (!by_resident || ee.eigen) ++I->clean_epoch; // (a kernel ran / dot_prod rewritten: the resident workgroups re-read)
+  }
+  return 0;
+}
+
 int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const int *child, const int *pm, const int *d1,
                                           const int *d2, const int *cw, const int *sf, const int *cs, int count,
                                           double *outSum, double *outD1, double *outD2)
@@ -2099,38 +2146,8 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
     return PHYHIP_SUCCESS;
   }
   EdgeEval ee{parent[0], child[0], pm[0], nullptr, true, nullptr};
-  rc = flush(I, &ee);
-  if (rc) return rc;
-  const bool by_resident = I->r_inflight != nullptr;
-  rc = wait_result(I);
-  if (rc == kResidentSilent)
-  { // the resident workgroups had left: retire them for good (no late record can arrive after this), put the evaluation
-    // back in the queue and launch it
-    ++I->rt.n_silent;
-    resident_stop(I->rt);
-    I->r_inflight = nullptr; I->host_sum_n = 0;
-    I->pending = I->rt_ops;
-    for (const DevOp &o : I->pending) { I->mat_in_queue[o.pm1] = 1; I->mat_in_queue[o.pm2] = 1; }
-    for (size_t k = 0; k < I->rt_pm_idx.size(); ++k)
-      if (I->pm_slot[I->rt_pm_idx[k]] < 0)
-      {
-        I->pm_slot[I->rt_pm_idx[k]] = (int)I->pm_idx.size();
-        I->pm_idx.push_back(I->rt_pm_idx[k]);
-        I->pm_len.push_back(I->rt_pm_len[k]);
-      }
-    I->rt_skip = true;
-    rc = flush(I, &ee);
-    I->rt_skip = false;
-    if (rc) return rc;
-    rc = wait_result(I);
-  }
-  if (rc) return rc;
+  if ((rc = flush_and_wait(I, ee))) return rc;
   *outSum = I->h_result[0];
-  if (I->fenced_eval)
-  { // every store of this evaluation -- and so everything queued before it -- is in memory
-    I->fenced_eval = false; I->stream_dirty = false; I->clean_after = 0;
-    if (!by_resident) ++I->clean_epoch; // (a kernel ran: the resident workgroups re-read what it wrote)
-  }
   return PHYHIP_SUCCESS;
 }
 
@@ -2637,7 +2654,16 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
       AuxProf  ap(I, 0);
       EdgeEval ee{left, rght, 0, nullptr, false, nullptr};
       ee.eigen = true;
+      const bool wc = I->warn_current;
       if ((rc = flush(I, &ee))) return rc;
+      if (I->host_sum_n > 0)
+      { // small alignment: the workgroups (launched or resident) post empty records once their products are in memory
+        const double keep = I->h_result[0];
+        if ((rc = flush_and_wait(I, ee, true))) return rc;
+        I->h_result[0] = keep; I->warn_current = wc;
+        I->eig_api_no = 0;
+        return PHYHIP_SUCCESS;
+      }
     }
     if (I->eig_fused_report) { I->stream_dirty = false; I->clean_after = I->eig_fused_stamp; }
     I->eig_api_no = I->eig_fused_report ? I->api_no : 0;

@@ -507,6 +507,11 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
           dst[1] = make_double2(d[2], d[3]);
         }
       }
+      if (q.host_blocks)
+      { // small alignment (launched or resident): completion as an evaluation's -- stores fenced, then an empty record
+        publish_block_sum(q, 0.0, lane);
+        return;
+      }
       if (q.eig_tickets)
       { // (as eigen_lr_kernel: every workgroup's stores complete and written back before its ticket is drawn)
         __threadfence();
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel
 // ~5 us kernel behind a ~3 us launch call, the dispatch, and the kernel's start and end.  While nothing else of the instance
 // is on its stream, the one-wave workgroups of this kernel stay on the device and take those evaluations from the command
 // record: payload words 0 tag, 1 flags (bits 0-1 operations, bit 2 device data changed, bits 4-7 matrices to rebuild, bits
-// 8-9 evaluation sides to fetch early), 2 evaluation edge (parent | child << 32), 3 its matrix | last destination << 32,
+// 8-9 evaluation sides to fetch early, bit 10 the eigen products of the edge -- Update_Eigen_Lr -- instead of its sum), 2 evaluation edge (parent | child << 32), 3 its matrix | last destination << 32,
 // 4-5 matrix indices, 6-9 their edge lengths, then per operation 12 words: the four child descriptors and the two
 // destination descriptors of the launch form's records.  Everything else is the launch's TreeParams, fixed at launch.
 // A workgroup completes and writes back its stores before it posts its sum (fence_post), so kernels launched afterwards
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     TreeParams               q = sq;
     q.host_tag = word(0);
     q.n_fresh = (int)((fl >> 4) & 15); q.e_prefetch = (int)((fl >> 8) & 3);
-    q.edge_eval = 1; q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
+    q.edge_eval = (fl >> 10) & 1 ? 2 : 1; q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
     q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
     if (lane < 4)
     {
