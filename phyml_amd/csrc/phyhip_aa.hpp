@@ -175,7 +175,9 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
   const int nw   = (int)(blockDim.x >> 6) - 1; // consumer waves
   const int C    = q.C;
   const size_t ntiles = (size_t)(q.Ppad / NPW);
-  const int n_items = q.n_ops + (q.edge_eval ? 1 : 0);
+  // (the list form is padded to an even length by the host -- the nucleotide kernel's convention; the argument form is not)
+  const int n_ops   = ARGS ? q.n_real_ops : q.n_ops;
+  const int n_items = n_ops + (q.edge_eval ? 1 : 0);
 
   if (threadIdx.x < 16)
   {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
     for (int j = 0; j < ((ABL & 8) ? 0 : n_items); ++j)
     {
       unsigned off1, off2;
-      if (j < q.n_ops) { const IssueRec rj = IR(j); off1 = rj.c1_data.x; off2 = rj.c2_data.x; }
+      if (j < n_ops) { const IssueRec rj = IR(j); off1 = rj.c1_data.x; off2 = rj.c2_data.x; }
       else off1 = off2 = (unsigned)q.e_pm * kMatB;
       // the slot is free once every consumer has finished item j - kAaRing
       const int need = j - kAaRing + 1;
@@ -392,9 +394,9 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
       double   prev[T] = {0., 0., 0., 0., 0.}; // result of the previous operation (this lane's D fragments)
       unsigned prev_sc = 0;
 
-      if (q.n_ops > 0)
+      if (n_ops > 0)
       {
-        const int last = q.n_ops - 1; // host pads the list to an even length
+        const int last = n_ops - 1;
         Raw       RA, RB;
         ExecRec   cur = XR(0);
         IssueRec  nx1 = IR((1 < last) ? 1 : last);
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           PHY_STAMP(k, 0)
           // The loads of operation k+1 go out first (their registers were consumed by step k-1), then the records of
           // k+2 / k+1 are requested into the scalar registers the issue just freed: both have the whole step to arrive.
-          issue_children(nx1, Rn);
+          if (!ARGS || k < last) issue_children(nx1, Rn);
           const IssueRec nx2 = IR((k + 2 < last) ? k + 2 : last);
           const ExecRec  nxe = XR((k + 1 < last) ? k + 1 : last);
           // A tip child whose patterns all carry ONE state contributes a column of its matrix (the reference's Exex / Exin
@@ -528,10 +530,18 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           cur     = nxe;
           nx1     = nx2;
         };
-        for (int k = 0; k < q.n_ops; k += 2)
+        if constexpr (ARGS)
         {
-          step(k, RA, RB);
-          step(k + 1, RB, RA);
+          step(0, RA, RB);
+          if (n_ops > 1) step(1, RB, RA);
+        }
+        else
+        {
+          for (int k = 0; k < n_ops; k += 2)
+          {
+            step(k, RA, RB);
+            step(k + 1, RB, RA);
+          }
         }
       }
 
@@ -564,10 +574,10 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         side(q.e_parent, x, sl);
         side(q.e_child, y, sr);
         {
-          const double *A = wait_item(q.n_ops);
+          const double *A = wait_item(n_ops);
 #pragma unroll
           for (int t = 0; t < T; ++t) mfma_chunk(A, t, x[t], u); // rows: right-side state
-          release_item(q.n_ops);
+          release_item(n_ops);
         }
         const double *pi_c = q.pi + ((cls && !idle) ? c * 20 : 0);
         double part = 0.0;

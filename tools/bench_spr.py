@@ -20,14 +20,15 @@ def main():
     ap.add_argument("--patterns", type=int, default=100000)
     ap.add_argument("--candidates", type=int, default=2000)
     ap.add_argument("--opt-every", type=int, default=0)
+    ap.add_argument("--states", type=int, default=4, choices=(4, 20))
     ap.add_argument("--host-pmat", action="store_true", help="transition matrices computed by the host layer's PMat() (bit-exact route)")
     args = ap.parse_args()
     from phyml_amd import lktree, replay, synth, workloads
-    blk = workloads.model_block("model_gtr_g4")
+    blk = workloads.model_block("model_gtr_g4" if args.states == 4 else "model_lg_g4")
     tree = synth.random_tree(args.taxa, 9, 0.02, 0.15)   # defaults = workloads cfg5_nt_500x100k (tests/test_gpu_cfg5.py checks
-    st = synth.simulate_states(tree, args.patterns, 4, 9)  # every scalar of this call pattern against the oracle at this size)
+    st = synth.simulate_states(tree, args.patterns, args.states, 9)  # every scalar of this call pattern against the oracle at this size)
     C = int(blk["ncatg"][0])
-    t = lktree.LkTree(args.taxa, tree.edge_left, tree.edge_rght, tree.edge_len, args.patterns, 4, C, host_pmat=args.host_pmat)
+    t = lktree.LkTree(args.taxa, tree.edge_left, tree.edge_rght, tree.edge_len, args.patterns, args.states, C, host_pmat=args.host_pmat)
     t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"])
     t.Make_Tree_For_Lk(np.ones(args.patterns))
     t.set_tips(tip_states=st.astype(np.int32))
@@ -42,7 +43,7 @@ def main():
     dt = time.perf_counter() - t0
     k = tr["kind"]
     n_upd = int((k == replay.UPDATE).sum()); n_lnl = int((k == replay.EDGE_LNL).sum()); n_dlk = int((k == replay.DLK).sum())
-    print(json.dumps({"matrices": "host PMat()" if args.host_pmat else "device", "taxa": args.taxa, "patterns": args.patterns, "candidates": args.candidates,
+    print(json.dumps({"matrices": "host PMat()" if args.host_pmat else "device", "states": args.states, "taxa": args.taxa, "patterns": args.patterns, "candidates": args.candidates,
                       "full_both_sides_Lk_ms": t_full * 1e3, "lnL": lnl,
                       "us_per_candidate": dt / args.candidates * 1e6, "candidates_per_s": args.candidates / dt,
                       "surface_calls": int(len(k)), "updates": n_upd, "edge_lnl": n_lnl, "dlk": n_dlk,
