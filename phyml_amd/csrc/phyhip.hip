@@ -2641,6 +2641,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
 
 // ---- eigen basis -------------------------------------------------------------------------------------
 
+constexpr int kFuseEigenMaxPatterns = 16384;
 int phyhip_update_eigen_lr(int instance, int left, int rght)
 {
   if (Group *G = get_group(instance)) return group_parallel(G, [&](int g) { return phyhip_update_eigen_lr(G->sub_id[g], left, rght); });
@@ -2648,7 +2649,9 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, rght, true))) return rc;
-  if (I->soa && !I->class_axis && I->NE == 1 && I->C <= 4 && I->fuse_eigen)
+  // (the lane-per-pattern kernel stores dot_prod 16 bytes per lane at a 64-byte stride: at 100 000 patterns its products take
+  // 24 us against eigen_lr_kernel's 10 -- more than the launch it saves; measured, bench.py extra.call_latency.brlen_500x100k)
+  if (I->soa && !I->class_axis && I->NE == 1 && I->C <= 4 && I->fuse_eigen && I->P <= kFuseEigenMaxPatterns)
   { // lane-per-pattern nucleotide kernel: the queued partial update(s) and the products are ONE launch (TreeParams::edge_eval 2)
     {
       AuxProf  ap(I, 0);
