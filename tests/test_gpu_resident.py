@@ -51,6 +51,11 @@ def test_resident_evaluator_matches_the_launch_path_and_the_oracle(patterns, mon
             if res == "1":
                 assert served >= 4 * 7 - 4 and silent == 0, (served, launches, silent, busy)
                 assert launches <= 5  # (the oracle runs between the chains: the workgroups may have left meanwhile)
+                if patterns <= 1500:
+                    # the chain's Lk(b) and its Update_Eigen_Lr (partial update + eigen products: ONE command) are served by
+                    # the short-launch evaluator (up to 64 one-wave workgroups: 2 048 patterns)
+                    s_served, _, s_silent, _ = t.inst.resident_stats(1)
+                    assert s_served >= 4 and s_silent == 0, (s_served, s_silent)
             else:
                 assert served == 0 and launches == 0
             for a, b in zip(dev, ref):
