@@ -164,7 +164,9 @@ def test_resident_protocol_under_stress(monkeypatch):
     -- and every scalar is still the launch path's double."""
     from phyml_amd import replay
     res = {}
-    for r, idle in (("0", "1000"), ("1", "15"), ("1", "40")):
+    # (3 us is below the time between any two commands on any host: the workgroups leave after nearly every command; 15 us is
+    # between the commands of a chain and the pause of an evaluator while the other one works -- on a slow enough host)
+    for r, idle in (("0", "1000"), ("1", "3"), ("1", "15")):
         monkeypatch.setenv("PHYHIP_RESIDENT", r)
         monkeypatch.setenv("PHYHIP_RESIDENT_IDLE_US", idle)
         t, ot, tree, st = synthetic_pair(30, 500, 4, 4, seed=71, host_pmat=False)
@@ -175,7 +177,7 @@ def test_resident_protocol_under_stress(monkeypatch):
             res[(r, idle)] = t.Replay_Surface_Trace(tr)
             if r == "1":
                 d, s = t.inst.resident_stats(0), t.inst.resident_stats(1)
-                assert d[0] + d[2] > 0 and s[0] + s[2] > 0 and d[1] + s[1] > 4, (d, s)
+                assert d[0] + d[2] > 0 and s[0] + s[2] > 0 and d[1] + s[1] > (4 if idle == "3" else 1), (d, s)
         finally:
             t.close()
     a, a2 = res[("0", "1000")]
