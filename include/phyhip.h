@@ -223,7 +223,8 @@ int phyhip_get_numerical_warning(int instance, int *outWarning);
    of every class instance, evaluates the given edge in each (the Lk_Core calls of src/mixt.c:997-1010) and combines
    the classes per pattern: 2^-sum rescaling, proba * r_mat_weight / rMatWeightSum * e_frq_weight / eFrqWeightSum /
    sumProbas (src/mixt.c:1048-1053), DBL_MIN floor, log, pattern weights of the FIRST instance.  All instances must sit
-   on the same device with the same pattern count and one category.  The per-pattern log-likelihoods
+   on the same device with the same pattern count and one category; up to 64 classes (profile mixtures of the C10-C60 kind:
+   one class tree per profile), PHYHIP_ERROR_OUT_OF_RANGE beyond.  The per-pattern log-likelihoods
    (mixt_tree->c_lnL_sorted) are left in the first instance (phyhip_get_site_log_likelihoods). */
 int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, const int *parentBufferIndices,
                                             const int *childBufferIndices, const int *probabilityIndices,

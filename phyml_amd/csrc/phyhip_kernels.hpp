@@ -1505,7 +1505,9 @@ __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, co
 // (fact_sum_scale) in device memory.  Here: common scale 2^-sum (sum capped at 1023 above 1024 with a warning, :1027-1034),
 // weights in the reference's operation order (:1048-1053), DBL_MIN floor (:1114-1117), log, weighted sum.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxMixClasses = 16;
+// (per-class instances: profile mixtures of the C10-C60 kind have up to 60 classes; the per-class tables below ride in the
+// kernel arguments, whose segment holds 4 KB)
+constexpr int kMaxMixClasses = 64;
 struct MixParams
 {
   int           count;
@@ -1585,6 +1587,8 @@ template <int S> struct MixDlkParams
   double        pi_inv[20];
   FinishParams  fin;
 };
+
+static_assert(sizeof(MixParams) <= 4096 && sizeof(MixDlkParams<20>) <= 4096, "the per-class tables ride in the kernel arguments");
 
 template <int S> __global__ __launch_bounds__(256) void mixture_dlk_kernel(const MixDlkParams<S> q)
 {

@@ -206,3 +206,76 @@ def test_lg4x_mixture_dlk_on_the_class_axis(host_matrices, layout, fx):
         assert abs(dlnl - ref_dlnl) <= 1e-8 * max(1.0, abs(ref_dlnl)), (dlnl, ref_dlnl)
     finally:
         t.close()
+
+
+def _many_classes(d, K):
+    """K synthetic class models from a dump's own classes (cycled, each with its own rate multiplier) and K weights that sum
+    to one: a profile mixture of the C10-C60 kind has one class tree per profile (src/mixt.c:2603-2640)."""
+    base, _ = replay.mixture_classes(d)
+    models, factors = [], []
+    rng = np.random.default_rng(7)
+    w = rng.uniform(0.2, 1.0, K); w = w / w.sum()
+    for k in range(K):
+        md = dict(base[k % len(base)])
+        md["gamma_rr"] = np.array([float(md["gamma_rr"][0]) * (0.35 + 0.11 * k)])
+        models.append(md)
+        factors.append((float(w[k]), 1.0, 1.0))
+    return models, factors
+
+
+@pytest.mark.parametrize("fx,K", [("nt4", 24), ("lg4x", 60)])
+def test_many_class_mixture_against_the_oracle(fx, K):
+    """More classes than the reference's example analyses have (phyhip_calculate_mixture_* take up to 64 class instances):
+    MIXT_Lk and MIXT_dLk over K class instances against the oracle's per-class evaluation + the restated combinations
+    (replay.mixture_combine / mixture_dlk, pinned to the reference's dumps by tests/test_mixture_oracle.py)."""
+    from test_mixture_oracle import class_tree
+    d = phyg.load(os.path.join(GOLDEN, f"mixture_{fx}_dlk.phyg"))
+    models, factors = _many_classes(d, K)
+    n, P, S = int(d["n_otu"][0]), int(d["n_pattern"][0]), int(d["ns"][0])
+    tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
+    e = int(d["eval_edge"][0])
+    l = float(d["dlk_l"][0])
+    # the oracle, class by class
+    unscaled, fact, dots = [], [], []
+    for md in models:
+        ot = class_tree(d, md)
+        ot.lk(both_sides=True)
+        ot.lk(e)
+        unscaled.append(ot.unscaled_site_lk_cat[:, 0].copy()); fact.append(ot.fact_sum_scale.copy())
+        ot.update_eigen_lr(e)
+        dots.append(ot.dot_prod.copy())
+    ref_lnl, ref_logs = replay.mixture_combine(unscaled, fact, factors, float(K), float(K), 1.0, d["wght"])
+    ref_l2, ref_dlnl = replay.mixture_dlk(dots, fact, models, factors, float(K), float(K), 1.0, d["wght"], l)
+    trees = []
+    try:
+        for md in models:
+            t = lktree.LkTree(n, d["edge_left"], d["edge_rght"], d["edge_len"], P, S, 1, host_pmat=True)
+            t.tip_root = 0
+            t.set_model(md["pi"], md["gamma_rr"], md["gamma_r_proba"], md["e_val"], md["r_e_vect"], md["l_e_vect"],
+                        float(md["l_min"][0]), float(md["l_max"][0]), float(md["br_len_mult"][0]), 1, 0, 0.0)
+            t.Make_Tree_For_Lk(d["wght"], None)
+            t.set_tips(tip_partials=tv)
+            t.Set_Both_Sides(1)
+            t.Lk()
+            trees.append(t)
+        ids = [t.tree.contents.b_inst for t in trees]
+        par = [t.side_buffer(e, 0) for t in trees]; chi = [t.side_buffer(e, 1) for t in trees]
+        lnl = capi.mixture_log_likelihood(ids, par, chi, [t.edge(e).contents.Pij_rr_idx for t in trees], [f[0] for f in factors],
+                                          [f[1] for f in factors], [f[2] for f in factors], float(K), float(K), 1.0)
+        assert abs(lnl - ref_lnl) <= 1e-12 * abs(ref_lnl), (lnl, ref_lnl)
+        assert np.max(np.abs(trees[0].inst.site_log_likelihoods() - ref_logs)) < 1e-10
+        for t in trees:
+            t.Update_Eigen_Lr(e)
+        _, lnl2, dlnl = capi.mixture_eigen_lnl_dlnl(ids, par, chi, l, [f[0] for f in factors], [f[1] for f in factors],
+                                                     [f[2] for f in factors], float(K), float(K), 1.0)
+        assert abs(lnl2 - ref_l2) <= 1e-12 * abs(ref_l2), (lnl2, ref_l2)
+        assert abs(dlnl - ref_dlnl) <= 1e-8 * max(1.0, abs(ref_dlnl)), (dlnl, ref_dlnl)
+        # one class more than the tables hold is refused, not truncated
+        if K == 60:
+            with pytest.raises(Exception):
+                capi.mixture_log_likelihood(ids + ids[:5], par + par[:5], chi + chi[:5],
+                                            [t.edge(e).contents.Pij_rr_idx for t in trees] + [0] * 5, [0.0] * 65, [1.0] * 65,
+                                            [1.0] * 65, float(K), float(K), 1.0)
+    finally:
+        for t in trees:
+            t.close()
