@@ -45,7 +45,7 @@
 
 #include "mixt.h"
 #include "../include/phyhip.h"
-#define kMaxClasses 16
+#define kMaxClasses 64
 
 static int g_check = 0, g_device_pmat = 0, g_host = 0;
 static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat = 0, g_n_eig = 0, g_n_mixt = 0, g_n_mixt_skipped = 0;
