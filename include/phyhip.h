@@ -271,9 +271,9 @@ int phyhip_get_class_scale_factors(int instance, int bufferIndex, int classIndex
 
 /* Update_Eigen_Lr(b,tree), src/lk.c:1038-1114 / src/avx.c:21-105: fills the instance's dot_prod
    [pattern][category][state] from the two sides of an edge (either side may be a tip).  Flushes the queue first: on
-   nucleotide instances up to 16 384 patterns the queued partial update(s) and the products are one launch (up to 2 048
-   patterns: one command of the resident evaluator, and the call returns when the products are in device memory); the
-   products are always ordered before whatever the instance is asked next. */
+   nucleotide instances up to 2 048 patterns the queued partial update(s) and the products are one launch -- mostly one
+   command of the resident evaluator -- and the call returns when the products are in device memory; the products are
+   always ordered before whatever the instance is asked next. */
 int phyhip_update_eigen_lr(int instance, int leftBufferIndex, int rightBufferIndex);
 
 /* dLk(&l,b,tree), src/lk.c:655-753: clamps *l to [l_min,l_max], returns lnL and dlnL/dl from dot_prod

@@ -262,7 +262,6 @@ struct Instance
   unsigned long long *d_dbg = nullptr; // cycle stamps of PHYHIP_ABLATE=8
   bool   args_recs = true;   // PHYHIP_ARGS_RECS=0: operation records of 1-2-operation launches go through the slot ring too
   bool   fuse_eigen = true;  // PHYHIP_FUSE_EIGEN=0 (diag): Update_Eigen_Lr always as its own eigen_lr_kernel launch
-  bool   eig_fused_report = false; unsigned long long eig_fused_stamp = 0;
   bool   arg_uploads = true; // PHYHIP_ARG_UPLOADS=0: host-computed matrices always go through upload_matrices_kernel
   bool   eager_pmats = true; // PHYHIP_EAGER_PMAT=0: whole-tree matrix batches wait for the traversal launch too
   bool   no_loads = false;   // PHYHIP_NOLOADS (-DPHYHIP_DIAG builds only): zero-size every child load (timing only)
@@ -597,6 +596,13 @@ static int resident_launch_dlk(Instance *I, const DlkParams &qs, int dgrid, unsi
 }
 
 
+// instances whose short launches (SPR candidates, Lk(b), Update_Eigen_Lr) the resident workgroups of resident_nt2_kernel may take
+static bool resident_short_eligible(const Instance *I)
+{
+  return I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis && I->grid_nt2 <= kResidentMaxGrid &&
+         !I->ablate && I->nt_groups <= 2;
+}
+
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush_impl(Instance *I, const EdgeEval *ee)
 {
@@ -774,8 +780,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     }
   }
   // small nucleotide alignments: the resident short-launch evaluator (resident_nt2_kernel) may take the call
-  const bool rt_grid = I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis &&
-                       I->grid_nt2 <= kResidentMaxGrid && !I->ablate && I->nt_groups <= 2;
+  const bool rt_grid = resident_short_eligible(I);
   if (ee && ee->eigen)
   { // Update_Eigen_Lr fused behind the queued partial update(s): no sums, the products go to d_dot
     q.edge_eval = 2; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = 0; q.dot_out = I->d_dot;
@@ -791,19 +796,11 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       };
       q.e_prefetch = (untouched(ee->parent) ? 1 : 0) | (untouched(ee->child) ? 2 : 0);
     }
-    // (the report is what the resident dLk evaluator waits for: ITS eligibility -- dlk_kernel's grid -- decides, see eigen_eval)
-    bool report = I->resident && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co;
-    if (rt_grid)
-    { // completion as an evaluation's: every workgroup fences its stores and posts an (empty) record the caller waits for --
-      // the stream is clean when phyhip_update_eigen_lr returns, and the resident workgroups can take the call
-      report = false;
-      q.host_blocks = I->h_blocks; q.host_tag = ++I->seq; q.warn = I->h_warn;
-      host_sum_n    = I->grid_nt2;
-    }
-    q.eig_tickets = report ? I->d_tickets : nullptr;
-    q.eig_stamp_host = reinterpret_cast<unsigned long long *>(I->h_result + 3);
-    q.eig_stamp = report ? ++I->stamp_seq : 0ull;
-    I->eig_fused_report = report; I->eig_fused_stamp = q.eig_stamp;
+    // completion as an evaluation's: every workgroup fences its stores and posts an (empty) record the caller waits for -- the
+    // stream is clean when phyhip_update_eigen_lr returns, and the resident workgroups can take the call (the only
+    // instances that come here: phyhip_update_eigen_lr)
+    q.host_blocks = I->h_blocks; q.host_tag = ++I->seq; q.warn = I->h_warn;
+    host_sum_n    = I->grid_nt2;
   }
   else if (ee)
   {
@@ -2641,7 +2638,6 @@ int phyhip_get_numerical_warning(int instance, int *out)
 
 // ---- eigen basis -------------------------------------------------------------------------------------
 
-constexpr int kFuseEigenMaxPatterns = 16384;
 int phyhip_update_eigen_lr(int instance, int left, int rght)
 {
   if (Group *G = get_group(instance)) return group_parallel(G, [&](int g) { return phyhip_update_eigen_lr(G->sub_id[g], left, rght); });
@@ -2649,27 +2645,22 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, rght, true))) return rc;
-  // (the lane-per-pattern kernel stores dot_prod 16 bytes per lane at a 64-byte stride: at 100 000 patterns its products take
-  // 24 us against eigen_lr_kernel's 10 -- more than the launch it saves; measured, bench.py extra.call_latency.brlen_500x100k)
-  if (I->soa && !I->class_axis && I->NE == 1 && I->C <= 4 && I->fuse_eigen && I->P <= kFuseEigenMaxPatterns)
-  { // lane-per-pattern nucleotide kernel: the queued partial update(s) and the products are ONE launch (TreeParams::edge_eval 2)
-    {
-      AuxProf  ap(I, 0);
-      EdgeEval ee{left, rght, 0, nullptr, false, nullptr};
-      ee.eigen = true;
-      const bool wc = I->warn_current;
-      if ((rc = flush(I, &ee))) return rc;
-      if (I->host_sum_n > 0)
-      { // small alignment: the workgroups (launched or resident) post empty records once their products are in memory
-        const double keep = I->h_result[0];
-        if ((rc = flush_and_wait(I, ee, true))) return rc;
-        I->h_result[0] = keep; I->warn_current = wc;
-        I->eig_api_no = 0;
-        return PHYHIP_SUCCESS;
-      }
-    }
-    if (I->eig_fused_report) { I->stream_dirty = false; I->clean_after = I->eig_fused_stamp; }
-    I->eig_api_no = I->eig_fused_report ? I->api_no : 0;
+  // Small nucleotide alignments (the resident short-launch evaluator's range, 2 048 patterns): the queued partial update(s) and
+  // the products are ONE launch of the lane-per-pattern kernel (TreeParams::edge_eval 2) -- or, mostly, one command of the
+  // resident workgroups.  Measured by chain (1 Update_Eigen_Lr + 5 dLk, tools/gpu_fuse_eigen_cross.sh): 40.3 vs 43.8 us at 382
+  // patterns, 53.7 vs 56.2 at 2 048; WITHOUT the resident evaluator the fused launch loses to eigen_lr_kernel at every size
+  // (+2 us: it stores dot_prod 16 bytes per lane at a 64-byte stride), beyond 4 096 patterns by 4-7 us -- so nowhere else.
+  if (I->NE == 1 && I->C <= 4 && I->fuse_eigen && resident_short_eligible(I))
+  {
+    AuxProf  ap(I, 0);
+    EdgeEval ee{left, rght, 0, nullptr, false, nullptr};
+    ee.eigen = true;
+    const bool   wc = I->warn_current;
+    const double keep = I->h_result[0];
+    // the workgroups (launched or resident) post empty records once their products are in memory
+    if ((rc = flush_and_wait(I, ee))) return rc;
+    I->h_result[0] = keep; I->warn_current = wc;
+    I->eig_api_no = 0;
     return PHYHIP_SUCCESS;
   }
   if ((rc = flush(I, nullptr))) return rc;

@@ -89,12 +89,9 @@ struct TreeParams
   int             last_dest;  // destination buffer of the last queued operation (-1: none)
   // fused root-edge evaluation (K2); 2: the eigen-basis products of Update_Eigen_Lr (K3) for the edge (e_parent = left side,
   // e_child = right side) instead -- lane-per-pattern nucleotide kernel only: the partial update Br_Len_Opt queues in front of
-  // Update_Eigen_Lr and the products are ONE launch (dot_out, eigen system in m_evec / m_ivec; eig_*: completion report)
+  // Update_Eigen_Lr and the products are ONE launch (dot_out, eigen system in m_evec / m_ivec; completion: an empty record per workgroup)
   int             edge_eval;
   double             *dot_out;
-  unsigned           *eig_tickets;    // small grids: the last workgroup reports the products (and everything before them on
-  unsigned long long *eig_stamp_host; // the stream) complete -- what the resident dLk evaluator waits for; nullptr: no report
-  unsigned long long  eig_stamp;
   int             e_parent, e_child, e_pm;
   const double   *pi;
   const double   *cat_w;

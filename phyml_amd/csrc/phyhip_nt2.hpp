@@ -507,20 +507,8 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
           dst[1] = make_double2(d[2], d[3]);
         }
       }
-      if (q.host_blocks)
-      { // small alignment (launched or resident): completion as an evaluation's -- stores fenced, then an empty record
-        publish_block_sum(q, 0.0, lane);
-        return;
-      }
-      if (q.eig_tickets)
-      { // (as eigen_lr_kernel: every workgroup's stores complete and written back before its ticket is drawn)
-        __threadfence();
-        if (lane == 0 && __hip_atomic_fetch_add(q.eig_tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
-        {
-          __hip_atomic_store(q.eig_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(q.eig_stamp_host, q.eig_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
+      // completion as an evaluation's (launched or resident): stores fenced, then an empty record per workgroup
+      publish_block_sum(q, 0.0, lane);
       return;
     }
     const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16) + c0 * 16; // rows: right-side state
