@@ -329,6 +329,12 @@ int phyhip_profile_read_eigen(int instance, double *outEigenLrMs, int *outEigenL
    wait for a command before they leave. */
 int phyhip_get_resident_stats(int instance, long long out[8]);
 
+/* The same four counters for the large-grid resident evaluator (phyml_amd/csrc/phyhip_big.hpp): nucleotide instances of more
+   than 64 pattern tiles (~2 000 patterns) whose scalar-returning calls -- SPR candidates, Lk(b), Update_Eigen_Lr, dLk -- are
+   served by one persistent workgroup per compute unit instead of a launch per call.  One instance per device at a time holds
+   those workgroups; they leave when the instance launches anything else, or after PHYHIP_RESIDENT_IDLE_US without a command. */
+int phyhip_get_big_resident_stats(int instance, long long out[4]);
+
 #ifdef __cplusplus
 }
 #endif

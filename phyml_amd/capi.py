@@ -45,7 +45,7 @@ SYMBOLS = [
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
     "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
-    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_profile_read_eigen", "phyhip_get_resident_stats", "phyhip_calculate_class_mixture_log_likelihood",
+    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_profile_read_eigen", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats", "phyhip_calculate_class_mixture_log_likelihood",
     "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors", "phyhip_set_mixture_invariant_sites",
 ]
 
@@ -301,7 +301,11 @@ class Instance:
 
     def resident_stats(self, which=0):
         """(evaluations served by the resident workgroups, their launches, unanswered commands, evaluations launched instead)
-        of the dLk evaluator; resident_stats(1): of the short-evaluation one"""
+        of the dLk evaluator; resident_stats(1): of the short-evaluation one; resident_stats(2): of the large-grid one"""
+        if which == 2:  # the large-grid evaluator (phyhip_big.hpp)
+            big = (C.c_longlong * 4)()
+            _chk(self.L.phyhip_get_big_resident_stats(self.id, big))
+            return tuple(int(v) for v in big)
         out = (C.c_longlong * 8)()
         _chk(self.L.phyhip_get_resident_stats(self.id, out))
         return tuple(int(v) for v in out[4 * which:4 * which + 4])

@@ -5,6 +5,7 @@
 #include "phyhip_kernels.hpp"
 #include "phyhip_aa.hpp"
 #include "phyhip_nt2.hpp"
+#include "phyhip_big.hpp"
 
 #include <rccl/rccl.h>
 
@@ -198,6 +199,17 @@ struct Instance
   int          resident_direct = kResidentDirect; // PHYHIP_RESIDENT_DIRECT: up to this many workgroups poll the host themselves
   double       resident_idle_us = 1000.0; // PHYHIP_RESIDENT_IDLE_US: the workgroups leave after this long without a command
   Resident     rd, rt;                // the dLk evaluator (resident_dlk_kernel) and the short-launch one (resident_nt2_kernel)
+  // large-grid resident evaluator (resident_big_kernel, phyhip_big.hpp): nucleotide instances of more than kResidentMaxGrid tiles
+  Resident     rb;
+  TreeParams   rb_static;             // what its workgroups were launched with
+  double      *d_tile_sums = nullptr; // [2][max(grid_nt2, n_vdlk)] tile sums of commands whose final sum runs on the device
+  unsigned    *d_big_tickets = nullptr;
+  int          n_vdlk = 0;            // virtual blocks (one wave each) of a dLk evaluation: dlk64_kernel's grid
+  int          big_wgs = 0, big_nw = 0; // its workgroups and waves per workgroup
+  int          big_device_sum = 1;    // commands of more tiles than this add their tile sums on the device (one record to the host)
+  int          big_streak = 0;        // consecutive evaluations the resident workgroups could have taken (they are launched at 2)
+  unsigned long long rb_dlk_api = 0;  // entry-point call of the last dLk command they served
+  int          cus = 256;
   Resident    *r_inflight = nullptr;  // whose command the evaluation in flight is
   DlkParams    r_static;              // what the resident workgroups were launched with
   TreeParams   rt_static;
@@ -413,8 +425,10 @@ int flush_uploads(Instance *I)
 }
 
 // Rebuild every queued transition matrix on the device: one staged copy of (index, length) pairs, one launch.
+static void big_release(Instance *I);
 int flush_pmats(Instance *I)
 {
+  big_release(I);
   I->touched_call = true;
   int done = 0, rc = 0;
   if (!I->up_idx.empty() && (rc = flush_uploads(I))) return rc;
@@ -603,6 +617,113 @@ static bool resident_short_eligible(const Instance *I)
          !I->ablate && I->nt_groups <= 2;
 }
 
+// ---- the large-grid resident evaluator (phyhip_big.hpp): host side ---------------------------------------------------
+// One instance per device at a time: the resident workgroups fill the device (a workgroup per CU at the register budget of
+// the traversal kernel), so a second set could not start before the first has left.
+static std::atomic<Instance *> g_big_owner[64];
+
+static bool big_eligible(const Instance *I)
+{
+  return I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis && I->grid_nt2 > kResidentMaxGrid &&
+         !I->ablate && I->nt_groups <= 2 && I->dev >= 0 && I->dev < 64;
+}
+
+// Tell the large-grid resident workgroups (if any) to leave -- without waiting for it: whatever this instance launches next
+// needs their wave slots, and gets them as they go.  (A new generation number is all it takes: workgroup 0 sees it at its
+// next poll of the host record and passes it on through the mailbox.)
+static void big_release(Instance *I)
+{
+  I->big_streak = 0;
+  Resident &R = I->rb;
+  if (!R.cmd || !R.launched) return;
+  ++R.gen;
+  __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
+  R.launched = false;
+  Instance *me = I;
+  g_big_owner[I->dev].compare_exchange_strong(me, nullptr);
+}
+
+// Is everything queued on the instance's stream known to have finished?  (The flags of enter_stream_work, the report of the
+// last Update_Eigen_Lr, or -- large grids only -- a query of the stream: after a long traversal launch nothing else says so.)
+static bool big_clean(Instance *I)
+{
+  if (I->touched_call) return false;
+  if (!I->dirty_prev) return true;
+  if (hipStreamQuery(I->stream) != hipSuccess) return false;
+  I->dirty_prev = false; I->clean_after = 0;
+  ++I->clean_epoch; // (kernels ran since the last command: the resident workgroups re-read device memory)
+  return true;
+}
+
+// Could the resident workgroups take an evaluation of this instance right now?  Counts the calls in a row for which the answer
+// was yes: the workgroups are only launched at the second (a launch per call that alternates with other launches would cost
+// more than it saves).
+static bool big_ready(Instance *I)
+{
+  if (!big_eligible(I) || I->prof || I->rt_skip) return false;
+  Instance *owner = g_big_owner[I->dev].load();
+  if (owner && owner != I) return false;
+  if (!big_clean(I)) return false;
+  return true;
+}
+
+static int big_launch(Instance *I, const TreeParams &sq)
+{
+  Resident &R = I->rb;
+  if (!I->d_tile_sums)
+  {
+    const size_t n = (size_t)std::max(I->grid_nt2, I->n_vdlk);
+    HIPCHK(hipMalloc((void **)&I->d_tile_sums, 2 * n * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&I->d_big_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
+    HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), I->stream));
+    HIPCHK(hipStreamSynchronize(I->stream)); // (the stream is idle: this evaluation was about to bypass it)
+  }
+  Instance *none = nullptr;
+  if (!g_big_owner[I->dev].compare_exchange_strong(none, I) && none != I) return 1; // (somebody else's: launch the evaluation)
+  ResidentCtl r;
+  hipStream_t st;
+  int rc = resident_prepare(I, R, I->big_wgs, kBigWords, R.seq, r, &st);
+  if (rc) return rc;
+  BigArgs a;
+  a.t = sq; a.r = r;
+  a.b.n_tiles = I->grid_nt2; a.b.n_vdlk = I->n_vdlk; a.b.tile_sums = I->d_tile_sums; a.b.tickets = I->d_big_tickets; a.b.dot_prod = I->d_dot;
+  a.pmats = I->d_pmats; a.tip_codes = I->d_tipcodes;
+  if (launch_resident_big(I->C, I->nt_groups, I->big_wgs, st, a) != 0)
+    return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: no kernel for %d categories in %d groups", I->C, I->nt_groups);
+  HIPCHK(hipGetLastError());
+  memcpy(&I->rb_static, &sq, sizeof sq);
+  resident_launched(R, I->big_wgs);
+  return 0;
+}
+
+// The launch arguments of the resident workgroups: everything of a short launch's TreeParams that does not change per call
+static TreeParams big_static_params(Instance *I)
+{
+  TreeParams sq = base_params(I);
+  sq.host_blocks = I->h_blocks; sq.warn = I->h_warn; sq.fence_post = 1; sq.recs_in_args = 1; sq.edge_eval = 1;
+  sq.br_len_mult = I->br_len_mult; sq.l_min = I->l_min; sq.l_max = I->l_max; sq.pmats_rw = I->d_pmats;
+  sq.dot_out = I->d_dot;
+  if (I->want_site_outputs) { sq.site_lnl = I->d_site_lnl; sq.site_lk = I->d_site_lk; sq.site_cat = I->d_site_cat; }
+  // (4 states, one eigen system, <= 4 categories: big_eligible) the eigen system and the category rates ride in the arguments
+  memcpy(sq.m_evec, I->h_evec.data(), 16 * sizeof(double)); memcpy(sq.m_ivec, I->h_ivec.data(), 16 * sizeof(double));
+  memcpy(sq.m_eval, I->h_eval.data(), 4 * sizeof(double));
+  for (int c = 0; c < 4; ++c) sq.m_rates[c] = c < I->C ? I->h_rates[c] : 0.0;
+  return sq;
+}
+
+// Make sure the resident workgroups are there (launched with the instance's current parameters).  Returns 0: they are,
+// 1: not this time (first call of a streak, or the device belongs to another instance's workgroups), < 0: error.
+static int big_ensure(Instance *I)
+{
+  Resident        &R = I->rb;
+  const TreeParams sq = big_static_params(I);
+  const bool       same = R.launched && memcmp(&I->rb_static, &sq, sizeof sq) == 0;
+  if (same && !resident_gone(R)) return 0;
+  if (R.launched && !same) big_release(I), I->big_streak = 2; // (parameters changed: a new generation with the new ones)
+  if (++I->big_streak < 2) return 1;
+  return big_launch(I, sq);
+}
+
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush_impl(Instance *I, const EdgeEval *ee)
 {
@@ -615,7 +736,10 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // is small (measured: 16.7 vs 17.8 us per scalar-returning call on a 382-pattern search prefix; at 100 000 patterns
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
   static const int fold_grid_max = diag_env("PHYHIP_FOLD_GRID") ? atoi(diag_env("PHYHIP_FOLD_GRID")) : 512;
-  const bool fold_pm = I->soa && I->fold_pmats && I->grid_nt2 <= fold_grid_max && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
+  // large grids: an evaluation the large-grid resident workgroups can take (phyhip_big.hpp) carries its matrices in the command
+  const bool big_try = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
+                       (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && big_ready(I);
+  const bool fold_pm = I->soa && I->fold_pmats && (I->grid_nt2 <= fold_grid_max || big_try) && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
                        I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
   // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
   // (TreeParams::n_up): no upload kernel in front of the traversal
@@ -942,6 +1066,60 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       return 0;
     }
   }
+  // ---- large nucleotide alignments: the large-grid resident evaluator (resident_big_kernel) -------------------------------
+  if (big_eligible(I) && host_sum_n > 0 && q.recs_in_args)
+  { // short launches of such an instance complete their stores before they post too: the stream is clean once the scalar is
+    // back, and the next evaluation can go to the resident workgroups (long operation lists do not -- a wave that waits for its
+    // result stores holds its slot, see fuse_reduce -- after those a query of the stream says when it is idle)
+    q.fence_post   = 1;
+    I->fenced_eval = true;
+  }
+  if (big_try && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0)
+  {
+    const int brc = big_ensure(I);
+    if (brc < 0) return brc;
+    if (brc == 0)
+    {
+      Resident &R = I->rb;
+      unsigned long long words[kBigWords];
+      memset(words, 0, sizeof words);
+      const bool changed = I->clean_epoch != I->rt_epoch; // the stream ran something since the last command
+      const bool dsum = host_sum_n > I->big_device_sum;
+      words[0] = q.host_tag;
+      words[1] = (unsigned long long)q.n_real_ops | (changed ? kBigChanged : 0ull) | ((unsigned long long)q.n_fresh << 4) |
+                 ((unsigned long long)q.e_prefetch << 8) | (q.edge_eval == 2 ? kBigEigen : 0ull) | (dsum ? kBigDeviceSum : 0ull);
+      words[2] = (unsigned long long)(unsigned)q.e_parent | ((unsigned long long)(unsigned)q.e_child << 32);
+      words[3] = (unsigned long long)(unsigned)q.e_pm | ((unsigned long long)(unsigned)q.last_dest << 32);
+      for (int k = 0; k < q.n_fresh; ++k)
+      {
+        words[4 + k / 2] |= (unsigned long long)(unsigned)q.fresh_idx[k] << (32 * (k & 1));
+        memcpy(&words[6 + k], &q.fresh_len[k], 8);
+      }
+      auto put = [&](int k, const Desc &d) { words[k] = d.base; words[k + 1] = (unsigned long long)d.bytes | ((unsigned long long)d.x << 32); };
+      for (int o = 0; o < q.n_real_ops; ++o)
+      {
+        put(10 + o * 12, q.arg_ir[o].c1_data); put(12 + o * 12, q.arg_ir[o].c2_data);
+        put(14 + o * 12, q.arg_ir[o].c1_scale); put(16 + o * 12, q.arg_ir[o].c2_scale);
+        put(18 + o * 12, q.arg_xr[o].dst_data); put(20 + o * 12, q.arg_xr[o].dst_scale);
+      }
+      // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (flush_and_wait)
+      I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
+      resident_send(I, R, words, kBigWords);
+      I->rt_epoch = I->clean_epoch;
+      I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
+      I->fenced_eval = true; // (the resident workgroups always complete their stores before they post)
+      if (fold_pm)
+      {
+        for (int m : I->pm_idx) I->pm_slot[m] = -1;
+        I->pm_idx.clear();
+        I->pm_len.clear();
+      }
+      I->pending.clear();
+      std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
+      return 0;
+    }
+  }
+  if (!big_try) big_release(I); // (what follows needs the wave slots the large-grid resident workgroups hold, if there are any)
   I->touched_call = true; // (everything below goes onto the stream)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (I->prof)
@@ -1387,16 +1565,19 @@ const char *phyhip_get_last_error(void) { return g_err.c_str(); }
 static void release_instance(Instance *I)
 {
   if (getenv("PHYHIP_RESIDENT_STATS"))
-    for (const Resident *R : {&I->rd, &I->rt})
+    for (const Resident *R : {&I->rd, &I->rt, &I->rb})
       if (R->n_cmd || R->n_busy)
         fprintf(stderr, "resident %s: %llu commands, %llu launches, %llu unanswered, %llu evaluations launched because the stream was busy\n",
-                R == &I->rd ? "dLk evaluator" : "short-launch evaluator", R->n_cmd, R->n_launch, R->n_silent, R->n_busy);
+                R == &I->rd ? "dLk evaluator" : (R == &I->rt ? "short-launch evaluator" : "large-grid evaluator"), R->n_cmd, R->n_launch,
+                R->n_silent, R->n_busy);
   resident_free(I->rd);
   resident_free(I->rt);
+  big_release(I);
+  resident_free(I->rb);
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks};
+                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks, I->d_tile_sums, I->d_big_tickets};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
@@ -1565,6 +1746,13 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipMemset(I->d_dot, 0, be * sizeof(double)));
 
   I->grid = (int)(((long long)I->P * I->CP + 255) / 256);
+  // large-grid resident evaluator (phyhip_big.hpp): a workgroup of big_nw waves per CU at the traversal kernel's register
+  // budget (two waves per SIMD with two lanes per pattern, one otherwise); dLk in up to 2 048 one-wave virtual blocks
+  I->cus     = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  I->n_vdlk  = (int)std::min<long long>(((long long)I->P * I->CP + 63) / 64, 2048);
+  I->big_nw  = I->nt_groups == 2 ? 8 : 4;
+  I->big_wgs = std::max(1, std::min(I->cus, (I->grid_nt2 + I->big_nw - 1) / I->big_nw));
+  if (const char *e = diag_env("PHYHIP_BIG_DEVICE_SUM")) I->big_device_sum = atoi(e);
   // The pipelined nucleotide kernel is instruction-issue bound per CU, so CU-level balance matters more than
   // workgroup size: one-wave workgroups let the dispatcher spread e.g. 3125 waves as 12-13 per CU instead of
   // 3-4 four-wave groups (measured: 100 taxa x 50 000 patterns, 288 -> 25x us).
@@ -2085,13 +2273,15 @@ static int flush_and_wait(Instance *I, EdgeEval &ee, bool flushed = false)
 {
   int rc = flushed ? 0 : flush(I, &ee);
   if (rc) return rc;
-  const bool by_resident = I->r_inflight != nullptr;
+  Resident  *const by = I->r_inflight;
+  const bool by_resident = by != nullptr;
   rc = wait_result(I);
   if (rc == kResidentSilent)
   { // the resident workgroups had left: retire them for good (no late record can arrive after this), put the evaluation
     // back in the queue and launch it
-    ++I->rt.n_silent;
-    resident_stop(I->rt);
+    ++by->n_silent;
+    resident_stop(*by);
+    if (by == &I->rb) big_release(I);
     I->r_inflight = nullptr; I->host_sum_n = 0;
     I->pending = I->rt_ops;
     for (const DevOp &o : I->pending) { I->mat_in_queue[o.pm1] = 1; I->mat_in_queue[o.pm2] = 1; }
@@ -2650,7 +2840,11 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   // resident workgroups.  Measured by chain (1 Update_Eigen_Lr + 5 dLk, tools/gpu_fuse_eigen_cross.sh): 40.3 vs 43.8 us at 382
   // patterns, 53.7 vs 56.2 at 2 048; WITHOUT the resident evaluator the fused launch loses to eigen_lr_kernel at every size
   // (+2 us: it stores dot_prod 16 bytes per lane at a 64-byte stride), beyond 4 096 patterns by 4-7 us -- so nowhere else.
-  if (I->NE == 1 && I->C <= 4 && I->fuse_eigen && resident_short_eligible(I))
+  // Large alignments: the same, when the large-grid resident workgroups (phyhip_big.hpp) can take it -- launched, the fused form
+  // loses to eigen_lr_kernel there, as a resident command it is the partial update and the products in one trip.
+  const bool big_eig = I->NE == 1 && I->C <= 4 && I->fuse_eigen && big_eligible(I) && I->pending.size() <= 2 && I->pm_idx.size() <= 4 &&
+                       I->up_idx.empty() && I->args_recs && I->fold_pmats && (I->rb.launched || I->big_streak >= 1) && big_ready(I);
+  if (I->NE == 1 && I->C <= 4 && I->fuse_eigen && (resident_short_eligible(I) || big_eig))
   {
     AuxProf  ap(I, 0);
     EdgeEval ee{left, rght, 0, nullptr, false, nullptr};
@@ -2664,6 +2858,8 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
     return PHYHIP_SUCCESS;
   }
   if ((rc = flush(I, nullptr))) return rc;
+  big_release(I);
+  I->touched_call = true;
   EigenParams e;
   e.t = base_params(I); e.ro = base_ro(I, nullptr); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;
   const bool report = I->resident && I->S == 4 && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co; // (see eigen_eval)
@@ -2703,8 +2899,12 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   const size_t dot_bytes = (size_t)I->P * I->C * I->S * sizeof(double);
   int          dgrid = std::min(I->grid, dot_bytes > (size_t)100 << 20 ? 2048 : 512);
   if (const char *e = diag_env("PHYHIP_DLK_GRID")) dgrid = std::min(I->grid, std::max(1, atoi(e)));
-  q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = dgrid; q.fin.warn = I->d_warn;
   const bool hsum  = !dev_out && I->host_sum;
+  // Large nucleotide alignments with the scalar wanted on the host: the evaluation is cut into one-wave virtual blocks
+  // (dlk_wave) -- what the large-grid resident workgroups serve (phyhip_big.hpp) and, launched, dlk64_kernel: the same doubles
+  const bool big = hsum && big_eligible(I);
+  if (big) dgrid = I->n_vdlk;
+  q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = dgrid; q.fin.warn = I->d_warn;
   const bool fused = !hsum && fuse_reduce(I, dgrid);
   if (hsum)
   { // both sums posted to the host per workgroup (see flush_impl)
@@ -2746,7 +2946,44 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   // the products are a few microseconds away: poll the stream that long, else launch as usual.
   // (4 states only: a 20-state command takes four 512-byte reads per poll instead of one and the round trip loses to the launch, 14.1-14.9 against
   // 12.4-12.5 us at 2 000 patterns -- measured, tools/gpu_resident_ab2.sh)
-  if (hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait)
+  if (big && big_ready(I))
+  {
+    I->stream_dirty = false; // (found idle; a dLk leaves nothing on the stream)
+    const int brc = big_ensure(I);
+    if (brc < 0) return brc;
+    if (brc == 0)
+    {
+      Resident          &R = I->rb;
+      unsigned long long words[kBigWords];
+      memset(words, 0, sizeof words);
+      const int  n_expl = I->C * (deriv ? 2 : 1) * I->S;
+      const bool changed = I->rb_dlk_api + 1 != I->api_no || I->clean_epoch != I->rt_epoch; // anything since the last dLk command
+      const bool dsum = dgrid > I->big_device_sum;
+      words[0] = q.fin.host_tag;
+      words[1] = kBigDlk | (q.with_derivative ? kBigDeriv : 0ull) | (q.invar_model ? kBigInvar : 0ull) | (q.apply_scaling ? kBigScaling : 0ull) |
+                 (changed ? kBigChanged : 0ull) | (dsum ? kBigDeviceSum : 0ull);
+      memcpy(&words[2], &q.pinvar, 8);
+      memcpy(&words[3], q.expl, sizeof(double) * (size_t)n_expl);
+      resident_send(I, R, words, kBigWords);
+      I->rb_dlk_api = I->api_no; I->rt_epoch = I->clean_epoch;
+      I->host_sum_n = dsum ? 1 : dgrid; I->host_sum_ns = 2;
+      rc = wait_result(I);
+      if (rc == 0)
+      {
+        *lnl = I->h_result[0];
+        if (dlnl) *dlnl = I->h_result[1];
+        return PHYHIP_SUCCESS;
+      }
+      if (rc != kResidentSilent) return rc;
+      // nobody there: make sure of it, then the ordinary launch below repeats the evaluation under the same tag
+      ++R.n_silent;
+      resident_stop(R);
+      big_release(I);
+      I->r_inflight = nullptr; I->host_sum_n = 0;
+    }
+  }
+  else if (big) ++I->rb.n_busy;
+  if (!big && hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait)
   {
     bool idle = !I->stream_dirty;
     if (idle && I->clean_after)
@@ -2810,7 +3047,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     const unsigned long long h1 = hp_now();
-    hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, I->stream, q);
+    if (big) hipLaunchKernelGGL((dlk64_kernel<S_, CP_>), dim3(dgrid), dim3(64), 0, I->stream, q);
+    else hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, I->stream, q);
     if (kDiag) { g_hp.launch += hp_now() - h1; ++g_hp.n_launch; }
     return 0;
   });
@@ -3055,6 +3293,17 @@ int phyhip_get_resident_stats(int instance, long long out[8])
   {
     out[k++] = (long long)R->n_cmd; out[k++] = (long long)R->n_launch; out[k++] = (long long)R->n_silent; out[k++] = (long long)R->n_busy;
   }
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_big_resident_stats(int instance, long long out[4])
+{
+  for (int k = 0; k < 4; ++k) out[k] = 0;
+  if (get_group(instance)) return PHYHIP_SUCCESS; // (sharded instances: never resident)
+  GET_INST(I, instance);
+  leave_query(I);
+  const Resident *R = &I->rb;
+  out[0] = (long long)R->n_cmd; out[1] = (long long)R->n_launch; out[2] = (long long)R->n_silent; out[3] = (long long)R->n_busy;
   return PHYHIP_SUCCESS;
 }
 

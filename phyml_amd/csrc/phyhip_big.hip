@@ -1,0 +1,32 @@
+// phyhip_big.hip -- the large-grid resident evaluator's kernel (phyhip_big.hpp), in a translation unit of its own because it
+// is compiled differently: -mllvm -disable-machine-licm.  The kernel is one loop around the bodies of three launched kernels;
+// the machine-level loop-invariant code motion hoists every constant those bodies materialise (the polynomial coefficients of
+// log / exp, lane masks, LDS offsets) in front of that loop and keeps them in vector registers across it -- at the two waves
+// per SIMD the kernel must run at that meant ~130 registers spilled to scratch (tools/kres.py on the listing); without the
+// pass: none.  Everything else of the library keeps the pass.
+#include "phyhip_big.hpp"
+
+namespace phyhip
+{
+
+// Launch the resident workgroups of an instance with C categories in G lanes per pattern; returns 0, or -1 when there is no
+// kernel for that shape.
+int launch_resident_big(int C, int G, int workgroups, hipStream_t stream, const BigArgs &a)
+{
+#define BIGRES(c_, g_, nw_)                                                                                                 \
+  hipLaunchKernelGGL((resident_big_kernel<c_, g_, nw_>), dim3(workgroups), dim3(64 * nw_), 0, stream, a);                     \
+  return 0;
+  switch (C * 8 + G)
+  {
+    case 1 * 8 + 1: BIGRES(1, 1, 4)
+    case 2 * 8 + 1: BIGRES(2, 1, 4)
+    case 2 * 8 + 2: BIGRES(2, 2, 8)
+    case 3 * 8 + 1: BIGRES(3, 1, 4)
+    case 4 * 8 + 1: BIGRES(4, 1, 4)
+    case 4 * 8 + 2: BIGRES(4, 2, 8)
+    default: return -1;
+  }
+#undef BIGRES
+}
+
+} // namespace phyhip

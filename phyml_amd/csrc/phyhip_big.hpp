@@ -1,0 +1,280 @@
+// phyhip_big.hpp -- the large-grid resident evaluator: launch-free SPR candidates, Lk(b), Update_Eigen_Lr and dLk for
+// nucleotide alignments of any size (the reference's call patterns: src/spr.c:640-646, src/optimiz.c:607-663, src/lk.c:655-753).
+//
+// resident_nt2_kernel / resident_dlk_kernel (one tile per workgroup, up to 64 of them) serve alignments of up to ~2 000
+// patterns.  Beyond that a scalar-returning call was a launch again: at 500 taxa x 100 000 patterns an SPR candidate cost
+// 33.7 us for 11 us of data (pmat_kernel + a one-operation traversal: two launch calls, two dispatches, two kernel starts and
+// ends, 3 126 block records handed to the host), a dLk 20 us for 3.  Here ONE kernel fills the device once -- a workgroup of
+// NW waves per CU -- and stays:
+//   * wave 0 of every workgroup polls (workgroup 0 the host-mapped command record, the others the device-memory mailbox it
+//     relays each command through -- the mechanism of resident_poll_wave); the other waves sleep at the workgroup barrier
+//     meanwhile: a parked wave issues nothing and reads nothing, so 2 048 resident waves cost 256 pollers;
+//   * a wave then walks ITS tiles (tile = wave, wave + waves, ...): the launched kernels' per-tile bodies (nt2_run, dlk_wave)
+//     unchanged, so every tile sum is the double the launched form computes; the transition matrices of the command are
+//     rebuilt in the wave's prologue (nt2_run's n_fresh), once per command;
+//   * one command kind per call of the surface: 0-2 partial updates + the edge evaluation (SPR candidate, Lk(b)), the same
+//     + the eigen products instead of the sum (Update_Eigen_Lr), or a dLk / eigen-basis Lk;
+//   * the sums leave either as one {sum, tag} record per tile (the host adds them, as after a launch) or -- flag bit 15 --
+//     through device memory: the workgroup that draws the last ticket adds the tile sums in final_reduce_kernel's order and
+//     posts ONE record per sum.  Same order, same double; which is faster depends on the number of tiles (measured).
+// The resident workgroups are not ordered with the instance's stream: the host side (phyhip.hip, big_*) uses them only while
+// the stream is known to be idle, exactly as for the small evaluators.
+#pragma once
+#include "phyhip_nt2.hpp"
+
+namespace phyhip
+{
+
+// payload words: 0 tag, 1 flags, then
+//   traversal command (resident_nt2_kernel's layout): 2 evaluation edge, 3 its matrix | last destination, 4-5 matrix indices,
+//     6-9 their lengths, 10.. two operations x 12 descriptor words;
+//   dLk command: 2 pinvar, 3.. the expl table (C x 2 x 4 doubles).
+// flags: bits 0-1 operations, 2 device data changed since the last command, 4-7 matrices to rebuild, 8-9 evaluation sides to
+// fetch early, 10 eigen products instead of the sum, 11 dLk command, 12 with derivative, 13 invariant-site model, 14 scaling,
+// 15 final sum on the device.
+constexpr int kBigWords = kResidentNtWords > 3 + 32 ? kResidentNtWords : 3 + 32;
+static_assert((kBigWords + kResidentPay - 1) / kResidentPay <= 15, "a command must fit the one 512-byte read of a poll");
+enum : unsigned long long
+{
+  kBigChanged = 1ull << 2, kBigEigen = 1ull << 10, kBigDlk = 1ull << 11, kBigDeriv = 1ull << 12, kBigInvar = 1ull << 13,
+  kBigScaling = 1ull << 14, kBigDeviceSum = 1ull << 15
+};
+
+struct BigCtl
+{
+  int           n_tiles;   // tiles of a traversal command (= the launched kernel's grid, grid_nt2)
+  int           n_vdlk;    // virtual blocks of a dLk command (= dlk64_kernel's grid)
+  double       *tile_sums; // device [2][max(n_tiles, n_vdlk)]: the tile sums of a command whose final sum runs on the device
+  unsigned     *tickets;   // device [1 + kTicketGroups], zero between commands
+  const double *dot_prod;  // the eigen products (Update_Eigen_Lr's output, dLk's input)
+};
+
+// Everything the kernel is launched with, in ONE argument: each command re-reads what it needs from the argument segment
+// (see the loop below), at fixed offsets.
+struct BigArgs
+{
+  TreeParams     t;
+  ResidentCtl    r;
+  BigCtl         b;
+  const double  *pmats;
+  const uint8_t *tip_codes;
+};
+
+// A struct out of the argument segment (constant address space: scalar loads), dword by dword
+template <typename T> __device__ __forceinline__ void karg_copy(T &dst, const __attribute__((address_space(4))) void *src)
+{
+  static_assert(sizeof(T) % 4 == 0, "whole dwords");
+  const __attribute__((address_space(4))) unsigned *s = reinterpret_cast<const __attribute__((address_space(4))) unsigned *>(src);
+  unsigned tmp[sizeof(T) / 4];
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) tmp[i] = s[i];
+  __builtin_memcpy(&dst, tmp, sizeof(T));
+}
+
+template <int C, int G, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const BigArgs args_)
+{
+  constexpr int                 CP = C == 3 ? 4 : C;
+  __shared__ unsigned long long sh_raw[64];
+  __shared__ int                sh_idx[4];
+  __shared__ double             sh_len[4];
+  __shared__ double             sh_expl[2 * 4 * 4];
+  __shared__ int                sh_act;
+  __shared__ unsigned           sh_last;
+  __shared__ IssueRec           sh_ir[2]; // the command's operation records: nt2_run reads them from here when it needs them
+  __shared__ ExecRec            sh_xr[2];
+  unsigned long long last = args_.r.start_seq, t_last = wall_clock64();
+  bool               mail_open = false;
+  for (;;)
+  {
+    // Nothing that is the same for every command may be computed once in front of this loop and kept: left to itself the
+    // compiler hoists all of it -- the launch arguments, every lane predicate, every address -- and holds it in registers
+    // across the whole command (two hundred scalar registers spilled into vector registers, which at two waves per SIMD
+    // spilled to scratch in turn; a launched kernel loads each argument next to its use).  So the roots of those
+    // computations -- the argument segment's address, the thread's and the workgroup's number -- are laundered through an
+    // empty asm at the top of every iteration, and everything derives from the laundered values.
+    typedef const __attribute__((address_space(4))) char karg_char;
+    unsigned long long kaddr = (unsigned long long)(karg_char *)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned           tid = threadIdx.x, bid = blockIdx.x, nwg = gridDim.x;
+    asm volatile("" : "+s"(kaddr), "+v"(tid), "+s"(bid), "+s"(nwg));
+    // (what comes out of an asm counts as different from lane to lane: say that these are not -- loads through the pointer
+    // are scalar loads, the workgroup's number and count scalar registers)
+    kaddr = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(kaddr >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kaddr);
+    bid = (unsigned)__builtin_amdgcn_readfirstlane((int)bid); nwg = (unsigned)__builtin_amdgcn_readfirstlane((int)nwg);
+    karg_char *ka = (karg_char *)kaddr;
+    // (the address space stays on the pointer: loads through it are scalar loads)
+    typedef const __attribute__((address_space(4))) BigArgs karg_args;
+    karg_args *A = reinterpret_cast<karg_args *>(ka);
+    const int      lane = (int)(tid & 63), wid = (int)(tid >> 6);
+    const int      gw = wid * (int)nwg + (int)bid, TW = NW * (int)nwg; // this wave among all of them
+    if (wid == 0)
+    {
+      ResidentCtl r;
+      karg_copy(r, &A->r);
+      int               act;
+      for (;;)
+      {
+        act = resident_poll_wave(r, last, t_last, mail_open, sh_raw, 1, lane, bid == 0);
+        if (act) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) sh_act = act;
+      if (act == 1)
+      {
+        if (lane < 4)
+        {
+          const unsigned long long ix = sh_raw[resident_slot(4 + lane / 2)];
+          sh_idx[lane] = (int)(unsigned)(ix >> (32 * (lane & 1)));
+          const unsigned long long lb = sh_raw[resident_slot(6 + lane)];
+          __builtin_memcpy(&sh_len[lane], &lb, 8);
+        }
+        if (lane < 2 * 4 * 4)
+        {
+          const unsigned long long eb = sh_raw[resident_slot(3 + lane)];
+          __builtin_memcpy(&sh_expl[lane], &eb, 8);
+        }
+        if (lane < 2 * 12)
+        { // a descriptor is two payload words (base; bytes | spare << 32): per operation four child descriptors into the
+          // issue record (its two tip descriptors are not used by this kernel), two destination descriptors into the other
+          const int                o = lane / 12, j = lane % 12;
+          const unsigned long long w = sh_raw[resident_slot(10 + lane)];
+          unsigned long long      *dst = j < 8 ? reinterpret_cast<unsigned long long *>(&sh_ir[o]) + j
+                                               : reinterpret_cast<unsigned long long *>(&sh_xr[o]) + (j - 8);
+          *dst = w;
+        }
+      }
+    }
+    __syncthreads(); // (the other waves of the workgroup have been asleep here since they finished the previous command)
+    if (sh_act == 2) return;
+    // every word is the same for all lanes: make that known (loop bounds and flags belong in scalar registers)
+    auto word = [&](int k) {
+      const unsigned long long v = sh_raw[resident_slot(k)];
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return ((unsigned long long)hi << 32) | lo;
+    };
+    const unsigned long long tag = word(0), fl = word(1);
+    const bool               dsum = (fl & kBigDeviceSum) != 0;
+    BigCtl b;
+    karg_copy(b, &A->b);
+    // what kernels on the stream wrote since the last command (the host says whether any did) is re-read from memory
+    if (fl & kBigChanged) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int n_rec, ns;
+    if (fl & kBigDlk)
+    { // ---- dLk / Lk in the eigen basis: dlk64_kernel's virtual blocks ----
+      DlkParams dq;
+      dq.dot_prod = b.dot_prod; dq.wght = A->t.wght; dq.fact = A->t.fact; dq.cat_w = A->t.cat_w; dq.pi = A->t.pi; dq.invar = A->t.invar;
+      dq.P = A->t.P; dq.C = C;
+      double pinvar;
+      {
+        const unsigned long long pb = word(2);
+        __builtin_memcpy(&pinvar, &pb, 8);
+      }
+      const DlkCall k = {(fl & kBigDeriv) ? 1 : 0, (fl & kBigInvar) ? 1 : 0, (fl & kBigScaling) ? 1 : 0, pinvar};
+      n_rec = b.n_vdlk; ns = 2;
+      for (int vb = gw; vb < n_rec; vb += TW)
+      {
+        double v[2];
+        dlk_wave<4, CP>(dq, k, sh_expl, A->t.warn, vb, n_rec, lane, v);
+        if (lane == 0)
+        {
+          if (dsum)
+          {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+            {
+              unsigned long long bits;
+              __builtin_memcpy(&bits, &v[s], 8);
+              __hip_atomic_store(reinterpret_cast<unsigned long long *>(b.tile_sums) + (size_t)s * n_rec + vb, bits, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          else
+          {
+            post_host_block(A->t.host_blocks + vb, v[0], tag);
+            post_host_block(A->t.host_blocks + (size_t)n_rec + vb, v[1], tag);
+          }
+        }
+      }
+    }
+    else
+    { // ---- 0-2 partial updates + the edge evaluation (or the eigen products): traverse_nt2_kernel's tiles ----
+      const unsigned long long ed = word(2), pm = word(3);
+      TreeParams               q;
+      karg_copy(q, &A->t);
+      q.host_tag = tag;
+      q.n_fresh = (int)((fl >> 4) & 15); q.e_prefetch = (int)((fl >> 8) & 3);
+      q.edge_eval = (fl & kBigEigen) ? 2 : 1; q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
+      q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
+      q.tile_sums = dsum ? b.tile_sums : nullptr;
+      const int n_ops = (int)(fl & 3);
+      NtFresh fr;
+      // (the eigen system rides in the launch's TreeParams, as in a launched kernel: scalar loads from the argument segment;
+      // a model change makes the host launch a new generation)
+      const char *kt = (const char *)ka + offsetof(BigArgs, t);
+      fr.idx = sh_idx; fr.len = sh_len;
+      fr.evec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_evec));
+      fr.ivec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_ivec));
+      fr.eval = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_eval));
+      fr.rates = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_rates));
+      n_rec = b.n_tiles; ns = 1;
+      for (int tile = gw; tile < n_rec; tile += TW)
+      {
+        if (n_ops == 1) nt2_run<C, G, false, 1, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid);
+        else if (n_ops == 2) nt2_run<C, G, false, 2, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid);
+        else nt2_run<C, G, false, 3, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid);
+        q.n_fresh = 0; // (this wave has rebuilt the command's matrices with its first tile)
+      }
+    }
+    if (dsum)
+    { // ---- the final sum on the device: tile sums written through, a ticket per workgroup, the last one adds and posts ----
+      __threadfence(); // this thread's stores (results, tile sums) are complete and written back ...
+      __syncthreads(); // ... for every wave of the workgroup, before its ticket is drawn
+      if (tid == 0)
+      { // two-level draw (see finish_sums: atomics on one address serialise)
+        const unsigned g = bid % kTicketGroups, ng = nwg < kTicketGroups ? nwg : kTicketGroups;
+        const unsigned members = (nwg - g + kTicketGroups - 1) / kTicketGroups;
+        unsigned       lastwg = 0;
+        if (__hip_atomic_fetch_add(b.tickets + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1)
+          lastwg = __hip_atomic_fetch_add(b.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1 ? 1u : 0u;
+        sh_last = lastwg;
+      }
+      __syncthreads();
+      if (sh_last && wid == 0)
+      {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double tot[2] = {0.0, 0.0};
+        for (int s = 0; s < ns; ++s)
+        { // final_reduce_kernel's order: 256 strided accumulators (four per lane), then the binary tree
+          const double *in = b.tile_sums + (size_t)s * n_rec;
+          double        acc[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+          {
+            acc[j] = 0.0;
+            for (int i = lane + 64 * j; i < n_rec; i += 256) acc[j] += in[i];
+          }
+          double t = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+          tot[s] = t;
+        }
+        if (lane == 0)
+        {
+#pragma unroll 1
+          for (int k = 0; k <= (int)kTicketGroups; ++k) __hip_atomic_store(b.tickets + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_s_waitcnt(0); // (the counters are zero again before the host can send the next command)
+          for (int s = 0; s < ns; ++s) post_host_block(A->t.host_blocks + s, tot[s], tag);
+        }
+      }
+    }
+    __syncthreads(); // (wave 0 rewrites the command's staging area with its next poll)
+    last = last + 1; t_last = wall_clock64();
+  }
+}
+
+// (defined in phyhip_big.hip, the only translation unit that instantiates the kernel)
+int launch_resident_big(int C, int G, int workgroups, hipStream_t stream, const BigArgs &a);
+
+} // namespace phyhip

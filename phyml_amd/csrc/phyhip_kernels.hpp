@@ -147,6 +147,9 @@ struct TreeParams
   // ([buffer][class][pattern]: every class tree rescales on its own, src/mixt.c:2603-2640), no mixing over categories in
   // the edge evaluation (per-class likelihoods and scale exponents go out, class_combine_kernel repeats MIXT_Lk's site loop).
   int             class_axis;
+  // Large-grid resident evaluator (phyhip_big.hpp) with the final sum on the device: a tile's sum goes here (device memory,
+  // [tile]) instead of to the host; the workgroup that finishes last adds them in final_reduce_kernel's order and posts ONE record.
+  double         *tile_sums;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -451,12 +454,24 @@ template <int NS> __device__ __forceinline__ void finish_sums(const FinishParams
 
 __device__ __forceinline__ void raise_warn(const TreeParams &q) { raise_warn(q.warn); }
 
-__device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s, int lane)
+// `tile`: which of the evaluation's per-tile sums this is -- the workgroup's number in a launched kernel, the tile a wave of
+// the large-grid resident evaluator has just finished
+__device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s, int lane, unsigned tile)
 {
+  if (q.tile_sums)
+  { // (written through: the workgroup that adds the tile sums may sit on another XCD)
+    if (lane == 0)
+    {
+      unsigned long long bits;
+      __builtin_memcpy(&bits, &s, 8);
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(q.tile_sums) + tile, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (q.host_blocks)
   {
     if (q.fence_post) __threadfence(); // (this wave's stores; kernels with several waves per workgroup fence before their last barrier)
-    if (lane == 0) post_host_block(q.host_blocks + blockIdx.x, s, q.host_tag);
+    if (lane == 0) post_host_block(q.host_blocks + tile, s, q.host_tag);
     return;
   }
   FinishParams f;
@@ -466,6 +481,7 @@ __device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s,
   const double v[1] = {s};
   finish_sums<1>(f, v, lane);
 }
+__device__ __forceinline__ void publish_block_sum(const TreeParams &q, double s, int lane) { publish_block_sum(q, s, lane, blockIdx.x); }
 
 template <int S, int CP>
 __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const DevOp *__restrict__ ops_,
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
 // out[k] = sum_i in[k*stride + i].  Results, the numerical-warning flag and finally a sequence number go to
 // host-mapped memory: the host spins on the sequence number instead of paying a stream-synchronise wake-up
 // (SPR enters the surface ~10^5 times per search, each time waiting for one scalar).
-__global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restrict__ in, int n, int nstreams, int stride,
+static __global__ __launch_bounds__(256) void final_reduce_kernel(const double *__restrict__ in, int n, int nstreams, int stride,
                                                           double *__restrict__ out, double *__restrict__ out_host,
                                                           int *warn, int *warn_host, unsigned long long seq,
                                                           double *warn_out)
@@ -1170,6 +1186,137 @@ struct DlkCall
   double pinvar;
 };
 
+// What one lane of a dLk evaluation has fetched for its (pattern, category): the S products and the pattern's weight, scale
+// exponent and invariant state (fetched together, before any arithmetic).
+template <int S> struct DlkIn
+{
+  double2 d[S / 2];
+  double  wt;
+  int     f, iv;
+};
+
+template <int S, int CP>
+__device__ __forceinline__ void dlk_fetch(const DlkParams &q, const DlkCall &k, const long long gl, DlkIn<S> &in)
+{
+  const long long p0 = gl / CP;
+  const int       c0 = (int)(gl % CP);
+  const long long p  = (p0 < q.P) ? p0 : (q.P - 1);
+  const int       c  = (c0 < q.C) ? c0 : 0;
+  in.wt = q.wght[p];
+  in.f  = q.fact[p];
+  in.iv = k.invar_model ? (int)q.invar[p] : -1;
+  const double2 *s2 = reinterpret_cast<const double2 *>(q.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S);
+#pragma unroll
+  for (int j = 0; j < S / 2; ++j) in.d[j] = s2[j];
+}
+
+// The arithmetic of one lane = one (pattern, category) of a dLk evaluation; the CP lanes of a pattern are adjacent and all
+// active.  Shared by every shape the evaluation runs in (dlk_kernel's 256-thread workgroups, the 64-lane virtual blocks of
+// dlk64_kernel and of the large-grid resident evaluator), so that the per-pattern terms are the same doubles everywhere.
+template <int S, int CP>
+__device__ __forceinline__ void dlk_lane(const DlkParams &q, const DlkCall &k, const double *expl, int *warn, const long long gl,
+                                         const DlkIn<S> &in, double &c_lnl, double &c_dlnl)
+{
+  const long long p0  = gl / CP;
+  const int       c0  = (int)(gl % CP);
+  const bool      act = (p0 < q.P) && (c0 < q.C);
+  const int       c   = (c0 < q.C) ? c0 : 0;
+  double          dp[S];
+#pragma unroll
+  for (int j = 0; j < S / 2; ++j)
+  {
+    dp[2 * j] = in.d[j].x;
+    dp[2 * j + 1] = in.d[j].y;
+  }
+  double lkc, dlkc = 0.0;
+  if (k.with_derivative)
+  { // four lanes (lk,dlk,lk,dlk) over pairs of states, then lane0+lane2 / lane1+lane3 (src/avx.c:257-274)
+    const double *ex = expl + c * 2 * S;
+    double        z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
+#pragma unroll
+    for (int i = 0; i < S / 2; ++i)
+    {
+      z0 = __builtin_fma(dp[2 * i], ex[4 * i], z0);
+      z1 = __builtin_fma(dp[2 * i], ex[4 * i + 1], z1);
+      z2 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 2], z2);
+      z3 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 3], z3);
+    }
+    lkc  = z0 + z2;
+    dlkc = z1 + z3;
+  }
+  else
+  { // elementwise product, blockwise lane sums, horizontal norm (src/avx.c:227-244)
+    const double *ex = expl + c * S;
+    double        l4[4] = {0., 0., 0., 0.};
+#pragma unroll
+    for (int b4 = 0; b4 < S / 4; ++b4)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) l4[kk] = l4[kk] + dp[b4 * 4 + kk] * ex[b4 * 4 + kk];
+    lkc = (l4[0] + l4[2]) + (l4[1] + l4[3]);
+  }
+  const double w  = (c0 < q.C) ? q.cat_w[c] : 0.0;
+  const double t1 = (c0 < q.C) ? lkc * w : 0.0, t2 = (c0 < q.C) ? dlkc * w : 0.0;
+  double       lk = 0.0, dlk = 0.0;
+#pragma unroll
+  for (int cc = 0; cc < CP; ++cc)
+  {
+    const double a = (CP == 1) ? t1 : __shfl(t1, cc, CP);
+    const double b = (CP == 1) ? t2 : __shfl(t2, cc, CP);
+    if (cc < q.C)
+    {
+      lk += a;
+      dlk += b;
+    }
+  }
+  c_lnl = c_dlnl = 0.0;
+  if (act && c == 0)
+  {
+    const double wt = in.wt;
+    if (wt > kSmall)
+    {
+      int f = in.f;
+      if (k.invar_model)
+      { // src/lk.c:1005-1025 (dLk) / :910-931 (Lk in the eigen basis)
+        const int iv  = in.iv;
+        double    inv = 0.0;
+        bool      issue = false;
+        if (iv >= 0)
+        {
+          inv = q.pi[iv];
+          if (k.apply_scaling)
+          {
+            int e = f;
+            do
+            {
+              const int piece = e < 63 ? e : 63;
+              inv *= (double)(1ull << piece);
+              e -= piece;
+            } while (e != 0);
+          }
+          issue = isinf(inv);
+        }
+        if (issue)
+        {
+          if (k.with_derivative) { lk = inv * k.pinvar; dlk = 0.0; }
+          else { f = 0; lk = q.pi[iv] * k.pinvar; }
+        }
+        else
+        {
+          lk  = lk * (1. - k.pinvar) + inv * k.pinvar;
+          dlk = dlk * (1. - k.pinvar);
+        }
+      }
+      if (lk < kSmall)
+      {
+        lk = kSmall;
+        raise_warn(warn);
+      }
+      c_dlnl = wt * (dlk / lk);                          // src/lk.c:742-744
+      c_lnl  = wt * (log(lk) - kLog2 * (double)f);       // src/lk.c:745
+    }
+  }
+}
+
 // One workgroup's share of an evaluation: on return wave 0 holds the workgroup's two sums (every lane of it).
 template <int S, int CP>
 __device__ __forceinline__ bool dlk_block(const DlkParams &q, const DlkCall k, const double *expl, int *warn, double (&v)[2])
@@ -1180,114 +1327,10 @@ __device__ __forceinline__ bool dlk_block(const DlkParams &q, const DlkCall k, c
   double          tot_lnl = 0.0, tot_dlnl = 0.0;
   for (long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x; gl < total; gl += (long long)gridDim.x * blockDim.x)
   {
-    const long long p0  = gl / CP;
-    const int       c0  = (int)(gl % CP);
-    const bool      act = (p0 < q.P) && (c0 < q.C);
-    const long long p   = (p0 < q.P) ? p0 : (q.P - 1);
-    const int       c   = (c0 < q.C) ? c0 : 0;
-    // (weight, scale exponent, invariant state: fetched with the products, not after the arithmetic)
-    const double    wt_pre = q.wght[p];
-    const int       f_pre  = q.fact[p];
-    const int       iv_pre = k.invar_model ? (int)q.invar[p] : -1;
-
-    double dp[S];
-    {
-      const double2 *s2 = reinterpret_cast<const double2 *>(q.dot_prod + (size_t)p * (q.C * S) + (size_t)c * S);
-#pragma unroll
-      for (int j = 0; j < S / 2; ++j)
-      {
-        const double2 v = s2[j];
-        dp[2 * j] = v.x;
-        dp[2 * j + 1] = v.y;
-      }
-    }
-    double lkc, dlkc = 0.0;
-    if (k.with_derivative)
-    { // four lanes (lk,dlk,lk,dlk) over pairs of states, then lane0+lane2 / lane1+lane3 (src/avx.c:257-274)
-      const double *ex = expl + c * 2 * S;
-      double        z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
-#pragma unroll
-      for (int i = 0; i < S / 2; ++i)
-      {
-        z0 = __builtin_fma(dp[2 * i], ex[4 * i], z0);
-        z1 = __builtin_fma(dp[2 * i], ex[4 * i + 1], z1);
-        z2 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 2], z2);
-        z3 = __builtin_fma(dp[2 * i + 1], ex[4 * i + 3], z3);
-      }
-      lkc  = z0 + z2;
-      dlkc = z1 + z3;
-    }
-    else
-    { // elementwise product, blockwise lane sums, horizontal norm (src/avx.c:227-244)
-      const double *ex = expl + c * S;
-      double        l4[4] = {0., 0., 0., 0.};
-#pragma unroll
-      for (int b4 = 0; b4 < S / 4; ++b4)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) l4[kk] = l4[kk] + dp[b4 * 4 + kk] * ex[b4 * 4 + kk];
-      lkc = (l4[0] + l4[2]) + (l4[1] + l4[3]);
-    }
-    const double w  = (c0 < q.C) ? q.cat_w[c] : 0.0;
-    const double t1 = (c0 < q.C) ? lkc * w : 0.0, t2 = (c0 < q.C) ? dlkc * w : 0.0;
-    double       lk = 0.0, dlk = 0.0;
-#pragma unroll
-    for (int cc = 0; cc < CP; ++cc)
-    {
-      const double a = (CP == 1) ? t1 : __shfl(t1, cc, CP);
-      const double b = (CP == 1) ? t2 : __shfl(t2, cc, CP);
-      if (cc < q.C)
-      {
-        lk += a;
-        dlk += b;
-      }
-    }
-    double c_lnl = 0.0, c_dlnl = 0.0;
-    if (act && c == 0)
-    {
-      const double wt = wt_pre;
-      if (wt > kSmall)
-      {
-        int f = f_pre;
-        if (k.invar_model)
-        { // src/lk.c:1005-1025 (dLk) / :910-931 (Lk in the eigen basis)
-          const int iv  = iv_pre;
-          double    inv = 0.0;
-          bool      issue = false;
-          if (iv >= 0)
-          {
-            inv = q.pi[iv];
-            if (k.apply_scaling)
-            {
-              int e = f;
-              do
-              {
-                const int piece = e < 63 ? e : 63;
-                inv *= (double)(1ull << piece);
-                e -= piece;
-              } while (e != 0);
-            }
-            issue = isinf(inv);
-          }
-          if (issue)
-          {
-            if (k.with_derivative) { lk = inv * k.pinvar; dlk = 0.0; }
-            else { f = 0; lk = q.pi[iv] * k.pinvar; }
-          }
-          else
-          {
-            lk  = lk * (1. - k.pinvar) + inv * k.pinvar;
-            dlk = dlk * (1. - k.pinvar);
-          }
-        }
-        if (lk < kSmall)
-        {
-          lk = kSmall;
-          raise_warn(warn);
-        }
-        c_dlnl = wt * (dlk / lk);                          // src/lk.c:742-744
-        c_lnl  = wt * (log(lk) - kLog2 * (double)f);       // src/lk.c:745
-      }
-    }
+    DlkIn<S> in;
+    dlk_fetch<S, CP>(q, k, gl, in);
+    double c_lnl, c_dlnl;
+    dlk_lane<S, CP>(q, k, expl, warn, gl, in, c_lnl, c_dlnl);
     tot_lnl += c_lnl;
     tot_dlnl += c_dlnl;
   }
@@ -1317,12 +1360,62 @@ __device__ __forceinline__ bool dlk_block(const DlkParams &q, const DlkCall k, c
   return wid == 0;
 }
 
+// The same evaluation cut into VIRTUAL BLOCKS of one wave: virtual block vb of nvb takes the (pattern, category) lanes
+// vb * 64 + lane + i * nvb * 64 (i = 0, 1, ...), each lane adds its terms in that order, then the wave's shuffle tree.  The sums
+// of a virtual block do not depend on who computes it -- a one-wave workgroup of dlk64_kernel or a wave of the large-grid
+// resident evaluator (phyhip_big.hpp) that takes several virtual blocks in turn -- so the launched and the resident form return
+// the same doubles.  The loads of up to four rounds are in flight at once (a round is a dependent trip to memory: at
+// 100 000 patterns in 2 048 virtual blocks there are three, and one after the other they were most of dlk_kernel's 10 us).
+// On return every lane of the wave holds the two sums in v.
+template <int S, int CP>
+__device__ __forceinline__ void dlk_wave(const DlkParams &q, const DlkCall k, const double *expl, int *warn, const int vb, const int nvb,
+                                         const int lane, double (&v)[2])
+{
+  const long long total = (((long long)q.P * CP + 63) / 64) * 64, stride = (long long)nvb * 64;
+  constexpr int   U = 4;
+  double          tot_lnl = 0.0, tot_dlnl = 0.0;
+  for (long long g0 = (long long)vb * 64 + lane; g0 < total; g0 += U * stride)
+  {
+    DlkIn<S> in[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (g0 + u * stride < total) dlk_fetch<S, CP>(q, k, g0 + u * stride, in[u]); // (the same for every lane of the wave)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (g0 + u * stride < total)
+      {
+        double c_lnl, c_dlnl;
+        dlk_lane<S, CP>(q, k, expl, warn, g0 + u * stride, in[u], c_lnl, c_dlnl);
+        tot_lnl += c_lnl;
+        tot_dlnl += c_dlnl;
+      }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    tot_lnl += __shfl_down(tot_lnl, off, 64);
+    tot_dlnl += __shfl_down(tot_dlnl, off, 64);
+  }
+  v[0] = __shfl(tot_lnl, 0, 64);
+  v[1] = __shfl(tot_dlnl, 0, 64);
+}
+
 template <int S, int CP>
 __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
 {
   const DlkCall k = {q.with_derivative, q.invar_model, q.apply_scaling, q.pinvar};
   double        v[2];
   if (dlk_block<S, CP>(q, k, q.expl, q.fin.warn, v)) finish_sums<2>(q.fin, v, (int)(threadIdx.x & 63));
+}
+
+// One virtual block (dlk_wave) per one-wave workgroup: the launched form of what the large-grid resident evaluator serves
+template <int S, int CP>
+__global__ __launch_bounds__(64) void dlk64_kernel(const DlkParams q)
+{
+  const DlkCall k = {q.with_derivative, q.invar_model, q.apply_scaling, q.pinvar};
+  double        v[2];
+  dlk_wave<S, CP>(q, k, q.expl, q.fin.warn, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, v);
+  finish_sums<2>(q.fin, v, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1380,10 +1473,11 @@ struct ResidentCtl
 // One poll by one (whole) wave: the record's lines go to sh_raw ([n_loads * 64] words); returns 0: nothing yet, 1: command
 // last + 1 is complete in sh_raw, 2: leave.  Workgroup 0 of a relaying launch also keeps the mailbox up to date.
 __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const unsigned long long last, const unsigned long long t_last,
-                                                  bool &mail_open, unsigned long long *sh_raw, const int n_loads, const int lane)
+                                                  bool &mail_open, unsigned long long *sh_raw, const int n_loads, const int lane,
+                                                  const bool decider)
 {
   // one aligned 8-byte word per lane and load: 512 contiguous bytes = 16 sectors per instruction
-  const bool                decider = blockIdx.x == 0, from_host = decider || !r.relay;
+  const bool                from_host = decider || !r.relay;
   const unsigned long long *base = from_host ? reinterpret_cast<const unsigned long long *>(r.cmd) : r.mail;
   bool                      good = true;
   unsigned long long        first = 0;
@@ -1456,7 +1550,7 @@ __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, co
   {
     if (threadIdx.x < 64)
     {
-      const int a = resident_poll_wave(r, last, t_last, mail_open, sh_raw, n_loads, (int)threadIdx.x);
+      const int a = resident_poll_wave(r, last, t_last, mail_open, sh_raw, n_loads, (int)threadIdx.x, blockIdx.x == 0);
       if (threadIdx.x == 0) sh_ctl[0] = (unsigned long long)a;
     }
     __syncthreads();
@@ -1524,7 +1618,7 @@ struct MixParams
   FinishParams  fin;
 };
 
-__global__ __launch_bounds__(256) void mixture_combine_kernel(const MixParams q)
+static __global__ __launch_bounds__(256) void mixture_combine_kernel(const MixParams q)
 {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   double          contrib = 0.0;

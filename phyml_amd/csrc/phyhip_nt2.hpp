@@ -60,14 +60,20 @@ struct NtFresh
 // One workgroup's (= one wave's) share of a launch: the whole kernel body, callable from a kernel that stays resident.
 // DIST: how many operations ahead the loads run (2: two register sets in flight; 1: one -- 34 registers less per lane,
 // a third wave per SIMD at G = 2; the host then flags forwarding from the previous operation only).
-template <int C, int G, bool DBG, int ARGS, int DIST = 2>
+// NW: waves per workgroup (the large-grid resident evaluator runs several independent waves per workgroup, each with its own
+// LDS staging area); tile: which PW patterns this wave works on -- the workgroup's number in a launched kernel.
+// LREC (with ARGS != 0): the one or two records are read through irec / xrec -- LDS, where the resident evaluator put the
+// command's -- each time they are needed, instead of living in scalar registers from the command's arrival to their use
+// (the records of a launched kernel sit in its argument segment and cost no register until they are loaded).
+template <int C, int G, bool DBG, int ARGS, int DIST = 2, int NW = 1, bool LREC = false>
 __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__restrict__ irec, const ExecRec *__restrict__ xrec,
                                         const double *pmats, // (not restrict: the prologue may rewrite entries)
-                                        const uint8_t *__restrict__ tip_codes, unsigned long long *dbg, const NtFresh fr)
-{
+                                        const uint8_t *__restrict__ tip_codes, unsigned long long *dbg, const NtFresh fr,
+                                        const unsigned tile, const unsigned tid)
+{ // (tid: threadIdx.x -- handed in, so that a kernel that runs this body inside a loop can keep what derives from it inside too)
   // DBG: cycle stamps of the first 64 steps of one wave (PHYHIP_ABLATE=8), kept in LDS until the end
   __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
-  const bool stamper = DBG && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+  const bool stamper = DBG && tile == gridDim.x / 2 && tid == 0;
 #define PHY_STAMP(k_, i_)                                                                                              \
   if (DBG)                                                                                                             \
   {                                                                                                                    \
@@ -76,12 +82,13 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   }
   static_assert(C % G == 0 && 64 % G == 0, "category groups must divide the categories and the wave");
   constexpr int S = 4, CL = C / G, CS = CL * S, PW = 64 / G; // categories per lane, entries per lane, patterns per wave
-  __shared__ __attribute__((aligned(16))) double lds_p[2][2 * C * 16]; // [buffer][matrix][c][i][j]
+  __shared__ __attribute__((aligned(16))) double lds_all[NW][2][2 * C * 16]; // [wave][buffer][matrix][c][i][j]
+  double (&lds_p)[2][2 * C * 16] = lds_all[NW > 1 ? (tid >> 6) : 0];
 
-  const int      lane = threadIdx.x;
+  const int      lane = NW > 1 ? (int)(tid & 63) : (int)tid;
   const int      grp  = lane / PW, pl = lane % PW;        // category group, pattern within the wave
   const int      c0   = grp * CL;                         // first category of this lane
-  const unsigned p    = blockIdx.x * (unsigned)PW + pl;   // < Ppad by construction of the grid
+  const unsigned p    = tile * (unsigned)PW + pl;         // < Ppad by construction of the grid
   constexpr int  HP   = CS / 2;                           // 16-byte state pairs per lane
   const unsigned rowb = (unsigned)(q.Ppad * 16);          // bytes between consecutive (c, state pair) rows
   // Class axis (mixture classes as categories, TreeParams::class_axis; the host then runs G = C: one class per lane): every
@@ -96,8 +103,12 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   };
   const __amdgpu_buffer_rsrc_t pm_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pmats), 0, 0x7fffffff, 0x00020000);
-  auto rsrc = [](const Desc &d) {
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000);
+  // (a descriptor is the same for every lane: said explicitly, so that records read from LDS end up in scalar registers --
+  // for records that already are, the compiler drops the instruction)
+  auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  auto rsrc = [&](const Desc &d) {
+    const unsigned long long base = ((unsigned long long)uni((unsigned)(d.base >> 32)) << 32) | uni((unsigned)d.base);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, (int)uni(d.bytes), 0x00020000);
   };
   auto first_d = [](const u32x4 &v) { double d; __builtin_memcpy(&d, &v, 8); return d; };
 
@@ -110,14 +121,14 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
     for (int e = 0; e < HP; ++e) r.a[e] = __builtin_amdgcn_raw_buffer_load_b128(d1r, voff16, (unsigned)e * rowb, PHYHIP_LOAD_AUX);
 #pragma unroll
     for (int e = 0; e < HP; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b128(d2r, voff16, (unsigned)e * rowb, PHYHIP_LOAD_AUX);
-    r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, o.c1_scale.x ? (p & ~3u) : voff4, 0, 0);
-    r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, o.c2_scale.x ? (p & ~3u) : voff4, 0, 0);
+    r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, uni(o.c1_scale.x) ? (p & ~3u) : voff4, 0, 0);
+    r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, uni(o.c2_scale.x) ? (p & ~3u) : voff4, 0, 0);
   };
   auto issue_pm = [&](const IssueRec &o, u32x4 &pc) {
     // this lane's 16-byte piece of [matrix 1 | matrix 2] (C*16 doubles each)
     int ch = (lane < 16 * C) ? lane : 0;
     const int      mat = ch / (8 * C), within = ch - mat * 8 * C;
-    const unsigned off = (mat ? o.c2_data.x : o.c1_data.x) + (unsigned)within * 16u;
+    const unsigned off = (mat ? uni(o.c2_data.x) : uni(o.c1_data.x)) + (unsigned)within * 16u;
     pc = __builtin_amdgcn_raw_buffer_load_b128(pm_rsrc, off, 0, 0);
   };
   auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc) {
@@ -179,11 +190,11 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
 
   // records: device slot ring, or the kernel arguments for launches of one or two operations (last <= 1)
   auto IR = [&](int i) -> IssueRec {
-    if constexpr (ARGS) return i ? q.arg_ir[1] : q.arg_ir[0];
+    if constexpr (ARGS != 0 && !LREC) return i ? q.arg_ir[1] : q.arg_ir[0];
     else return irec[i];
   };
   auto XR = [&](int i) -> ExecRec {
-    if constexpr (ARGS) return i ? q.arg_xr[1] : q.arg_xr[0];
+    if constexpr (ARGS != 0 && !LREC) return i ? q.arg_xr[1] : q.arg_xr[0];
     else return xrec[i];
   };
   const int last = ARGS ? 1 : q.n_ops - 1; // host pads the list to an even length
@@ -300,7 +311,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
       __builtin_amdgcn_wave_barrier();
       const double *bufd = &lds_p[parity][0];
 
-      const unsigned fl = cur.dst_data.x;
+      const unsigned fl = uni(cur.dst_data.x);
       double         u1[CS], u2[CS];
       unsigned       s1, s2;
       bool           one1, one2; // first-entry test of the all-ones shortcut
@@ -508,7 +519,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         }
       }
       // completion as an evaluation's (launched or resident): stores fenced, then an empty record per workgroup
-      publish_block_sum(q, 0.0, lane);
+      publish_block_sum(q, 0.0, lane, tile);
       return;
     }
     const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16) + c0 * 16; // rows: right-side state
@@ -582,7 +593,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
-  publish_block_sum(q, contrib, lane);
+  publish_block_sum(q, contrib, lane, tile);
 }
 
 template <int C, int G = 1, bool DBG = false, int ARGS = 0, int DIST = 2>
@@ -602,7 +613,7 @@ __global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel
   fr.rates = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_rates));
   fr.up_idx = reinterpret_cast<const int *>(ka + offsetof(TreeParams, up_idx));
   fr.up_val = reinterpret_cast<const double *>(ka + offsetof(TreeParams, up_val));
-  nt2_run<C, G, DBG, ARGS, DIST>(q, irec, xrec, pmats, tip_codes, dbg, fr);
+  nt2_run<C, G, DBG, ARGS, DIST>(q, irec, xrec, pmats, tip_codes, dbg, fr, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
   bool               mail_open = false;
   for (;;)
   {
-    const int act = resident_poll_wave(r, last, t_last, mail_open, sh_raw, 1, lane);
+    const int act = resident_poll_wave(r, last, t_last, mail_open, sh_raw, 1, lane, blockIdx.x == 0);
     if (act == 2) return;
     if (act == 0) continue;
     __builtin_amdgcn_wave_barrier();
@@ -674,9 +685,9 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     __builtin_amdgcn_wave_barrier();
     NtFresh fr;
     fr.idx = sh_idx; fr.len = sh_len; fr.evec = evec; fr.ivec = ivec; fr.eval = eval; fr.rates = rates;
-    if (n_ops == 1) nt2_run<C, G, false, 1>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr);
-    else if (n_ops == 2) nt2_run<C, G, false, 2>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr);
-    else nt2_run<C, G, false, 3>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr);
+    if (n_ops == 1) nt2_run<C, G, false, 1>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x);
+    else if (n_ops == 2) nt2_run<C, G, false, 2>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x);
+    else nt2_run<C, G, false, 3>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x);
     last = last + 1; t_last = wall_clock64();
   }
 }
