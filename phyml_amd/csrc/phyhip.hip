@@ -147,6 +147,7 @@ struct Resident
   int                 grid = 0;
   struct timespec     t_launch = {0, 0}, t_cmd = {0, 0};
   unsigned long long  n_cmd = 0, n_launch = 0, n_silent = 0, n_busy = 0; // phyhip_get_resident_stats
+  double              ns_wait = 0.0;   // PHYHIP_RESIDENT_STATS: host time from a command's last word to its answer, summed
 };
 
 struct Instance
@@ -204,6 +205,7 @@ struct Instance
   TreeParams   rb_static;             // what its workgroups were launched with
   double      *d_tile_sums = nullptr; // [2][max(grid_nt2, n_vdlk)] tile sums of commands whose final sum runs on the device
   unsigned    *d_big_tickets = nullptr;
+  unsigned long long *d_big_stamps = nullptr; // PHYHIP_RESIDENT_STATS: stamps of the last command per workgroup (BigCtl::stamps)
   int          n_vdlk = 0;            // virtual blocks (one wave each) of a dLk evaluation: dlk64_kernel's grid
   int          big_wgs = 0, big_nw = 0; // its workgroups and waves per workgroup
   int          big_device_sum = 1;    // commands of more tiles than this add their tile sums on the device (one record to the host)
@@ -282,6 +284,7 @@ struct Instance
   bool       prof = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   hipEvent_t ev_sync = nullptr; // orders this instance's stream before another instance's (mixture evaluations)
+  hipEvent_t ev_big = nullptr;  // ... and behind the exit of its large-grid resident workgroups (big_release)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pairs;
   struct ProfPair { hipEvent_t a, b; int kind; };
   std::vector<ProfPair> prof_aux;          // eigen-basis kernels while profiling: kind 0 eigen_lr_kernel (K3), 1 dlk_kernel (K4)
@@ -326,7 +329,12 @@ static inline void leave_query(Instance *I) { I->stream_dirty = I->dirty_prev; -
 
 // hipSetDevice costs about a microsecond; the surface is entered hundreds of thousands of times per tree
 // search, so only switch when the calling thread is actually on another device
-#define GET_INST(I, id)                                                                                      \
+// GET_INST_RES: the entry points the large-grid resident workgroups (phyhip_big.hpp) serve or that only queue -- they keep
+// those workgroups and release them themselves where they launch.  GET_INST: everything else may put copies or kernels on the
+// instance's stream, which must then be ordered behind the resident workgroups' exit (what they wrote sits in their L2s until
+// they leave): big_release() first.
+static void big_release(Instance *I, bool restart_streak = true);
+#define GET_INST_RES(I, id)                                                                                  \
   Instance *I = get(id);                                                                                     \
   if (!I) return fail(PHYHIP_ERROR_UNINITIALIZED_INSTANCE, "instance %d does not exist", id);                 \
   if (g_cur_dev != I->dev)                                                                                   \
@@ -335,6 +343,9 @@ static inline void leave_query(Instance *I) { I->stream_dirty = I->dirty_prev; -
     g_cur_dev = I->dev;                                                                                      \
   }                                                                                                          \
   enter_stream_work(I);
+#define GET_INST(I, id)                                                                                      \
+  GET_INST_RES(I, id)                                                                                        \
+  big_release(I);
 
 int next_pow2(int x)
 {
@@ -424,8 +435,17 @@ int flush_uploads(Instance *I)
   return 0;
 }
 
+// "Everything queued on this stream before me has finished and is in memory": one thread, one store into host-mapped
+// memory.  Launched behind evaluations of large nucleotide instances that the resident workgroups could not take (stream
+// not known to be idle, first call of a streak): the host finds the stream idle again without synchronising it -- and without
+// the launched kernel's waves writing back their L2 before they post (megabytes of dirty lines at these sizes).
+static __global__ void stream_stamp_kernel(unsigned long long *stamp_host, unsigned long long stamp)
+{
+  __hip_atomic_store(stamp_host, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int stamp_stream(Instance *I);
+
 // Rebuild every queued transition matrix on the device: one staged copy of (index, length) pairs, one launch.
-static void big_release(Instance *I);
 int flush_pmats(Instance *I)
 {
   big_release(I);
@@ -526,6 +546,13 @@ static void resident_stop(Resident &R)
 
 static void resident_free(Resident &R)
 {
+  if (R.cmd)
+  { // (also a generation that was only told to leave, big_release: nobody may still be polling the record when it is freed)
+    __atomic_store_n(&R.cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
+    for (hipStream_t st : R.stream)
+      if (st) (void)hipStreamSynchronize(st);
+    R.launched = false;
+  }
   resident_stop(R);
   if (R.cmd) (void)hipHostFree(R.cmd);
   if (R.mail) (void)hipFree(R.mail);
@@ -622,37 +649,78 @@ static bool resident_short_eligible(const Instance *I)
 // the traversal kernel), so a second set could not start before the first has left.
 static std::atomic<Instance *> g_big_owner[64];
 
-static bool big_eligible(const Instance *I)
+// Instances whose dLk runs in the traversal's tiles (dlk_tile / dlk64_kernel) -- a property of the instance alone, so that
+// its evaluations return the same doubles whether the resident workgroups are enabled or not ...
+static bool big_shape(const Instance *I)
 {
-  return I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis && I->grid_nt2 > kResidentMaxGrid &&
-         !I->ablate && I->nt_groups <= 2 && I->dev >= 0 && I->dev < 64;
+  return I->host_sum && I->soa && !I->co && !I->class_axis && I->grid_nt2 > kResidentMaxGrid && I->nt_groups <= 2 && !I->ablate;
 }
+// ... and whether those workgroups may serve it
+static bool big_eligible(const Instance *I) { return big_shape(I) && I->resident && I->spin_wait && I->dev >= 0 && I->dev < 64; }
 
 // Tell the large-grid resident workgroups (if any) to leave -- without waiting for it: whatever this instance launches next
 // needs their wave slots, and gets them as they go.  (A new generation number is all it takes: workgroup 0 sees it at its
 // next poll of the host record and passes it on through the mailbox.)
-static void big_release(Instance *I)
+// The instance's stream is ordered behind their exit: the resident workgroups do not write back what they store while they
+// stay (a write-back per command of megabytes of dirty lines cost more than the command: measured, round 4) -- the end of
+// their kernel does, and kernels and copies of this instance that come later must find it in memory.
+static void big_release(Instance *I, bool restart_streak)
 {
-  I->big_streak = 0;
+  if (restart_streak) I->big_streak = 0;
   Resident &R = I->rb;
-  if (!R.cmd || !R.launched) return;
-  ++R.gen;
-  __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
-  R.launched = false;
-  Instance *me = I;
-  g_big_owner[I->dev].compare_exchange_strong(me, nullptr);
+  if (R.cmd && R.launched)
+  {
+    hipStream_t st = R.stream[R.gen & 1]; // (where this generation runs)
+    ++R.gen;
+    __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
+    R.launched = false;
+    if (I->ev_big && hipEventRecord(I->ev_big, st) == hipSuccess) (void)hipStreamWaitEvent(I->stream, I->ev_big, 0);
+    else (void)hipStreamSynchronize(st);
+    I->stream_dirty = true; I->touched_call = true; // (the stream now waits for something)
+  }
+  if (I->dev >= 0 && I->dev < 64)
+  {
+    Instance *me = I;
+    g_big_owner[I->dev].compare_exchange_strong(me, nullptr);
+  }
 }
 
-// Is everything queued on the instance's stream known to have finished?  (The flags of enter_stream_work, the report of the
-// last Update_Eigen_Lr, or -- large grids only -- a query of the stream: after a long traversal launch nothing else says so.)
+// Is everything queued on the instance's stream known to have finished?  (The flags of enter_stream_work and the stamp
+// launched behind the last evaluation.  hipStreamQuery was tried instead: it answers "not ready" for a stream whose last
+// command is a kernel until a marker it inserts itself has completed -- with a new launch after every query, never.)
 static bool big_clean(Instance *I)
 {
-  if (I->touched_call) return false;
-  if (!I->dirty_prev) return true;
-  if (hipStreamQuery(I->stream) != hipSuccess) return false;
-  I->dirty_prev = false; I->clean_after = 0;
-  ++I->clean_epoch; // (kernels ran since the last command: the resident workgroups re-read device memory)
+  if (I->touched_call || I->dirty_prev) return false;
+  if (I->clean_after)
+  { // the stamp launched behind the last kernel of the stream (stamp_stream): arrived = idle; not yet = launch this one too
+    // (a bounded wait: the stamp runs a launch gap behind the kernel whose scalar the host already has -- a host that comes
+    // back within microseconds would otherwise find it missing call after call and never get to the resident workgroups)
+    volatile unsigned long long *stamp = reinterpret_cast<volatile unsigned long long *>(I->h_result + 3);
+    if (*stamp < I->clean_after)
+    {
+      struct timespec t0;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (long it = 1; *stamp < I->clean_after; ++it)
+      {
+        __builtin_ia32_pause();
+        if ((it & 63) == 0 && ns_since(t0) > 40000.0) return false;
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    I->clean_after = 0;
+    ++I->clean_epoch; // (kernels ran since the last command: the resident workgroups re-read device memory)
+  }
   return true;
+}
+
+// Launch the stamp behind what the call has just put on the stream; from now on the stream counts as idle once it arrives.
+static int stamp_stream(Instance *I)
+{
+  const unsigned long long v = ++I->stamp_seq;
+  hipLaunchKernelGGL(stream_stamp_kernel, dim3(1), dim3(1), 0, I->stream, reinterpret_cast<unsigned long long *>(I->h_result + 3), v);
+  HIPCHK(hipGetLastError());
+  I->stream_dirty = false; I->clean_after = v;
+  return 0;
 }
 
 // Could the resident workgroups take an evaluation of this instance right now?  Counts the calls in a row for which the answer
@@ -676,6 +744,11 @@ static int big_launch(Instance *I, const TreeParams &sq)
     HIPCHK(hipMalloc((void **)&I->d_tile_sums, 2 * n * sizeof(double)));
     HIPCHK(hipMalloc((void **)&I->d_big_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
     HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), I->stream));
+    if (getenv("PHYHIP_RESIDENT_STATS"))
+    {
+      HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs));
+      HIPCHK(hipMemsetAsync(I->d_big_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs, I->stream));
+    }
     HIPCHK(hipStreamSynchronize(I->stream)); // (the stream is idle: this evaluation was about to bypass it)
   }
   Instance *none = nullptr;
@@ -687,6 +760,7 @@ static int big_launch(Instance *I, const TreeParams &sq)
   BigArgs a;
   a.t = sq; a.r = r;
   a.b.n_tiles = I->grid_nt2; a.b.n_vdlk = I->n_vdlk; a.b.tile_sums = I->d_tile_sums; a.b.tickets = I->d_big_tickets; a.b.dot_prod = I->d_dot;
+  a.b.stamps = I->d_big_stamps;
   a.pmats = I->d_pmats; a.tip_codes = I->d_tipcodes;
   if (launch_resident_big(I->C, I->nt_groups, I->big_wgs, st, a) != 0)
     return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: no kernel for %d categories in %d groups", I->C, I->nt_groups);
@@ -700,7 +774,7 @@ static int big_launch(Instance *I, const TreeParams &sq)
 static TreeParams big_static_params(Instance *I)
 {
   TreeParams sq = base_params(I);
-  sq.host_blocks = I->h_blocks; sq.warn = I->h_warn; sq.fence_post = 1; sq.recs_in_args = 1; sq.edge_eval = 1;
+  sq.host_blocks = I->h_blocks; sq.warn = I->h_warn; sq.fence_post = 0; sq.recs_in_args = 1; sq.edge_eval = 1;
   sq.br_len_mult = I->br_len_mult; sq.l_min = I->l_min; sq.l_max = I->l_max; sq.pmats_rw = I->d_pmats;
   sq.dot_out = I->d_dot;
   if (I->want_site_outputs) { sq.site_lnl = I->d_site_lnl; sq.site_lk = I->d_site_lk; sq.site_cat = I->d_site_cat; }
@@ -724,6 +798,13 @@ static int big_ensure(Instance *I)
   return big_launch(I, sq);
 }
 
+// dLk in the traversal's tiles (dlk_tile): the launched form of what the large-grid resident workgroups serve
+template <int CP> static void launch_dlk64(Instance *I, const DlkParams &q, int dgrid)
+{
+  if (I->nt_groups == 2) hipLaunchKernelGGL((dlk64_kernel<4, CP, (CP >= 2 ? CP / 2 : 1)>), dim3(dgrid), dim3(64), 0, I->stream, q);
+  else hipLaunchKernelGGL((dlk64_kernel<4, CP, CP>), dim3(dgrid), dim3(64), 0, I->stream, q);
+}
+
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush_impl(Instance *I, const EdgeEval *ee)
 {
@@ -737,8 +818,14 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
   static const int fold_grid_max = diag_env("PHYHIP_FOLD_GRID") ? atoi(diag_env("PHYHIP_FOLD_GRID")) : 512;
   // large grids: an evaluation the large-grid resident workgroups can take (phyhip_big.hpp) carries its matrices in the command
-  const bool big_try = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
-                       (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && big_ready(I);
+  const bool big_fit = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
+                       (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && big_eligible(I) && !I->prof && !I->rt_skip;
+  const bool big_try = big_fit && big_ready(I);
+  if (kDiag && ee && getenv("PHYHIP_RESIDENT_DEBUG") && big_shape(I))
+    fprintf(stderr, "big: fit %d try %d | eligible %d ops %d pm %zu up %zu prof %d skip %d | dirty_prev %d touched %d clean_after %llu stamp %llu streak %d launched %d owner %p me %p\n",
+            (int)big_fit, (int)big_try, (int)big_eligible(I), n_ops, I->pm_idx.size(), I->up_idx.size(), (int)I->prof, (int)I->rt_skip, (int)I->dirty_prev,
+            (int)I->touched_call, I->clean_after, *reinterpret_cast<volatile unsigned long long *>(I->h_result + 3), I->big_streak, (int)I->rb.launched,
+            (void *)g_big_owner[I->dev < 64 ? I->dev : 0].load(), (void *)I);
   const bool fold_pm = I->soa && I->fold_pmats && (I->grid_nt2 <= fold_grid_max || big_try) && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
                        I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
   // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
@@ -1067,13 +1154,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     }
   }
   // ---- large nucleotide alignments: the large-grid resident evaluator (resident_big_kernel) -------------------------------
-  if (big_eligible(I) && host_sum_n > 0 && q.recs_in_args)
-  { // short launches of such an instance complete their stores before they post too: the stream is clean once the scalar is
-    // back, and the next evaluation can go to the resident workgroups (long operation lists do not -- a wave that waits for its
-    // result stores holds its slot, see fuse_reduce -- after those a query of the stream says when it is idle)
-    q.fence_post   = 1;
-    I->fenced_eval = true;
-  }
+  // (launches of such an instance do not fence their stores before they post -- with megabytes of results in the L2s a
+  // write-back per wave costs more than the launch; whether the stream is idle again is found by querying it, big_clean)
   if (big_try && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0)
   {
     const int brc = big_ensure(I);
@@ -1107,7 +1189,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       resident_send(I, R, words, kBigWords);
       I->rt_epoch = I->clean_epoch;
       I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
-      I->fenced_eval = true; // (the resident workgroups always complete their stores before they post)
+      I->fenced_eval = true; // (nothing went onto the stream: it is as idle as it was found)
       if (fold_pm)
       {
         for (int m : I->pm_idx) I->pm_slot[m] = -1;
@@ -1333,6 +1415,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   }
   I->pending.clear();
   std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
+  // an evaluation the large-grid resident workgroups would have taken, had the stream been known to be idle: say when it is
+  if (big_fit && host_sum_n > 0 && (rc = stamp_stream(I))) return rc;
   return 0;
 }
 
@@ -1376,8 +1460,14 @@ int wait_host_sum(Instance *I)
   volatile HostBlock      *hb  = I->h_blocks;
   struct timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
-  bool synced = false;
-  for (int i = 0; i < n; ++i)
+  bool   synced = false;
+  // final_reduce_kernel's order -- 256 strided accumulators per sum, then a binary tree -- with the records taken as they
+  // arrive, front to back: accumulator t receives records t, t + 256, ... in that order either way, and one sequential pass
+  // over the records costs a fraction of 256 strided ones (thousands of records per evaluation on large grids)
+  double acc[2][256];
+  for (int k = 0; k < I->host_sum_ns; ++k)
+    for (int t = 0; t < 256; ++t) acc[k][t] = 0.0;
+  for (int i = 0, k = 0, j = 0; i < n; ++i)
   {
     long it = 0;
     while (hb[i].tag != tag)
@@ -1405,23 +1495,18 @@ int wait_host_sum(Instance *I)
       else if (synced && it > 100000000L)
         return fail(PHYHIP_ERROR_GENERAL, "evaluation %llu finished without posting block sum %d", tag, i);
     }
+    acc[k][j & 255] += hb[i].sum; // (the record is ONE 16-byte store of the device: the sum is there when the tag is)
+    if (++j == per) { j = 0; ++k; }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int k = 0; k < I->host_sum_ns; ++k)
   {
-    const HostBlock *in = I->h_blocks + (size_t)k * per;
-    double           acc[256];
-    for (int t = 0; t < 256; ++t)
-    {
-      double a = 0.0;
-      for (int i = t; i < per; i += 256) a += in[i].sum;
-      acc[t] = a;
-    }
     for (int off = 128; off > 0; off >>= 1)
-      for (int t = 0; t < off; ++t) acc[t] += acc[t + off];
-    I->h_result[k] = acc[0];
+      for (int t = 0; t < off; ++t) acc[k][t] += acc[k][t + off];
+    I->h_result[k] = acc[k][0];
   }
   I->host_sum_n    = 0;
+  if (I->r_inflight) I->r_inflight->ns_wait += ns_since(I->r_inflight->t_cmd);
   I->r_inflight    = nullptr;
   I->warn_current  = true;
   *reinterpret_cast<volatile unsigned long long *>(I->h_result + 2) = tag;
@@ -1567,23 +1652,48 @@ static void release_instance(Instance *I)
   if (getenv("PHYHIP_RESIDENT_STATS"))
     for (const Resident *R : {&I->rd, &I->rt, &I->rb})
       if (R->n_cmd || R->n_busy)
-        fprintf(stderr, "resident %s: %llu commands, %llu launches, %llu unanswered, %llu evaluations launched because the stream was busy\n",
+        fprintf(stderr, "resident %s: %llu commands, %llu launches, %llu unanswered, %llu evaluations launched because the stream was busy; "
+                        "%.2f us from command to answer\n",
                 R == &I->rd ? "dLk evaluator" : (R == &I->rt ? "short-launch evaluator" : "large-grid evaluator"), R->n_cmd, R->n_launch,
-                R->n_silent, R->n_busy);
+                R->n_silent, R->n_busy, R->n_cmd ? R->ns_wait * 1e-3 / (double)R->n_cmd : 0.0);
   resident_free(I->rd);
   resident_free(I->rt);
   big_release(I);
+  const bool big_used = I->rb.n_cmd > 0;
   resident_free(I->rb);
+  if (I->d_big_stamps && big_used)
+  { // where the last command's time went, per workgroup, relative to workgroup 0 seeing it (wall-clock ticks of 10 ns)
+    std::vector<unsigned long long> h((size_t)8 * I->big_wgs);
+    if (hipMemcpy(h.data(), I->d_big_stamps, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+    {
+      const char *names[6] = {"command seen", "after the barrier", "wave 0 through", "all waves through", "ticket drawn", "final sum posted"};
+      const unsigned long long t0 = h[0];
+      for (int k = 0; k < 6; ++k)
+      {
+        double mn = 1e30, mx = -1e30, sum = 0.0; int n = 0;
+        for (int w = 0; w < I->big_wgs; ++w)
+        {
+          const unsigned long long v = h[(size_t)w * 8 + k];
+          if (!v || v < t0) continue;
+          const double d = (double)(v - t0) * 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3);
+          mn = std::min(mn, d); mx = std::max(mx, d); sum += d; ++n;
+        }
+        if (n) fprintf(stderr, "  big resident, last command: %-18s min %7.2f  mean %7.2f  max %7.2f us after workgroup 0 saw it (%d workgroups)\n",
+                       names[k], mn, sum / n, mx, n);
+      }
+    }
+  }
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks, I->d_tile_sums, I->d_big_tickets};
+                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks, I->d_tile_sums, I->d_big_tickets, I->d_big_stamps};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
   if (I->h_warn) (void)hipHostFree(I->h_warn);
   if (I->h_blocks) (void)hipHostFree(I->h_blocks);
   if (I->ev_sync) (void)hipEventDestroy(I->ev_sync);
+  if (I->ev_big) (void)hipEventDestroy(I->ev_big);
   I->ring.destroy();
   if (I->own_stream && I->stream) (void)hipStreamDestroy(I->stream);
   delete I;
@@ -1671,6 +1781,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   (void)prop;
   HIPCHK(hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&I->ev_big, hipEventDisableTiming));
 
   I->perm = (I->S == 20) && (I->C <= 4) && (I->class_axis || !(diag_env("PHYHIP_GENERIC_AA") && atoi(diag_env("PHYHIP_GENERIC_AA"))));
   I->soa  = (I->S == 4) && (I->C <= 4) &&
@@ -1749,7 +1860,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   // large-grid resident evaluator (phyhip_big.hpp): a workgroup of big_nw waves per CU at the traversal kernel's register
   // budget (two waves per SIMD with two lanes per pattern, one otherwise); dLk in up to 2 048 one-wave virtual blocks
   I->cus     = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  I->n_vdlk  = (int)std::min<long long>(((long long)I->P * I->CP + 63) / 64, 2048);
+  I->n_vdlk  = I->grid_nt2; // (a dLk tile = the patterns of a traversal tile: dlk_tile)
   I->big_nw  = I->nt_groups == 2 ? 8 : 4;
   I->big_wgs = std::max(1, std::min(I->cus, (I->grid_nt2 + I->big_nw - 1) / I->big_nw));
   if (const char *e = diag_env("PHYHIP_BIG_DEVICE_SUM")) I->big_device_sum = atoi(e);
@@ -1780,7 +1891,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   *I->h_warn = 0;
   {
     // traversal grids (one sum), dLk grids (two sums, <= 2048 workgroups), mixture combination grids ((P + 255) / 256)
-    const size_t nb = std::max<size_t>((size_t)std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2)), 2 * 2048);
+    const size_t nb = std::max<size_t>((size_t)std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, 2 * I->grid_nt2)), 2 * 2048);
     HIPCHK(hipHostMalloc((void **)&I->h_blocks, nb * sizeof(HostBlock), hipHostMallocMapped));
     memset(I->h_blocks, 0, nb * sizeof(HostBlock));
     I->h_blocks_cap = nb;
@@ -2164,7 +2275,7 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
       return phyhip_update_transition_matrices(G->sub_id[g], eigenIndex, probabilityIndices, firstDerivativeIndices,
                                                secondDerivativeIndices, edgeLengths, count);
     });
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   if (eigenIndex != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
   if (firstDerivativeIndices || secondDerivativeIndices)
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "derivative matrices are not used by PhyML's path (see phyhip_calculate_eigen_lnl_dlnl)");
@@ -2202,7 +2313,7 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
   if (Group *G = get_group(instance))
     return group_each(G, [&](int id, long long, long long) { return phyhip_set_transition_matrix(id, matrixIndex, inMatrix, paddedValue); });
   (void)paddedValue;
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   int rc = matrices_touch(I, &matrixIndex, 1);
   if (rc) return rc;
   if (I->pm_slot[matrixIndex] >= 0 && (rc = flush_pmats(I))) return rc; // keep rebuild-then-upload order
@@ -2242,7 +2353,7 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
   if (Group *G = get_group(instance))
     return group_each(G, [&](int id, long long, long long) { return phyhip_update_partials(id, ops, n, cumulativeScaleIndex); });
   (void)cumulativeScaleIndex;
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   for (int i = 0; i < n; ++i)
   {
     const phyhip_operation &o = ops[i];
@@ -2313,7 +2424,7 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
 {
   (void)cs;
   Group *G = get_group(instance);
-  GET_INST(I, G ? G->sub_id[0] : instance);
+  GET_INST_RES(I, G ? G->sub_id[0] : instance);
   if (count != 1) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "count must be 1");
   if (d1 || d2 || outD1 || outD2)
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "derivatives: use phyhip_calculate_eigen_lnl_dlnl (PhyML's dLk path)");
@@ -2812,7 +2923,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
     *out = G->last_warn;
     return PHYHIP_SUCCESS;
   }
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   if (!(I->warn_current && I->pending.empty()))
   { // an evaluation whose result the host did not wait for (device-side output) may still be running
     int rc = flush_sync(I);
@@ -2831,7 +2942,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
 int phyhip_update_eigen_lr(int instance, int left, int rght)
 {
   if (Group *G = get_group(instance)) return group_parallel(G, [&](int g) { return phyhip_update_eigen_lr(G->sub_id[g], left, rght); });
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, rght, true))) return rc;
@@ -2858,7 +2969,7 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
     return PHYHIP_SUCCESS;
   }
   if ((rc = flush(I, nullptr))) return rc;
-  big_release(I);
+  big_release(I, false);
   I->touched_call = true;
   EigenParams e;
   e.t = base_params(I); e.ro = base_ro(I, nullptr); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;
@@ -2877,6 +2988,7 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   if (report) { I->stream_dirty = false; I->clean_after = e.stamp; }
+  else if (big_eligible(I) && !I->prof && (rc = stamp_stream(I))) return rc; // (large instance: the dLk calls that follow can be served resident)
   I->eig_api_no = report ? I->api_no : 0;
   return PHYHIP_SUCCESS;
 }
@@ -2901,8 +3013,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   if (const char *e = diag_env("PHYHIP_DLK_GRID")) dgrid = std::min(I->grid, std::max(1, atoi(e)));
   const bool hsum  = !dev_out && I->host_sum;
   // Large nucleotide alignments with the scalar wanted on the host: the evaluation is cut into one-wave virtual blocks
-  // (dlk_wave) -- what the large-grid resident workgroups serve (phyhip_big.hpp) and, launched, dlk64_kernel: the same doubles
-  const bool big = hsum && big_eligible(I);
+  // (dlk_tile) -- what the large-grid resident workgroups serve (phyhip_big.hpp) and, launched, dlk64_kernel: the same doubles
+  const bool big = hsum && big_shape(I);
   if (big) dgrid = I->n_vdlk;
   q.pinvar = I->pinvar; q.fin.block_sums = I->d_block; q.fin.stride = dgrid; q.fin.warn = I->d_warn;
   const bool fused = !hsum && fuse_reduce(I, dgrid);
@@ -2946,7 +3058,11 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   // the products are a few microseconds away: poll the stream that long, else launch as usual.
   // (4 states only: a 20-state command takes four 512-byte reads per poll instead of one and the round trip loses to the launch, 14.1-14.9 against
   // 12.4-12.5 us at 2 000 patterns -- measured, tools/gpu_resident_ab2.sh)
-  if (big && big_ready(I))
+  if (kDiag && getenv("PHYHIP_RESIDENT_DEBUG") && big)
+    fprintf(stderr, "big dLk: eligible %d | dirty %d dirty_prev %d touched %d clean_after %llu stamp %llu streak %d launched %d\n", (int)big_eligible(I),
+            (int)I->stream_dirty, (int)I->dirty_prev, (int)I->touched_call, I->clean_after, *reinterpret_cast<volatile unsigned long long *>(I->h_result + 3),
+            I->big_streak, (int)I->rb.launched);
+  if (big && big_eligible(I) && big_ready(I))
   {
     I->stream_dirty = false; // (found idle; a dLk leaves nothing on the stream)
     const int brc = big_ensure(I);
@@ -2982,7 +3098,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       I->r_inflight = nullptr; I->host_sum_n = 0;
     }
   }
-  else if (big) ++I->rb.n_busy;
+  else if (big && big_eligible(I)) { ++I->rb.n_busy; I->big_streak = 0; }
+  if (big) big_release(I, false); // (launched on the stream: behind the resident workgroups' exit, if there are any)
   if (!big && hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait)
   {
     bool idle = !I->stream_dirty;
@@ -3047,7 +3164,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     const unsigned long long h1 = hp_now();
-    if (big) hipLaunchKernelGGL((dlk64_kernel<S_, CP_>), dim3(dgrid), dim3(64), 0, I->stream, q);
+    if (big) { if constexpr (S_ == 4 && CP_ <= 4) launch_dlk64<CP_>(I, q, dgrid); }
     else hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, I->stream, q);
     if (kDiag) { g_hp.launch += hp_now() - h1; ++g_hp.n_launch; }
     return 0;
@@ -3056,6 +3173,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   if (hsum) { I->host_sum_n = dgrid; I->host_sum_ns = 2; }
+  if (big && big_eligible(I) && !I->prof && (rc = stamp_stream(I))) return rc; // (the next one can go to the resident workgroups)
   if (!fused && !hsum)
   {
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, dgrid, 2, dgrid,
@@ -3104,7 +3222,7 @@ static int rank_eigen_eval(Instance *I, double l, bool deriv, double *lnl, doubl
 int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, double *outDLnL)
 {
   Group *G = get_group(instance);
-  GET_INST(I, G ? G->sub_id[0] : instance);
+  GET_INST_RES(I, G ? G->sub_id[0] : instance);
   leave_untouched(I); // (queues nothing by itself; flush() says so if it does)
   if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN"); // src/lk.c:671
   if (*l < I->l_min) *l = I->l_min;                                                     // src/lk.c:673-674
@@ -3117,7 +3235,7 @@ int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, dou
 int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL)
 {
   if (Group *G = get_group(instance)) return group_eigen_eval(G, l, false, outLnL, nullptr);
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   leave_untouched(I);
   if (I->co) return rank_eigen_eval(I, l, false, outLnL, nullptr);
   return eigen_eval(I, l, false, outLnL, nullptr);
@@ -3285,7 +3403,7 @@ int phyhip_get_resident_stats(int instance, long long out[8])
     for (int k = 0; k < 8; ++k) out[k] = 0;
     return PHYHIP_SUCCESS;
   }
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   leave_query(I);
   for (int k = 0; k < 8; ++k) out[k] = 0;
   int k = 0;
@@ -3300,7 +3418,7 @@ int phyhip_get_big_resident_stats(int instance, long long out[4])
 {
   for (int k = 0; k < 4; ++k) out[k] = 0;
   if (get_group(instance)) return PHYHIP_SUCCESS; // (sharded instances: never resident)
-  GET_INST(I, instance);
+  GET_INST_RES(I, instance);
   leave_query(I);
   const Resident *R = &I->rb;
   out[0] = (long long)R->n_cmd; out[1] = (long long)R->n_launch; out[2] = (long long)R->n_silent; out[3] = (long long)R->n_busy;

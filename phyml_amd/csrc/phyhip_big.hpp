@@ -9,7 +9,7 @@
 //   * wave 0 of every workgroup polls (workgroup 0 the host-mapped command record, the others the device-memory mailbox it
 //     relays each command through -- the mechanism of resident_poll_wave); the other waves sleep at the workgroup barrier
 //     meanwhile: a parked wave issues nothing and reads nothing, so 2 048 resident waves cost 256 pollers;
-//   * a wave then walks ITS tiles (tile = wave, wave + waves, ...): the launched kernels' per-tile bodies (nt2_run, dlk_wave)
+//   * a wave then walks ITS tiles (tile = wave, wave + waves, ...): the launched kernels' per-tile bodies (nt2_run, dlk_tile)
 //     unchanged, so every tile sum is the double the launched form computes; the transition matrices of the command are
 //     rebuilt in the wave's prologue (nt2_run's n_fresh), once per command;
 //   * one command kind per call of the surface: 0-2 partial updates + the edge evaluation (SPR candidate, Lk(b)), the same
@@ -43,10 +43,13 @@ enum : unsigned long long
 struct BigCtl
 {
   int           n_tiles;   // tiles of a traversal command (= the launched kernel's grid, grid_nt2)
-  int           n_vdlk;    // virtual blocks of a dLk command (= dlk64_kernel's grid)
+  int           n_vdlk;    // tiles of a dLk command (= dlk64_kernel's grid = n_tiles)
   double       *tile_sums; // device [2][max(n_tiles, n_vdlk)]: the tile sums of a command whose final sum runs on the device
   unsigned     *tickets;   // device [1 + kTicketGroups], zero between commands
   const double *dot_prod;  // the eigen products (Update_Eigen_Lr's output, dLk's input)
+  // PHYHIP_RESIDENT_STATS: wall-clock stamps of the last command per workgroup, [workgroup][8]: 0 command seen, 1 after the
+  // workgroup's barrier, 2 wave 0 through with its tiles, 3 all waves through, 4 ticket drawn, 5 final sum posted (nullptr: none)
+  unsigned long long *stamps;
 };
 
 // Everything the kernel is launched with, in ONE argument: each command re-reads what it needs from the argument segment
@@ -83,6 +86,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
   __shared__ unsigned           sh_last;
   __shared__ IssueRec           sh_ir[2]; // the command's operation records: nt2_run reads them from here when it needs them
   __shared__ ExecRec            sh_xr[2];
+  __shared__ __attribute__((aligned(16))) double sh_dot[NW][(64 / G) * C * 4]; // per wave: staging of a tile's eigen products
+  __shared__ double             sh_red[2][256];                                // the final sum's accumulators
   unsigned long long last = args_.r.start_seq, t_last = wall_clock64();
   bool               mail_open = false;
   for (;;)
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
       int               act;
       for (;;)
       {
-        act = resident_poll_wave(r, last, t_last, mail_open, sh_raw, 1, lane, bid == 0);
+        act = resident_poll_wave<true>(r, last, t_last, mail_open, sh_raw, 1, lane, bid == 0);
         if (act) break;
         __builtin_amdgcn_s_sleep(2);
       }
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
         }
       }
     }
+    const unsigned long long st0 = wall_clock64();
     __syncthreads(); // (the other waves of the workgroup have been asleep here since they finished the previous command)
     if (sh_act == 2) return;
     // every word is the same for all lanes: make that known (loop bounds and flags belong in scalar registers)
@@ -158,9 +164,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
     const bool               dsum = (fl & kBigDeviceSum) != 0;
     BigCtl b;
     karg_copy(b, &A->b);
+    auto stamp = [&](int i, unsigned long long t) {
+      if (b.stamps && tid == 0) b.stamps[(size_t)bid * 8 + i] = t;
+    };
+    stamp(0, st0);
+    stamp(1, wall_clock64());
     // what kernels on the stream wrote since the last command (the host says whether any did) is re-read from memory
     if (fl & kBigChanged) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    int n_rec, ns;
+    constexpr int IT = CP / G > 0 ? CP / G : 1; // rounds of 64 (pattern, category) lanes per tile (dlk_tile)
+    int           n_rec, ns;
     if (fl & kBigDlk)
     { // ---- dLk / Lk in the eigen basis: dlk64_kernel's virtual blocks ----
       DlkParams dq;
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
       for (int vb = gw; vb < n_rec; vb += TW)
       {
         double v[2];
-        dlk_wave<4, CP>(dq, k, sh_expl, A->t.warn, vb, n_rec, lane, v);
+        dlk_tile<4, CP, IT>(dq, k, sh_expl, A->t.warn, (unsigned)vb, lane, v);
         if (lane == 0)
         {
           if (dsum)
@@ -221,16 +233,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
       n_rec = b.n_tiles; ns = 1;
       for (int tile = gw; tile < n_rec; tile += TW)
       {
-        if (n_ops == 1) nt2_run<C, G, false, 1, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid);
-        else if (n_ops == 2) nt2_run<C, G, false, 2, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid);
-        else nt2_run<C, G, false, 3, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid);
+        if (n_ops == 1) nt2_run<C, G, false, 1, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid, sh_dot[wid]);
+        else if (n_ops == 2) nt2_run<C, G, false, 2, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid, sh_dot[wid]);
+        else nt2_run<C, G, false, 3, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid, sh_dot[wid]);
         q.n_fresh = 0; // (this wave has rebuilt the command's matrices with its first tile)
       }
     }
+    stamp(2, wall_clock64());
     if (dsum)
     { // ---- the final sum on the device: tile sums written through, a ticket per workgroup, the last one adds and posts ----
-      __threadfence(); // this thread's stores (results, tile sums) are complete and written back ...
-      __syncthreads(); // ... for every wave of the workgroup, before its ticket is drawn
+      __builtin_amdgcn_s_waitcnt(0); // this wave's tile sums (atomic stores at agent scope: written through) are acknowledged ...
+      __syncthreads();               // ... and every other wave's of the workgroup, before its ticket is drawn
+      stamp(3, wall_clock64());
       if (tid == 0)
       { // two-level draw (see finish_sums: atomics on one address serialise)
         const unsigned g = bid % kTicketGroups, ng = nwg < kTicketGroups ? nwg : kTicketGroups;
@@ -240,36 +254,65 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
           lastwg = __hip_atomic_fetch_add(b.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1 ? 1u : 0u;
         sh_last = lastwg;
       }
+      stamp(4, wall_clock64());
       __syncthreads();
-      if (sh_last && wid == 0)
-      {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        double tot[2] = {0.0, 0.0};
-        for (int s = 0; s < ns; ++s)
-        { // final_reduce_kernel's order: 256 strided accumulators (four per lane), then the binary tree
-          const double *in = b.tile_sums + (size_t)s * n_rec;
-          double        acc[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
+      if (sh_last)
+      { // final_reduce_kernel's order: 256 strided accumulators, then the binary tree.  Thread t < 256 owns accumulator t of
+        // both sums; its loads go out together, up to sixteen per sum (one after the other -- a dependent trip to memory each
+        // -- the 13 loads per thread of a 3 126-tile evaluation took 27 us, measured; the sums themselves were in memory
+        // after 7), as atomic loads at agent scope: they see what the other XCDs' workgroups wrote through.
+        double acc[2] = {0.0, 0.0};
+        if (tid < 256)
+          for (int i0 = (int)tid; i0 < n_rec; i0 += 16 * 256)
           {
-            acc[j] = 0.0;
-            for (int i = lane + 64 * j; i < n_rec; i += 256) acc[j] += in[i];
-          }
-          double t = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+            unsigned long long v[2][16];
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-          tot[s] = t;
-        }
-        if (lane == 0)
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int u = 0; u < 16; ++u)
+                v[s][u] = (s < ns && i0 + u * 256 < n_rec)
+                              ? __hip_atomic_load(reinterpret_cast<const unsigned long long *>(b.tile_sums) + (size_t)s * n_rec + i0 + u * 256,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : 0ull;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int u = 0; u < 16; ++u)
+                if (s < ns && i0 + u * 256 < n_rec)
+                {
+                  double d;
+                  __builtin_memcpy(&d, &v[s][u], 8);
+                  acc[s] += d;
+                }
+          }
+        if (tid < 256) { sh_red[0][tid] = acc[0]; sh_red[1][tid] = acc[1]; }
+        __syncthreads();
+        if (tid < 128) { sh_red[0][tid] += sh_red[0][tid + 128]; sh_red[1][tid] += sh_red[1][tid + 128]; }
+        __syncthreads();
+        if (wid == 0)
         {
-#pragma unroll 1
-          for (int k = 0; k <= (int)kTicketGroups; ++k) __hip_atomic_store(b.tickets + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __builtin_amdgcn_s_waitcnt(0); // (the counters are zero again before the host can send the next command)
-          for (int s = 0; s < ns; ++s) post_host_block(A->t.host_blocks + s, tot[s], tag);
+          double t0 = sh_red[0][lane] + sh_red[0][lane + 64], t1 = sh_red[1][lane] + sh_red[1][lane + 64];
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1)
+          {
+            t0 += __shfl_down(t0, off, 64);
+            t1 += __shfl_down(t1, off, 64);
+          }
+          // the counters are zero again before the host can send the next command (one store instruction of this wave,
+          // acknowledged before lane 0 posts)
+          if (lane <= (int)kTicketGroups) __hip_atomic_store(b.tickets + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_s_waitcnt(0);
+          if (lane == 0)
+          {
+            post_host_block(A->t.host_blocks, t0, tag);
+            if (ns == 2) post_host_block(A->t.host_blocks + 1, t1, tag);
+            stamp(5, wall_clock64());
+          }
         }
       }
     }
     __syncthreads(); // (wave 0 rewrites the command's staging area with its next poll)
+    if (!dsum) stamp(3, wall_clock64());
     last = last + 1; t_last = wall_clock64();
   }
 }

@@ -1360,35 +1360,30 @@ __device__ __forceinline__ bool dlk_block(const DlkParams &q, const DlkCall k, c
   return wid == 0;
 }
 
-// The same evaluation cut into VIRTUAL BLOCKS of one wave: virtual block vb of nvb takes the (pattern, category) lanes
-// vb * 64 + lane + i * nvb * 64 (i = 0, 1, ...), each lane adds its terms in that order, then the wave's shuffle tree.  The sums
-// of a virtual block do not depend on who computes it -- a one-wave workgroup of dlk64_kernel or a wave of the large-grid
-// resident evaluator (phyhip_big.hpp) that takes several virtual blocks in turn -- so the launched and the resident form return
-// the same doubles.  The loads of up to four rounds are in flight at once (a round is a dependent trip to memory: at
-// 100 000 patterns in 2 048 virtual blocks there are three, and one after the other they were most of dlk_kernel's 10 us).
-// On return every lane of the wave holds the two sums in v.
-template <int S, int CP>
-__device__ __forceinline__ void dlk_wave(const DlkParams &q, const DlkCall k, const double *expl, int *warn, const int vb, const int nvb,
+// The same evaluation cut along the TILES of the lane-per-pattern traversal kernel: tile t holds the patterns
+// [t * 64 / G, (t + 1) * 64 / G) -- IT = CP / G rounds of 64 (pattern, category) lanes, each lane adding its rounds in order, then
+// the wave's shuffle tree.  A tile's sums do not depend on who computes them -- a one-wave workgroup of dlk64_kernel or a wave
+// of the large-grid resident evaluator (phyhip_big.hpp) -- so the launched and the resident form return the same doubles; and
+// the wave that evaluates a tile is the one that wrote its products and scale exponents (Update_Eigen_Lr and the edge
+// evaluation run on the same tiles): the resident workgroups need no write-back between commands.  The loads of all rounds
+// are in flight at once (a round is a dependent trip to memory; one after the other they were most of dlk_kernel's 10 us at
+// 100 000 patterns).  On return every lane of the wave holds the two sums in v.
+template <int S, int CP, int IT>
+__device__ __forceinline__ void dlk_tile(const DlkParams &q, const DlkCall k, const double *expl, int *warn, const unsigned tile,
                                          const int lane, double (&v)[2])
 {
-  const long long total = (((long long)q.P * CP + 63) / 64) * 64, stride = (long long)nvb * 64;
-  constexpr int   U = 4;
-  double          tot_lnl = 0.0, tot_dlnl = 0.0;
-  for (long long g0 = (long long)vb * 64 + lane; g0 < total; g0 += U * stride)
+  const long long g0 = (long long)tile * (IT * 64) + lane;
+  DlkIn<S>        in[IT];
+#pragma unroll
+  for (int u = 0; u < IT; ++u) dlk_fetch<S, CP>(q, k, g0 + u * 64, in[u]);
+  double tot_lnl = 0.0, tot_dlnl = 0.0;
+#pragma unroll
+  for (int u = 0; u < IT; ++u)
   {
-    DlkIn<S> in[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (g0 + u * stride < total) dlk_fetch<S, CP>(q, k, g0 + u * stride, in[u]); // (the same for every lane of the wave)
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (g0 + u * stride < total)
-      {
-        double c_lnl, c_dlnl;
-        dlk_lane<S, CP>(q, k, expl, warn, g0 + u * stride, in[u], c_lnl, c_dlnl);
-        tot_lnl += c_lnl;
-        tot_dlnl += c_dlnl;
-      }
+    double c_lnl, c_dlnl;
+    dlk_lane<S, CP>(q, k, expl, warn, g0 + u * 64, in[u], c_lnl, c_dlnl);
+    tot_lnl += c_lnl;
+    tot_dlnl += c_dlnl;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
@@ -1408,13 +1403,13 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
   if (dlk_block<S, CP>(q, k, q.expl, q.fin.warn, v)) finish_sums<2>(q.fin, v, (int)(threadIdx.x & 63));
 }
 
-// One virtual block (dlk_wave) per one-wave workgroup: the launched form of what the large-grid resident evaluator serves
-template <int S, int CP>
+// One tile (dlk_tile) per one-wave workgroup: the launched form of what the large-grid resident evaluator serves
+template <int S, int CP, int IT>
 __global__ __launch_bounds__(64) void dlk64_kernel(const DlkParams q)
 {
   const DlkCall k = {q.with_derivative, q.invar_model, q.apply_scaling, q.pinvar};
   double        v[2];
-  dlk_wave<S, CP>(q, k, q.expl, q.fin.warn, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, v);
+  dlk_tile<S, CP, IT>(q, k, q.expl, q.fin.warn, blockIdx.x, (int)threadIdx.x, v);
   finish_sums<2>(q.fin, v, (int)threadIdx.x);
 }
 
@@ -1472,6 +1467,9 @@ struct ResidentCtl
 
 // One poll by one (whole) wave: the record's lines go to sh_raw ([n_loads * 64] words); returns 0: nothing yet, 1: command
 // last + 1 is complete in sh_raw, 2: leave.  Workgroup 0 of a relaying launch also keeps the mailbox up to date.
+// LIGHT: the relay orders payload before sector numbers by waiting for the (written-through) payload stores instead of a
+// release fence -- which writes back the whole L2 of the XCD, megabytes of results when the evaluator serves a large alignment
+template <bool LIGHT = false>
 __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const unsigned long long last, const unsigned long long t_last,
                                                   bool &mail_open, unsigned long long *sh_raw, const int n_loads, const int lane,
                                                   const bool decider)
@@ -1525,7 +1523,8 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
                              __HIP_MEMORY_SCOPE_AGENT);
       if (r.relay)
       {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control word) before the sector numbers
+        if (LIGHT) __builtin_amdgcn_s_waitcnt(0); // (the payload stores are atomic at agent scope: acknowledged = visible)
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // payload (and the control word) before the sector numbers
         if (act == 1)
           for (int j = 0; j < n_loads; ++j)
             if ((lane & 3) == 3 && j * 16 + (lane >> 2) != 0)

@@ -69,8 +69,8 @@ template <int C, int G, bool DBG, int ARGS, int DIST = 2, int NW = 1, bool LREC 
 __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__restrict__ irec, const ExecRec *__restrict__ xrec,
                                         const double *pmats, // (not restrict: the prologue may rewrite entries)
                                         const uint8_t *__restrict__ tip_codes, unsigned long long *dbg, const NtFresh fr,
-                                        const unsigned tile, const unsigned tid)
-{ // (tid: threadIdx.x -- handed in, so that a kernel that runs this body inside a loop can keep what derives from it inside too)
+                                        const unsigned tile, const unsigned tid, double *lds_dot)
+{ // lds_dot: this wave's LDS staging area for the eigen products of its tile, (64 / G) * C * 4 doubles (edge_eval == 2) // (tid: threadIdx.x -- handed in, so that a kernel that runs this body inside a loop can keep what derives from it inside too)
   // DBG: cycle stamps of the first 64 steps of one wave (PHYHIP_ABLATE=8), kept in LDS until the end
   __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
   const bool stamper = DBG && tile == gridDim.x / 2 && tid == 0;
@@ -492,8 +492,12 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
     if (q.edge_eval == 2)
     { // K3 behind the partial update it needs (Update_Eigen_Lr, src/lk.c:1038-1114; arithmetic of src/avx.c:79-82 as in
       // eigen_lr_kernel): dot_prod[p][c][k] = (sum_i R[i][k] (x_i pi_i)) (sum_i L[k][i] y_i), first product, then the FMA chains
-      if (p < (unsigned)q.P)
+      // The products go out through LDS: a lane holds the CL x 32 bytes of its (pattern, categories) -- stored directly, every
+      // instruction of the wave touched 32 different 128-byte lines, 16 bytes each (the fused form lost 2 us to eigen_lr_kernel
+      // at small sizes and 4-7 us beyond 4 096 patterns for that).  The tile's PW x C x 32 bytes are one contiguous piece of
+      // dot_prod ([pattern][category][state], padded patterns included): staged, then written 1 KiB per instruction.
       {
+        double2 *stg = reinterpret_cast<double2 *>(lds_dot);
 #pragma unroll
         for (int c = 0; c < CL; ++c)
         {
@@ -513,10 +517,15 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
             }
             d[kq] = a * b;
           }
-          double2 *dst = reinterpret_cast<double2 *>(q.dot_out + ((size_t)p * C + c0 + c) * 4);
-          dst[0] = make_double2(d[0], d[1]);
-          dst[1] = make_double2(d[2], d[3]);
+          stg[(pl * C + c0 + c) * 2] = make_double2(d[0], d[1]);
+          stg[(pl * C + c0 + c) * 2 + 1] = make_double2(d[2], d[3]);
         }
+        __builtin_amdgcn_wave_barrier();
+        double2 *dst = reinterpret_cast<double2 *>(q.dot_out + (size_t)tile * (PW * C * 4));
+        constexpr int NCH = PW * C * 2 / 64; // 16-byte pieces per lane
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) dst[j * 64 + lane] = stg[j * 64 + lane];
+        __builtin_amdgcn_wave_barrier(); // (the next tile of a resident wave stages into the same area)
       }
       // completion as an evaluation's (launched or resident): stores fenced, then an empty record per workgroup
       publish_block_sum(q, 0.0, lane, tile);
@@ -613,7 +622,8 @@ __global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel
   fr.rates = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_rates));
   fr.up_idx = reinterpret_cast<const int *>(ka + offsetof(TreeParams, up_idx));
   fr.up_val = reinterpret_cast<const double *>(ka + offsetof(TreeParams, up_val));
-  nt2_run<C, G, DBG, ARGS, DIST>(q, irec, xrec, pmats, tip_codes, dbg, fr, blockIdx.x, threadIdx.x);
+  __shared__ __attribute__((aligned(16))) double lds_dot[(64 / G) * C * 4];
+  nt2_run<C, G, DBG, ARGS, DIST>(q, irec, xrec, pmats, tip_codes, dbg, fr, blockIdx.x, threadIdx.x, lds_dot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -638,6 +648,7 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
   __shared__ unsigned long long sh_raw[64];
   __shared__ int                sh_idx[4];
   __shared__ double             sh_len[4];
+  __shared__ __attribute__((aligned(16))) double sh_dot[(64 / G) * C * 4];
   const int          lane = threadIdx.x;
   unsigned long long last = r.start_seq, t_last = wall_clock64();
   bool               mail_open = false;
@@ -685,9 +696,9 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     __builtin_amdgcn_wave_barrier();
     NtFresh fr;
     fr.idx = sh_idx; fr.len = sh_len; fr.evec = evec; fr.ivec = ivec; fr.eval = eval; fr.rates = rates;
-    if (n_ops == 1) nt2_run<C, G, false, 1>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x);
-    else if (n_ops == 2) nt2_run<C, G, false, 2>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x);
-    else nt2_run<C, G, false, 3>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x);
+    if (n_ops == 1) nt2_run<C, G, false, 1>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
+    else if (n_ops == 2) nt2_run<C, G, false, 2>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
+    else nt2_run<C, G, false, 3>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
     last = last + 1; t_last = wall_clock64();
   }
 }

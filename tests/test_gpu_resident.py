@@ -37,7 +37,8 @@ def _chain(t, ot, edges, pause=0.0):
 
 @pytest.mark.parametrize("patterns", [60, 382, 1500, 4000])
 def test_resident_evaluator_matches_the_launch_path_and_the_oracle(patterns, monkeypatch):
-    """382 patterns: every workgroup polls the host; 1500 / 4000: workgroup 0 relays the commands through device memory."""
+    """382 patterns: every workgroup polls the host; 1500: workgroup 0 relays the commands through device memory; 4000: the
+    large-grid evaluator."""
     vals = {}
     for res in ("0", "1"):
         monkeypatch.setenv("PHYHIP_RESIDENT", res)
@@ -47,9 +48,10 @@ def test_resident_evaluator_matches_the_launch_path_and_the_oracle(patterns, mon
             t.Lk(None)
             ot.lk(None, both_sides=True)
             dev, ref = _chain(t, ot, [3, 11, 20, 3])
-            served, launches, silent, busy = t.inst.resident_stats()
+            # (4000 patterns = 125 tiles: beyond the small evaluators' 64 -- served by the large-grid one, phyhip_big.hpp)
+            served, launches, silent, busy = t.inst.resident_stats(0 if patterns <= 2000 else 2)
             if res == "1":
-                assert served >= 4 * 7 - 4 and silent == 0, (served, launches, silent, busy)
+                assert served >= 4 * 7 - (4 if patterns <= 2000 else 8) and silent == 0, (served, launches, silent, busy)
                 assert launches <= 5  # (the oracle runs between the chains: the workgroups may have left meanwhile)
                 if patterns <= 1500:
                     # the chain's Lk(b) and its Update_Eigen_Lr (partial update + eigen products: ONE command) are served by
@@ -183,3 +185,123 @@ def test_resident_protocol_under_stress(monkeypatch):
     a, a2 = res[("0", "1000")]
     for k, (b, b2) in res.items():
         assert np.array_equal(a, b) and np.array_equal(a2, b2), k
+
+
+# ---- the large-grid resident evaluator (phyml_amd/csrc/phyhip_big.hpp) ----------------------------------------------------
+
+@pytest.mark.parametrize("taxa,patterns,categories", [(16, 5000, 4), (12, 40000, 4), (12, 9000, 2), (12, 7000, 3), (12, 6000, 1),
+                                                      (8, 110000, 4)])
+def test_large_grid_resident_evaluator_spr_and_brlen_call_pattern(taxa, patterns, categories, monkeypatch):
+    """Beyond 64 pattern tiles the scalar-returning calls of a search are served by resident_big_kernel -- one persistent
+    workgroup per compute unit, commands relayed through device memory, a wave walks several tiles, the tile sums added on the
+    device (more than 1 024 tiles) or by the host: the seeded SPR / Br_Len_Opt stream returns the launch path's doubles, scalar
+    by scalar, and the oracle's values.  Covers every instantiation: two lanes per pattern (4 and 2 categories, eight waves per
+    workgroup), one lane per pattern (3 and 1 categories; 4 categories beyond 102 400 patterns)."""
+    from phyml_amd import replay
+    import replay_oracle
+    res, stats = {}, {}
+    ncand = 60 if patterns <= 40000 else 24
+    for r in ("0", "1"):
+        monkeypatch.setenv("PHYHIP_RESIDENT", r)
+        t, ot, tree, st = synthetic_pair(taxa, patterns, 4, categories, seed=67, host_pmat=False, ambiguous_every=13)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            tr = replay.make_trace(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, ncand, seed=9, walk_every=3, opt_every=4, n_dlk=4)
+            res[r] = t.Replay_Surface_Trace(tr)
+            again = t.Lk(None)  # a long traversal launch after the resident phase: the workgroups make room
+            res[r] = (res[r][0], res[r][1], again)
+            stats[r] = t.inst.resident_stats(2)
+            assert t.inst.numerical_warning() == 0
+            if r == "1":
+                full = ot.lk(None, both_sides=True)
+                ref, ref2 = replay_oracle.OracleReplayer(ot).run(tr)
+                m = ref != 0
+                assert np.max(np.abs(res[r][0][m] - ref[m]) / np.abs(ref[m])) < 1e-9  # (device exp in the matrices)
+                dl = tr["kind"] == replay.DLK
+                assert np.max(np.abs(res[r][1][dl] - ref2[dl]) / np.maximum(1.0, np.abs(ref2[dl]))) < 1e-7
+                assert abs(again - full) / abs(full) < 1e-11
+        finally:
+            t.close()
+    assert np.array_equal(res["0"][0], res["1"][0]) and np.array_equal(res["0"][1], res["1"][1]) and res["0"][2] == res["1"][2]
+    assert stats["0"] == (0, 0, 0, 0)
+    served, launches, silent, busy = stats["1"]
+    n_scalar = int(np.isin(tr["kind"], (replay.EDGE_LNL, replay.DLK, replay.EIGEN_LR)).sum())
+    assert served >= n_scalar - 8 and silent == 0 and launches <= 3, (stats["1"], n_scalar)
+
+
+def test_large_grid_resident_evaluator_brlen_chains_weights_and_invariant_sites(monkeypatch):
+    """Br_Len_Opt's chains (Lk(b) with Update_Eigen_Lr, dLk at several lengths, Lk(b) in the eigen basis) on 20 000 weighted
+    patterns with the invariant-site model: resident against launched (the same doubles) against the oracle."""
+    vals = {}
+    rng = np.random.default_rng(5)
+    P = 20000
+    wght = rng.integers(0, 4, P).astype(np.float64)
+    for res in ("0", "1"):
+        monkeypatch.setenv("PHYHIP_RESIDENT", res)
+        t, ot, *_ = synthetic_pair(14, P, 4, 4, seed=29, ambiguous_every=17, wght=wght)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            ot.lk(None, both_sides=True)
+            dev, ref = _chain(t, ot, [3, 11, 20, 3, 7])
+            for a, b in zip(dev, ref):
+                assert abs(a - b) <= 1e-11 * max(1.0, abs(b)), (a, b)
+            if res == "1":
+                served, launches, silent, busy = t.inst.resident_stats(2)
+                assert served >= 5 * 7 - 6 and silent == 0, (served, launches, silent, busy)
+            vals[res] = dev
+        finally:
+            t.close()
+    assert vals["0"] == vals["1"]
+
+
+def test_large_grid_resident_workgroups_leave_and_come_back(monkeypatch):
+    """Idle time below the time between commands: the workgroups leave all the time, commands meet nobody (detected,
+    launched instead), long launches in between -- every scalar still the launch path's."""
+    from phyml_amd import replay
+    res = {}
+    for r, idle in (("0", "1000"), ("1", "5"), ("1", "40")):
+        monkeypatch.setenv("PHYHIP_RESIDENT", r)
+        monkeypatch.setenv("PHYHIP_RESIDENT_IDLE_US", idle)
+        t, ot, tree, st = synthetic_pair(20, 12000, 4, 4, seed=73, host_pmat=False)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            out = []
+            for rep in range(3):
+                tr = replay.make_trace(20, tree.edge_left, tree.edge_rght, tree.edge_len, 50, seed=12 + rep, walk_every=3, opt_every=3, n_dlk=3)
+                out.append(t.Replay_Surface_Trace(tr))
+                out.append((t.Lk(None),))
+            res[(r, idle)] = out
+            if r == "1":
+                s = t.inst.resident_stats(2)
+                assert s[0] + s[2] > 0 and s[1] >= 3, s
+        finally:
+            t.close()
+    a = res[("0", "1000")]
+    for k, b in res.items():
+        for x, y in zip(a, b):
+            assert all(np.array_equal(u, v) for u, v in zip(x, y)), k
+
+
+def test_two_large_instances_share_one_device(monkeypatch):
+    """Only one instance per device holds large-grid resident workgroups; the other one's evaluations are launched -- both
+    return the oracle's values, whichever gets them."""
+    from phyml_amd import replay
+    import replay_oracle
+    pairs = [synthetic_pair(10, 6000 + 3000 * k, 4, 4, seed=50 + k, host_pmat=False) for k in range(2)]
+    try:
+        for t, ot, tree, st in pairs:
+            t.Set_Both_Sides(True); t.Lk(None); ot.lk(None, both_sides=True)
+        for rep in range(2):
+            for t, ot, tree, st in pairs:
+                tr = replay.make_trace(10, tree.edge_left, tree.edge_rght, tree.edge_len, 20, seed=3 + rep, walk_every=3, opt_every=4, n_dlk=3)
+                got, got2 = t.Replay_Surface_Trace(tr)
+                ref, ref2 = replay_oracle.OracleReplayer(ot).run(tr)
+                m = ref != 0
+                assert np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m])) < 1e-9
+        assert sum(t.inst.resident_stats(2)[0] for t, *_ in pairs) > 0
+    finally:
+        for t, *_ in pairs:
+            t.close()
