@@ -265,7 +265,8 @@ def call_latency():
         rows[name] = {"us_per_candidate": dt / cand * 1e6, "us_per_scalar_returning_call": dt / n_scalar * 1e6, "candidates": cand,
                       "scalar_returning_calls": n_scalar, "dlk_calls": int((k == replay.DLK).sum()), "surface_calls": int(len(k)),
                       "finite": bool(np.isfinite(res).all()),
-                      "served_by_resident_workgroups": {"dlk": t.inst.resident_stats(0)[0], "short_evaluations": t.inst.resident_stats(1)[0]}}
+                      "served_by_resident_workgroups": {"dlk": t.inst.resident_stats(0)[0], "short_evaluations": t.inst.resident_stats(1)[0],
+                                                        "large_grid": t.inst.resident_stats(2)[0]}}
         t.close()
     rows["brlen_500x100k"] = brlen
     return rows
@@ -281,16 +282,30 @@ def brlen_block(t, taxa, P, S, C):
     t.Set_Update_Eigen_Lr(0); t.Set_Use_Eigen_Lr(1)
     for i in range(3):
         t.dLk(0.05, e)
+    # kernel times of K3 / K4 (HIP events around each launch: profiling an instance makes every call a launch) ...
     t.inst.profile(1)
     n_chain, n_dlk = 40, 5
+    for k in range(8):
+        t.Set_Update_Eigen_Lr(1); t.Update_Eigen_Lr(e); t.Set_Update_Eigen_Lr(0)
+        for i in range(n_dlk):
+            t.dLk(0.05 + 1e-3 * i + 1e-5 * k, e)
+    (k3_ms, k3_n), (k4_ms, k4_n) = t.inst.profile_read_eigen()
+    t.inst.profile(0)
+    # ... and the wall time of Br_Len_Opt's chain as a caller sees it (resident workgroups where the engine uses them)
+    for k in range(4):
+        t.Set_Update_Eigen_Lr(1); t.Update_Eigen_Lr(e); t.Set_Update_Eigen_Lr(0)
+        for i in range(n_dlk):
+            t.dLk(0.05 + 1e-3 * i, e)
     t0 = time.perf_counter()
     for k in range(n_chain):
         t.Set_Update_Eigen_Lr(1); t.Update_Eigen_Lr(e); t.Set_Update_Eigen_Lr(0)
         for i in range(n_dlk):
             t.dLk(0.05 + 1e-3 * i + 1e-5 * k, e)
     wall = time.perf_counter() - t0
-    (k3_ms, k3_n), (k4_ms, k4_n) = t.inst.profile_read_eigen()
-    t.inst.profile(0)
+    t0 = time.perf_counter()
+    for i in range(200):
+        t.dLk(0.05 + 1e-4 * i, e)
+    dlk_wall = (time.perf_counter() - t0) / 200 * 1e6
     t.Set_Use_Eigen_Lr(0)
     vec = float(P) * C * S * 8.0
     k3_bytes, k4_bytes = 3.0 * vec + 2.0 * 4.0 * P, vec + 8.0 * P + 4.0 * P
@@ -300,7 +315,8 @@ def brlen_block(t, taxa, P, S, C):
                                 "frac_of_8TBps": k3_bytes / (k3_us * 1e-6) / 8e12 if k3_us else 0.0},
             "dlk_kernel": {"launches": k4_n, "avg_us": k4_us, "bytes": k4_bytes, "GBps": k4_bytes / (k4_us * 1e-6) / 1e9 if k4_us else 0.0,
                            "frac_of_8TBps": k4_bytes / (k4_us * 1e-6) / 8e12 if k4_us else 0.0},
-            "us_per_chain_of_1_eigen_lr_and_5_dlk": wall / n_chain * 1e6}
+            "us_per_chain_of_1_eigen_lr_and_5_dlk": wall / n_chain * 1e6, "us_per_dlk_call": dlk_wall,
+            "served_by_large_grid_resident_workgroups": t.inst.resident_stats(2)[0]}
 
 
 def extra_line(name, args, torch):

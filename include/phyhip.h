@@ -120,8 +120,11 @@ int phyhip_set_tip_partials(int instance, int tipIndex, const double *inPartials
 int phyhip_set_tip_states(int instance, int tipIndex, const int *inStates);
 /* One pattern of one tip rewritten in place: inPartials[stateCount] of 0.0 / 1.0, as a row of phyhip_set_tip_partials.
    Init_Partial_Lk_Tips_Double_One_Character (src/lk.c:2092), the tip rewrite of the leave-one-out cross-validation loops
-   (src/mixt.c:4225-4258, src/cv.c:51-118).  Takes effect in stream order; partial vectors that depend on the tip are the
-   caller's to update, as in the reference. */
+   (src/mixt.c:4225-4258, src/cv.c:51-118).  Takes effect in stream order, without a host synchronisation for the single states and
+   for "every state" (the hidden character of the leave-one-out loop: its table entry exists from instance creation); on
+   20-state instances the FIRST use of any other state set adds an entry to the device's table of state sets, which costs one
+   stream synchronisation.  A row with no state allowed is rejected (PHYHIP_ERROR_OUT_OF_RANGE).  Partial vectors that depend
+   on the tip are the caller's to update, as in the reference. */
 int phyhip_set_tip_partials_at_pattern(int instance, int tipIndex, int pattern, const double *inPartials);
 
 /* replaces beagleSetPartials: upload an internal partials buffer ([pattern][category][state]). */

@@ -127,7 +127,7 @@ static void die(const char *what)
 /* one device instance per tree object that reaches the surface: the tree of an ordinary run, or every class tree of a
    mixture (src/mixt.c:2603-2640); pointer -> device index tables per instance */
 #define MAXID 2048
-#define MAXCTX 32
+#define MAXCTX (kMaxClasses + 32) /* one context per class tree: a 64-class profile mixture and then some */
 typedef struct
 {
   t_tree     *tree;

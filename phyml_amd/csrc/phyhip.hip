@@ -494,7 +494,11 @@ int flush_pmats(Instance *I)
     // (20 states: a short list is latency -- 1024 threads, two entries each, products pre-formed: 7.9 vs 11.5 us for three
     // matrices; a whole tree's 397 matrices: 512 threads without the extra phase 14.7 us; 256 / 1024 threads 16.3-17.4 / 15.5)
     int threads = (I->S == 4) ? 64 : (n <= 16 ? 1024 : 512);
-    if (const char *e = diag_env("PHYHIP_PMAT_THREADS")) threads = atoi(e);
+    if (const char *e = diag_env("PHYHIP_PMAT_THREADS"))
+    { // (a multiple of 64 within the kernel's launch bounds, or ignored)
+      const int v = atoi(e);
+      if (v >= 64 && v % 64 == 0 && v <= (I->S == 4 ? 64 : 1024)) threads = v;
+    }
     q.afrag = I->perm ? I->d_afrag : nullptr; // 20 states: the MFMA A-operand fragments come out of the same kernel
     q.class_axis = I->class_axis ? 1 : 0;
     const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)2 * I->C * I->S * I->S + (size_t)2 * I->NE * I->S * I->S);
@@ -564,7 +568,10 @@ static void resident_free(Resident &R)
 // First half of a (re)launch: generation gen + 1 supersedes whatever is left of the previous one (its workgroups see the
 // new number at their next poll and leave); commands up to `served` count as done.  The caller launches its kernel with `r`
 // on `*st`, then calls resident_launched().
-static int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned long long served, ResidentCtl &r, hipStream_t *st)
+// in_order: every generation on the SAME stream -- the large-grid workgroups leave what they stored to the end of their
+// kernel (no write-back per command), so a new generation must not start before the previous one has ended.
+static int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned long long served, ResidentCtl &r, hipStream_t *st,
+                            bool in_order = false)
 {
   if (!R.cmd)
   {
@@ -587,7 +594,7 @@ static int resident_prepare(Instance *I, Resident &R, int grid, int n_words, uns
     I->wall_khz = khz;
   }
   r.idle_ticks = (unsigned long long)(I->resident_idle_us * 1e-3 * (double)I->wall_khz); // wall_clock64 ticks
-  *st = R.stream[R.gen & 1];
+  *st = R.stream[in_order ? 0 : (R.gen & 1)];
   return 0;
 }
 static void resident_launched(Resident &R, int grid)
@@ -670,7 +677,7 @@ static void big_release(Instance *I, bool restart_streak)
   Resident &R = I->rb;
   if (R.cmd && R.launched)
   {
-    hipStream_t st = R.stream[R.gen & 1]; // (where this generation runs)
+    hipStream_t st = R.stream[0]; // (where every generation of these workgroups runs, resident_prepare)
     ++R.gen;
     __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
     R.launched = false;
@@ -755,8 +762,11 @@ static int big_launch(Instance *I, const TreeParams &sq)
   if (!g_big_owner[I->dev].compare_exchange_strong(none, I) && none != I) return 1; // (somebody else's: launch the evaluation)
   ResidentCtl r;
   hipStream_t st;
-  int rc = resident_prepare(I, R, I->big_wgs, kBigWords, R.seq, r, &st);
+  int rc = resident_prepare(I, R, I->big_wgs, kBigWords, R.seq, r, &st, true);
   if (rc) return rc;
+  // (a generation that left in the middle of a command -- workgroups that started late find "leave" in the mailbox before they
+  // find the command -- leaves tickets drawn and never reset: every generation starts from zero, in stream order)
+  HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), st));
   BigArgs a;
   a.t = sq; a.r = r;
   a.b.n_tiles = I->grid_nt2; a.b.n_vdlk = I->n_vdlk; a.b.tile_sums = I->d_tile_sums; a.b.tickets = I->d_big_tickets; a.b.dot_prod = I->d_dot;
@@ -821,6 +831,15 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   const bool big_fit = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
                        (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && big_eligible(I) && !I->prof && !I->rt_skip;
   const bool big_try = big_fit && big_ready(I);
+  // ... and they are there (or launched now): decided before the records are built -- a resident command of two operations runs
+  // them one after the other per tile, without register forwarding between them (phyhip_big.hpp)
+  bool big_take = false;
+  if (big_try)
+  {
+    const int brc = big_ensure(I);
+    if (brc < 0) return brc;
+    big_take = brc == 0;
+  }
   if (kDiag && ee && getenv("PHYHIP_RESIDENT_DEBUG") && big_shape(I))
     fprintf(stderr, "big: fit %d try %d | eligible %d ops %d pm %zu up %zu prof %d skip %d | dirty_prev %d touched %d clean_after %llu stamp %llu streak %d launched %d owner %p me %p\n",
             (int)big_fit, (int)big_try, (int)big_eligible(I), n_ops, I->pm_idx.size(), I->up_idx.size(), (int)I->prof, (int)I->rt_skip, (int)I->dirty_prev,
@@ -940,7 +959,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       for (int k = 0; k < n_rec; ++k)
       {
         const DevOp &o  = at(k);
-        const int    e1 = k >= 1 ? at(k - 1).dest : -1;
+        const int    e1 = (k >= 1 && !big_take) ? at(k - 1).dest : -1;
         const int    e2 = (k >= 2 && I->prefetch_dist == 2) ? at(k - 2).dest : -1;
         unsigned     fl = 0;
         auto child = [&](int c, unsigned tipbit, unsigned f1bit, unsigned f2bit, Desc &data, Desc &scale, Desc &tip,
@@ -1156,11 +1175,10 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // ---- large nucleotide alignments: the large-grid resident evaluator (resident_big_kernel) -------------------------------
   // (launches of such an instance do not fence their stores before they post -- with megabytes of results in the L2s a
   // write-back per wave costs more than the launch; whether the stream is idle again is found by querying it, big_clean)
-  if (big_try && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0)
+  if (big_take)
   {
-    const int brc = big_ensure(I);
-    if (brc < 0) return brc;
-    if (brc == 0)
+    if (!(host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0))
+      return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: an evaluation it cannot take (%d records, %d matrices)", host_sum_n, q.n_fresh);
     {
       Resident &R = I->rb;
       unsigned long long words[kBigWords];
@@ -1861,8 +1879,10 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   // budget (two waves per SIMD with two lanes per pattern, one otherwise); dLk in up to 2 048 one-wave virtual blocks
   I->cus     = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   I->n_vdlk  = I->grid_nt2; // (a dLk tile = the patterns of a traversal tile: dlk_tile)
-  I->big_nw  = I->nt_groups == 2 ? 8 : 4;
-  I->big_wgs = std::max(1, std::min(I->cus, (I->grid_nt2 + I->big_nw - 1) / I->big_nw));
+  I->big_nw  = std::max(1, big_waves_per_workgroup(I->C, I->nt_groups));
+  // (as many workgroups as there are tiles, up to one per CU: the tiles spread over the CUs first -- wave w of workgroup b takes
+  // tile w * workgroups + b -- and fill a CU's wave slots only then)
+  I->big_wgs = std::max(1, std::min(I->cus, I->grid_nt2));
   if (const char *e = diag_env("PHYHIP_BIG_DEVICE_SUM")) I->big_device_sum = atoi(e);
   // The pipelined nucleotide kernel is instruction-issue bound per CU, so CU-level balance matters more than
   // workgroup size: one-wave workgroups let the dispatcher spread e.g. 3125 waves as 12-13 per CU instead of
@@ -1944,6 +1964,13 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     I->masks.push_back(1u << s);
     I->mask_code[1u << s] = s;
   }
+  if (I->S > 8)
+  { // ... and "every state" (a gap, a hidden character of the leave-one-out loop, phyhip_set_tip_partials_at_pattern): present
+    // from the start, so that the first one costs no upload of the table (a synchronisation of the stream)
+    const uint32_t all = (1u << I->S) - 1u;
+    I->mask_code[all] = (int)I->masks.size();
+    I->masks.push_back(all);
+  }
   I->masks_dirty = true;
 
   return 0;
@@ -2002,6 +2029,9 @@ static int set_tip_codes(Instance *I, int tip, const std::vector<uint8_t> &codes
 
 static int code_for_mask(Instance *I, uint32_t m, int *code)
 {
+  // (no state allowed: the reference builds no such tip vector, src/lk.c:26-161, and the fragment-major 20-state kernel reads a
+  // zero mask word as padding)
+  if (m == 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "a tip vector with no state allowed (all zeros)");
   auto it = I->mask_code.find(m);
   if (it != I->mask_code.end())
   {
@@ -2413,7 +2443,9 @@ static int flush_and_wait(Instance *I, EdgeEval &ee, bool flushed = false)
   if (I->fenced_eval)
   { // every store of this evaluation -- and so everything queued before it -- is in memory
     I->fenced_eval = false; I->stream_dirty = false; I->clean_after = 0;
-    if (!by_resident || ee.eigen) ++I->clean_epoch; // (a kernel ran / dot_prod rewritten: the resident workgroups re-read)
+    // (a kernel ran, or the small evaluators' dot_prod was rewritten by another set of workgroups: they re-read.  Not the
+    // large-grid evaluator's: the wave that evaluates a tile's dLk is the one that wrote its products, phyhip_big.hpp)
+    if (!by_resident || (ee.eigen && by != &I->rb)) ++I->clean_epoch;
   }
   return 0;
 }
@@ -3073,7 +3105,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       unsigned long long words[kBigWords];
       memset(words, 0, sizeof words);
       const int  n_expl = I->C * (deriv ? 2 : 1) * I->S;
-      const bool changed = I->rb_dlk_api + 1 != I->api_no || I->clean_epoch != I->rt_epoch; // anything since the last dLk command
+      const bool changed = I->clean_epoch != I->rt_epoch; // kernels ran on the stream since the last command
       const bool dsum = dgrid > I->big_device_sum;
       words[0] = q.fin.host_tag;
       words[1] = kBigDlk | (q.with_derivative ? kBigDeriv : 0ull) | (q.invar_model ? kBigInvar : 0ull) | (q.apply_scaling ? kBigScaling : 0ull) |
@@ -3091,11 +3123,14 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
         return PHYHIP_SUCCESS;
       }
       if (rc != kResidentSilent) return rc;
-      // nobody there: make sure of it, then the ordinary launch below repeats the evaluation under the same tag
+      // nobody there: make sure of it, then the ordinary launch below repeats the evaluation -- under a NEW tag: workgroups
+      // that had started on the command may have posted the (single) record of a device-side final sum under the old one,
+      // where the launched form's first tile record goes
       ++R.n_silent;
       resident_stop(R);
       big_release(I);
       I->r_inflight = nullptr; I->host_sum_n = 0;
+      q.fin.host_tag = ++I->seq;
     }
   }
   else if (big && big_eligible(I)) { ++I->rb.n_busy; I->big_streak = 0; }
@@ -3164,6 +3199,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     const unsigned long long h1 = hp_now();
+    // (the last-workgroup sum instead of 2 x 3 126 records was measured for this launch: 37 against 28-33 us per call -- a ticket
+    // per one-wave workgroup is thousands of atomics at the memory side)
     if (big) { if constexpr (S_ == 4 && CP_ <= 4) launch_dlk64<CP_>(I, q, dgrid); }
     else hipLaunchKernelGGL((dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, I->stream, q);
     if (kDiag) { g_hp.launch += hp_now() - h1; ++g_hp.n_launch; }

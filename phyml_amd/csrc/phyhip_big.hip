@@ -11,19 +11,35 @@ namespace phyhip
 
 // Launch the resident workgroups of an instance with C categories in G lanes per pattern; returns 0, or -1 when there is no
 // kernel for that shape.
+int big_waves_per_workgroup(int C, int G)
+{
+  switch (C * 8 + G)
+  {
+    case 1 * 8 + 1: return 16;
+    case 2 * 8 + 1: return 12;
+    case 2 * 8 + 2: return 16;
+    case 3 * 8 + 1: return 8;
+    case 4 * 8 + 1: return 8;
+    case 4 * 8 + 2: return 12;
+    default: return 0;
+  }
+}
+
 int launch_resident_big(int C, int G, int workgroups, hipStream_t stream, const BigArgs &a)
 {
 #define BIGRES(c_, g_, nw_)                                                                                                 \
   hipLaunchKernelGGL((resident_big_kernel<c_, g_, nw_>), dim3(workgroups), dim3(64 * nw_), 0, stream, a);                     \
   return 0;
+  // waves per workgroup (one workgroup per CU): what the kernel's registers allow -- 158 / 112 (4 / 2 categories in two lanes
+  // per pattern), 252 / 204 / 156 / 106 (4 / 3 / 2 / 1 categories, one lane per pattern); tools/kres.py on the listing
   switch (C * 8 + G)
   {
-    case 1 * 8 + 1: BIGRES(1, 1, 4)
-    case 2 * 8 + 1: BIGRES(2, 1, 4)
-    case 2 * 8 + 2: BIGRES(2, 2, 8)
-    case 3 * 8 + 1: BIGRES(3, 1, 4)
-    case 4 * 8 + 1: BIGRES(4, 1, 4)
-    case 4 * 8 + 2: BIGRES(4, 2, 8)
+    case 1 * 8 + 1: BIGRES(1, 1, 16)
+    case 2 * 8 + 1: BIGRES(2, 1, 12)
+    case 2 * 8 + 2: BIGRES(2, 2, 16)
+    case 3 * 8 + 1: BIGRES(3, 1, 8)
+    case 4 * 8 + 1: BIGRES(4, 1, 8)
+    case 4 * 8 + 2: BIGRES(4, 2, 12)
     default: return -1;
   }
 #undef BIGRES

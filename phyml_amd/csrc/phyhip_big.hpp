@@ -74,8 +74,26 @@ template <typename T> __device__ __forceinline__ void karg_copy(T &dst, const __
   __builtin_memcpy(&dst, tmp, sizeof(T));
 }
 
+// A pointer that came out of the re-read argument segment is, to the compiler, a pointer to anywhere (flat loads and stores,
+// which count against the LDS counter too and wait for each other); those of a launched kernel's own arguments are known to
+// be global.  Rebuilt as global pointers from their bits, they say the same.
+template <typename T> __device__ __forceinline__ T *as_global(T *p)
+{ // (through an integer: a pointer-to-pointer round trip between the address spaces is folded away before it can tell)
+  const unsigned long long v = (unsigned long long)p;
+  return (T *)(__attribute__((address_space(1))) T *)v;
+}
+__device__ __forceinline__ void globalize(TreeParams &q)
+{
+  q.partials = as_global(q.partials); q.scales = as_global(q.scales); q.wght = as_global(q.wght); q.pi = as_global(q.pi);
+  q.cat_w = as_global(q.cat_w); q.invar = as_global(q.invar); q.site_lnl = as_global(q.site_lnl); q.site_lk = as_global(q.site_lk);
+  q.site_cat = as_global(q.site_cat); q.fact = as_global(q.fact); q.dot_out = as_global(q.dot_out); q.warn = as_global(q.warn);
+  q.pmats_rw = as_global(q.pmats_rw); q.host_blocks = as_global(q.host_blocks); q.tile_sums = as_global(q.tile_sums);
+  q.block_sums = as_global(q.block_sums); q.tickets = as_global(q.tickets); q.result = as_global(q.result);
+  q.result_host = as_global(q.result_host); q.warn_host = as_global(q.warn_host); q.warn_out = as_global(q.warn_out);
+}
+
 template <int C, int G, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const BigArgs args_)
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(const BigArgs args_)
 {
   constexpr int                 CP = C == 3 ? 4 : C;
   __shared__ unsigned long long sh_raw[64];
@@ -117,6 +135,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
     {
       ResidentCtl r;
       karg_copy(r, &A->r);
+      r.cmd = as_global(r.cmd); r.mail = as_global(r.mail);
       int               act;
       for (;;)
       {
@@ -164,6 +183,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
     const bool               dsum = (fl & kBigDeviceSum) != 0;
     BigCtl b;
     karg_copy(b, &A->b);
+    b.tile_sums = as_global(b.tile_sums); b.tickets = as_global(b.tickets); b.dot_prod = as_global(b.dot_prod); b.stamps = as_global(b.stamps);
+    HostBlock *const host_blocks = as_global(A->t.host_blocks);
     auto stamp = [&](int i, unsigned long long t) {
       if (b.stamps && tid == 0) b.stamps[(size_t)bid * 8 + i] = t;
     };
@@ -176,7 +197,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
     if (fl & kBigDlk)
     { // ---- dLk / Lk in the eigen basis: dlk64_kernel's virtual blocks ----
       DlkParams dq;
-      dq.dot_prod = b.dot_prod; dq.wght = A->t.wght; dq.fact = A->t.fact; dq.cat_w = A->t.cat_w; dq.pi = A->t.pi; dq.invar = A->t.invar;
+      dq.dot_prod = b.dot_prod; dq.wght = as_global(A->t.wght); dq.fact = as_global(A->t.fact); dq.cat_w = as_global(A->t.cat_w);
+      dq.pi = as_global(A->t.pi); dq.invar = as_global(A->t.invar);
       dq.P = A->t.P; dq.C = C;
       double pinvar;
       {
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
       for (int vb = gw; vb < n_rec; vb += TW)
       {
         double v[2];
-        dlk_tile<4, CP, IT>(dq, k, sh_expl, A->t.warn, (unsigned)vb, lane, v);
+        dlk_tile<4, CP, IT>(dq, k, sh_expl, as_global(A->t.warn), (unsigned)vb, lane, v);
         if (lane == 0)
         {
           if (dsum)
@@ -204,39 +226,62 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
           }
           else
           {
-            post_host_block(A->t.host_blocks + vb, v[0], tag);
-            post_host_block(A->t.host_blocks + (size_t)n_rec + vb, v[1], tag);
+            post_host_block(host_blocks + vb, v[0], tag);
+            post_host_block(host_blocks + (size_t)n_rec + vb, v[1], tag);
           }
         }
       }
     }
     else
     { // ---- 0-2 partial updates + the edge evaluation (or the eigen products): traverse_nt2_kernel's tiles ----
-      const unsigned long long ed = word(2), pm = word(3);
-      TreeParams               q;
-      karg_copy(q, &A->t);
-      q.host_tag = tag;
-      q.n_fresh = (int)((fl >> 4) & 15); q.e_prefetch = (int)((fl >> 8) & 3);
-      q.edge_eval = (fl & kBigEigen) ? 2 : 1; q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
-      q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
-      q.tile_sums = dsum ? b.tile_sums : nullptr;
-      const int n_ops = (int)(fl & 3);
-      NtFresh fr;
-      // (the eigen system rides in the launch's TreeParams, as in a launched kernel: scalar loads from the argument segment;
-      // a model change makes the host launch a new generation)
-      const char *kt = (const char *)ka + offsetof(BigArgs, t);
-      fr.idx = sh_idx; fr.len = sh_len;
-      fr.evec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_evec));
-      fr.ivec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_ivec));
-      fr.eval = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_eval));
-      fr.rates = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_rates));
       n_rec = b.n_tiles; ns = 1;
-      for (int tile = gw; tile < n_rec; tile += TW)
+      // A command of two operations runs as two passes of the one-operation body per tile -- the first operation alone, then
+      // the second with the evaluation; the host built its records without forwarding between the two, the second pass reads
+      // what the first stored (same wave, program order) -- so that the kernel needs the registers of the one-operation form
+      // only: three waves per SIMD instead of two at four categories in two lanes (158 against 206 registers), i.e. 3 072
+      // resident waves: one round of tiles for alignments of up to 98 304 patterns instead of 65 536.
+      const int n_tiles = n_rec, passes = ((int)(fl & 3) == 2) ? 2 : 1;
+      bool      first = true;
+      for (int it = 0, tile = gw; tile < n_tiles; ++it, tile = gw + (it / passes) * TW)
       {
-        if (n_ops == 1) nt2_run<C, G, false, 1, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid, sh_dot[wid]);
-        else if (n_ops == 2) nt2_run<C, G, false, 2, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid, sh_dot[wid]);
-        else nt2_run<C, G, false, 3, 2, NW, true>(q, sh_ir, sh_xr, A->pmats, A->tip_codes, nullptr, fr, (unsigned)tile, tid, sh_dot[wid]);
-        q.n_fresh = 0; // (this wave has rebuilt the command's matrices with its first tile)
+        const int pass = it % passes;
+        // (per tile what the outer loop does per command: nothing tile-invariant -- the launch's TreeParams, the command's
+        // fields, every lane predicate and address -- may be computed in front of THIS loop and kept either: 50 vector and
+        // 100 scalar registers, measured on the listing)
+        unsigned long long kaddr2 = kaddr;
+        unsigned           tid2 = tid;
+        asm volatile("" : "+s"(kaddr2), "+v"(tid2));
+        kaddr2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(kaddr2 >> 32)) << 32) |
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kaddr2);
+        karg_char *ka2 = (karg_char *)kaddr2;
+        karg_args *A2 = reinterpret_cast<karg_args *>(ka2);
+        const unsigned long long fl2 = word(1), ed = word(2), pm = word(3);
+        TreeParams               q;
+        karg_copy(q, &A2->t);
+        q.host_tag = word(0);
+        q.n_fresh = first ? (int)((fl2 >> 4) & 15) : 0; // (a wave rebuilds the command's matrices with its first tile)
+        const bool mid = passes == 2 && pass == 0;      // the first of two operations: no evaluation behind it
+        q.e_prefetch = mid ? 0 : (int)((fl2 >> 8) & 3);
+        q.edge_eval = mid ? 0 : ((fl2 & kBigEigen) ? 2 : 1); q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
+        q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
+        q.tile_sums = (fl2 & kBigDeviceSum) ? A2->b.tile_sums : nullptr;
+        globalize(q);
+        const int n_ops = (int)(fl2 & 3);
+        NtFresh   fr;
+        // (the eigen system rides in the launch's TreeParams, as in a launched kernel: scalar loads from the argument segment;
+        // a model change makes the host launch a new generation)
+        const char *kt = (const char *)ka2 + offsetof(BigArgs, t);
+        fr.idx = sh_idx; fr.len = sh_len;
+        fr.evec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_evec));
+        fr.ivec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_ivec));
+        fr.eval = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_eval));
+        fr.rates = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_rates));
+        double *const my_dot = sh_dot[tid2 >> 6];
+        const double  *pmats = as_global(A2->pmats);
+        const uint8_t *tip_codes = as_global(A2->tip_codes);
+        if (n_ops != 0) nt2_run<C, G, false, 1, 2, NW, true>(q, sh_ir + pass, sh_xr + pass, pmats, tip_codes, nullptr, fr, (unsigned)tile, tid2, my_dot);
+        else nt2_run<C, G, false, 3, 2, NW, true>(q, sh_ir, sh_xr, pmats, tip_codes, nullptr, fr, (unsigned)tile, tid2, my_dot);
+        first = false;
       }
     }
     stamp(2, wall_clock64());
@@ -304,8 +349,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
           __builtin_amdgcn_s_waitcnt(0);
           if (lane == 0)
           {
-            post_host_block(A->t.host_blocks, t0, tag);
-            if (ns == 2) post_host_block(A->t.host_blocks + 1, t1, tag);
+            post_host_block(host_blocks, t0, tag);
+            if (ns == 2) post_host_block(host_blocks + 1, t1, tag);
             stamp(5, wall_clock64());
           }
         }
@@ -319,5 +364,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void resident_big_kernel(const Big
 
 // (defined in phyhip_big.hip, the only translation unit that instantiates the kernel)
 int launch_resident_big(int C, int G, int workgroups, hipStream_t stream, const BigArgs &a);
+int big_waves_per_workgroup(int C, int G); // (0: no kernel for that shape)
 
 } // namespace phyhip

@@ -411,9 +411,10 @@ template <int NS> __device__ __forceinline__ void finish_sums(const FinishParams
   ticket = __shfl(ticket, 0, 64);
   if (!ticket) return;
   const int n = (int)gridDim.x;
-  // every block sum was written through to memory before its ticket was drawn; drop whatever stale copies this
-  // CU's L1 / this XCD's L2 may hold, then read them with ordinary (pipelined) loads
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // every block sum was written through to memory before its ticket was drawn: read them with atomic loads at agent scope
+  // (they bypass whatever stale copies this CU's L1 / this XCD's L2 may hold).  NOT an acquire fence and ordinary loads: the
+  // fence invalidates the L2, which first writes back every dirty line in it -- with a traversal's results there, tens of
+  // microseconds (measured in round 4 on the resident evaluators: one such fence per command cost 20 us at 100 000 patterns)
   double tot[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k)
@@ -421,10 +422,27 @@ template <int NS> __device__ __forceinline__ void finish_sums(const FinishParams
     const double *in = f.block_sums + (size_t)k * f.stride;
     double        acc[4]; // the four "threads" lane, lane+64, lane+128, lane+192 of the 256-thread reduction
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) acc[j] = 0.0;
+    // (eight rounds of loads in flight at once: one after the other -- a dependent trip to memory each -- the 13 rounds of a
+    // 3 126-workgroup evaluation took 27 us, measured in round 4; each accumulator still adds its terms in ascending order)
+    for (int i0 = lane; i0 < n; i0 += 8 * 256)
     {
-      acc[j] = 0.0;
-      for (int i = lane + 64 * j; i < n; i += 256) acc[j] += in[i];
+      double v[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          unsigned long long bits = 0ull;
+          if (i0 + u * 256 + 64 * j < n)
+            bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(in) + i0 + u * 256 + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_memcpy(&v[u][j], &bits, 8);
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (i0 + u * 256 + 64 * j < n) acc[j] += v[u][j];
     }
     double t = (acc[0] + acc[2]) + (acc[1] + acc[3]); // tree levels 128 and 64
 #pragma unroll
@@ -439,15 +457,21 @@ template <int NS> __device__ __forceinline__ void finish_sums(const FinishParams
     __hip_atomic_store(f.warn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll 1
     for (int k = 0; k <= kTicketGroups; ++k) __hip_atomic_store(f.tickets + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (f.warn_host) *f.warn_host = w;
+    if (f.warn_host) __hip_atomic_store(f.warn_host, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (f.warn_out) *f.warn_out = (double)w;
     if (f.result_host)
-    {
+    { // results and flag written through at system scope and ACKNOWLEDGED, then the sequence number: the same order as a
+      // release fence gives, without the fence's write-back of this XCD's whole L2 (megabytes of a traversal's results: tens of
+      // microseconds on large alignments)
 #pragma unroll
-      for (int k = 0; k < NS; ++k) f.result_host[k] = tot[k];
-      __threadfence_system(); // results before the sequence number, system scope (host reads over PCIe)
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.result_host + 2), f.seq, __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+      for (int k = 0; k < NS; ++k)
+      {
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &tot[k], 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.result_host) + k, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.result_host + 2), f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -1499,8 +1523,10 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
   if (!from_host) m0 = w0;
   int act = 0;
   if (from_host && (stop != 0 || gen != r.gen)) act = 2;                                   // the host says so
-  else if (!decider && ((m0 >> 1) > r.gen || ((m0 >> 1) == r.gen && (m0 & 1)))) act = 2; // workgroup 0 (or a newer one) says so
+  // (a complete command of this generation is served even when "leave" already stands behind it: a workgroup that starts
+  // late -- hundreds of them take microseconds to start -- would otherwise leave the command it was launched for unanswered)
   else if (all_good && gen == r.gen) act = 1;
+  else if (!decider && ((m0 >> 1) > r.gen || ((m0 >> 1) == r.gen && (m0 & 1)))) act = 2; // workgroup 0 (or a newer one) says so
   else if (wall_clock64() - t_last > (decider ? r.idle_ticks : 16 * r.idle_ticks)) act = 2; // (the others: a safety net only)
   if (decider)
   {

@@ -42,6 +42,25 @@ def main():
         t.close()
     res["stream"] = [float.hex(float(x)) for x in a]
     res["stream2"] = [float.hex(float(x)) for x in a2]
+    # the same stream with host-computed matrices (the argument-upload route), and on an alignment of 157 tiles (the
+    # large-grid resident evaluator's range)
+    t, ot, tree, st = synthetic_pair(26, 900, 4, 4, seed=19, host_pmat=True, ambiguous_every=11)
+    try:
+        t.Set_Both_Sides(True)
+        t.Lk(None)
+        h, h2 = t.Replay_Surface_Trace(tr)
+    finally:
+        t.close()
+    t, ot, tree, st = synthetic_pair(14, 5000, 4, 4, seed=21, host_pmat=False, ambiguous_every=11)
+    try:
+        t.Set_Both_Sides(True)
+        t.Lk(None)
+        trb = replay.make_trace(14, tree.edge_left, tree.edge_rght, tree.edge_len, 30, seed=4, walk_every=3, opt_every=4, n_dlk=3)
+        b, b2 = t.Replay_Surface_Trace(trb)
+    finally:
+        t.close()
+    res["stream_host"] = [float.hex(float(x)) for x in list(h) + list(h2)]
+    res["stream_big"] = [float.hex(float(x)) for x in list(b) + list(b2)]
     # 20 states: the golden proteic fixture (generic kernel against the MFMA kernel)
     d = phyg.load(os.path.join(ROOT, "tests", "golden", "proteic_lg_g4.phyg"))
     t, ot = device_tree_from_golden(d)

@@ -82,8 +82,12 @@ def main():
     diag = os.path.join(ROOT, "phyml_amd", "lib_diag")
     cfgs = {"launch": {"PHYHIP_RESIDENT": "0"}, "product": {},
             "host_sum": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_DEVICE_SUM": "100000000"},
-            "device_sum": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_DEVICE_SUM": "0"}}
+            "device_sum": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_DEVICE_SUM": "0"},
+            "g1": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1"}, "g2": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "2"},
+            "g1_launch": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1", "PHYHIP_RESIDENT": "0"}}
     for name in args.configs.split(","):
+        if name.startswith("lib_"):  # another build of the engine (tools/build_variant.sh <name>): phyml_amd/lib_<name>
+            cfgs[name] = {"PHYHIP_LIBDIR": os.path.join(ROOT, "phyml_amd", name)}
         env = dict(os.environ); env.update(cfgs[name])
         cmd = [sys.executable, os.path.abspath(__file__), "--label", name, "--taxa", str(args.taxa), "--patterns", str(args.patterns),
                "--candidates", str(args.candidates)] + (["--host-pmat"] if args.host_pmat else [])
