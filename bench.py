@@ -36,6 +36,19 @@ import numpy as np  # noqa: E402
 METRIC = "M partial-lk site-updates/sec on full-tree Lk()"
 
 
+def cpu_model():
+    """The host CPU's model string and core count (what the one-core baseline ran on)."""
+    model, cores = "unknown", os.cpu_count() or 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, cores
+
+
 def cpu_baseline(wl, sample_patterns, reps):
     """Reference AVX path (oracle/_ref, the real PhyML objects) on a bounded sample, 1 host core.
     Falls back to the repo's CPU restatement (kind 'port') if the reference binary did not travel."""
@@ -59,7 +72,8 @@ def cpu_baseline(wl, sample_patterns, reps):
                                  cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
             import re
             info = json.loads(re.search(r"REF_BENCH (\{.*\})", out).group(1))
-            return dict(value=info["site_updates_per_s"] / 1e6, unit="M site-updates/s", cores=1, kind="reference",
+            cpu, ncores = cpu_model()
+            return dict(value=info["site_updates_per_s"] / 1e6, unit="M site-updates/s", cores=1, kind="reference", cpu=cpu, host_cores=ncores,
                         sample=f"PhyML AVX Lk(NULL) x{reps} on {info['n_otu']} taxa x {info['n_pattern']} patterns of the same workload",
                         lnL_sample=info["lnL"])
         except Exception as e:  # noqa: BLE001
@@ -78,7 +92,8 @@ def cpu_baseline(wl, sample_patterns, reps):
     for _ in range(reps):
         lnl = ot.lk(None)
     dt = (time.perf_counter() - t0) / reps
-    return dict(value=n_s * (tree.n_otu - 2) / dt / 1e6, unit="M site-updates/s", cores=1, kind="port",
+    cpu, ncores = cpu_model()
+    return dict(value=n_s * (tree.n_otu - 2) / dt / 1e6, unit="M site-updates/s", cores=1, kind="port", cpu=cpu, host_cores=ncores,
                 sample=f"oracle Lk(NULL) x{reps} on {tree.n_otu} taxa x {n_s} patterns", lnL_sample=lnl)
 
 
@@ -87,7 +102,7 @@ def measured_roofline():
     denominator the north star calls the 'measured HBM-read roofline'."""
     mb = os.path.join(ROOT, "phyml_amd", "lib", "membench")
     try:
-        out = subprocess.run([mb, "1", "7"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120).stdout
+        out = subprocess.run([mb, "1", "7", "sweep"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=180).stdout
         return json.loads(out.strip().splitlines()[-1])
     except Exception:  # noqa: BLE001
         return None
@@ -201,8 +216,22 @@ def run_single(args, torch):
     if mr:
         roof["measured_read_GBps"] = mr["read_GBps"]
         roof["measured_write_GBps"] = mr["write_GBps"]
-        roof["frac_of_measured_read"] = roof["achieved"] / mr["read_GBps"]
-        roof["write_stream_frac_of_measured_write"] = roof["write_bytes"] / kdur / 1e9 / mr["write_GBps"]
+        # the streams this GPU sustains (phyml_amd/lib/membench: plain and NON-TEMPORAL accesses -- the traversal kernels' policy --
+        # over 1-32 workgroups per CU of 256 / 64 lanes; best_* = the best geometry): what "fraction of the measured roofline" divides by
+        for k in ("read_nt_GBps", "write_nt_GBps", "r1w2_GBps", "r1w2_nt_GBps", "best_read_GBps", "best_write_GBps", "best_copy_GBps",
+                  "best_r1w2_GBps"):
+            if k in mr:
+                roof["measured_" + k] = mr[k]
+        mixed = max(mr.get("best_r1w2_GBps", 0.0), mr.get("r1w2_nt_GBps", 0.0), mr.get("r1w2_GBps", 0.0))
+        best_write = max(mr.get("best_write_GBps", 0.0), mr.get("write_nt_GBps", 0.0), mr["write_GBps"])
+        # SURVEY 8(d)'s unit over the measured read stream.  The algorithmic bytes charge every child of every operation; a
+        # fused launch forwards most children in registers, so this can exceed 1 -- it is NOT a physical rate (those follow)
+        roof["algorithmic_frac_of_measured_read"] = roof["achieved"] / max(mr["read_GBps"], mr.get("best_read_GBps", 0.0))
+        roof["write_stream_frac_of_measured_write"] = roof["write_bytes"] / kdur / 1e9 / best_write
+        if roof.get("hbm_achieved") and mixed > 0:
+            roof["frac_real_bytes_of_measured_mixed"] = roof["hbm_achieved"] / mixed
+        elif mixed > 0:  # (no counter profile of these kernel sources: the launch's traffic model instead)
+            roof["frac_min_traffic_of_measured_mixed"] = roof["min_traffic_bytes"] / kdur / 1e9 / mixed
     exp = workloads.manifest()["expected"].get(args.workload)
     if exp and P == exp["n_pattern"]:
         out["lnL_reference_avx"] = exp["lnL"]
@@ -211,6 +240,12 @@ def run_single(args, torch):
     t.close()
     if not args.no_extra and args.workload == "cfg2_nt_100x50k" and args.patterns is None:
         out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch)}
+        # the strong-scaling reference of the N > 1 lines (cfg4, 100 taxa x 1 M patterns) on THIS one GPU, same protocol: a
+        # 1 -> 8 curve over one workload is value(N > 1) against this value, whatever the N = 1 headline workload is
+        try:
+            out["extra"]["cfg4_nt_100x1M_one_gpu"] = scaling_reference_line(args, torch)
+        except Exception as e:  # (an extra must never cost the run its headline line)
+            out["extra"]["cfg4_nt_100x1M_one_gpu"] = {"error": repr(e)}
         if not args.no_call_latency:
             try:
                 out["extra"]["call_latency"] = call_latency()
@@ -317,6 +352,23 @@ def brlen_block(t, taxa, P, S, C):
                            "frac_of_8TBps": k4_bytes / (k4_us * 1e-6) / 8e12 if k4_us else 0.0},
             "us_per_chain_of_1_eigen_lr_and_5_dlk": wall / n_chain * 1e6, "us_per_dlk_call": dlk_wall,
             "served_by_large_grid_resident_workgroups": t.inst.resident_stats(2)[0]}
+
+
+def scaling_reference_line(args, torch):
+    """cfg4 (the workload of the N > 1 lines) whole on one GPU: the denominator of the strong-scaling curve."""
+    from phyml_amd import workloads
+    name = "cfg4_nt_100x1M"
+    wl = workloads.make(name)
+    tree, st = wl["tree"], wl["states"]
+    n, P = tree.n_otu, st.shape[1]
+    t = build_tree(wl, device=0)
+    steps = max(5, min(args.steps, 20))
+    dt, lnl = timed_steps(t, steps, min(args.warmup, 3), torch.cuda.synchronize)
+    t.close()
+    exp = workloads.manifest()["expected"][name]
+    return {"value": float(P) * (n - 2) * steps / dt / 1e6, "unit": "M site-updates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "n_gpus": 1, "patterns": P, "lnL": lnl, "lnL_rel_err": abs(lnl - exp["lnL"]) / abs(exp["lnL"]),
+            "note": "strong-scaling reference: bench.py --gpus N (N > 1) runs this workload in N pattern shards"}
 
 
 def extra_line(name, args, torch):

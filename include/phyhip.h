@@ -60,6 +60,12 @@ extern "C" {
    class, and evaluations go through phyhip_calculate_class_mixture_*.  20 states x up to 4 classes, or 4 states x 1, 2 or 4
    classes; with a resource list the instance is sharded like any other (one all-reduce per mixture evaluation). */
 #define PHYHIP_FLAG_CLASS_AXIS (1L << 41)
+/* requirementFlags bit: the arithmetic of the reference's GENERIC partial-likelihood loop (Update_Partial_Lk_Generic,
+   src/lk.c:1332-1587) as `phyml --cov` runs it on 4- or 20-state data (mod->use_m4mod, src/cl.c:753-757, src/lk.c:1303-1324):
+   no all-ones shortcut -- a fully ambiguous subtree yields the rounded row sums of the transition matrices instead of exactly
+   1.0 -- everything else as the default path (the same fused multiply-add chains; pinned by tests/golden/nucleic_cov_generic.phyg).
+   Served by the plain, non-pipelined kernel: the door is there for parity, the reference itself runs it at half speed. */
+#define PHYHIP_FLAG_GENERIC_LOOP (1L << 42)
 
 /* BeagleOperation (src/beagle_utils.c:243).  The two scale-index fields are accepted and ignored:
    scale vectors are implicit, one per partials buffer, as in PhyML. */

@@ -68,6 +68,9 @@ typedef struct __Model
   phydbl  br_len_mult;
   int     invar;                 /* mod->ras->invar */
   phydbl  pinvar;
+  int     use_m4mod;             /* mod->use_m4mod (`phyml --cov`, src/cl.c:753-757): Update_Partial_Lk sends the data through the
+                                    generic loop instead of the SIMD kernels, src/lk.c:1303-1324 -- the device instance is then
+                                    created with PHYHIP_FLAG_GENERIC_LOOP (that loop's arithmetic) */
 } t_mod;
 
 typedef struct __Tree

@@ -256,8 +256,9 @@ static void push_model(ctx_t *c)
 static ctx_t *ensure_instance(t_tree *tree)
 { /* create_beagle_instance, src/beagle_utils.c:97-190: after Make_Tree_For_Lk (src/main.c:235) */
   for (int i = 0; i < g_nctx; ++i) if (g_ctx[i].tree == tree) return &g_ctx[i];
-  if (tree->is_mixt_tree || tree->n_root || tree->mod->gamma_mgf_bl == YES || tree->mod->log_l == YES || tree->mod->use_m4mod)
-  { fprintf(stderr, "glue_driver: unsupported tree kind (rooted / mgf / log_l / m4, or the mixture tree itself)\n"); exit(5); }
+  if (tree->is_mixt_tree || tree->n_root || tree->mod->gamma_mgf_bl == YES || tree->mod->log_l == YES ||
+      (tree->mod->use_m4mod && tree->mixt_tree))
+  { fprintf(stderr, "glue_driver: unsupported tree kind (rooted / mgf / log_l / m4 class tree, or the mixture tree itself)\n"); exit(5); }
   if (!tree->mixt_tree && g_nctx > 0)
   { /* a fresh tree object for the same data (aLRT_From_String rebuilds the tree from its Newick string and calls
        Make_Tree_For_Lk again; under BEAGLE it creates a fresh instance there too, src/utilities.c:9314): the old instance goes */
@@ -324,7 +325,9 @@ static ctx_t *ensure_instance(t_tree *tree)
         if (*p == ',') ++p;
       }
     c->inst = phyhip_create_instance(n, n + c->bufcap, 0, S, P, 1, c->matcap, C, 0, nd ? devs : NULL, nd,
-                                     0, nd == 1 ? PHYHIP_FLAG_SHARDED : 0, NULL);
+                                     0, (nd == 1 ? PHYHIP_FLAG_SHARDED : 0) |
+                                            /* `--cov` (mod->use_m4mod): the reference's generic loop, src/lk.c:1303-1324 */
+                                            (tree->mod->use_m4mod ? PHYHIP_FLAG_GENERIC_LOOP : 0), NULL);
   }
   if (c->inst < 0) die("phyhip_create_instance");
   OK(phyhip_set_pattern_weights(c->inst, tree->data->wght));

@@ -154,7 +154,9 @@ void orc_update_pmat_edge(double l, int ns, int ncatg, const double *gamma_rr, d
 static void matvec(const double *P, const double *v, int ns, double *u, int arith)
 {
   if (arith)
-  { /* src/avx.c:593-616: u = col_0 * v0, then u = fma(col_j, v_j, u) */
+  { /* src/avx.c:593-616: u = col_0 * v0, then u = fma(col_j, v_j, u).  arith == 2 (the generic loop as the reference's build
+       compiles it, src/lk.c:1463-1476: acc = 0, acc += P[i][j] * v[j] contracted to a fused multiply-add chain) gives the same
+       doubles: fma(a, b, +0.0) is the rounded product */
     for (int i = 0; i < ns; ++i) u[i] = P[i * ns] * v[0];
     for (int j = 1; j < ns; ++j)
       for (int i = 0; i < ns; ++i) u[i] = fma(P[i * ns + j], v[j], u[i]);
@@ -181,11 +183,20 @@ void orc_update_partial(int P, int C, int S, const double *wght,
 
   for (int site = 0; site < P; ++site)
   {
-    if (!(wght[site] > ORC_SMALL)) continue; /* src/avx.c:399,515-520: zero-weight patterns untouched */
+    if (!(wght[site] > ORC_SMALL))
+    { /* src/avx.c:399,515-520: zero-weight patterns untouched; the generic loop zeroes them, src/lk.c:1581-1584 */
+      if (arith == 2)
+        for (int i = 0; i < CS; ++i) plk0[(size_t)site * CS + i] = 0.0;
+      continue;
+    }
 
     int amb1 = 1, amb2 = 1, st1 = -1, st2 = -1; /* src/avx.c:401-414 */
     if (v1->is_tip) { amb1 = v1->is_ambigu[site]; if (!amb1) st1 = v1->d_state[site]; }
     if (v2->is_tip) { amb2 = v2->is_ambigu[site]; if (!amb2) st2 = v2->d_state[site]; }
+    /* arith == 2: Update_Partial_Lk_Generic under mod->use_m4mod (the `--cov` door, src/cl.c:753-757, src/lk.c:1303-1324):
+       every tip counts as ambiguous (src/lk.c:1431-1435: full sums, the same doubles as the look-up) and there is NO all-ones
+       shortcut -- a fully ambiguous subtree yields the rounded row sums of the matrices, not exactly 1.0 */
+    if (arith == 2) amb1 = amb2 = 1;
 
     double *out = plk0 + (size_t)site * CS;
     for (int c = 0; c < C; ++c)
@@ -214,7 +225,7 @@ void orc_update_partial(int P, int C, int S, const double *wght,
         int k;
         for (k = 0; k < S; ++k)
           if (x1[k] > 1.0 || x1[k] < 1.0 || x2[k] > 1.0 || x2[k] < 1.0) break;
-        if (k != S)
+        if (k != S || arith == 2)
         {
           matvec(P1, x1, S, u1, arith);
           matvec(P2, x2, S, u2, arith);

@@ -12,8 +12,13 @@
 #   * NEXUS datatype=standard: Init_Model() -> Update_Eigen() -> Eigen() -> elemhess() never returns (killed after 20 s).
 # (A named -m model cannot be added: every one of them resets the data type to NT or AA, src/cl.c:945-1100; `-o n` without
 # `-m` dereferences a NULL r_mat in Read_Command_Line, src/cl.c:1882, whatever the data type -- hence the bare command.)
-# So no generic state count has a reference behaviour to pin an implementation against; the engine
+# So no generic STATE COUNT has a reference behaviour to pin an implementation against; the engine
 # answers PHYHIP_ERROR_NO_IMPLEMENTATION for state counts other than 4 and 20.
+# The third door (round 4) does open: `--cov` (src/cl.c:753-757) sets mod->use_m4mod, M4_Init_Model is compiled out of the
+# `phyml` program (src/main.c:151, -DM4 only), so Update_Partial_Lk (src/lk.c:1303-1324) sends the unchanged 4-state data
+# through Update_Partial_Lk_Generic -- the probe prints its lnL next to the default path's (equal to the last digit on
+# examples/nucleic, at half the speed).  That behaviour IS pinned: tests/golden/nucleic_cov_generic.phyg
+# (tests/golden/make_cov.py), oracle arith = 2, PHYHIP_FLAG_GENERIC_LOOP.
 # Control: the nucleotide recoding of the same alignment runs to its likelihood with the same driver.
 set -e
 REF=${REF:-/root/reference}
@@ -51,4 +56,8 @@ echo "== NEXUS, datatype=standard symbols=\"012\" (aborted after 20 s)"
 timeout -s ABRT 20 ./probe bench 1 -- -i gen.nex -b 0 < /dev/null > out2.txt 2>&1; st=$?
 echo -n "backtrace: "; show out2.txt
 echo "exit status $st; likelihood functions in the backtrace: $(grep -cE 'Update_Partial_Lk|Lk_Core|\(Lk\+' out2.txt)"
+echo "== --cov on examples/nucleic (GTR+G4): the generic loop on 4-state data, against the default path"
+cp $REF/examples/nucleic nuc.phy; chmod 644 nuc.phy
+timeout 120 ./probe bench 1 -- -i nuc.phy -d nt -m GTR -c 4 -a 1.0 -o n -b 0 < /dev/null 2>&1 | grep -o 'REF_BENCH.\{0,160\}' | head -1
+timeout 120 ./probe bench 1 -- -i nuc.phy -d nt -m GTR -c 4 -a 1.0 -o n -b 0 --cov < /dev/null 2>&1 | grep -o 'REF_BENCH.\{0,160\}' | head -1
 rm -rf $T

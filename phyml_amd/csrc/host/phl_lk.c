@@ -212,7 +212,8 @@ void Make_Tree_For_Lk_On_Devices(t_tree *tree, int n_pattern, const phydbl *wght
   phyhip_instance_details det;
   int inst = phyhip_create_instance(n, next, 0, m->ns, n_pattern, 1, n_edges + PHL_N_SPARE, m->n_catg, 0,
                                     n_devices > 0 ? devices : NULL, n_devices, 0,
-                                    ((flags & 1) ? PHYHIP_FLAG_SHARDED : 0) | ((flags & 2) ? PHYHIP_FLAG_CLASS_AXIS : 0), &det);
+                                    ((flags & 1) ? PHYHIP_FLAG_SHARDED : 0) | ((flags & 2) ? PHYHIP_FLAG_CLASS_AXIS : 0) |
+                                        (m->use_m4mod ? PHYHIP_FLAG_GENERIC_LOOP : 0), &det);
   if (inst < 0) { Lk_Exit("phyhip_create_instance", phyhip_get_last_error()); return; }
   tree->b_inst = inst;
   CHK(phyhip_set_pattern_weights(inst, tree->wght));

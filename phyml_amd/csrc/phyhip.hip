@@ -160,6 +160,7 @@ struct Instance
   int         tips = 0, nbuf = 0, S = 0, C = 0, CP = 0, nmat = 0;
   long long   P = 0, Ppad = 0; // Ppad: patterns per buffer as allocated (P, or P rounded up to 16 when perm)
   bool        class_axis = false; // categories are the classes of a mixture (PHYHIP_FLAG_CLASS_AXIS; TreeParams::class_axis)
+  bool        generic_loop = false; // PHYHIP_FLAG_GENERIC_LOOP: the reference's generic loop (`--cov`): plain kernel, no all-ones shortcut
   int         NE = 1;          // eigen systems / frequency vectors held: C with the class axis, else 1
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
   int         aa_nw = 1;               // 20 states: consumer waves (= wave-tiles) per workgroup of traverse_aa_kernel
@@ -305,7 +306,20 @@ Instance *get(int id)
   return g_inst[id];
 }
 
-thread_local int g_cur_dev = -1;
+// The calling thread's current device is ASKED, not remembered: a host application (or another library in its process) may
+// call hipSetDevice between two calls of this ABI, and a remembered value would then send the next launch to the wrong device
+// without any error.  hipGetDevice reads a thread-local of the runtime (tens of nanoseconds).
+thread_local int g_cur_dev = -1; // (what this library last set: only a hint for the cases below that do not ask)
+static inline int make_current(int dev)
+{
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != dev)
+  {
+    HIPCHK(hipSetDevice(dev));
+  }
+  g_cur_dev = dev;
+  return 0;
+}
 
 // THE choke point of the resident protocol: resident workgroups are not ordered with the
 // instance's stream, so they may only be used while nothing queued on it is still running.  Every entry point of the C ABI
@@ -328,7 +342,7 @@ static inline void leave_untouched(Instance *I) { I->stream_dirty = I->dirty_pre
 static inline void leave_query(Instance *I) { I->stream_dirty = I->dirty_prev; --I->api_no; }
 
 // hipSetDevice costs about a microsecond; the surface is entered hundreds of thousands of times per tree
-// search, so only switch when the calling thread is actually on another device
+// search, so only switch when the calling thread is actually on another device (make_current)
 // GET_INST_RES: the entry points the large-grid resident workgroups (phyhip_big.hpp) serve or that only queue -- they keep
 // those workgroups and release them themselves where they launch.  GET_INST: everything else may put copies or kernels on the
 // instance's stream, which must then be ordered behind the resident workgroups' exit (what they wrote sits in their L2s until
@@ -337,10 +351,9 @@ static void big_release(Instance *I, bool restart_streak = true);
 #define GET_INST_RES(I, id)                                                                                  \
   Instance *I = get(id);                                                                                     \
   if (!I) return fail(PHYHIP_ERROR_UNINITIALIZED_INSTANCE, "instance %d does not exist", id);                 \
-  if (g_cur_dev != I->dev)                                                                                   \
   {                                                                                                          \
-    HIPCHK(hipSetDevice(I->dev));                                                                            \
-    g_cur_dev = I->dev;                                                                                      \
+    const int rc_dev_ = make_current(I->dev);                                                                \
+    if (rc_dev_) return rc_dev_;                                                                             \
   }                                                                                                          \
   enter_stream_work(I);
 #define GET_INST(I, id)                                                                                      \
@@ -374,6 +387,7 @@ TreeParams base_params(Instance *I)
   q.apply_scaling = I->apply_scaling; q.pi = I->d_pi; q.cat_w = I->d_catw; q.invar_model = I->invar_model;
   q.pinvar = I->pinvar; q.invar = I->d_invar; q.block_sums = I->d_block; q.warn = I->d_warn; q.fact = I->d_fact;
   q.class_axis = I->class_axis ? 1 : 0;
+  q.generic_loop = I->generic_loop ? 1 : 0;
   return q;
 }
 
@@ -1744,7 +1758,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
       if (resourceList[g] < 0 || resourceList[g] >= ndev)
         return fail(PHYHIP_ERROR_NO_RESOURCE, "device %d not present (%d visible)", resourceList[g], ndev);
     return create_group(tipCount, partialsBufferCount, stateCount, patternCount, matrixBufferCount, categoryCount, resourceList,
-                        resourceCount, returnInfo, requirementFlags & PHYHIP_FLAG_CLASS_AXIS);
+                        resourceCount, returnInfo, requirementFlags & (PHYHIP_FLAG_CLASS_AXIS | PHYHIP_FLAG_GENERIC_LOOP));
   }
   int dev = 0;
   if (resourceList && resourceCount > 0) dev = resourceList[0];
@@ -1759,7 +1773,11 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   if (class_axis && !((stateCount == 20 && categoryCount <= 4) || (stateCount == 4 && (categoryCount == 1 || categoryCount == 2 || categoryCount == 4))))
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "the class axis is built for 20 states x up to 4 classes and 4 states x 1, 2 or 4 classes "
                                                 "(one instance per class otherwise)");
+  const bool generic_loop = (requirementFlags & PHYHIP_FLAG_GENERIC_LOOP) != 0;
+  if (generic_loop && class_axis)
+    return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "the generic loop (PHYHIP_FLAG_GENERIC_LOOP) is built for plain instances, not for the class axis");
   Instance *I = new Instance();
+  I->generic_loop = generic_loop;
   I->class_axis = class_axis; I->NE = class_axis ? categoryCount : 1;
   I->dev = dev; I->tips = tipCount; I->nbuf = partialsBufferCount; I->S = stateCount; I->C = categoryCount;
   I->CP = next_pow2(categoryCount); I->P = patternCount; I->nmat = matrixBufferCount;
@@ -1801,8 +1819,9 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipEventCreateWithFlags(&I->ev_sync, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&I->ev_big, hipEventDisableTiming));
 
-  I->perm = (I->S == 20) && (I->C <= 4) && (I->class_axis || !(diag_env("PHYHIP_GENERIC_AA") && atoi(diag_env("PHYHIP_GENERIC_AA"))));
-  I->soa  = (I->S == 4) && (I->C <= 4) &&
+  I->perm = (I->S == 20) && (I->C <= 4) && !I->generic_loop &&
+            (I->class_axis || !(diag_env("PHYHIP_GENERIC_AA") && atoi(diag_env("PHYHIP_GENERIC_AA"))));
+  I->soa  = (I->S == 4) && (I->C <= 4) && !I->generic_loop &&
             (I->class_axis || (!(diag_env("PHYHIP_NT_SOA") && atoi(diag_env("PHYHIP_NT_SOA")) == 0) &&
                                !(diag_env("PHYHIP_GENERIC_NT") && atoi(diag_env("PHYHIP_GENERIC_NT")))));
   I->Ppad = I->perm ? ((I->P + 15) / 16) * 16 : (I->soa ? ((I->P + 63) / 64) * 64 : I->P);
@@ -1937,6 +1956,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = diag_env("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
+  if (I->generic_loop) I->generic_nt = true;
 #ifdef PHYHIP_DIAG
   if (const char *e = diag_env("PHYHIP_ABLATE")) I->ablate = atoi(e);
   if (const char *e = diag_env("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;

@@ -150,6 +150,9 @@ struct TreeParams
   // Large-grid resident evaluator (phyhip_big.hpp) with the final sum on the device: a tile's sum goes here (device memory,
   // [tile]) instead of to the host; the workgroup that finishes last adds them in final_reduce_kernel's order and posts ONE record.
   double         *tile_sums;
+  // PHYHIP_FLAG_GENERIC_LOOP: the arithmetic of Update_Partial_Lk_Generic under mod->use_m4mod (`phyml --cov`): no all-ones
+  // shortcut (src/lk.c:1463-1528 has none; src/avx.c:575-587 does)
+  int             generic_loop;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
     bool ones = true;
 #pragma unroll
     for (int j = 0; j < S; ++j) ones = ones && (x1[j] == 1.0) && (x2[j] == 1.0);
+    ones = ones && !q.generic_loop;
 
     if (S <= 4)
     {

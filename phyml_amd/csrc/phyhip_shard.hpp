@@ -45,11 +45,17 @@ __global__ void shard_local_sum_kernel(double *slots, int n, int count)
 __global__ void shard_publish_kernel(const double *red, double *result_host, int *warn_host, unsigned long long seq)
 {
   if (threadIdx.x != 0) return;
-  *warn_host     = red[0] != 0.0 ? 1 : 0;
-  result_host[0] = red[1];
-  result_host[1] = red[2];
-  __threadfence_system();
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(result_host + 2), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (written through at system scope and acknowledged, then the sequence number: the order a release fence gives without
+  // its write-back of the L2 -- see finish_sums)
+  unsigned long long b1, b2;
+  const double       r1 = red[1], r2 = red[2];
+  __builtin_memcpy(&b1, &r1, 8);
+  __builtin_memcpy(&b2, &r2, 8);
+  __hip_atomic_store(warn_host, red[0] != 0.0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(result_host), b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(result_host + 1), b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_waitcnt(0);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(result_host + 2), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct DevCtx
@@ -68,15 +74,7 @@ struct Collective
   bool                own_comms = true;
 };
 
-static int set_dev(int dev)
-{
-  if (g_cur_dev != dev)
-  {
-    HIPCHK(hipSetDevice(dev));
-    g_cur_dev = dev;
-  }
-  return 0;
-}
+static int set_dev(int dev) { return make_current(dev); }
 
 // where shard number `k` of its device writes {warning, lnL, dlnL}
 static double *shard_slot(const DevCtx &c, int k) { return c.d_red + (size_t)(c.nsub > 1 ? k + 1 : 0) * kRedStride; }

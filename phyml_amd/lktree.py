@@ -38,7 +38,7 @@ class t_mod(C.Structure):
                 ("gamma_rr", C.POINTER(C.c_double)), ("gamma_r_proba", C.POINTER(C.c_double)),
                 ("e_val", C.POINTER(C.c_double)), ("r_e_vect", C.POINTER(C.c_double)),
                 ("l_e_vect", C.POINTER(C.c_double)), ("l_min", C.c_double), ("l_max", C.c_double),
-                ("br_len_mult", C.c_double), ("invar", C.c_int), ("pinvar", C.c_double)]
+                ("br_len_mult", C.c_double), ("invar", C.c_int), ("pinvar", C.c_double), ("use_m4mod", C.c_int)]
 
 
 class t_tree(C.Structure):
@@ -93,7 +93,7 @@ class LkTree:
     """Owns a C `t_tree` + `t_mod`.  Methods are one-line forwards to the C functions of the same name."""
 
     def __init__(self, n_otu, edge_left, edge_rght, edge_len, n_pattern, ns, ncatg, device=None, node_v=None,
-                 node_b=None, host_pmat=False, devices=None, force_sharded=False, class_axis=False):
+                 node_b=None, host_pmat=False, devices=None, force_sharded=False, class_axis=False, use_m4mod=False):
         L = load()
         self.L = L
         self.n, self.P, self.S, self.C = int(n_otu), int(n_pattern), int(ns), int(ncatg)
@@ -108,6 +108,7 @@ class LkTree:
         self.mod = L.Make_Model_Basic(self.S, self.C)
         self.tree.contents.mod = self.mod
         self.tree.contents.host_pmat = 1 if host_pmat else 0
+        self.mod.contents.use_m4mod = 1 if use_m4mod else 0  # `phyml --cov`: the reference's generic loop (PHYHIP_FLAG_GENERIC_LOOP)
         self.device = -1 if device is None else int(device)
         # multi-GPU: pattern shards over `devices` inside libphyhip.so (one RCCL all-reduce per evaluation)
         self.devices = None if devices is None else [int(x) for x in devices]

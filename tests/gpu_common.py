@@ -5,14 +5,15 @@ import orc
 from phyml_amd import lktree
 
 
-def device_tree_from_golden(d, host_pmat=True, devices=None, force_sharded=False):
+def device_tree_from_golden(d, host_pmat=True, devices=None, force_sharded=False, use_m4mod=False, arith=1):
     """Device tree with the reference's own neighbour order (node_v/node_b of the dump); tips come from the
     oracle's tip encoder.  host_pmat=True: the C host layer's own PMat() + upload (bit-exact route, src/lk.c:2360);
     False: device PMat from the eigen system (src/lk.c:2344)."""
-    ot = orc.tree_from_golden(d)
+    ot = orc.tree_from_golden(d, arith=arith)
     m = ot.m
     t = lktree.LkTree(ot.n, d["edge_left"], d["edge_rght"], d["edge_len"], ot.P, m.ns, m.ncatg,
-                      node_v=d["node_v"], node_b=d["node_b"], host_pmat=host_pmat, devices=devices, force_sharded=force_sharded)
+                      node_v=d["node_v"], node_b=d["node_b"], host_pmat=host_pmat, devices=devices, force_sharded=force_sharded,
+                      use_m4mod=use_m4mod)
     t.tip_root = ot.tip_root
     t.set_model(m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, m.br_len_mult,
                 int(d["apply_lk_scaling"][0]), m.invar_model, m.pinvar)

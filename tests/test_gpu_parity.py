@@ -139,3 +139,35 @@ def test_deferred_queue_is_transparent(golden):
             assert np.array_equal(t1.partials(b, side), t2.partials(b, side))
     finally:
         t1.close(); t2.close()
+
+
+def test_generic_loop_door(golden):
+    """PHYHIP_FLAG_GENERIC_LOOP (the host layer sets it for mod->use_m4mod, `phyml --cov`): the device reproduces the reference's
+    generic loop (Update_Partial_Lk_Generic, src/lk.c:1332-1587) -- the dumped partial vector and the scale vector bit for bit,
+    every edge side bit-equal to the pinned restatement (arith = 2, tests/test_oracle_golden.py), lnL and per-site values."""
+    d = golden("nucleic_cov_generic")
+    t, ot = device_tree_from_golden(d, use_m4mod=True, arith=2)
+    try:
+        t.Set_Both_Sides(True)
+        lnl = t.Lk(None)
+        ref = ot.lk(None, both_sides=True)
+        assert abs(lnl - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-12 and abs(lnl - ref) / abs(ref) < 1e-12
+        w = d["wght"] > 0
+        assert np.array_equal(t.partials(0, 0)[w], np.asarray(d["p_lk_left_0"])[w])
+        assert np.array_equal(t.scale_factors(0, 0)[w], np.asarray(d["sum_scale_left_0"])[w])
+        for (e, side), p in ot.plk.items():
+            assert np.array_equal(t.partials(e, side)[w], p[w]), (e, side)
+            assert np.array_equal(t.scale_factors(e, side)[w], ot.scale[(e, side)][w]), (e, side)
+        c_lnL_sorted, cur_site_lk, unscaled, fact = t.inst.site_outputs()
+        assert np.array_equal(fact, d["fact_sum_scale"])
+        assert np.max(np.abs(c_lnL_sorted[w] - d["c_lnL_sorted"][w]) / np.abs(d["c_lnL_sorted"][w])) < 1e-10
+        # the SIMD-path instance of the same data differs from it exactly where the reference's two paths differ
+        t2, _ = device_tree_from_golden(d)
+        try:
+            t2.Set_Both_Sides(True)
+            t2.Lk(None)
+            assert (t2.partials(0, 0)[w] != t.partials(0, 0)[w]).any(axis=1).sum() == 51
+        finally:
+            t2.close()
+    finally:
+        t.close()

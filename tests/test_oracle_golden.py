@@ -152,3 +152,33 @@ def test_update_order_counts(golden):
     t.n_updates = 0
     t.lk(None, both_sides=True)
     assert t.n_updates == 3 * (t.n - 2)
+
+
+def test_generic_loop_door_is_pinned(golden):
+    """`phyml --cov` (src/cl.c:753-757 -> mod->use_m4mod -> src/lk.c:1303-1324) is the one door through which the reference's
+    `phyml` program reaches Update_Partial_Lk_Generic (src/lk.c:1332-1587) and returns a likelihood: 4-state data through the
+    plain C loop.  tests/golden/nucleic_cov_generic.phyg (tests/golden/make_cov.py) is the same command as nucleic_gtr_g4_inv
+    plus --cov.  The loop's arithmetic is the default path's (fused multiply-add chains) WITHOUT the all-ones shortcut of the
+    SIMD kernels (src/avx.c:575-587): fully ambiguous subtrees yield rounded row sums instead of exactly 1.0 -- 51 of the 382
+    patterns differ in the last bits.  The restatement with arith = 2 reproduces the dumped partial vector bit for bit; with
+    the SIMD arithmetic it does not."""
+    d, ref = golden("nucleic_cov_generic"), golden("nucleic_gtr_g4_inv")
+    w = d["wght"] > 0
+    assert np.array_equal(d["Pij_rr"], ref["Pij_rr"]) and not np.array_equal(d["p_lk_left_0"], ref["p_lk_left_0"])
+    assert (np.asarray(d["p_lk_left_0"]) != np.asarray(ref["p_lk_left_0"])).any(axis=1).sum() == 51
+    t = orc.tree_from_golden(d, arith=2)
+    lnl = t.lk(None, both_sides=True)
+    assert abs(lnl - d["lnL"][0]) / abs(lnl) < 1e-14
+    assert np.array_equal(t.plk[(0, 0)][w], np.asarray(d["p_lk_left_0"])[w])
+    assert np.array_equal(t.scale[(0, 0)][w], np.asarray(d["sum_scale_left_0"])[w])
+    assert np.array_equal(t.fact_sum_scale, d["fact_sum_scale"])
+    assert np.max(np.abs(t.c_lnL_sorted - d["c_lnL_sorted"]) / np.abs(d["c_lnL_sorted"])) < 1e-14
+    for e in range(d["side_digest"].shape[0]):
+        for side in range(2):
+            if d["side_valid"][e, side]:
+                p, sc = t.plk[(e, side)][w], t.scale[(e, side)][w]
+                got = np.array([p.sum(), (p * p).sum(), float(sc.sum())])
+                assert np.allclose(got, d["side_digest"][e, side], rtol=1e-12, atol=0), (e, side)
+    t1 = orc.tree_from_golden(d, arith=1)
+    t1.lk(None, both_sides=True)
+    assert not np.array_equal(t1.plk[(0, 0)][w], np.asarray(d["p_lk_left_0"])[w])  # (the SIMD arithmetic is another one)
