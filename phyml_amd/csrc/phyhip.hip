@@ -209,7 +209,10 @@ struct Instance
   unsigned long long *d_big_stamps = nullptr; // PHYHIP_RESIDENT_STATS: stamps of the last command per workgroup (BigCtl::stamps)
   int          n_vdlk = 0;            // virtual blocks (one wave each) of a dLk evaluation: dlk64_kernel's grid
   int          big_wgs = 0, big_nw = 0; // its workgroups and waves per workgroup
-  int          big_device_sum = 1;    // commands of more tiles than this add their tile sums on the device (one record to the host)
+  // commands of more tiles than this add their tile sums on the device (one record to the host); below, a record per tile to the
+  // host.  Measured (SPR candidate / dLk, us): 79 tiles 11.3 / 8.9 against 14.0 / 10.6, 125 tiles 12.1 / 9.0 against 14.0 / 10.4,
+  // 250 tiles 14.6 / 12.4 against 14.6 / 11.0, 625 tiles 16.5 / 13.1 against 15.3 / 11.1 (host / device)
+  int          big_device_sum = 200;
   int          big_streak = 0;        // consecutive evaluations the resident workgroups could have taken (they are launched at 2)
   unsigned long long rb_dlk_api = 0;  // entry-point call of the last dLk command they served
   int          cus = 256;
@@ -3155,6 +3158,9 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   }
   else if (big && big_eligible(I)) { ++I->rb.n_busy; I->big_streak = 0; }
   if (big) big_release(I, false); // (launched on the stream: behind the resident workgroups' exit, if there are any)
+  // (20 states, re-measured in round 4 with compact commands -- exp() values only, two 512-byte reads instead of four, ONE
+  // polling workgroup, the others on the device-memory mailbox: 10.7 us from command to answer on the recorded proteic search,
+  // 18.2 against 17.5 us per scalar-returning call, 13.2 against 13.4 us per dLk at 2 000 patterns -- still no gain: removed)
   if (!big && hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait)
   {
     bool idle = !I->stream_dirty;

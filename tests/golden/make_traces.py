@@ -30,6 +30,18 @@ TRACES = {
 }
 
 
+# A LARGE real search (round 4): 200 taxa, synthetic alignment (phyml_amd/synth.py: seeded integer-hash generator, 260 sites so
+# that the reference's `int` slab holds it), PhyML's own SPR search from its BioNJ tree.  The first 46 000 surface calls: the
+# initial Lk, four rounds of Br_Len_Opt over the 397 edges (3 570 Update_Eigen_Lr, 12 757 dLk), then ~9 000 records of the SPR
+# phase proper (src/spr.c:149,813: path updates, regraft candidates).  tests/test_gpu_cfg5.py replays this stream at 100 000
+# patterns: cfg5's pin with a recorded instead of a seeded call stream.
+SYNTH_TRACES = {
+    # name: (n_otu, n_sites, seed, lmin, lmax, max records, driver opts, phyml args)
+    "trace_synth200_spr": (200, 260, 41, 0.02, 0.12, 46000, ["--gtr-rr", "1,2.5,0.8,1.2,3.0,1"],
+                           ["-d", "nt", "-m", "GTR", "-f", "0.3,0.2,0.2,0.3", "-c", "4", "-a", "0.8", "-s", "SPR", "-o", "tl", "-b", "0",
+                            "--r_seed", "1"]),
+}
+
 GLUE = os.path.join(ROOT, "oracle", "_ref", "phyml_glue_driver")
 SEARCHES = {
     # name: (example file, driver opts, phyml args) -- SPR topology search + branch lengths, model fixed
@@ -45,7 +57,10 @@ def main():
     if not os.path.exists(DRIVER):
         raise SystemExit("build oracle/_ref first: make -C oracle ref")
     tmp = tempfile.mkdtemp(prefix="traces_")
+    only = set(sys.argv[1:])  # (names on the command line: regenerate only those)
     for name, (example, nrec, dopts, pargs) in TRACES.items():
+        if only and name not in only:
+            continue
         shutil.copy(os.path.join(REF, "examples", example), tmp)
         os.chmod(os.path.join(tmp, example), 0o644)
         out = os.path.join(HERE, name + ".phyg")
@@ -56,6 +71,26 @@ def main():
             print(r.stdout[-3000:])
             raise SystemExit(f"trace driver failed for {name}")
         print(f"{name:22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
+
+    sys.path.insert(0, ROOT)
+    from phyml_amd import synth
+    for name, (n, sites, seed, lmin, lmax, nrec, dopts, pargs) in SYNTH_TRACES.items():
+        if only and name not in only:
+            continue
+        tree = synth.random_tree(n, seed, lmin, lmax)
+        st = synth.simulate_states(tree, sites, 4, seed)
+        synth.write_phylip(os.path.join(tmp, name + ".phy"), tree.names, synth.states_to_chars(st, 4))
+        out = os.path.join(HERE, name + ".phyg")
+        r = subprocess.run([DRIVER, out, str(nrec)] + dopts + ["--", "-i", name + ".phy"] + pargs, cwd=tmp,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        m = re.search(r"TRACE_DRIVER records=.*", r.stdout)
+        if r.returncode != 0 or not m:
+            print(r.stdout[-3000:])
+            raise SystemExit(f"trace driver failed for {name}")
+        print(f"{name:22s} {m.group(0)}  {os.path.getsize(out) / 1024:.0f} KiB")
+    if only:
+        shutil.rmtree(tmp, ignore_errors=True)
+        return 0
 
     # --- whole searches: the CPU-only run of the command lines tests/test_gpu_search.py repeats on the GPU ----------
     import json

@@ -27,7 +27,7 @@ def device_tree_from_recorded(d, host_pmat):
     return t
 
 
-@pytest.mark.parametrize("name", ["trace_nucleic_spr", "trace_proteic_spr"])
+@pytest.mark.parametrize("name", ["trace_nucleic_spr", "trace_proteic_spr", "trace_synth200_spr"])
 @pytest.mark.parametrize("host_pmat", [True, False])
 def test_device_reproduces_recorded_search(name, host_pmat):
     d = phyg.load(os.path.join(GOLDEN, name + ".phyg"))

@@ -15,7 +15,7 @@ from conftest import GOLDEN
 from phyml_amd import phyg, replay
 import replay_oracle
 
-TRACES = ["trace_nucleic_spr", "trace_proteic_spr"]
+TRACES = ["trace_nucleic_spr", "trace_proteic_spr", "trace_synth200_spr"]  # (the last: 200 taxa, 46 000 calls, round 4)
 
 
 @pytest.mark.parametrize("name", TRACES)
