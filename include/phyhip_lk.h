@@ -94,6 +94,13 @@ typedef struct __Tree
                                  rooted form the `phyml` program evaluates): the edge the root sits on, else NULL.  The
                                  ignore_root == NO special cases of src/lk.c:2988-3146 are not built: the reference's own AVX
                                  path cannot run them (oracle/probe_rooted.sh) */
+  /* `phyml --alias_subpatt` (src/cl.c:502, off by default src/init.c:624): Update_Partial_Lk calls Alias_One_Subpatt on the
+     node opposite d before anything else (src/lk.c:1294-1296), tips included.  That function only maintains the host
+     application's patt_id / p_lk_loc arrays (src/utilities.c:13547-13666); no likelihood function of the reference reads them
+     (they are written at src/lk.c:2501-2513 and in Alias_One_Subpatt, nowhere indexed else), so the option changes no number
+     of this path.  The gate is mirrored, the bookkeeping stays the application's: its own function goes here. */
+  short    do_alias_subpatt, update_alias_subpatt; /* tree->io->do_alias_subpatt, tree->update_alias_subpatt */
+  void   (*alias_one_subpatt)(struct __Node *a, struct __Node *d, struct __Tree *tree);
 } t_tree;
 
 #define PHL_N_SPARE 4

@@ -48,7 +48,7 @@
 #define kMaxClasses 64
 
 static int g_check = 0, g_device_pmat = 0, g_host = 0;
-static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat = 0, g_n_eig = 0, g_n_mixt = 0, g_n_mixt_skipped = 0;
+static long    g_n_lk = 0, g_n_lk_full = 0, g_n_upd = 0, g_n_dlk = 0, g_n_pmat = 0, g_n_eig = 0, g_n_mixt = 0, g_n_mixt_skipped = 0, g_n_alias = 0;
 static double  g_worst_lnl = 0.0, g_worst_dlnl = 0.0, g_worst_mixt = 0.0, g_worst_mixt_dlnl = 0.0;
 static long    g_n_mixt_dlk = 0;
 static double  g_last_mixt_lnl = 0.0, g_best_full_lnl = -1e300;
@@ -471,6 +471,12 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   if (b->left == d && b->update_partial_lk_left == NO) return;
   if (b->rght == d && b->update_partial_lk_rght == NO) return;
   if (tree->is_mixt_tree) { real(tree, b, d); return; } /* MIXT_Update_Partial_Lk: per class tree, back through this wrapper */
+  /* `--alias_subpatt` (src/lk.c:1294-1296): the application's own bookkeeping, at the place the reference calls it.  Nothing
+     of the likelihood reads what it writes (include/phyhip_lk.h), so the device path needs nothing from it.  (When real()
+     runs below -- host mode, check mode on an internal node -- it makes this call itself: not twice.) */
+  const int alias_here = tree->io->do_alias_subpatt == YES && tree->update_alias_subpatt == YES &&
+                         !(g_host || (g_check && !d->tax) || (tree->mixt_tree && tree->mod->ras->invar == YES));
+  if (alias_here) { Alias_One_Subpatt((d == b->left) ? b->rght : b->left, d, tree); ++g_n_alias; }
   if (d->tax) return;
   ++g_n_upd;
   if (g_host || (tree->mixt_tree && tree->mod->ras->invar == YES)) { real(tree, b, d); return; }
@@ -986,9 +992,9 @@ int main(int argc, char **argv)
          "\"calls\": {\"Lk\": %ld, \"Lk_full\": %ld, \"Update_Partial_Lk\": %ld, \"dLk\": %ld, \"Update_PMat\": %ld, "
          "\"Update_Eigen_Lr\": %ld}, \"worst_rel_lnL\": %.3g, \"worst_rel_dlnL\": %.3g, \"buffers\": %d, \"matrices\": %d, "
          "\"site_output_downloads\": %ld, \"worst_rel_site_output\": %.3g, \"mirrored_buffers\": %ld, \"mirror_mismatches\": %ld, \"instances_created\": %ld, "
-         "\"support_tree\": \"%s\", \"tree\": \"%s\"}\n",
+         "\"alias_one_subpatt_calls_made_here\": %ld, \"support_tree\": \"%s\", \"tree\": \"%s\"}\n",
          g_host ? "host" : (g_check ? "check" : "device"), g_device_pmat, lnl_init, lnl_final, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
-         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, g_mirror_buffers, g_mirror_mismatch, g_n_created, support_nwk ? support_nwk : "", nwk ? nwk : "");
+         g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, g_mirror_buffers, g_mirror_mismatch, g_n_created, g_n_alias, support_nwk ? support_nwk : "", nwk ? nwk : "");
   fflush(stdout);
   for (int k = 0; k < g_nctx; ++k) OK(phyhip_finalize_instance(g_ctx[k].inst));
   _exit(0);

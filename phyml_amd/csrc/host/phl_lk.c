@@ -406,6 +406,8 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
 {
   if (b->left == d && b->update_partial_lk_left == NO) return; /* src/lk.c:1285-1286 */
   if (b->rght == d && b->update_partial_lk_rght == NO) return;
+  if (tree->do_alias_subpatt == YES && tree->update_alias_subpatt == YES && tree->alias_one_subpatt) /* :1294-1296 */
+    tree->alias_one_subpatt((d == b->left) ? b->rght : b->left, d, tree);
   if (d->tax) return;                                          /* :1297 */
   phyhip_operation op;
   if (Fill_Operation(b, d, &op) < 0) { Lk_Exit("Update_Partial_Lk", "node is not an internal node of degree 3"); return; }

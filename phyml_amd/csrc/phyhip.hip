@@ -206,6 +206,8 @@ struct Instance
   TreeParams   rb_static;             // what its workgroups were launched with
   double      *d_tile_sums = nullptr; // [2][max(grid_nt2, n_vdlk)] tile sums of commands whose final sum runs on the device
   unsigned    *d_big_tickets = nullptr;
+  HostBlock   *d_big_recs = nullptr;  // [2][kBigGroupWgs] partial sums per workgroup (BigCtl::wg_recs)
+  bool         big_group_sum = true;  // (diag: PHYHIP_BIG_GROUP_SUM=0 keeps the per-tile sums and the tickets)
   unsigned long long *d_big_stamps = nullptr; // PHYHIP_RESIDENT_STATS: stamps of the last command per workgroup (BigCtl::stamps)
   int          n_vdlk = 0;            // virtual blocks (one wave each) of a dLk evaluation: dlk64_kernel's grid
   int          big_wgs = 0, big_nw = 0; // its workgroups and waves per workgroup
@@ -299,16 +301,6 @@ struct Instance
   int        prof_n = 0;
 };
 
-std::mutex              g_mu;
-std::vector<Instance *> g_inst;
-
-Instance *get(int id)
-{
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (id < 0 || id >= (int)g_inst.size()) return nullptr;
-  return g_inst[id];
-}
-
 // The calling thread's current device is ASKED, not remembered: a host application (or another library in its process) may
 // call hipSetDevice between two calls of this ABI, and a remembered value would then send the next launch to the wrong device
 // without any error.  hipGetDevice reads a thread-local of the runtime (tens of nanoseconds).
@@ -324,44 +316,114 @@ static inline int make_current(int dev)
   return 0;
 }
 
-// THE choke point of the resident protocol: resident workgroups are not ordered with the
-// instance's stream, so they may only be used while nothing queued on it is still running.  Every entry point of the C ABI
-// that names an instance comes through here (GET_INST) and thereby declares the stream dirty -- "may have enqueued work" is
-// the default.  The only ways back are the three leave_* helpers below, used by the entry points on the explicit lists of
-// tests/test_abi.py::test_resident_choke_point (a new entry point that touches an instance without GET_INST, or a new use
-// of a leave_* helper, fails that test until it is reviewed and listed).
-static inline void enter_stream_work(Instance *I)
-{
-  I->dirty_prev   = I->stream_dirty;
-  I->stream_dirty = true;
-  I->touched_call = false;
-  ++I->api_no;
-}
-// the call only queued (operations, matrix rebuilds): nothing went onto the stream unless a flush inside it said so
-static inline void leave_queued_only(Instance *I) { if (!I->touched_call) I->stream_dirty = I->dirty_prev; }
-// the call queues nothing by itself; whatever it runs (flush / eigen_eval) marks the stream itself
-static inline void leave_untouched(Instance *I) { I->stream_dirty = I->dirty_prev; }
-// a query: queues nothing and is not a step of the call sequence the resident evaluators watch
-static inline void leave_query(Instance *I) { I->stream_dirty = I->dirty_prev; --I->api_no; }
-
-// hipSetDevice costs about a microsecond; the surface is entered hundreds of thousands of times per tree
-// search, so only switch when the calling thread is actually on another device (make_current)
-// GET_INST_RES: the entry points the large-grid resident workgroups (phyhip_big.hpp) serve or that only queue -- they keep
-// those workgroups and release them themselves where they launch.  GET_INST: everything else may put copies or kernels on the
-// instance's stream, which must then be ordered behind the resident workgroups' exit (what they wrote sits in their L2s until
-// they leave): big_release() first.
 static void big_release(Instance *I, bool restart_streak = true);
-#define GET_INST_RES(I, id)                                                                                  \
-  Instance *I = get(id);                                                                                     \
-  if (!I) return fail(PHYHIP_ERROR_UNINITIALIZED_INSTANCE, "instance %d does not exist", id);                 \
-  {                                                                                                          \
-    const int rc_dev_ = make_current(I->dev);                                                                \
-    if (rc_dev_) return rc_dev_;                                                                             \
-  }                                                                                                          \
-  enter_stream_work(I);
-#define GET_INST(I, id)                                                                                      \
-  GET_INST_RES(I, id)                                                                                        \
-  big_release(I);
+
+// ---- the instance table and THE choke point of the resident protocol -------------------------------
+// Resident workgroups are not ordered with the instance's stream, so they may only be used while nothing queued on it is still
+// running.  That is kept true by construction, not by convention:
+//   * the table of instances is PRIVATE to InstanceTable.  The only way from an instance number to an Instance inside an entry
+//     point of the C ABI is an Entered<...> object (GET_INST / GET_INST_RES below), whose constructor declares the stream dirty
+//     -- "may have enqueued work" is the default -- and, unless the entry point says it keeps them, makes the large-grid
+//     resident workgroups leave before anything of this call can reach the stream;
+//   * the three ways back to "the stream is as it was found" are member functions that exist only on Entered<true>: an entry
+//     point that did not declare itself resident-aware cannot call them (static_assert: it does not compile).
+// What remains a reviewed list (tests/test_abi.py::test_resident_choke_point) is WHICH entry points say GET_INST_RES.
+// Construction and teardown (create / finalize, the wiring of a sharded group) use the lifecycle accessors, which run no call.
+template <bool KeepsResidents> class Entered;
+class InstanceTable
+{
+  static std::mutex              mu_;
+  static std::vector<Instance *> tab_;
+  static Instance *at(int id)
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (id < 0 || id >= (int)tab_.size()) return nullptr;
+    return tab_[id];
+  }
+  template <bool> friend class Entered;
+
+ public:
+  static int add(Instance *I) // phyhip_create_instance
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (size_t i = 0; i < tab_.size(); ++i)
+      if (!tab_[i])
+      {
+        tab_[i] = I;
+        return (int)i;
+      }
+    tab_.push_back(I);
+    return (int)tab_.size() - 1;
+  }
+  static Instance *remove(int id) // phyhip_finalize_instance: out of the table, the caller frees it
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (id < 0 || id >= (int)tab_.size()) return nullptr;
+    Instance *I = tab_[id];
+    tab_[id]    = nullptr;
+    return I;
+  }
+  static Instance *wiring(int id) { return at(id); } // a sharded group attaching / detaching its sub-instances: no call runs
+};
+std::mutex              InstanceTable::mu_;
+std::vector<Instance *> InstanceTable::tab_;
+
+template <bool KeepsResidents> class Entered
+{
+  Instance *I_  = nullptr;
+  int       rc_ = 0;
+
+ public:
+  explicit Entered(int id)
+  {
+    I_ = InstanceTable::at(id);
+    if (!I_)
+    {
+      rc_ = fail(PHYHIP_ERROR_UNINITIALIZED_INSTANCE, "instance %d does not exist", id);
+      return;
+    }
+    // hipSetDevice costs about a microsecond; the surface is entered hundreds of thousands of times per tree search (SURVEY
+    // section 6), so only switch when the calling thread is actually on another device (make_current)
+    if ((rc_ = make_current(I_->dev)) != 0) return;
+    I_->dirty_prev   = I_->stream_dirty;
+    I_->stream_dirty = true;
+    I_->touched_call = false;
+    ++I_->api_no;
+    // Everything but the entry points the large-grid resident workgroups (phyhip_big.hpp) serve, the ones that only queue and
+    // the queries that touch no device memory may put copies or kernels on the instance's stream, which must then be ordered
+    // behind the resident workgroups' exit (what they wrote sits in their L2s until they leave)
+    if (!KeepsResidents) big_release(I_);
+  }
+  Entered(const Entered &) = delete;
+  Entered &operator=(const Entered &) = delete;
+  int       rc() const { return rc_; }
+  Instance *inst() const { return I_; }
+  // the call only queued (operations, matrix rebuilds): nothing went onto the stream unless a flush inside it said so
+  void leave_queued_only() const
+  {
+    static_assert(KeepsResidents, "only an entry point that declared itself resident-aware (GET_INST_RES) may restore the stream's state");
+    if (!I_->touched_call) I_->stream_dirty = I_->dirty_prev;
+  }
+  // the call queues nothing by itself; whatever it runs (flush / eigen_eval) marks the stream itself
+  void leave_untouched() const
+  {
+    static_assert(KeepsResidents, "only an entry point that declared itself resident-aware (GET_INST_RES) may restore the stream's state");
+    I_->stream_dirty = I_->dirty_prev;
+  }
+  // a query: queues nothing and is not a step of the call sequence the resident evaluators watch
+  void leave_query() const
+  {
+    static_assert(KeepsResidents, "only an entry point that declared itself resident-aware (GET_INST_RES) may restore the stream's state");
+    I_->stream_dirty = I_->dirty_prev;
+    --I_->api_no;
+  }
+};
+#define GET_INST_AS(I, id, keeps)                                                                            \
+  const Entered<keeps> I##_call(id);                                                                         \
+  if (I##_call.rc()) return I##_call.rc();                                                                   \
+  Instance *const I = I##_call.inst();
+#define GET_INST_RES(I, id) GET_INST_AS(I, id, true)
+#define GET_INST(I, id) GET_INST_AS(I, id, false)
 
 int next_pow2(int x)
 {
@@ -759,6 +821,13 @@ static bool big_ready(Instance *I)
   return true;
 }
 
+// The final sum through one partial sum per workgroup (phyhip_big.hpp, kBigGroupSum): the tiles of a workgroup are one
+// accumulator of final_reduce_kernel's order only when there are exactly as many workgroups as accumulators
+static bool big_sum_by_group(const Instance *I, int tiles)
+{
+  return I->big_group_sum && I->big_wgs == kBigGroupWgs && tiles <= kBigGroupWgs * kBigGroupTiles;
+}
+
 static int big_launch(Instance *I, const TreeParams &sq)
 {
   Resident &R = I->rb;
@@ -768,6 +837,8 @@ static int big_launch(Instance *I, const TreeParams &sq)
     HIPCHK(hipMalloc((void **)&I->d_tile_sums, 2 * n * sizeof(double)));
     HIPCHK(hipMalloc((void **)&I->d_big_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
     HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), I->stream));
+    HIPCHK(hipMalloc((void **)&I->d_big_recs, sizeof(HostBlock) * 2 * kBigGroupWgs));
+    HIPCHK(hipMemsetAsync(I->d_big_recs, 0, sizeof(HostBlock) * 2 * kBigGroupWgs, I->stream)); // (tag 0: no evaluation's)
     if (getenv("PHYHIP_RESIDENT_STATS"))
     {
       HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs));
@@ -787,7 +858,7 @@ static int big_launch(Instance *I, const TreeParams &sq)
   BigArgs a;
   a.t = sq; a.r = r;
   a.b.n_tiles = I->grid_nt2; a.b.n_vdlk = I->n_vdlk; a.b.tile_sums = I->d_tile_sums; a.b.tickets = I->d_big_tickets; a.b.dot_prod = I->d_dot;
-  a.b.stamps = I->d_big_stamps;
+  a.b.stamps = I->d_big_stamps; a.b.wg_recs = I->d_big_recs;
   a.pmats = I->d_pmats; a.tip_codes = I->d_tipcodes;
   if (launch_resident_big(I->C, I->nt_groups, I->big_wgs, st, a) != 0)
     return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: no kernel for %d categories in %d groups", I->C, I->nt_groups);
@@ -1204,7 +1275,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       const bool dsum = host_sum_n > I->big_device_sum;
       words[0] = q.host_tag;
       words[1] = (unsigned long long)q.n_real_ops | (changed ? kBigChanged : 0ull) | ((unsigned long long)q.n_fresh << 4) |
-                 ((unsigned long long)q.e_prefetch << 8) | (q.edge_eval == 2 ? kBigEigen : 0ull) | (dsum ? kBigDeviceSum : 0ull);
+                 ((unsigned long long)q.e_prefetch << 8) | (q.edge_eval == 2 ? kBigEigen : 0ull) | (dsum ? kBigDeviceSum : 0ull) |
+                 (dsum && big_sum_by_group(I, host_sum_n) ? kBigGroupSum : 0ull);
       words[2] = (unsigned long long)(unsigned)q.e_parent | ((unsigned long long)(unsigned)q.e_child << 32);
       words[3] = (unsigned long long)(unsigned)q.e_pm | ((unsigned long long)(unsigned)q.last_dest << 32);
       for (int k = 0; k < q.n_fresh; ++k)
@@ -1721,7 +1793,7 @@ static void release_instance(Instance *I)
   if (I->stream) (void)hipStreamSynchronize(I->stream);
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
-                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks, I->d_tile_sums, I->d_big_tickets, I->d_big_stamps};
+                  I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks, I->d_tile_sums, I->d_big_tickets, I->d_big_stamps, I->d_big_recs};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (I->h_result) (void)hipHostFree(I->h_result);
@@ -1802,15 +1874,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
     returnInfo->computeUnits   = prop.multiProcessorCount;
     returnInfo->globalMemBytes = (long long)prop.totalGlobalMem;
   }
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (size_t i = 0; i < g_inst.size(); ++i)
-    if (!g_inst[i])
-    {
-      g_inst[i] = I;
-      return (int)i;
-    }
-  g_inst.push_back(I);
-  return (int)g_inst.size() - 1;
+  return InstanceTable::add(I);
 }
 
 // Device memory, staging, launch geometry and environment switches of a new instance.
@@ -1906,6 +1970,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   // tile w * workgroups + b -- and fill a CU's wave slots only then)
   I->big_wgs = std::max(1, std::min(I->cus, I->grid_nt2));
   if (const char *e = diag_env("PHYHIP_BIG_DEVICE_SUM")) I->big_device_sum = atoi(e);
+  if (const char *e = diag_env("PHYHIP_BIG_GROUP_SUM")) I->big_group_sum = atoi(e) != 0;
   // The pipelined nucleotide kernel is instruction-issue bound per CU, so CU-level balance matters more than
   // workgroup size: one-wave workgroups let the dispatcher spread e.g. 3125 waves as 12-13 per CU instead of
   // 3-4 four-wave groups (measured: 100 taxa x 50 000 patterns, 288 -> 25x us).
@@ -2015,20 +2080,14 @@ int phyhip_finalize_instance(int instance)
   }
   if (Group *G = get_group(instance))
   {
-    {
-      std::lock_guard<std::mutex> lk(g_mu);
-      g_groups[instance - kGroupBase] = nullptr;
-    }
+    forget_group(instance);
     release_group(G);
     return PHYHIP_SUCCESS;
   }
   GET_INST(I, instance);
   (void)hipStreamSynchronize(I->stream);
   collect_profile(I);
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_inst[instance] = nullptr;
-  }
+  (void)InstanceTable::remove(instance);
   if (I->co) release_collective(I->co);
   release_instance(I);
   return PHYHIP_SUCCESS;
@@ -2357,7 +2416,7 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
   // A whole-tree batch (Update_All_PMat, src/lk.c:500-512) is launched now rather than with the traversal: the device
   // rebuilds the matrices while the host walks the tree and fills the operation list.
   if (count >= kEagerPmBatch && I->eager_pmats) return flush_pmats(I);
-  leave_queued_only(I);
+  I_call.leave_queued_only();
   return PHYHIP_SUCCESS;
 }
 
@@ -2427,7 +2486,7 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
     I->mat_in_queue[o.child1TransitionMatrix] = 1;
     I->mat_in_queue[o.child2TransitionMatrix] = 1;
   }
-  leave_queued_only(I);
+  I_call.leave_queued_only();
   return PHYHIP_SUCCESS;
 }
 
@@ -2986,7 +3045,7 @@ int phyhip_get_numerical_warning(int instance, int *out)
   }
   else
   { // a query: it queues nothing and is not a step of the call sequence the resident evaluators watch
-    leave_query(I);
+    I_call.leave_query();
   }
   *out = *I->h_warn; // written by the final reduction of the last edge evaluation, ahead of its sequence number
   return PHYHIP_SUCCESS;
@@ -3132,7 +3191,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       const bool dsum = dgrid > I->big_device_sum;
       words[0] = q.fin.host_tag;
       words[1] = kBigDlk | (q.with_derivative ? kBigDeriv : 0ull) | (q.invar_model ? kBigInvar : 0ull) | (q.apply_scaling ? kBigScaling : 0ull) |
-                 (changed ? kBigChanged : 0ull) | (dsum ? kBigDeviceSum : 0ull);
+                 (changed ? kBigChanged : 0ull) | (dsum ? kBigDeviceSum : 0ull) | (dsum && big_sum_by_group(I, dgrid) ? kBigGroupSum : 0ull);
       memcpy(&words[2], &q.pinvar, 8);
       memcpy(&words[3], q.expl, sizeof(double) * (size_t)n_expl);
       resident_send(I, R, words, kBigWords);
@@ -3286,7 +3345,7 @@ int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, dou
 {
   Group *G = get_group(instance);
   GET_INST_RES(I, G ? G->sub_id[0] : instance);
-  leave_untouched(I); // (queues nothing by itself; flush() says so if it does)
+  I_call.leave_untouched(); // (queues nothing by itself; flush() says so if it does)
   if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN"); // src/lk.c:671
   if (*l < I->l_min) *l = I->l_min;                                                     // src/lk.c:673-674
   else if (*l > I->l_max) *l = I->l_max;
@@ -3299,7 +3358,7 @@ int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL)
 {
   if (Group *G = get_group(instance)) return group_eigen_eval(G, l, false, outLnL, nullptr);
   GET_INST_RES(I, instance);
-  leave_untouched(I);
+  I_call.leave_untouched();
   if (I->co) return rank_eigen_eval(I, l, false, outLnL, nullptr);
   return eigen_eval(I, l, false, outLnL, nullptr);
 }
@@ -3467,7 +3526,7 @@ int phyhip_get_resident_stats(int instance, long long out[8])
     return PHYHIP_SUCCESS;
   }
   GET_INST_RES(I, instance);
-  leave_query(I);
+  I_call.leave_query();
   for (int k = 0; k < 8; ++k) out[k] = 0;
   int k = 0;
   for (const Resident *R : {&I->rd, &I->rt})
@@ -3482,7 +3541,7 @@ int phyhip_get_big_resident_stats(int instance, long long out[4])
   for (int k = 0; k < 4; ++k) out[k] = 0;
   if (get_group(instance)) return PHYHIP_SUCCESS; // (sharded instances: never resident)
   GET_INST_RES(I, instance);
-  leave_query(I);
+  I_call.leave_query();
   const Resident *R = &I->rb;
   out[0] = (long long)R->n_cmd; out[1] = (long long)R->n_launch; out[2] = (long long)R->n_silent; out[3] = (long long)R->n_busy;
   return PHYHIP_SUCCESS;

@@ -31,14 +31,23 @@ namespace phyhip
 //   dLk command: 2 pinvar, 3.. the expl table (C x 2 x 4 doubles).
 // flags: bits 0-1 operations, 2 device data changed since the last command, 4-7 matrices to rebuild, 8-9 evaluation sides to
 // fetch early, 10 eigen products instead of the sum, 11 dLk command, 12 with derivative, 13 invariant-site model, 14 scaling,
-// 15 final sum on the device.
+// 15 final sum on the device, 16 (with 15) through one partial sum per workgroup.
 constexpr int kBigWords = kResidentNtWords > 3 + 32 ? kResidentNtWords : 3 + 32;
 static_assert((kBigWords + kResidentPay - 1) / kResidentPay <= 15, "a command must fit the one 512-byte read of a poll");
 enum : unsigned long long
 {
   kBigChanged = 1ull << 2, kBigEigen = 1ull << 10, kBigDlk = 1ull << 11, kBigDeriv = 1ull << 12, kBigInvar = 1ull << 13,
-  kBigScaling = 1ull << 14, kBigDeviceSum = 1ull << 15
+  kBigScaling = 1ull << 14, kBigDeviceSum = 1ull << 15, kBigGroupSum = 1ull << 16
 };
+// Final sum through one partial sum per workgroup: final_reduce_kernel adds the tile sums into 256 accumulators, tile i into
+// accumulator i % 256 in the order of i, and then the accumulators in a binary tree.  With EXACTLY 256 resident workgroups the
+// tiles of workgroup b are b, 256 + b, 512 + b, ... (tile = (round * NW + wave) * 256 + b): accumulator b, and nobody else's.
+// So the waves leave their tile sums in LDS (in their staging areas), the workgroup adds them in that order and posts ONE {sum, tag} record to device
+// memory, and workgroup 255 -- no tickets -- watches the 256 records until all carry the command's tag, then runs the tree:
+// same additions, same double; no per-tile stores to memory, no wait for their acknowledgement, no dependent atomics (two
+// round trips to memory), one load per thread instead of thirteen (3 126 tiles).  At most kBigGroupTiles tiles per workgroup.
+constexpr int kBigGroupTiles = 8 * 16; // (16 rounds of the smallest workgroup fit every staging area twice over)
+constexpr unsigned long long kBigGroupPatience = 20000; // wall-clock ticks (200 us) the watching workgroup waits for a record
 
 struct BigCtl
 {
@@ -47,6 +56,7 @@ struct BigCtl
   double       *tile_sums; // device [2][max(n_tiles, n_vdlk)]: the tile sums of a command whose final sum runs on the device
   unsigned     *tickets;   // device [1 + kTicketGroups], zero between commands
   const double *dot_prod;  // the eigen products (Update_Eigen_Lr's output, dLk's input)
+  HostBlock    *wg_recs;   // device [2][kBigGroupWgs] {sum, tag}: a workgroup's partial sums (kBigGroupSum), tags never 0
   // PHYHIP_RESIDENT_STATS: wall-clock stamps of the last command per workgroup, [workgroup][8]: 0 command seen, 1 after the
   // workgroup's barrier, 2 wave 0 through with its tiles, 3 all waves through, 4 ticket drawn, 5 final sum posted (nullptr: none)
   unsigned long long *stamps;
@@ -106,6 +116,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
   __shared__ ExecRec            sh_xr[2];
   __shared__ __attribute__((aligned(16))) double sh_dot[NW][(64 / G) * C * 4]; // per wave: staging of a tile's eigen products
   __shared__ double             sh_red[2][256];                                // the final sum's accumulators
+  __shared__ int                sh_late;
   unsigned long long last = args_.r.start_seq, t_last = wall_clock64();
   bool               mail_open = false;
   for (;;)
@@ -179,12 +190,34 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
       return ((unsigned long long)hi << 32) | lo;
     };
-    const unsigned long long tag = word(0), fl = word(1);
-    const bool               dsum = (fl & kBigDeviceSum) != 0;
-    BigCtl b;
-    karg_copy(b, &A->b);
-    b.tile_sums = as_global(b.tile_sums); b.tickets = as_global(b.tickets); b.dot_prod = as_global(b.dot_prod); b.stamps = as_global(b.stamps);
-    HostBlock *const host_blocks = as_global(A->t.host_blocks);
+    // The command's fields and the launch's control block are read where they are needed and AGAIN behind the tiles (from LDS
+    // and from the argument segment: a few scalar loads) instead of living in registers across them -- scalar registers that
+    // do not fit are kept in vector registers, and the four-category, one-lane-group kernel has none to spare.
+    struct Cmd
+    {
+      unsigned long long tag, fl;
+      BigCtl             b;
+      HostBlock         *host_blocks;
+    };
+    auto fetch = [&](unsigned long long k0) {
+      asm volatile("" : "+s"(k0) : : "memory");
+      k0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(k0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k0);
+      karg_args *A0 = reinterpret_cast<karg_args *>((karg_char *)k0);
+      Cmd        c;
+      c.tag = word(0); c.fl = word(1);
+      karg_copy(c.b, &A0->b);
+      c.b.tile_sums = as_global(c.b.tile_sums); c.b.tickets = as_global(c.b.tickets); c.b.dot_prod = as_global(c.b.dot_prod);
+      c.b.stamps = as_global(c.b.stamps); c.b.wg_recs = as_global(c.b.wg_recs);
+      c.host_blocks = as_global(A0->t.host_blocks);
+      return c;
+    };
+    int n_rec, ns;
+    {
+    const Cmd                cm = fetch(kaddr);
+    const unsigned long long tag = cm.tag, fl = cm.fl;
+    const bool               dsum = (fl & kBigDeviceSum) != 0, gsum = (fl & kBigGroupSum) != 0;
+    const BigCtl            &b = cm.b;
+    HostBlock *const         host_blocks = cm.host_blocks;
     auto stamp = [&](int i, unsigned long long t) {
       if (b.stamps && tid == 0) b.stamps[(size_t)bid * 8 + i] = t;
     };
@@ -193,7 +226,6 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
     // what kernels on the stream wrote since the last command (the host says whether any did) is re-read from memory
     if (fl & kBigChanged) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     constexpr int IT = CP / G > 0 ? CP / G : 1; // rounds of 64 (pattern, category) lanes per tile (dlk_tile)
-    int           n_rec, ns;
     if (fl & kBigDlk)
     { // ---- dLk / Lk in the eigen basis: dlk64_kernel's virtual blocks ----
       DlkParams dq;
@@ -207,13 +239,18 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
       }
       const DlkCall k = {(fl & kBigDeriv) ? 1 : 0, (fl & kBigInvar) ? 1 : 0, (fl & kBigScaling) ? 1 : 0, pinvar};
       n_rec = b.n_vdlk; ns = 2;
-      for (int vb = gw; vb < n_rec; vb += TW)
+      for (int vb = gw, round = 0; vb < n_rec; vb += TW, ++round)
       {
         double v[2];
         dlk_tile<4, CP, IT>(dq, k, sh_expl, as_global(A->t.warn), (unsigned)vb, lane, v);
         if (lane == 0)
         {
-          if (dsum)
+          if (gsum)
+          {
+            sh_dot[wid][2 * round] = v[0];
+            sh_dot[wid][2 * round + 1] = v[1];
+          }
+          else if (dsum)
           {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -266,6 +303,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
         q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
         q.tile_sums = (fl2 & kBigDeviceSum) ? A2->b.tile_sums : nullptr;
         globalize(q);
+        if (fl2 & kBigGroupSum) q.tile_sums = tile_sums_in_wave();
         const int n_ops = (int)(fl2 & 3);
         NtFresh   fr;
         // (the eigen system rides in the launch's TreeParams, as in a launched kernel: scalar loads from the argument segment;
@@ -285,7 +323,75 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
       }
     }
     stamp(2, wall_clock64());
-    if (dsum)
+    }
+    const Cmd                cm = fetch(kaddr);
+    const unsigned long long tag = cm.tag, fl = cm.fl;
+    const bool               dsum = (fl & kBigDeviceSum) != 0, gsum = (fl & kBigGroupSum) != 0;
+    const BigCtl            &b = cm.b;
+    HostBlock *const         host_blocks = cm.host_blocks;
+    auto stamp = [&](int i, unsigned long long t) {
+      if (b.stamps && tid == 0) b.stamps[(size_t)bid * 8 + i] = t;
+    };
+    if (gsum)
+    { // ---- the final sum on the device, one partial sum per workgroup (kBigGroupSum above) ----
+      __syncthreads(); // every wave's tile sums are in LDS
+      stamp(3, wall_clock64());
+      if (wid == 0 && lane < ns)
+      {
+        // (a wave's sums sit in its staging area: [round] of a traversal command, [round][2] of a dLk command)
+        // (an Update_Eigen_Lr command has no sum: its record says "done", the staging areas hold eigen products)
+        const int mine = (int)bid < n_rec && !(fl & kBigEigen) ? (n_rec - (int)bid + kBigGroupWgs - 1) / kBigGroupWgs : 0;
+        double    acc = 0.0;
+        for (int m = 0; m < mine; ++m) acc += sh_dot[m % NW][(m / NW) * ns + lane];
+        post_host_block(b.wg_recs + lane * kBigGroupWgs + bid, acc, tag); // (written through, sum and tag in one piece)
+      }
+      stamp(4, wall_clock64());
+      if (bid == kBigGroupWgs - 1)
+      {
+        if (tid == 0) sh_late = 0;
+        __syncthreads();
+        if (tid < kBigGroupWgs)
+        {
+          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+          const unsigned long long t_poll = wall_clock64();
+          for (int sidx = 0; sidx < ns; ++sidx)
+          {
+            u64x2 rec;
+            for (;;)
+            { // (like the atomic loads of the ticket path: from memory, where the other XCDs' workgroups wrote it through)
+              asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(rec) : "v"(b.wg_recs + sidx * kBigGroupWgs + tid) : "memory");
+              if (rec.y == tag) break;
+              if (wall_clock64() - t_poll > kBigGroupPatience) { sh_late = 1; break; } // (a workgroup that left: nobody answers, the host launches)
+            }
+            double d;
+            const unsigned long long bits = rec.x;
+            __builtin_memcpy(&d, &bits, 8);
+            sh_red[sidx][tid] = d;
+          }
+          if (ns == 1) sh_red[1][tid] = 0.0;
+        }
+        __syncthreads();
+        if (tid < 128) { sh_red[0][tid] += sh_red[0][tid + 128]; sh_red[1][tid] += sh_red[1][tid + 128]; }
+        __syncthreads();
+        if (wid == 0)
+        {
+          double t0 = sh_red[0][lane] + sh_red[0][lane + 64], t1 = sh_red[1][lane] + sh_red[1][lane + 64];
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1)
+          {
+            t0 += __shfl_down(t0, off, 64);
+            t1 += __shfl_down(t1, off, 64);
+          }
+          if (lane == 0 && !sh_late)
+          {
+            post_host_block(host_blocks, t0, tag);
+            if (ns == 2) post_host_block(host_blocks + 1, t1, tag);
+            stamp(5, wall_clock64());
+          }
+        }
+      }
+    }
+    else if (dsum)
     { // ---- the final sum on the device: tile sums written through, a ticket per workgroup, the last one adds and posts ----
       __builtin_amdgcn_s_waitcnt(0); // this wave's tile sums (atomic stores at agent scope: written through) are acknowledged ...
       __syncthreads();               // ... and every other wave's of the workgroup, before its ticket is drawn
@@ -357,7 +463,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
       }
     }
     __syncthreads(); // (wave 0 rewrites the command's staging area with its next poll)
-    if (!dsum) stamp(3, wall_clock64());
+    if (!dsum && !gsum) stamp(3, wall_clock64());
     last = last + 1; t_last = wall_clock64();
   }
 }

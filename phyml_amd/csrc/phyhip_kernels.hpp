@@ -149,11 +149,15 @@ struct TreeParams
   int             class_axis;
   // Large-grid resident evaluator (phyhip_big.hpp) with the final sum on the device: a tile's sum goes here (device memory,
   // [tile]) instead of to the host; the workgroup that finishes last adds them in final_reduce_kernel's order and posts ONE record.
+  // (tile_sums_in_wave(): the same evaluator adding per workgroup, kBigGroupSum -- the sum stays in the wave's LDS area)
   double         *tile_sums;
   // PHYHIP_FLAG_GENERIC_LOOP: the arithmetic of Update_Partial_Lk_Generic under mod->use_m4mod (`phyml --cov`): no all-ones
   // shortcut (src/lk.c:1463-1528 has none; src/avx.c:575-587 does)
   int             generic_loop;
 };
+
+constexpr int kBigGroupWgs = 256; // workgroups of the large-grid resident evaluator when it adds per workgroup (phyhip_big.hpp)
+__device__ __forceinline__ double *tile_sums_in_wave() { return reinterpret_cast<double *>(8ull); } // (no buffer's address)
 
 // ---------------------------------------------------------------------------------------------
 // cross-lane helpers over the CP adjacent lanes that share a pattern

@@ -528,6 +528,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         __builtin_amdgcn_wave_barrier(); // (the next tile of a resident wave stages into the same area)
       }
       // completion as an evaluation's (launched or resident): stores fenced, then an empty record per workgroup
+      if (LREC && q.tile_sums == tile_sums_in_wave()) return; // (adding per workgroup: the workgroup reports, phyhip_big.hpp)
       publish_block_sum(q, 0.0, lane, tile);
       return;
     }
@@ -602,6 +603,12 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+  if (LREC && q.tile_sums == tile_sums_in_wave())
+  { // (large-grid resident evaluator adding per workgroup, phyhip_big.hpp: the sum of the wave's n-th tile stays in the wave's
+    // staging area, which a sum command does not use otherwise; tile = (n * NW + wave) * kBigGroupWgs + workgroup)
+    if (lane == 0) lds_dot[tile / (unsigned)(NW * kBigGroupWgs)] = contrib;
+    return;
+  }
   publish_block_sum(q, contrib, lane, tile);
 }
 

@@ -219,15 +219,21 @@ struct Group
   std::vector<ShardWorker *> workers; // one per shard when the shards sit on more than one device (or PHYHIP_SHARD_THREADS=1)
 };
 
+std::mutex           g_groups_mu;
 std::vector<Group *> g_groups;
 
 Group *get_group(int id)
 {
   if (id < kGroupBase) return nullptr;
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_groups_mu);
   const int k = id - kGroupBase;
   if (k >= (int)g_groups.size()) return nullptr;
   return g_groups[k];
+}
+static void forget_group(int id)
+{
+  std::lock_guard<std::mutex> lk(g_groups_mu);
+  g_groups[id - kGroupBase] = nullptr;
 }
 
 template <typename F> int group_each(Group *G, F &&f)
@@ -279,7 +285,7 @@ static void release_group(Group *G)
   for (int id : G->sub_id)
     if (id >= 0)
     {
-      Instance *I = get(id);
+      Instance *I = InstanceTable::wiring(id);
       if (I && !I->own_stream) I->stream = nullptr; // shared stream: owned by the device's first shard
       (void)phyhip_finalize_instance(id);
     }
@@ -326,7 +332,7 @@ static int create_group(int tipCount, int partialsBufferCount, int stateCount, i
       return id;
     }
     if (g == 0 && returnInfo) *returnInfo = det;
-    Instance *I = get(id);
+    Instance *I = InstanceTable::wiring(id);
     int ci = -1;
     for (size_t k = 0; k < G->co->ctx.size(); ++k)
       if (G->co->ctx[k].dev == dev) ci = (int)k;
@@ -389,7 +395,7 @@ static int create_group(int tipCount, int partialsBufferCount, int stateCount, i
         G->workers.push_back(w);
       }
   }
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_groups_mu);
   for (size_t i = 0; i < g_groups.size(); ++i)
     if (!g_groups[i])
     {

@@ -49,7 +49,8 @@ class t_tree(C.Structure):
                 ("update_eigen_lr", C.c_short), ("apply_lk_scaling", C.c_short), ("numerical_warning", C.c_short),
                 ("host_pmat", C.c_short), ("c_lnL", C.c_double), ("old_lnL", C.c_double), ("c_dlnL", C.c_double),
                 ("n_edges_traversed", C.c_int), ("spare_p_lk_idx", C.c_int), ("spare_Pij_idx", C.c_int),
-                ("e_root", C.POINTER(t_edge))]
+                ("e_root", C.POINTER(t_edge)), ("do_alias_subpatt", C.c_short), ("update_alias_subpatt", C.c_short),
+                ("alias_one_subpatt", C.c_void_p)]
 
 
 _lib = None

@@ -42,7 +42,7 @@ def main():
         t.close()
     res["stream"] = [float.hex(float(x)) for x in a]
     res["stream2"] = [float.hex(float(x)) for x in a2]
-    # the same stream with host-computed matrices (the argument-upload route), and on an alignment of 157 tiles (the
+    # the same stream with host-computed matrices (the argument-upload route), and on an alignment of 282 tiles (the
     # large-grid resident evaluator's range)
     t, ot, tree, st = synthetic_pair(26, 900, 4, 4, seed=19, host_pmat=True, ambiguous_every=11)
     try:
@@ -51,7 +51,7 @@ def main():
         h, h2 = t.Replay_Surface_Trace(tr)
     finally:
         t.close()
-    t, ot, tree, st = synthetic_pair(14, 5000, 4, 4, seed=21, host_pmat=False, ambiguous_every=11)
+    t, ot, tree, st = synthetic_pair(14, 9000, 4, 4, seed=21, host_pmat=False, ambiguous_every=11)
     try:
         t.Set_Both_Sides(True)
         t.Lk(None)

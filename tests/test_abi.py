@@ -150,13 +150,14 @@ def test_every_environment_switch_is_documented():
 
 def test_resident_choke_point():
     """The resident evaluators are only safe while every entry point that names an instance declares the stream dirty unless it
-    is KNOWN not to have enqueued anything.  Enforced statically on the source: every exported `phyhip_*` function either goes
-    through GET_INST (= enter_stream_work, the choke point) or is on the reviewed list of functions that never touch an
-    instance's stream themselves; the three `leave_*` helpers (the only ways back to "clean") are used by exactly the reviewed
-    functions; nothing else writes `stream_dirty = ... dirty_prev`."""
+    is KNOWN not to have enqueued anything.  That part is enforced by the compiler (phyhip.hip, `InstanceTable` / `Entered`): the
+    instance table is private, so an entry point reaches an Instance only through an `Entered<...>` object (GET_INST /
+    GET_INST_RES) whose constructor is the choke point, and the three ways back to "clean" are members of `Entered<true>` only
+    (a static_assert in each: test_choke_point_is_a_compile_time_property compiles the counter-example).  What is left to review
+    by list is WHICH entry points declare themselves resident-aware, and which of the three ways back each one takes."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "phyml_amd", "csrc", "phyhip.hip")).read()
+    src = "".join(open(os.path.join(root, "phyml_amd", "csrc", f)).read() for f in ("phyhip.hip", "phyhip_shard.hpp"))
     ext = src[src.index('extern "C" {'):]
     heads = [(m.start(), m.group(1)) for m in re.finditer(r'^(?:int|const char \*)\s*(phyhip_[a-z_0-9]+)\(', ext, flags=re.M)]
     bodies = {}
@@ -164,42 +165,19 @@ def test_resident_choke_point():
         bodies[name] = ext[a:nxt[0]]
     from phyml_amd import capi
     assert set(capi.SYMBOLS) <= set(bodies), sorted(set(capi.SYMBOLS) - set(bodies))
-    # functions that never name ONE instance's stream themselves: no instance at all, creation, or a loop that calls GET_INST
-    # per class instance
-    NO_INSTANCE = {"phyhip_get_last_error", "phyhip_create_instance", "phyhip_comm_get_unique_id"}
-    # static *_impl functions (the body of an entry point that also has a sharded form): they carry the GET_INST themselves
-    impls = {}
-    ih = [(m.start(), m.group(1)) for m in re.finditer(r'^static int\s*([a-z_0-9]+_impl)\(', ext, flags=re.M)]
-    allh = sorted(heads + ih)
-    for (a, name), nxt in zip(allh, allh[1:] + [(len(ext), None)]):
-        if name.endswith("_impl"):
-            impls[name] = ext[a:nxt[0]]
-            bodies.pop(name, None)
-    for name, body in list(bodies.items()):
-        for iname in impls:   # (an entry point's text ends where the next function starts: cut a following *_impl off)
-            k = body.find("static int " + iname)
-            if k >= 0:
-                bodies[name] = body = body[:k]
-    assert all("GET_INST(" in b for b in impls.values()), [n for n, b in impls.items() if "GET_INST(" not in b]
-    # GET_INST_RES (= GET_INST without releasing the large-grid resident workgroups): the entry points those workgroups serve,
-    # the ones that only queue, and the queries that touch no device memory -- a reviewed list
     keepers = {name for name, body in bodies.items() if "GET_INST_RES(" in body}
     assert keepers == {"phyhip_update_transition_matrices", "phyhip_set_transition_matrix", "phyhip_update_partials",
                        "phyhip_update_eigen_lr", "phyhip_calculate_edge_log_likelihoods", "phyhip_calculate_eigen_lnl_dlnl",
                        "phyhip_calculate_eigen_lnl", "phyhip_get_numerical_warning", "phyhip_get_resident_stats",
                        "phyhip_get_big_resident_stats"}, sorted(keepers)
-    for name, body in bodies.items():
-        if name in NO_INSTANCE:
-            continue
-        through_impl = any(iname + "(" in body for iname in impls)
-        assert "GET_INST(" in body or "GET_INST_RES(" in body or through_impl, \
-            f"{name}: touches an instance without the choke point (GET_INST / enter_stream_work)"
     REVIEWED = {"leave_queued_only": {"phyhip_update_transition_matrices", "phyhip_update_partials"},
                 "leave_untouched": {"phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl"},
                 "leave_query": {"phyhip_get_numerical_warning", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats"}}
     for helper, allowed in REVIEWED.items():
-        users = {name for name, body in bodies.items() if helper + "(" in body}
+        users = {name for name, body in bodies.items() if "." + helper + "(" in body}
         assert users == allowed, (helper, sorted(users ^ allowed))
-    # ... and nobody restores the flag by hand
-    assert len(re.findall(r"stream_dirty\s*=\s*I->dirty_prev", src)) == 3  # the three helpers themselves
-    assert src.count("enter_stream_work(I)") == 1  # called from GET_INST and nowhere else
+    # the table is reachable through the class only, and nobody restores the flag by hand
+    assert len(re.findall(r"tab_\[", src)) == len(re.findall(r"tab_\[", src[src.index("class InstanceTable"):src.index("template <bool KeepsResidents> class Entered\n")]))
+    assert len(re.findall(r"stream_dirty\s*=\s*I_?->dirty_prev", src)) == 3  # the three members themselves
+    assert set(re.findall(r"InstanceTable::(\w+)\(", src)) == {"at", "add", "remove", "wiring"}
+    assert src.count("InstanceTable::wiring(") == 2 and "phyhip_shard.hpp" and src.count("InstanceTable::at(") == 1

@@ -265,6 +265,45 @@ def test_update_lk_at_given_edge(golden):
         t.close()
 
 
+def test_alias_subpatt_gate_is_mirrored(golden):
+    """`phyml --alias_subpatt` (src/lk.c:1294-1296): Update_Partial_Lk hands (the node opposite d, d) to the application's
+    Alias_One_Subpatt before anything else -- for tips too, and not when the update flag of that side is off -- and the numbers
+    do not change (no likelihood function reads that bookkeeping, include/phyhip_lk.h)."""
+    import ctypes as C
+    d = golden("nucleic_gtr_g4")
+    t, ot = gpu_common.device_tree_from_golden(d)
+    try:
+        t.Set_Both_Sides(True)
+        lnl = t.Lk(None)
+        seen = []
+        cb_t = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
+        num = lambda p: C.cast(p, C.POINTER(type(t.node(0).contents))).contents.num
+        cb = cb_t(lambda a, dd, tree: seen.append((num(a), num(dd))))
+        tr = t.tree.contents
+        tr.alias_one_subpatt = C.cast(cb, C.c_void_p).value
+        tr.do_alias_subpatt = 1
+        tr.update_alias_subpatt = 0
+        t.Lk(None)
+        assert not seen                                        # both switches, like the reference
+        tr.update_alias_subpatt = 1
+        n0 = tr.n_edges_traversed
+        assert t.Lk(None) == lnl
+        # the traversals never reach Update_Partial_Lk with a tip (src/lk.c:285, 362): one call per partial update they make
+        assert len(seen) == t.tree.contents.n_edges_traversed - n0 and len(seen) >= 2 * (t.n - 2)
+        assert all(dd >= t.n for a, dd in seen)
+        e = next(k for k in range(t.ne) if t.edge(k).contents.rght.contents.tax == 1)
+        eb = t.edge(e).contents
+        del seen[:]
+        t.Update_Partial_Lk(e, eb.rght.contents.num)           # a tip: the call is made, nothing is queued
+        assert seen == [(eb.left.contents.num, eb.rght.contents.num)]
+        eb.update_partial_lk_rght = 0
+        t.Update_Partial_Lk(e, eb.rght.contents.num)
+        assert len(seen) == 1
+        eb.update_partial_lk_rght = 1
+    finally:
+        t.close()
+
+
 def test_rooted_input_tree_with_the_root_ignored(golden):
     """tree->n_root != NULL with ignore_root == YES (src/lk.c:420-429, 545-556, 573-576): the traversal starts from the two
     ends of the root edge and the likelihood is evaluated there; by the pulley principle it is the unrooted tree's value,

@@ -33,20 +33,20 @@ EXPECTED = json.load(open(os.path.join(GOLDEN, "search_expected.json")))
 _cache = {}
 
 
-def run_search(name, mode, tmp_path, device_pmat=False, devices=None):
-    key = (name, mode, device_pmat, devices)
+def run_search(name, mode, tmp_path, device_pmat=False, devices=None, extra=()):
+    key = (name, mode, device_pmat, devices, tuple(extra))
     if key in _cache:
         return _cache[key]
     if not os.path.exists(GLUE):
         pytest.skip("oracle/_ref/phyml_glue_driver not built (needs the reference: make -C oracle ref in the build container)")
     e = EXPECTED[name]
-    wd = os.path.join(str(tmp_path), mode + ("_dp" if device_pmat else "") + ("_sh" if devices else ""))
+    wd = os.path.join(str(tmp_path), mode + ("_dp" if device_pmat else "") + ("_sh" if devices else "") + "".join(extra).replace("-", "_"))
     os.makedirs(wd, exist_ok=True)
     shutil.copy(os.path.join(GOLDEN, "examples_" + e["example"] + ".phy"), os.path.join(wd, e["example"]))
     env = dict(os.environ, GLUE_MODE=mode, GLUE_DEVICE_PMAT="1" if device_pmat else "0")
     if devices:
         env["GLUE_DEVICES"] = devices
-    r = subprocess.run([GLUE] + e["driver_opts"] + ["--", "-i", e["example"]] + e["phyml_args"], cwd=wd, env=env,
+    r = subprocess.run([GLUE] + e["driver_opts"] + ["--", "-i", e["example"]] + e["phyml_args"] + list(extra), cwd=wd, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
     assert r.returncode == 0 and m, r.stdout[-2000:]
@@ -85,6 +85,20 @@ def test_real_search_driven_by_the_device(name, tmp_path):
         assert 0.5 * ref["calls"][k] < info["calls"][k] < 2.0 * ref["calls"][k]
     if info["calls"] == ref["calls"]:
         assert abs(info["lnL_final"] - ref["lnL_final"]) <= 1e-9 * abs(ref["lnL_final"])
+
+
+def test_real_search_with_alias_subpatt(tmp_path):
+    """`phyml --alias_subpatt` (src/cl.c:502 -> src/lk.c:1294-1296): the application's Alias_One_Subpatt runs
+    where the reference calls it -- hundreds of thousands of times in a search -- and, as in the reference (CPU counterpart:
+    tests/test_oracle_golden.py), not one number of the path depends on it: the device-driven search is the same search."""
+    base = run_search("search_nucleic_spr", "device", tmp_path)
+    info = run_search("search_nucleic_spr", "device", tmp_path, extra=("--alias_subpatt",))
+    assert info["alias_one_subpatt_calls_made_here"] >= info["calls"]["Update_Partial_Lk"] > 100000
+    assert base["alias_one_subpatt_calls_made_here"] == 0
+    assert info["calls"] == base["calls"]
+    assert info["lnL_init"] == base["lnL_init"] and info["lnL_final"] == base["lnL_final"] and info["tree"] == base["tree"]
+    chk = run_search("search_nucleic_spr", "check", tmp_path, extra=("--alias_subpatt",))
+    assert chk["worst_rel_lnL"] < 1e-10 and chk["worst_rel_dlnL"] < 1e-6
 
 
 def test_real_search_on_a_sharded_instance(tmp_path):

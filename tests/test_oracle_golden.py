@@ -182,3 +182,31 @@ def test_generic_loop_door_is_pinned(golden):
     t1 = orc.tree_from_golden(d, arith=1)
     t1.lk(None, both_sides=True)
     assert not np.array_equal(t1.plk[(0, 0)][w], np.asarray(d["p_lk_left_0"])[w])  # (the SIMD arithmetic is another one)
+
+
+def test_alias_subpatt_changes_no_number_of_the_reference(tmp_path):
+    """`phyml --alias_subpatt` (src/cl.c:502; SURVEY 8 row a2: Update_Partial_Lk calls Alias_One_Subpatt first, src/lk.c:1294-1296).
+    The function fills the edges' patt_id / p_lk_loc arrays (src/utilities.c:13547-13666) and no likelihood function indexes them
+    (`grep 'p_lk_loc[a-z_]*\\['` over src/: lk.c:2501-2502 and Alias_One_Subpatt itself, all writes).  Evidence from the reference
+    itself (oracle/_ref, host mode = its own AVX path, nothing of this repo in the arithmetic): the full SPR search of
+    tests/golden/search_expected.json with and without the option makes the same calls and ends on the same doubles and the same
+    tree.  So the drop-in mirrors the gate (phl_lk.c, glue driver) and needs no device work for it."""
+    import json, os, re, shutil, subprocess
+    from conftest import GOLDEN, ROOT
+    glue = os.path.join(ROOT, "oracle", "_ref", "phyml_glue_driver")
+    if not os.path.exists(glue):
+        pytest.skip("oracle/_ref not built (make -C oracle ref in the build container)")
+    e = json.load(open(os.path.join(GOLDEN, "search_expected.json")))["search_nucleic_spr"]
+    out = []
+    for extra in ([], ["--alias_subpatt"]):
+        wd = os.path.join(str(tmp_path), "a%d" % len(extra))
+        os.makedirs(wd)
+        shutil.copy(os.path.join(GOLDEN, "examples_nucleic.phy"), os.path.join(wd, "nucleic"))
+        r = subprocess.run([glue] + e["driver_opts"] + ["--", "-i", "nucleic"] + e["phyml_args"] + extra, cwd=wd,
+                           env=dict(os.environ, GLUE_MODE="host"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
+        assert r.returncode == 0 and m, r.stdout[-2000:]
+        out.append(json.loads(m.group(1)))
+    a, b = out
+    assert a["calls"] == b["calls"] and a["calls"]["Update_Partial_Lk"] > 100000
+    assert a["lnL_init"] == b["lnL_init"] and a["lnL_final"] == b["lnL_final"] and a["tree"] == b["tree"]

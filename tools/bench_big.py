@@ -83,6 +83,8 @@ def main():
     cfgs = {"launch": {"PHYHIP_RESIDENT": "0"}, "product": {},
             "host_sum": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_DEVICE_SUM": "100000000"},
             "device_sum": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_DEVICE_SUM": "0"},
+            "tickets": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_GROUP_SUM": "0"},  # device sum through per-tile sums and tickets
+            "diag": {"PHYHIP_LIBDIR": diag},
             "g1": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1"}, "g2": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "2"},
             "g1_launch": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1", "PHYHIP_RESIDENT": "0"}}
     for name in args.configs.split(","):
