@@ -109,13 +109,14 @@ def measured_roofline():
 
 
 def kernel_source_hash():
-    """Identity of the kernels a counter profile belongs to: hash of the device code, i.e. every header under
-    phyml_amd/csrc (all kernels live in *.hpp; phyhip.hip is the host side)."""
+    """Identity of the kernels a counter profile belongs to: hash of the device code, i.e. the kernel headers under
+    phyml_amd/csrc (all kernels of the path live in *.hpp; the *.hip units and phyhip_host.hpp / phyhip_shard.hpp are the
+    host side)."""
     h = hashlib.sha256()
     base = os.path.join(ROOT, "phyml_amd", "csrc")
     for f in sorted(os.listdir(base)):
         p = os.path.join(base, f)
-        if os.path.isfile(p) and f.endswith(".hpp"):
+        if os.path.isfile(p) and f.endswith(".hpp") and f not in ("phyhip_host.hpp", "phyhip_shard.hpp"):
             h.update(f.encode()); h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
@@ -318,8 +319,11 @@ def brlen_block(t, taxa, P, S, C):
     for i in range(3):
         t.dLk(0.05, e)
     # kernel times of K3 / K4 (HIP events around each launch: profiling an instance makes every call a launch) ...
-    t.inst.profile(1)
     n_chain, n_dlk = 40, 5
+    t.inst.profile(1)  # (one round unmeasured: the first launch of a kernel also loads its code object -- each translation unit's lazily)
+    t.Set_Update_Eigen_Lr(1); t.Update_Eigen_Lr(e); t.Set_Update_Eigen_Lr(0)
+    t.dLk(0.05, e)
+    t.inst.profile(1)  # (resets the sums)
     for k in range(8):
         t.Set_Update_Eigen_Lr(1); t.Update_Eigen_Lr(e); t.Set_Update_Eigen_Lr(0)
         for i in range(n_dlk):

@@ -82,7 +82,7 @@ struct FragParams
   double       *afrag;
 };
 
-__global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
+static __global__ __launch_bounds__(256) void aa_frag_kernel(const FragParams q)
 {
   int m;
   if (q.indices) m = q.indices[blockIdx.x];
@@ -111,7 +111,7 @@ struct MatUploadParams
   double       *afrag;             // nullptr unless 20 states
 };
 
-__global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadParams q)
+static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadParams q)
 {
   extern __shared__ __attribute__((aligned(16))) double mat[]; // [C][S][S]
   int           m   = q.idx[0];

@@ -1,0 +1,270 @@
+// phyhip_resident.hip -- host side of the resident evaluators: launching, commanding and releasing the persistent workgroups
+// (libphyhip.so, gfx950 only; the units and what they share: phyhip_host.hpp)
+#include "phyhip_host.hpp"
+
+namespace phyhip_host
+{
+
+// "Everything queued on this stream before me has finished and is in memory": one thread, one store into host-mapped
+// memory.  Launched behind evaluations of large nucleotide instances that the resident workgroups could not take (stream
+// not known to be idle, first call of a streak): the host finds the stream idle again without synchronising it -- and without
+// the launched kernel's waves writing back their L2 before they post (megabytes of dirty lines at these sizes).
+static __global__ void stream_stamp_kernel(unsigned long long *stamp_host, unsigned long long stamp)
+{
+  __hip_atomic_store(stamp_host, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Tell the resident workgroups (if any) to leave and wait until they have.
+void resident_stop(Resident &R)
+{
+  if (!R.cmd || !R.launched) return;
+  __atomic_store_n(&R.cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
+  for (hipStream_t st : R.stream)
+    if (st) (void)hipStreamSynchronize(st);
+  __atomic_store_n(&R.cmd->ctl.w[1], 0ull, __ATOMIC_RELEASE);
+  R.launched = false;
+}
+
+void resident_free(Resident &R)
+{
+  if (R.cmd)
+  { // (also a generation that was only told to leave, big_release: nobody may still be polling the record when it is freed)
+    __atomic_store_n(&R.cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
+    for (hipStream_t st : R.stream)
+      if (st) (void)hipStreamSynchronize(st);
+    R.launched = false;
+  }
+  resident_stop(R);
+  if (R.cmd) (void)hipHostFree(R.cmd);
+  if (R.mail) (void)hipFree(R.mail);
+  for (hipStream_t st : R.stream)
+    if (st) (void)hipStreamDestroy(st);
+  R = Resident();
+}
+
+// First half of a (re)launch: generation gen + 1 supersedes whatever is left of the previous one (its workgroups see the
+// new number at their next poll and leave); commands up to `served` count as done.  The caller launches its kernel with `r`
+// on `*st`, then calls resident_launched().
+// in_order: every generation on the SAME stream -- the large-grid workgroups leave what they stored to the end of their
+// kernel (no write-back per command), so a new generation must not start before the previous one has ended.
+int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned long long served, ResidentCtl &r, hipStream_t *st,
+                     bool in_order)
+{
+  if (!R.cmd)
+  {
+    HIPCHK(hipHostMalloc((void **)&R.cmd, sizeof(ResidentCmd), hipHostMallocMapped | hipHostMallocCoherent)); // (polled from the device while it changes)
+    memset(R.cmd, 0, sizeof(ResidentCmd));
+    HIPCHK(hipMalloc((void **)&R.mail, sizeof(ResidentCmd)));
+    HIPCHK(hipMemset(R.mail, 0, sizeof(ResidentCmd)));
+    for (hipStream_t &s2 : R.stream) HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  }
+  ++R.n_launch;
+  ++R.gen;
+  __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
+  r.cmd = R.cmd; r.gen = R.gen; r.start_seq = served; r.n_sectors = (n_words + kResidentPay - 1) / kResidentPay;
+  r.mail = R.mail; r.relay = grid > I->resident_direct ? 1 : 0;
+  if (I->wall_khz <= 0)
+  {
+    int dev = 0, khz = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    I->wall_khz = khz;
+  }
+  r.idle_ticks = (unsigned long long)(I->resident_idle_us * 1e-3 * (double)I->wall_khz); // wall_clock64 ticks
+  *st = R.stream[in_order ? 0 : (R.gen & 1)];
+  return 0;
+}
+void resident_launched(Resident &R, int grid)
+{
+  R.grid = grid; R.launched = true;
+  clock_gettime(CLOCK_MONOTONIC, &R.t_launch);
+}
+
+// Have the workgroups of the current generation left?  (Workgroup 0 reports it, see ResidentCmd::report.)
+bool resident_gone(const Resident &R)
+{
+  return R.cmd && __atomic_load_n(&R.cmd->report.w[0], __ATOMIC_ACQUIRE) == R.gen;
+}
+
+// The command: payload words into their sectors, each sector's number last (see ResidentCmd)
+void resident_send(Instance *I, Resident &R, const unsigned long long *words, int n_words)
+{
+  ++R.seq;
+  for (int l = 0; l * kResidentPay < n_words; ++l)
+  {
+    ResidentSector &sc = R.cmd->sec[l];
+    for (int k = 0; k < kResidentPay && l * kResidentPay + k < n_words; ++k) sc.w[k] = words[l * kResidentPay + k];
+    __atomic_store_n(&sc.seq, R.seq, __ATOMIC_RELEASE);
+  }
+  R.api_no = I->api_no;
+  ++R.n_cmd;
+  clock_gettime(CLOCK_MONOTONIC, &R.t_cmd);
+  I->r_inflight = &R;
+}
+
+int resident_launch_dlk(Instance *I, const DlkParams &qs, int dgrid, unsigned long long served)
+{
+  ResidentCtl r;
+  hipStream_t st;
+  int rc = resident_prepare(I, I->rd, dgrid, 3 + I->C * 2 * I->S, served, r, &st);
+  if (rc) return rc;
+  rc = dispatch_shape(I, [&](auto s, auto cp) {
+    constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
+    hipLaunchKernelGGL((resident_dlk_kernel<S_, CP_>), dim3(dgrid), dim3(256), 0, st, qs, r);
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  I->r_static = qs;
+  resident_launched(I->rd, dgrid);
+  return 0;
+}
+
+// Tell the large-grid resident workgroups (if any) to leave -- without waiting for it: whatever this instance launches next
+// needs their wave slots, and gets them as they go.  (A new generation number is all it takes: workgroup 0 sees it at its
+// next poll of the host record and passes it on through the mailbox.)
+// The instance's stream is ordered behind their exit: the resident workgroups do not write back what they store while they
+// stay (a write-back per command of megabytes of dirty lines cost more than the command: measured, round 4) -- the end of
+// their kernel does, and kernels and copies of this instance that come later must find it in memory.
+void big_release(Instance *I, bool restart_streak)
+{
+  if (restart_streak) I->big_streak = 0;
+  Resident &R = I->rb;
+  if (R.cmd && R.launched)
+  {
+    hipStream_t st = R.stream[0]; // (where every generation of these workgroups runs, resident_prepare)
+    ++R.gen;
+    __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
+    R.launched = false;
+    if (I->ev_big && hipEventRecord(I->ev_big, st) == hipSuccess) (void)hipStreamWaitEvent(I->stream, I->ev_big, 0);
+    else (void)hipStreamSynchronize(st);
+    I->stream_dirty = true; I->touched_call = true; // (the stream now waits for something)
+  }
+  if (I->dev >= 0 && I->dev < 64)
+  {
+    Instance *me = I;
+    g_big_owner[I->dev].compare_exchange_strong(me, nullptr);
+  }
+}
+
+// Is everything queued on the instance's stream known to have finished?  (The flags of enter_stream_work and the stamp
+// launched behind the last evaluation.  hipStreamQuery was tried instead: it answers "not ready" for a stream whose last
+// command is a kernel until a marker it inserts itself has completed -- with a new launch after every query, never.)
+bool big_clean(Instance *I)
+{
+  if (I->touched_call || I->dirty_prev) return false;
+  if (I->clean_after)
+  { // the stamp launched behind the last kernel of the stream (stamp_stream): arrived = idle; not yet = launch this one too
+    // (a bounded wait: the stamp runs a launch gap behind the kernel whose scalar the host already has -- a host that comes
+    // back within microseconds would otherwise find it missing call after call and never get to the resident workgroups)
+    volatile unsigned long long *stamp = reinterpret_cast<volatile unsigned long long *>(I->h_result + 3);
+    if (*stamp < I->clean_after)
+    {
+      struct timespec t0;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (long it = 1; *stamp < I->clean_after; ++it)
+      {
+        __builtin_ia32_pause();
+        if ((it & 63) == 0 && ns_since(t0) > 40000.0) return false;
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    I->clean_after = 0;
+    ++I->clean_epoch; // (kernels ran since the last command: the resident workgroups re-read device memory)
+  }
+  return true;
+}
+
+// Launch the stamp behind what the call has just put on the stream; from now on the stream counts as idle once it arrives.
+int stamp_stream(Instance *I)
+{
+  const unsigned long long v = ++I->stamp_seq;
+  hipLaunchKernelGGL(stream_stamp_kernel, dim3(1), dim3(1), 0, I->stream, reinterpret_cast<unsigned long long *>(I->h_result + 3), v);
+  HIPCHK(hipGetLastError());
+  I->stream_dirty = false; I->clean_after = v;
+  return 0;
+}
+
+// Could the resident workgroups take an evaluation of this instance right now?  Counts the calls in a row for which the answer
+// was yes: the workgroups are only launched at the second (a launch per call that alternates with other launches would cost
+// more than it saves).
+bool big_ready(Instance *I)
+{
+  if (!big_eligible(I) || I->prof || I->rt_skip) return false;
+  Instance *owner = g_big_owner[I->dev].load();
+  if (owner && owner != I) return false;
+  if (!big_clean(I)) return false;
+  return true;
+}
+
+int big_launch(Instance *I, const TreeParams &sq)
+{
+  Resident &R = I->rb;
+  if (!I->d_tile_sums)
+  {
+    const size_t n = (size_t)std::max(I->grid_nt2, I->n_vdlk);
+    HIPCHK(hipMalloc((void **)&I->d_tile_sums, 2 * n * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&I->d_big_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
+    HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), I->stream));
+    HIPCHK(hipMalloc((void **)&I->d_big_recs, sizeof(HostBlock) * 2 * kBigGroupWgs));
+    HIPCHK(hipMemsetAsync(I->d_big_recs, 0, sizeof(HostBlock) * 2 * kBigGroupWgs, I->stream)); // (tag 0: no evaluation's)
+    if (getenv("PHYHIP_RESIDENT_STATS"))
+    {
+      HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs));
+      HIPCHK(hipMemsetAsync(I->d_big_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs, I->stream));
+    }
+    HIPCHK(hipStreamSynchronize(I->stream)); // (the stream is idle: this evaluation was about to bypass it)
+  }
+  Instance *none = nullptr;
+  if (!g_big_owner[I->dev].compare_exchange_strong(none, I) && none != I) return 1; // (somebody else's: launch the evaluation)
+  ResidentCtl r;
+  hipStream_t st;
+  int rc = resident_prepare(I, R, I->big_wgs, kBigWords, R.seq, r, &st, true);
+  if (rc) return rc;
+  // (a generation that left in the middle of a command -- workgroups that started late find "leave" in the mailbox before they
+  // find the command -- leaves tickets drawn and never reset: every generation starts from zero, in stream order)
+  HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), st));
+  BigArgs a;
+  a.t = sq; a.r = r;
+  a.b.n_tiles = I->grid_nt2; a.b.n_vdlk = I->n_vdlk; a.b.tile_sums = I->d_tile_sums; a.b.tickets = I->d_big_tickets; a.b.dot_prod = I->d_dot;
+  a.b.stamps = I->d_big_stamps; a.b.wg_recs = I->d_big_recs;
+  a.pmats = I->d_pmats; a.tip_codes = I->d_tipcodes;
+  if (launch_resident_big(I->C, I->nt_groups, I->big_wgs, st, a) != 0)
+    return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: no kernel for %d categories in %d groups", I->C, I->nt_groups);
+  HIPCHK(hipGetLastError());
+  memcpy(&I->rb_static, &sq, sizeof sq);
+  resident_launched(R, I->big_wgs);
+  return 0;
+}
+
+// The launch arguments of the resident workgroups: everything of a short launch's TreeParams that does not change per call
+TreeParams big_static_params(Instance *I)
+{
+  TreeParams sq = base_params(I);
+  sq.host_blocks = I->h_blocks; sq.warn = I->h_warn; sq.fence_post = 0; sq.recs_in_args = 1; sq.edge_eval = 1;
+  sq.br_len_mult = I->br_len_mult; sq.l_min = I->l_min; sq.l_max = I->l_max; sq.pmats_rw = I->d_pmats;
+  sq.dot_out = I->d_dot;
+  if (I->want_site_outputs) { sq.site_lnl = I->d_site_lnl; sq.site_lk = I->d_site_lk; sq.site_cat = I->d_site_cat; }
+  // (4 states, one eigen system, <= 4 categories: big_eligible) the eigen system and the category rates ride in the arguments
+  memcpy(sq.m_evec, I->h_evec.data(), 16 * sizeof(double)); memcpy(sq.m_ivec, I->h_ivec.data(), 16 * sizeof(double));
+  memcpy(sq.m_eval, I->h_eval.data(), 4 * sizeof(double));
+  for (int c = 0; c < 4; ++c) sq.m_rates[c] = c < I->C ? I->h_rates[c] : 0.0;
+  return sq;
+}
+
+// Make sure the resident workgroups are there (launched with the instance's current parameters).  Returns 0: they are,
+// 1: not this time (first call of a streak, or the device belongs to another instance's workgroups), < 0: error.
+int big_ensure(Instance *I)
+{
+  Resident        &R = I->rb;
+  const TreeParams sq = big_static_params(I);
+  const bool       same = R.launched && memcmp(&I->rb_static, &sq, sizeof sq) == 0;
+  if (same && !resident_gone(R)) return 0;
+  if (R.launched && !same) big_release(I), I->big_streak = 2; // (parameters changed: a new generation with the new ones)
+  if (++I->big_streak < 2) return 1;
+  return big_launch(I, sq);
+}
+
+
+} // namespace phyhip_host
+

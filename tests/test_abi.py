@@ -150,15 +150,18 @@ def test_every_environment_switch_is_documented():
 
 def test_resident_choke_point():
     """The resident evaluators are only safe while every entry point that names an instance declares the stream dirty unless it
-    is KNOWN not to have enqueued anything.  That part is enforced by the compiler (phyhip.hip, `InstanceTable` / `Entered`): the
+    is KNOWN not to have enqueued anything.  That part is enforced by the compiler (phyhip_host.hpp, `InstanceTable` / `Entered`): the
     instance table is private, so an entry point reaches an Instance only through an `Entered<...>` object (GET_INST /
     GET_INST_RES) whose constructor is the choke point, and the three ways back to "clean" are members of `Entered<true>` only
     (a static_assert in each: test_choke_point_is_a_compile_time_property compiles the counter-example).  What is left to review
     by list is WHICH entry points declare themselves resident-aware, and which of the three ways back each one takes."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = "".join(open(os.path.join(root, "phyml_amd", "csrc", f)).read() for f in ("phyhip.hip", "phyhip_shard.hpp"))
-    ext = src[src.index('extern "C" {'):]
+    import glob
+    csrc = os.path.join(root, "phyml_amd", "csrc")
+    units = sorted(glob.glob(os.path.join(csrc, "phyhip*.hip")))
+    src = "".join(open(f).read() for f in [os.path.join(csrc, "phyhip_host.hpp"), os.path.join(csrc, "phyhip_shard.hpp")] + units)
+    ext = "".join(t[t.index('extern "C" {'):] for t in (open(f).read() for f in units) if 'extern "C" {' in t)
     heads = [(m.start(), m.group(1)) for m in re.finditer(r'^(?:int|const char \*)\s*(phyhip_[a-z_0-9]+)\(', ext, flags=re.M)]
     bodies = {}
     for (a, name), nxt in zip(heads, heads[1:] + [(len(ext), None)]):
@@ -180,4 +183,34 @@ def test_resident_choke_point():
     assert len(re.findall(r"tab_\[", src)) == len(re.findall(r"tab_\[", src[src.index("class InstanceTable"):src.index("template <bool KeepsResidents> class Entered\n")]))
     assert len(re.findall(r"stream_dirty\s*=\s*I_?->dirty_prev", src)) == 3  # the three members themselves
     assert set(re.findall(r"InstanceTable::(\w+)\(", src)) == {"at", "add", "remove", "wiring"}
-    assert src.count("InstanceTable::wiring(") == 2 and "phyhip_shard.hpp" and src.count("InstanceTable::at(") == 1
+    assert src.count("InstanceTable::wiring(") == 2 and src.count("InstanceTable::at(") == 1  # (the sharded group's two; Entered)
+
+
+def test_choke_point_is_a_compile_time_property(tmp_path):
+    """The counter-examples do not compile: an entry point that did not declare itself resident-aware (GET_INST) cannot take
+    one of the three ways back to "the stream is as it was found", and nothing outside InstanceTable / Entered can turn an
+    instance number into an Instance.  (Host pass only, syntax only: a few seconds each.)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = '#include "%s"\nusing namespace phyhip_host;\n' % os.path.join(root, "phyml_amd", "csrc", "phyhip_host.hpp")
+    cases = {
+        "control": 'extern "C" int probe(int id) { GET_INST_RES(I, id); I_call.leave_query(); return I->dev; }',
+        "way_back_without_declaring": 'extern "C" int probe(int id) { GET_INST(I, id); I_call.leave_query(); return I->dev; }',
+        "queued_only_without_declaring": 'extern "C" int probe(int id) { GET_INST(I, id); I_call.leave_queued_only(); return I->dev; }',
+        "table_from_outside": 'extern "C" int probe(int id) { Instance *I = InstanceTable::at(id); return I ? I->dev : -1; }',
+    }
+    out = {}
+    for name, body in cases.items():
+        f = tmp_path / (name + ".hip")
+        f.write_text(head + body + "\n")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "--cuda-host-only", "-fsyntax-only", str(f)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        out[name] = (r.returncode, r.stdout)
+    assert out["control"][0] == 0, out["control"][1][-2000:]
+    for name in ("way_back_without_declaring", "queued_only_without_declaring"):
+        assert out[name][0] != 0 and "resident-aware" in out[name][1], out[name][1][-2000:]
+    assert out["table_from_outside"][0] != 0 and "private" in out["table_from_outside"][1], out["table_from_outside"][1][-2000:]

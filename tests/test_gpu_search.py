@@ -89,11 +89,12 @@ def test_real_search_driven_by_the_device(name, tmp_path):
 
 def test_real_search_with_alias_subpatt(tmp_path):
     """`phyml --alias_subpatt` (src/cl.c:502 -> src/lk.c:1294-1296): the application's Alias_One_Subpatt runs
-    where the reference calls it -- hundreds of thousands of times in a search -- and, as in the reference (CPU counterpart:
+    where the reference calls it -- tens of thousands of times in a search -- and, as in the reference (CPU counterpart:
     tests/test_oracle_golden.py), not one number of the path depends on it: the device-driven search is the same search."""
     base = run_search("search_nucleic_spr", "device", tmp_path)
     info = run_search("search_nucleic_spr", "device", tmp_path, extra=("--alias_subpatt",))
-    assert info["alias_one_subpatt_calls_made_here"] >= info["calls"]["Update_Partial_Lk"] > 100000
+    # (the reference switches tree->update_alias_subpatt on for parts of a search only: src/spr.c:1235-1352, src/utilities.c:1742-1818)
+    assert info["alias_one_subpatt_calls_made_here"] > 10000 and info["calls"]["Update_Partial_Lk"] > 100000
     assert base["alias_one_subpatt_calls_made_here"] == 0
     assert info["calls"] == base["calls"]
     assert info["lnL_init"] == base["lnL_init"] and info["lnL_final"] == base["lnL_final"] and info["tree"] == base["tree"]
