@@ -63,6 +63,8 @@ static void release_instance(Instance *I)
     }
   }
   if (I->stream) (void)hipStreamSynchronize(I->stream);
+  for (hipEvent_t e : I->prof_spare) (void)hipEventDestroy(e);
+  I->prof_spare.clear();
   void *ptrs[] = {I->d_partials, I->d_scales, I->d_tipcodes, I->d_masks, I->d_pmats, I->d_wght, I->d_invar, I->d_model,
                   I->d_site_lnl, I->d_site_lk, I->d_site_cat, I->d_fact, I->d_dot, I->d_block, I->d_result, I->d_warn, I->d_ops,
                   I->d_pmscratch, I->d_afrag, I->d_tickets, I->d_mixexpl, I->d_dbg, I->d_tipmasks, I->d_tile_sums, I->d_big_tickets, I->d_big_stamps, I->d_big_recs};
@@ -146,7 +148,13 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
     returnInfo->computeUnits   = prop.multiProcessorCount;
     returnInfo->globalMemBytes = (long long)prop.totalGlobalMem;
   }
-  return InstanceTable::add(I);
+  const int id = InstanceTable::add(I);
+  if (id < 0)
+  {
+    release_instance(I);
+    return fail(PHYHIP_ERROR_OUT_OF_RANGE, "too many instances");
+  }
+  return id;
 }
 
 // Device memory, staging, launch geometry and environment switches of a new instance.
@@ -958,6 +966,12 @@ int phyhip_profile(int instance, int enable)
   if (rc) return rc;
   collect_profile(I);
   I->prof = enable != 0;
+  while (I->prof && I->prof_spare.size() < 256)
+  { // a supply of events for the launches to come (flush_impl)
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    I->prof_spare.push_back(e);
+  }
   I->prof_ms = 0.0; I->prof_n = 0; I->prof_updates = 0.0; I->prof_rd_bytes = 0.0; I->prof_wr_bytes = 0.0;
   I->prof_aux_ms[0] = I->prof_aux_ms[1] = 0.0; I->prof_aux_n[0] = I->prof_aux_n[1] = 0;
   return PHYHIP_SUCCESS;

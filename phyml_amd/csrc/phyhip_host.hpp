@@ -291,6 +291,7 @@ struct Instance
   hipEvent_t ev_big = nullptr;  // ... and behind the exit of its large-grid resident workgroups (big_release)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pairs;
   struct ProfPair { hipEvent_t a, b; int kind; };
+  std::vector<hipEvent_t> prof_spare;      // events of collected launches, reused (creating one costs more than recording it)
   std::vector<ProfPair> prof_aux;          // eigen-basis kernels while profiling: kind 0 eigen_lr_kernel (K3), 1 dlk_kernel (K4)
   double     prof_aux_ms[2] = {0.0, 0.0};
   int        prof_aux_n[2]  = {0, 0};
@@ -330,36 +331,34 @@ void big_release(Instance *I, bool restart_streak = true); // (phyhip_resident.h
 template <bool KeepsResidents> class Entered;
 class InstanceTable
 {
-  static inline std::mutex              mu_;
-  static inline std::vector<Instance *> tab_;
-  static Instance *at(int id)
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    if (id < 0 || id >= (int)tab_.size()) return nullptr;
-    return tab_[id];
-  }
+  // (a fixed array of atomic pointers: the lookup of every entry-point call takes no lock -- hundreds of thousands of calls
+  // per tree search, a hundred in front of every full traversal)
+  static constexpr int                  kCapacity = 1 << 16;
+  static inline std::mutex              mu_;  // add / remove
+  static inline std::atomic<Instance *> tab_[kCapacity];
+  static inline int                     used_ = 0; // slots ever handed out
+  static Instance *at(int id) { return (id >= 0 && id < kCapacity) ? tab_[id].load(std::memory_order_acquire) : nullptr; }
   template <bool> friend class Entered;
 
  public:
-  static int add(Instance *I) // phyhip_create_instance
+  static int add(Instance *I) // phyhip_create_instance (-1: the table is full)
   {
     std::lock_guard<std::mutex> lk(mu_);
-    for (size_t i = 0; i < tab_.size(); ++i)
-      if (!tab_[i])
+    for (int i = 0; i < used_; ++i)
+      if (!tab_[i].load(std::memory_order_relaxed))
       {
-        tab_[i] = I;
-        return (int)i;
+        tab_[i].store(I, std::memory_order_release);
+        return i;
       }
-    tab_.push_back(I);
-    return (int)tab_.size() - 1;
+    if (used_ == kCapacity) return -1;
+    tab_[used_].store(I, std::memory_order_release);
+    return used_++;
   }
   static Instance *remove(int id) // phyhip_finalize_instance: out of the table, the caller frees it
   {
     std::lock_guard<std::mutex> lk(mu_);
-    if (id < 0 || id >= (int)tab_.size()) return nullptr;
-    Instance *I = tab_[id];
-    tab_[id]    = nullptr;
-    return I;
+    if (id < 0 || id >= used_) return nullptr;
+    return tab_[id].exchange(nullptr, std::memory_order_acq_rel);
   }
   static Instance *wiring(int id) { return at(id); } // a sharded group attaching / detaching its sub-instances: no call runs
 };

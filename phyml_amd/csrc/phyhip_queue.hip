@@ -519,8 +519,11 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (I->prof)
   {
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    for (hipEvent_t *e : {&e0, &e1})
+    { // (phyhip_profile(1) left a supply: creating an event costs about a microsecond of the step that is being timed)
+      if (!I->prof_spare.empty()) { *e = I->prof_spare.back(); I->prof_spare.pop_back(); }
+      else HIPCHK(hipEventCreate(e));
+    }
     HIPCHK(hipEventRecord(e0, I->stream));
   }
   const unsigned long long hp1 = hp_now();
@@ -878,8 +881,9 @@ int collect_profile(Instance *I)
     HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
     I->prof_ms += ms;
     I->prof_n += 1;
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+    for (hipEvent_t e : {pr.first, pr.second})
+      if (I->prof_spare.size() < 1024) I->prof_spare.push_back(e);
+      else (void)hipEventDestroy(e);
   }
   I->prof_pairs.clear();
   for (auto &pr : I->prof_aux)
