@@ -251,6 +251,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->big_wgs = std::max(1, std::min(I->cus, I->grid_nt2));
   if (const char *e = diag_env("PHYHIP_BIG_DEVICE_SUM")) I->big_device_sum = atoi(e);
   if (const char *e = diag_env("PHYHIP_BIG_GROUP_SUM")) I->big_group_sum = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_BIG_ONE_SHOT")) I->big_oneshot = atoi(e) != 0;
   // The pipelined nucleotide kernel is instruction-issue bound per CU, so CU-level balance matters more than
   // workgroup size: one-wave workgroups let the dispatcher spread e.g. 3125 waves as 12-13 per CU instead of
   // 3-4 four-wave groups (measured: 100 taxa x 50 000 patterns, 288 -> 25x us).

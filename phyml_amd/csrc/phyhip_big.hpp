@@ -71,6 +71,13 @@ struct BigArgs
   BigCtl         b;
   const double  *pmats;
   const uint8_t *tip_codes;
+  // One-shot form: the same kernel LAUNCHED for one evaluation, the command in its arguments -- what an evaluation of a large
+  // grid costs when the resident workgroups are not there (stream busy, first call of a streak, another instance holds the
+  // device, profiling): one launch of 256 workgroups that rebuild the matrices themselves, walk the tiles and add per workgroup
+  // (one record to the host), instead of pmat_kernel + a traversal of thousands of one-wave workgroups + thousands of records.
+  // Same tile bodies, same order of additions: the same double.  n_one_shot = payload words used (0: resident form).
+  int                n_one_shot;
+  unsigned long long one_shot[kBigWords];
 };
 
 // A struct out of the argument segment (constant address space: scalar loads), dword by dword
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
   __shared__ double             sh_red[2][256];                                // the final sum's accumulators
   __shared__ int                sh_late;
   unsigned long long last = args_.r.start_seq, t_last = wall_clock64();
-  bool               mail_open = false;
+  bool               mail_open = false, served = false;
   for (;;)
   {
     // Nothing that is the same for every command may be computed once in front of this loop and kept: left to itself the
@@ -142,17 +149,27 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
     karg_args *A = reinterpret_cast<karg_args *>(ka);
     const int      lane = (int)(tid & 63), wid = (int)(tid >> 6);
     const int      gw = wid * (int)nwg + (int)bid, TW = NW * (int)nwg; // this wave among all of them
+    const int      n_one_shot = A->n_one_shot;
     if (wid == 0)
     {
-      ResidentCtl r;
-      karg_copy(r, &A->r);
-      r.cmd = as_global(r.cmd); r.mail = as_global(r.mail);
-      int               act;
-      for (;;)
+      int act;
+      if (n_one_shot)
+      { // the launched form: the command is in the arguments, and there is only one
+        act = served ? 2 : 1;
+        if (!served && lane < n_one_shot) sh_raw[resident_slot(lane)] = A->one_shot[lane];
+        static_assert(kBigWords <= 64, "one lane per payload word");
+      }
+      else
       {
-        act = resident_poll_wave<true>(r, last, t_last, mail_open, sh_raw, 1, lane, bid == 0);
-        if (act) break;
-        __builtin_amdgcn_s_sleep(2);
+        ResidentCtl r;
+        karg_copy(r, &A->r);
+        r.cmd = as_global(r.cmd); r.mail = as_global(r.mail);
+        for (;;)
+        {
+          act = resident_poll_wave<true>(r, last, t_last, mail_open, sh_raw, 1, lane, bid == 0);
+          if (act) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
       }
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) sh_act = act;
@@ -361,7 +378,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
             { // (like the atomic loads of the ticket path: from memory, where the other XCDs' workgroups wrote it through)
               asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(rec) : "v"(b.wg_recs + sidx * kBigGroupWgs + tid) : "memory");
               if (rec.y == tag) break;
-              if (wall_clock64() - t_poll > kBigGroupPatience) { sh_late = 1; break; } // (a workgroup that left: nobody answers, the host launches)
+              // (a resident workgroup that left: nobody answers, the host launches; the workgroups of a launch all come)
+              if (!n_one_shot && wall_clock64() - t_poll > kBigGroupPatience) { sh_late = 1; break; }
             }
             double d;
             const unsigned long long bits = rec.x;
@@ -464,7 +482,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
     }
     __syncthreads(); // (wave 0 rewrites the command's staging area with its next poll)
     if (!dsum && !gsum) stamp(3, wall_clock64());
-    last = last + 1; t_last = wall_clock64();
+    last = last + 1; t_last = wall_clock64(); served = true;
   }
 }
 

@@ -246,6 +246,30 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       I->r_inflight = nullptr; I->host_sum_n = 0;
     }
   }
+  // the large-grid kernel launched for this one evaluation (BigArgs::n_one_shot): 256 workgroups that add per workgroup and
+  // post one record per sum, instead of one workgroup and two records per tile
+  const bool one_shot = big && hsum && !dev_out && I->big_oneshot && I->spin_wait && dgrid > I->big_device_sum && big_sum_by_group(I, dgrid);
+  if (one_shot)
+  {
+    unsigned long long words[kBigWords];
+    memset(words, 0, sizeof words);
+    const int n_expl = I->C * (deriv ? 2 : 1) * I->S;
+    words[0] = q.fin.host_tag;
+    words[1] = kBigDlk | (q.with_derivative ? kBigDeriv : 0ull) | (q.invar_model ? kBigInvar : 0ull) | (q.apply_scaling ? kBigScaling : 0ull) |
+               kBigDeviceSum | kBigGroupSum;
+    memcpy(&words[2], &q.pinvar, 8);
+    memcpy(&words[3], q.expl, sizeof(double) * (size_t)n_expl);
+    {
+      AuxProf ap(I, 1);
+      if ((rc = big_one_shot(I, words, kBigWords))) return rc;
+    }
+    I->host_sum_n = 1; I->host_sum_ns = 2;
+    if (big_eligible(I) && !I->prof && (rc = stamp_stream(I))) return rc; // (the next one can go to the resident workgroups)
+    if ((rc = wait_result(I))) return rc;
+    *lnl = I->h_result[0];
+    if (dlnl) *dlnl = I->h_result[1];
+    return PHYHIP_SUCCESS;
+  }
   {
   AuxProf ap(I, 1);
   rc = dispatch_shape(I, [&](auto s, auto cp) {

@@ -206,6 +206,7 @@ struct Instance
   unsigned    *d_big_tickets = nullptr;
   HostBlock   *d_big_recs = nullptr;  // [2][kBigGroupWgs] partial sums per workgroup (BigCtl::wg_recs)
   bool         big_group_sum = true;  // (diag: PHYHIP_BIG_GROUP_SUM=0 keeps the per-tile sums and the tickets)
+  bool         big_oneshot = true;    // (diag: PHYHIP_BIG_ONE_SHOT=0 launches such evaluations the old way: pmat_kernel + one-wave workgroups)
   unsigned long long *d_big_stamps = nullptr; // PHYHIP_RESIDENT_STATS: stamps of the last command per workgroup (BigCtl::stamps)
   int          n_vdlk = 0;            // virtual blocks (one wave each) of a dLk evaluation: dlk64_kernel's grid
   int          big_wgs = 0, big_nw = 0; // its workgroups and waves per workgroup
@@ -524,6 +525,7 @@ bool       big_clean(Instance *I);
 int        stamp_stream(Instance *I);
 bool       big_ready(Instance *I);
 int        big_launch(Instance *I, const TreeParams &sq);
+int        big_one_shot(Instance *I, const unsigned long long *words, int n_words);
 TreeParams big_static_params(Instance *I);
 int        big_ensure(Instance *I);
 

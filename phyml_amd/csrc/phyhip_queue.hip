@@ -122,8 +122,9 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
   static const int fold_grid_max = diag_env("PHYHIP_FOLD_GRID") ? atoi(diag_env("PHYHIP_FOLD_GRID")) : 512;
   // large grids: an evaluation the large-grid resident workgroups can take (phyhip_big.hpp) carries its matrices in the command
-  const bool big_fit = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
-                       (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && big_eligible(I) && !I->prof && !I->rt_skip;
+  const bool big_form = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
+                        (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && !I->rt_skip; // (an evaluation that kernel can take)
+  const bool big_fit = big_form && big_eligible(I) && !I->prof;
   const bool big_try = big_fit && big_ready(I);
   // ... and they are there (or launched now): decided before the records are built -- a resident command of two operations runs
   // them one after the other per tile, without register forwarding between them (phyhip_big.hpp)
@@ -134,12 +135,18 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     if (brc < 0) return brc;
     big_take = brc == 0;
   }
+  // ... or they are not, and the same kernel is LAUNCHED for this one evaluation (BigArgs::n_one_shot) instead of pmat_kernel +
+  // a traversal of one-wave workgroups + a record per workgroup: where the final sum can run through one partial sum per
+  // workgroup (256 workgroups, more tiles than the host adds itself)
+  const bool one_shot = big_form && !big_take && I->big_oneshot && big_shape(I) && I->spin_wait && I->dev >= 0 && I->grid_nt2 > I->big_device_sum &&
+                        big_sum_by_group(I, I->grid_nt2);
+  const bool big_cmd = big_take || one_shot; // (the records below are built for that kernel: no forwarding between two operations)
   if (kDiag && ee && getenv("PHYHIP_RESIDENT_DEBUG") && big_shape(I))
     fprintf(stderr, "big: fit %d try %d | eligible %d ops %d pm %zu up %zu prof %d skip %d | dirty_prev %d touched %d clean_after %llu stamp %llu streak %d launched %d owner %p me %p\n",
             (int)big_fit, (int)big_try, (int)big_eligible(I), n_ops, I->pm_idx.size(), I->up_idx.size(), (int)I->prof, (int)I->rt_skip, (int)I->dirty_prev,
             (int)I->touched_call, I->clean_after, *reinterpret_cast<volatile unsigned long long *>(I->h_result + 3), I->big_streak, (int)I->rb.launched,
             (void *)g_big_owner[I->dev < 64 ? I->dev : 0].load(), (void *)I);
-  const bool fold_pm = I->soa && I->fold_pmats && (I->grid_nt2 <= fold_grid_max || big_try) && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
+  const bool fold_pm = I->soa && I->fold_pmats && (I->grid_nt2 <= fold_grid_max || big_try || one_shot) && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
                        I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
   // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
   // (TreeParams::n_up): no upload kernel in front of the traversal
@@ -253,7 +260,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       for (int k = 0; k < n_rec; ++k)
       {
         const DevOp &o  = at(k);
-        const int    e1 = (k >= 1 && !big_take) ? at(k - 1).dest : -1;
+        const int    e1 = (k >= 1 && !big_cmd) ? at(k - 1).dest : -1;
         const int    e2 = (k >= 2 && I->prefetch_dist == 2) ? at(k - 2).dest : -1;
         unsigned     fl = 0;
         auto child = [&](int c, unsigned tipbit, unsigned f1bit, unsigned f2bit, Desc &data, Desc &scale, Desc &tip,
@@ -469,7 +476,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // ---- large nucleotide alignments: the large-grid resident evaluator (resident_big_kernel) -------------------------------
   // (launches of such an instance do not fence their stores before they post -- with megabytes of results in the L2s a
   // write-back per wave costs more than the launch; whether the stream is idle again is found by querying it, big_clean)
-  if (big_take)
+  if (big_cmd)
   {
     if (!(host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0))
       return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: an evaluation it cannot take (%d records, %d matrices)", host_sum_n, q.n_fresh);
@@ -477,7 +484,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       Resident &R = I->rb;
       unsigned long long words[kBigWords];
       memset(words, 0, sizeof words);
-      const bool changed = I->clean_epoch != I->rt_epoch; // the stream ran something since the last command
+      const bool changed = big_take && I->clean_epoch != I->rt_epoch; // the stream ran something since the last command
       const bool dsum = host_sum_n > I->big_device_sum;
       words[0] = q.host_tag;
       words[1] = (unsigned long long)q.n_real_ops | (changed ? kBigChanged : 0ull) | ((unsigned long long)q.n_fresh << 4) |
@@ -497,12 +504,40 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         put(14 + o * 12, q.arg_ir[o].c1_scale); put(16 + o * 12, q.arg_ir[o].c2_scale);
         put(18 + o * 12, q.arg_xr[o].dst_data); put(20 + o * 12, q.arg_xr[o].dst_scale);
       }
+      if (one_shot)
+      { // launched, on the instance's stream: behind the resident workgroups' exit, if there are any (not when they were about
+        // to be asked: there are none then, and the streak that launches them at its second call goes on)
+        if (!big_try) big_release(I);
+        I->touched_call = true;
+        hipEvent_t p0 = nullptr, p1 = nullptr;
+        const bool timed = I->prof && !ee->eigen; // (Update_Eigen_Lr: the caller's own events are around this call)
+        if (timed)
+        {
+          for (hipEvent_t *e : {&p0, &p1})
+          {
+            if (!I->prof_spare.empty()) { *e = I->prof_spare.back(); I->prof_spare.pop_back(); }
+            else HIPCHK(hipEventCreate(e));
+          }
+          HIPCHK(hipEventRecord(p0, I->stream));
+        }
+        if ((rc = big_one_shot(I, words, kBigWords))) return rc;
+        if (timed)
+        {
+          HIPCHK(hipEventRecord(p1, I->stream));
+          I->prof_pairs.emplace_back(p0, p1);
+          I->prof_updates += (double)n_ops * (double)I->P;
+        }
+        I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
+      }
+      else
+      {
       // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (flush_and_wait)
       I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
       resident_send(I, R, words, kBigWords);
       I->rt_epoch = I->clean_epoch;
       I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
       I->fenced_eval = true; // (nothing went onto the stream: it is as idle as it was found)
+      }
       if (fold_pm)
       {
         for (int m : I->pm_idx) I->pm_slot[m] = -1;
@@ -511,6 +546,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       }
       I->pending.clear();
       std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
+      // (launched: say when the stream is idle again, so that the resident workgroups can take the next one)
+      if (one_shot && big_fit && (rc = stamp_stream(I))) return rc;
       return 0;
     }
   }

@@ -197,23 +197,57 @@ bool big_ready(Instance *I)
   return true;
 }
 
+// device memory of the final sums (both forms of the kernel), on first use
+static int big_alloc(Instance *I)
+{
+  if (I->d_tile_sums) return 0;
+  const size_t n = (size_t)std::max(I->grid_nt2, I->n_vdlk);
+  HIPCHK(hipMalloc((void **)&I->d_tile_sums, 2 * n * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_big_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
+  HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), I->stream));
+  HIPCHK(hipMalloc((void **)&I->d_big_recs, sizeof(HostBlock) * 2 * kBigGroupWgs));
+  HIPCHK(hipMemsetAsync(I->d_big_recs, 0, sizeof(HostBlock) * 2 * kBigGroupWgs, I->stream)); // (tag 0: no evaluation's)
+  if (getenv("PHYHIP_RESIDENT_STATS"))
+  {
+    HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs));
+    HIPCHK(hipMemsetAsync(I->d_big_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs, I->stream));
+  }
+  HIPCHK(hipStreamSynchronize(I->stream));
+  return 0;
+}
+
+static void big_fill_args(Instance *I, const TreeParams &sq, BigArgs &a)
+{
+  memset(&a, 0, sizeof a);
+  a.t = sq;
+  a.b.n_tiles = I->grid_nt2; a.b.n_vdlk = I->n_vdlk; a.b.tile_sums = I->d_tile_sums; a.b.tickets = I->d_big_tickets; a.b.dot_prod = I->d_dot;
+  a.b.stamps = I->d_big_stamps; a.b.wg_recs = I->d_big_recs;
+  a.pmats = I->d_pmats; a.tip_codes = I->d_tipcodes;
+}
+
+// The launched form of the same kernel: ONE evaluation, its command in the arguments, on the instance's own stream (ordered
+// with everything else there: no idle stream needed).  The answer arrives as after a resident command: one {sum, tag} record
+// per sum in the host blocks.
+int big_one_shot(Instance *I, const unsigned long long *words, int n_words)
+{
+  int rc = big_alloc(I);
+  if (rc) return rc;
+  BigArgs a;
+  big_fill_args(I, big_static_params(I), a);
+  a.n_one_shot = n_words;
+  memcpy(a.one_shot, words, sizeof(unsigned long long) * (size_t)n_words);
+  if (launch_resident_big(I->C, I->nt_groups, I->big_wgs, I->stream, a) != 0)
+    return fail(PHYHIP_ERROR_GENERAL, "large-grid evaluator: no kernel for %d categories in %d groups", I->C, I->nt_groups);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int big_launch(Instance *I, const TreeParams &sq)
 {
   Resident &R = I->rb;
-  if (!I->d_tile_sums)
   {
-    const size_t n = (size_t)std::max(I->grid_nt2, I->n_vdlk);
-    HIPCHK(hipMalloc((void **)&I->d_tile_sums, 2 * n * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&I->d_big_tickets, sizeof(unsigned) * (1 + kTicketGroups)));
-    HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), I->stream));
-    HIPCHK(hipMalloc((void **)&I->d_big_recs, sizeof(HostBlock) * 2 * kBigGroupWgs));
-    HIPCHK(hipMemsetAsync(I->d_big_recs, 0, sizeof(HostBlock) * 2 * kBigGroupWgs, I->stream)); // (tag 0: no evaluation's)
-    if (getenv("PHYHIP_RESIDENT_STATS"))
-    {
-      HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs));
-      HIPCHK(hipMemsetAsync(I->d_big_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs, I->stream));
-    }
-    HIPCHK(hipStreamSynchronize(I->stream)); // (the stream is idle: this evaluation was about to bypass it)
+    const int rc = big_alloc(I); // (the stream is idle: this evaluation was about to bypass it)
+    if (rc) return rc;
   }
   Instance *none = nullptr;
   if (!g_big_owner[I->dev].compare_exchange_strong(none, I) && none != I) return 1; // (somebody else's: launch the evaluation)
@@ -225,10 +259,8 @@ int big_launch(Instance *I, const TreeParams &sq)
   // find the command -- leaves tickets drawn and never reset: every generation starts from zero, in stream order)
   HIPCHK(hipMemsetAsync(I->d_big_tickets, 0, sizeof(unsigned) * (1 + kTicketGroups), st));
   BigArgs a;
-  a.t = sq; a.r = r;
-  a.b.n_tiles = I->grid_nt2; a.b.n_vdlk = I->n_vdlk; a.b.tile_sums = I->d_tile_sums; a.b.tickets = I->d_big_tickets; a.b.dot_prod = I->d_dot;
-  a.b.stamps = I->d_big_stamps; a.b.wg_recs = I->d_big_recs;
-  a.pmats = I->d_pmats; a.tip_codes = I->d_tipcodes;
+  big_fill_args(I, sq, a);
+  a.r = r;
   if (launch_resident_big(I->C, I->nt_groups, I->big_wgs, st, a) != 0)
     return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: no kernel for %d categories in %d groups", I->C, I->nt_groups);
   HIPCHK(hipGetLastError());

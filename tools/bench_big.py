@@ -85,6 +85,7 @@ def main():
             "device_sum": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_DEVICE_SUM": "0"},
             "tickets": {"PHYHIP_LIBDIR": diag, "PHYHIP_BIG_GROUP_SUM": "0"},  # device sum through per-tile sums and tickets
             "diag": {"PHYHIP_LIBDIR": diag},
+            "launch_old": {"PHYHIP_LIBDIR": diag, "PHYHIP_RESIDENT": "0", "PHYHIP_BIG_ONE_SHOT": "0"},  # round 3's launch per call
             "g1": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1"}, "g2": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "2"},
             "g1_launch": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1", "PHYHIP_RESIDENT": "0"}}
     for name in args.configs.split(","):
