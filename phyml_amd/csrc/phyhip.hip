@@ -288,6 +288,14 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   if (const char *e = getenv("PHYHIP_RESIDENT")) I->resident = atoi(e) != 0;
   if (const char *e = getenv("PHYHIP_RESIDENT_IDLE_US")) I->resident_idle_us = atof(e);
   if (const char *e = diag_env("PHYHIP_RESIDENT_DIRECT")) I->resident_direct = atoi(e);
+  {
+    // Where the host can store straight into device memory (large BAR), the resident evaluators' command records live there
+    // and the host pushes each command (phyhip_resident.hip): every workgroup polls locally, nobody relays.
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, I->dev) != hipSuccess) large_bar = 0;
+    I->push_cmds = large_bar ? kPushCmdsDefault : 0;
+    if (const char *e = diag_env("PHYHIP_PUSH_CMDS")) I->push_cmds = large_bar ? atoi(e) : 0;
+  }
 
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));

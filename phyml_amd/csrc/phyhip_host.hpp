@@ -132,12 +132,20 @@ struct StagingRing
 
 struct Collective;
 
+constexpr int kPushCmdsDefault = 3;    // uncached device memory (see Instance::push_cmds; measured against 1 / 2 / host memory, profiles/r04_latency.md)
 constexpr int kResidentDirect = 16;    // up to this many resident workgroups poll the host themselves, above that workgroup 0 relays (measured: 8 / 16 / 32, tools/gpu_direct_ab.sh)
 // Host side of one set of resident workgroups (see resident_dlk_kernel / resident_nt2_kernel)
 struct Resident
 {
-  ResidentCmd        *cmd = nullptr;   // host-mapped command record
-  unsigned long long *mail = nullptr;  // device mailbox (larger grids: workgroup 0 relays the commands)
+  // The command record as the device reads it.  Either host-mapped memory, polled over the link (a read round trip per poll:
+  // only a few workgroups may do that, the others get the commands relayed through the mailbox) -- or, where the host can store
+  // straight into device memory (large BAR), DEVICE memory the host pushes each command into, 64 bytes per store: every
+  // workgroup then polls it locally and nobody relays.  `shadow` is the host's copy of a pushed record (what it last wrote).
+  ResidentCmd        *cmd = nullptr;
+  ResidentCmd        *shadow = nullptr;
+  bool                pushed = false;
+  unsigned long long *report = nullptr; // host-mapped: the generation whose workgroups have left (written by workgroup 0)
+  unsigned long long *mail = nullptr;  // device mailbox (word 0: what workgroup 0 decided; relayed commands)
   hipStream_t         stream[2] = {nullptr, nullptr};
   unsigned long long  gen = 0, seq = 0; // launch generation; commands issued
   unsigned long long  api_no = 0;       // entry-point call of the last command
@@ -197,6 +205,7 @@ struct Instance
   // resident evaluator (resident_dlk_kernel): dLk / eigen-basis Lk of small alignments without a launch per call
   bool         resident = true;       // PHYHIP_RESIDENT=0: every evaluation is a kernel launch
   int          resident_direct = kResidentDirect; // PHYHIP_RESIDENT_DIRECT: up to this many workgroups poll the host themselves
+  int          push_cmds = 0;  // resident command records in device memory, pushed by the host (1 hipMalloc, 2 fine-grained, 3 uncached; 0: host memory)
   double       resident_idle_us = 1000.0; // PHYHIP_RESIDENT_IDLE_US: the workgroups leave after this long without a command
   Resident     rd, rt;                // the dLk evaluator (resident_dlk_kernel) and the short-launch one (resident_nt2_kernel)
   // large-grid resident evaluator (resident_big_kernel, phyhip_big.hpp): nucleotide instances of more than kResidentMaxGrid tiles

@@ -1478,7 +1478,7 @@ struct ResidentCmd
 {
   ResidentSector ctl;
   ResidentSector sec[kResidentSectors];
-  ResidentSector report; // written by the DEVICE: word 0 = the generation whose workgroups have left (idle, told to, superseded)
+  ResidentSector spare;  // (formerly the device's report; that is ResidentCtl::report now)
 };
 // index of payload word k among the record's words (sector 0 is control)
 __host__ __device__ constexpr int resident_slot(int k) { return (1 + k / kResidentPay) * kResidentUnit + k % kResidentPay; }
@@ -1493,6 +1493,9 @@ struct ResidentCtl
   // it copies each command into a mailbox in device memory -- same line format, payload before numbers -- which the others poll.
   unsigned long long *mail;      // device, a copy of the record's layout
   int                 relay;     // != 0: the other workgroups take their commands from the mailbox instead of the host
+  // host-mapped: the generation whose workgroups have left (not in the record: the record may live in DEVICE memory, where the
+  // host pushes the commands through the BAR -- every workgroup then polls it locally, no relay, phyhip_resident.hip)
+  unsigned long long *report;
   // Workgroup 0 alone decides when a generation leaves (idle time-out): it says so in the mailbox's word 0, which the others
   // watch, and reports to the host -- which therefore KNOWS whether anybody is there instead of guessing from elapsed time.
 };
@@ -1546,7 +1549,7 @@ __device__ __forceinline__ int resident_poll_wave(const ResidentCtl &r, const un
         if ((cur >> 1) <= r.gen)
           __hip_atomic_compare_exchange_strong(r.mail, &cur, (r.gen << 1) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(const_cast<unsigned long long *>(&r.cmd->report.w[0]), r.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(r.report, r.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     else if (r.relay ? (act == 1 || !mail_open) : !mail_open)

@@ -2,6 +2,8 @@
 // (libphyhip.so, gfx950 only; the units and what they share: phyhip_host.hpp)
 #include "phyhip_host.hpp"
 
+#include <immintrin.h>
+
 namespace phyhip_host
 {
 
@@ -14,14 +16,60 @@ static __global__ void stream_stamp_kernel(unsigned long long *stamp_host, unsig
   __hip_atomic_store(stamp_host, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- writing the command record ------------------------------------------------------------------------------------------
+// A pushed record (device memory behind the BAR, write-combining for the host) is written 64 bytes at a time -- two sectors,
+// payload and number together -- with MOVDIR64B where the CPU has it: one store, one write on the link, never seen half.
+// Without it: the payload words of the line, a store fence, the sector numbers, a store fence (posted writes stay in order).
+static bool cpu_has_movdir64b()
+{
+  static const int have = [] {
+    unsigned a = 0, b = 0, c = 0, d = 0;
+    __asm__ volatile("cpuid" : "=a"(a), "=b"(b), "=c"(c), "=d"(d) : "a"(7), "c"(0));
+    return (int)((c >> 28) & 1u);
+  }();
+  return have != 0;
+}
+__attribute__((target("movdir64b"))) static void store64_direct(void *dst, const void *src) { _movdir64b(dst, src); }
+static void push_lines(Resident &R, int first_sector, int last_sector) // sectors of ResidentCmd, counted from the control sector
+{
+  const char *src = reinterpret_cast<const char *>(R.shadow);
+  char       *dst = reinterpret_cast<char *>(R.cmd);
+  const int   l0 = first_sector / 2, l1 = last_sector / 2;
+  if (cpu_has_movdir64b())
+    for (int l = l0; l <= l1; ++l) store64_direct(dst + 64 * l, src + 64 * l);
+  else
+  {
+    for (int l = l0; l <= l1; ++l)
+      for (int h = 0; h < 2; ++h)
+        for (int k = 0; k < kResidentPay; ++k)
+          reinterpret_cast<volatile unsigned long long *>(dst + 64 * l + 32 * h)[k] = reinterpret_cast<const unsigned long long *>(src + 64 * l + 32 * h)[k];
+    _mm_sfence();
+    for (int l = l0; l <= l1; ++l)
+      for (int h = 0; h < 2; ++h)
+        reinterpret_cast<volatile unsigned long long *>(dst + 64 * l + 32 * h)[kResidentPay] =
+            reinterpret_cast<const unsigned long long *>(src + 64 * l + 32 * h)[kResidentPay];
+  }
+  _mm_sfence();
+}
+// control word 0 (generation in charge) / 1 (leave)
+static void set_ctl(Resident &R, int word, unsigned long long v)
+{
+  if (R.pushed)
+  {
+    R.shadow->ctl.w[word] = v;
+    push_lines(R, 0, 0);
+  }
+  else __atomic_store_n(&R.cmd->ctl.w[word], v, __ATOMIC_RELEASE);
+}
+
 // Tell the resident workgroups (if any) to leave and wait until they have.
 void resident_stop(Resident &R)
 {
   if (!R.cmd || !R.launched) return;
-  __atomic_store_n(&R.cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
+  set_ctl(R, 1, 1ull);
   for (hipStream_t st : R.stream)
     if (st) (void)hipStreamSynchronize(st);
-  __atomic_store_n(&R.cmd->ctl.w[1], 0ull, __ATOMIC_RELEASE);
+  set_ctl(R, 1, 0ull);
   R.launched = false;
 }
 
@@ -29,13 +77,15 @@ void resident_free(Resident &R)
 {
   if (R.cmd)
   { // (also a generation that was only told to leave, big_release: nobody may still be polling the record when it is freed)
-    __atomic_store_n(&R.cmd->ctl.w[1], 1ull, __ATOMIC_RELEASE);
+    set_ctl(R, 1, 1ull);
     for (hipStream_t st : R.stream)
       if (st) (void)hipStreamSynchronize(st);
     R.launched = false;
   }
   resident_stop(R);
-  if (R.cmd) (void)hipHostFree(R.cmd);
+  if (R.cmd) (void)(R.pushed ? hipFree(R.cmd) : hipHostFree(R.cmd));
+  if (R.shadow) free(R.shadow);
+  if (R.report) (void)hipHostFree(R.report);
   if (R.mail) (void)hipFree(R.mail);
   for (hipStream_t st : R.stream)
     if (st) (void)hipStreamDestroy(st);
@@ -52,17 +102,41 @@ int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned l
 {
   if (!R.cmd)
   {
-    HIPCHK(hipHostMalloc((void **)&R.cmd, sizeof(ResidentCmd), hipHostMallocMapped | hipHostMallocCoherent)); // (polled from the device while it changes)
-    memset(R.cmd, 0, sizeof(ResidentCmd));
+    const size_t bytes = (sizeof(ResidentCmd) + 63) & ~size_t(63);
+    if (I->push_cmds)
+    { // device memory the host stores into (checked at instance creation: large BAR); the record starts on a 64-byte line
+      hipError_t e = I->push_cmds == 1 ? hipMalloc((void **)&R.cmd, bytes)
+                                       : hipExtMallocWithFlags((void **)&R.cmd, bytes, I->push_cmds == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+      if (e == hipSuccess && posix_memalign((void **)&R.shadow, 64, bytes) == 0)
+      {
+        HIPCHK(hipMemset(R.cmd, 0, bytes));
+        HIPCHK(hipDeviceSynchronize());
+        memset(R.shadow, 0, bytes);
+        R.pushed = true;
+      }
+      else
+      {
+        if (e == hipSuccess) (void)hipFree(R.cmd);
+        R.cmd = nullptr; R.shadow = nullptr;
+      }
+    }
+    if (!R.pushed)
+    {
+      HIPCHK(hipHostMalloc((void **)&R.cmd, bytes, hipHostMallocMapped | hipHostMallocCoherent)); // (polled from the device while it changes)
+      memset(R.cmd, 0, bytes);
+    }
+    HIPCHK(hipHostMalloc((void **)&R.report, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(R.report, 0, 64);
     HIPCHK(hipMalloc((void **)&R.mail, sizeof(ResidentCmd)));
     HIPCHK(hipMemset(R.mail, 0, sizeof(ResidentCmd)));
     for (hipStream_t &s2 : R.stream) HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   }
   ++R.n_launch;
   ++R.gen;
-  __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
+  set_ctl(R, 0, R.gen);
   r.cmd = R.cmd; r.gen = R.gen; r.start_seq = served; r.n_sectors = (n_words + kResidentPay - 1) / kResidentPay;
-  r.mail = R.mail; r.relay = grid > I->resident_direct ? 1 : 0;
+  r.mail = R.mail; r.report = R.report;
+  r.relay = (!R.pushed && grid > I->resident_direct) ? 1 : 0; // (a pushed record is polled locally: by everybody)
   if (I->wall_khz <= 0)
   {
     int dev = 0, khz = 0;
@@ -83,19 +157,23 @@ void resident_launched(Resident &R, int grid)
 // Have the workgroups of the current generation left?  (Workgroup 0 reports it, see ResidentCmd::report.)
 bool resident_gone(const Resident &R)
 {
-  return R.cmd && __atomic_load_n(&R.cmd->report.w[0], __ATOMIC_ACQUIRE) == R.gen;
+  return R.cmd && __atomic_load_n(R.report, __ATOMIC_ACQUIRE) == R.gen;
 }
 
 // The command: payload words into their sectors, each sector's number last (see ResidentCmd)
 void resident_send(Instance *I, Resident &R, const unsigned long long *words, int n_words)
 {
   ++R.seq;
-  for (int l = 0; l * kResidentPay < n_words; ++l)
+  ResidentCmd *const rec = R.pushed ? R.shadow : R.cmd;
+  int               nsec = 0;
+  for (int l = 0; l * kResidentPay < n_words; ++l, ++nsec)
   {
-    ResidentSector &sc = R.cmd->sec[l];
+    ResidentSector &sc = rec->sec[l];
     for (int k = 0; k < kResidentPay && l * kResidentPay + k < n_words; ++k) sc.w[k] = words[l * kResidentPay + k];
-    __atomic_store_n(&sc.seq, R.seq, __ATOMIC_RELEASE);
+    if (R.pushed) sc.seq = R.seq;
+    else __atomic_store_n(&sc.seq, R.seq, __ATOMIC_RELEASE);
   }
+  if (R.pushed) push_lines(R, 1, nsec); // (sector 0 is control; it shares its line with the first command sector)
   R.api_no = I->api_no;
   ++R.n_cmd;
   clock_gettime(CLOCK_MONOTONIC, &R.t_cmd);
@@ -134,7 +212,7 @@ void big_release(Instance *I, bool restart_streak)
   {
     hipStream_t st = R.stream[0]; // (where every generation of these workgroups runs, resident_prepare)
     ++R.gen;
-    __atomic_store_n(&R.cmd->ctl.w[0], R.gen, __ATOMIC_RELEASE);
+    set_ctl(R, 0, R.gen);
     R.launched = false;
     if (I->ev_big && hipEventRecord(I->ev_big, st) == hipSuccess) (void)hipStreamWaitEvent(I->stream, I->ev_big, 0);
     else (void)hipStreamSynchronize(st);

@@ -33,6 +33,10 @@ def worker(args):
     t0 = time.perf_counter()
     res, _ = t.Replay_Surface_Trace(tr)
     spr_us = (time.perf_counter() - t0) / args.candidates * 1e6
+    if args.end == "spr":  # (the candidate phase alone: PHYHIP_HOSTPROF / PHYHIP_RESIDENT_STATS then describe candidates only)
+        t.close()
+        print(json.dumps({"label": args.label, "us_per_spr_candidate": spr_us}))
+        return
     # Br_Len_Opt chains
     e = t.ne // 2
     t.Lk(e)
@@ -89,6 +93,8 @@ def main():
             "g1": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1"}, "g2": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "2"},
             "g1_launch": {"PHYHIP_LIBDIR": diag, "PHYHIP_NT_GROUPS": "1", "PHYHIP_RESIDENT": "0"}}
     for name in args.configs.split(","):
+        if name.startswith("push"):  # pushN: command records in device memory (1 hipMalloc, 2 fine-grained, 3 uncached), diag build
+            cfgs[name] = {"PHYHIP_LIBDIR": diag, "PHYHIP_PUSH_CMDS": name[4:]}
         if name.startswith("lib_"):  # another build of the engine (tools/build_variant.sh <name>): phyml_amd/lib_<name>
             cfgs[name] = {"PHYHIP_LIBDIR": os.path.join(ROOT, "phyml_amd", name)}
         env = dict(os.environ); env.update(cfgs[name])
