@@ -25,6 +25,7 @@ static bool cpu_has_movdir64b()
   static const int have = [] {
     unsigned a = 0, b = 0, c = 0, d = 0;
     __asm__ volatile("cpuid" : "=a"(a), "=b"(b), "=c"(c), "=d"(d) : "a"(7), "c"(0));
+    if (diag_env("PHYHIP_PUSH_NO_MOVDIR")) return 0; // (diag: the two-pass form on a CPU that has the instruction)
     return (int)((c >> 28) & 1u);
   }();
   return have != 0;
