@@ -122,6 +122,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // the redundant per-workgroup rebuild costs more than the launch it saves: 45.1 vs 42.5 us per SPR candidate)
   static const int fold_grid_max = diag_env("PHYHIP_FOLD_GRID") ? atoi(diag_env("PHYHIP_FOLD_GRID")) : 512;
   // large grids: an evaluation the large-grid resident workgroups can take (phyhip_big.hpp) carries its matrices in the command
+  // (host-computed matrices -- the bit-exact route -- stay with the one-wave launch that takes them in its arguments: the
+  // large-grid kernel launched with them in ITS arguments was measured, 30-31 against 28.4 us per candidate at 500 x 100 000)
   const bool big_form = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
                         (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && !I->rt_skip; // (an evaluation that kernel can take)
   const bool big_fit = big_form && big_eligible(I) && !I->prof;
@@ -530,13 +532,12 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
       }
       else
-      {
-      // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (flush_and_wait)
-      I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
-      resident_send(I, R, words, kBigWords);
-      I->rt_epoch = I->clean_epoch;
-      I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
-      I->fenced_eval = true; // (nothing went onto the stream: it is as idle as it was found)
+      { // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (flush_and_wait)
+        I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
+        resident_send(I, R, words, kBigWords);
+        I->rt_epoch = I->clean_epoch;
+        I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
+        I->fenced_eval = true; // (nothing went onto the stream: it is as idle as it was found)
       }
       if (fold_pm)
       {
