@@ -137,7 +137,10 @@ def pmc_traffic(workload):
     return None
 
 
-def build_tree(wl, device=None, devices=None):
+VIRTUAL = None  # --virtual-buffers: threshold handed to phyhip_set_virtual_buffers (None: the library's default, 0: off)
+
+
+def build_tree(wl, device=None, devices=None, virtual="default"):
     from phyml_amd import lktree
     tree, st, blk, cfg = wl["tree"], wl["states"], wl["model"], wl["cfg"]
     n, P, S = tree.n_otu, st.shape[1], cfg["ns"]
@@ -147,7 +150,24 @@ def build_tree(wl, device=None, devices=None):
                 float(blk["l_min"][0]), float(blk["l_max"][0]), 1.0, 1)
     t.Make_Tree_For_Lk(np.ones(P))
     t.set_tips(tip_states=st.astype(np.int32))
+    v = VIRTUAL if virtual == "default" else virtual
+    if v is not None:
+        t.inst.set_virtual_buffers(int(v))
     return t
+
+
+def all_stored_companion(wl, args, torch, n, P):
+    """The same workload with every buffer stored (phyhip_set_virtual_buffers(0)): what the traversal costs when the tip x tip
+    results are written like all the others -- reported next to the headline so that nobody has to guess what the virtual
+    buffers are worth."""
+    t = build_tree(wl, device=0, virtual=0)
+    steps = max(5, min(args.steps, 20))
+    dt, lnl = timed_steps(t, steps, min(args.warmup, 5), torch.cuda.synchronize)
+    kern_ms, kern_n, _ = t.inst.profile_read()
+    _, wr = t.inst.profile_read_traffic()
+    t.close()
+    return {"ms_per_step": dt / steps * 1e3, "kernel_avg_us": kern_ms / max(kern_n, 1) * 1e3, "value": float(P) * (n - 2) * steps / dt / 1e6,
+            "write_bytes": wr / max(kern_n, 1), "lnL": lnl, "steps": steps}
 
 
 def timed_steps(t, steps, warmup, sync, barrier=None):
@@ -179,7 +199,17 @@ def roofline_block(t, n, P, S, C, workload_key, with_traffic, shards=1):
     achieved = alg_bytes / kdur / 1e9 if kdur > 0 else 0.0
     rd, wr = rd / max(kern_n, 1) / shards, wr / max(kern_n, 1) / shards  # per launch of ONE shard
     traffic = pmc_traffic(workload_key) if with_traffic else None
+    vnow, vskip, vre, vstored = t.inst.virtual_stats()
     r = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+         # `achieved` / `frac` are SURVEY 8(d)'s ALGORITHMIC figure: it charges every child read and every result write of a
+         # post-order, also the ones this launch keeps in registers, so it is not a physical rate and may exceed 1.  The physical
+         # one is `frac_real` (counter bytes of this very launch / kernel time / 8 TB/s), null without a counter profile of these sources.
+         "frac_is": "algorithmic (SURVEY 8d bytes / kernel time / peak); physical: frac_real",
+         "frac_real": (traffic / kdur / 8e12) if (traffic and kdur > 0) else None,
+         # buffers whose tip x tip result the launch did NOT store (include/phyhip.h: phyhip_set_virtual_buffers) -- they are
+         # recomputed in registers in front of their readers and stored on demand; `all_buffers_stored` is the same run without that
+         "virtual_buffers": {"virtual_after_launch": vnow, "internal_buffers": n - 2, "stores_skipped": vskip,
+                             "reissued_not_storing": vre, "materialised": vstored},
          "kernel": ("traverse_nt2_kernel" if C <= 4 else "traverse_nt_kernel") if S == 4 else "traverse_aa_kernel",
          "kernel_avg_us": kdur * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
          "algorithmic_bytes_per_site_update": alg_bytes / (float(P) * (n - 2)),
@@ -203,6 +233,8 @@ def run_single(args, torch):
     dt, lnl = timed_steps(t, args.steps, args.warmup, torch.cuda.synchronize)
     value = float(P) * (n - 2) * args.steps / dt / 1e6
     roof, kdur = roofline_block(t, n, P, S, C, args.workload, args.patterns is None)
+    if roof["virtual_buffers"]["virtual_after_launch"] > 0:
+        roof["all_buffers_stored"] = all_stored_companion(wl, args, torch, n, P)
     # ("scaling": the N = 1 line is the cfg2 workload on one GPU -- neither weak nor strong; --gpus N > 1 is STRONG scaling of cfg4)
     out = {"metric": METRIC, "value": value, "unit": "M site-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "none", "vs_baseline": None, "dtype": "f64",
@@ -384,6 +416,8 @@ def extra_line(name, args, torch):
     t = build_tree(wl, device=0)
     dt, lnl = timed_steps(t, args.steps, args.warmup, torch.cuda.synchronize)
     roof, kdur = roofline_block(t, n, P, S, C, name, True)
+    if roof["virtual_buffers"]["virtual_after_launch"] > 0:
+        roof["all_buffers_stored"] = all_stored_companion(wl, args, torch, n, P)
     exp = workloads.manifest()["expected"][name]
     line = {"value": float(P) * (n - 2) * args.steps / dt / 1e6, "unit": "M site-updates/s", "ms_per_step": dt / args.steps * 1e3,
             "steps": args.steps, "lnL": lnl, "lnL_rel_err": abs(lnl - exp["lnL"]) / abs(exp["lnL"]),
@@ -493,9 +527,13 @@ def main():
     ap.add_argument("--no-call-latency", action="store_true",
                     help="skip the call_latency part of `extra` (kernel-stats profiles: its launches share kernel names with the bench's)")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 line (N = 1) / the single-GPU reference (N > 1)")
+    ap.add_argument("--virtual-buffers", type=int, default=None,
+                    help="phyhip_set_virtual_buffers threshold (default: the library's, 16 operations; 0: every buffer stored)")
     ap.add_argument("--cpu-sample", type=int, default=50000)
     ap.add_argument("--cpu-reps", type=int, default=30)
     args = ap.parse_args()
+    global VIRTUAL
+    VIRTUAL = args.virtual_buffers
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

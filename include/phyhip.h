@@ -344,6 +344,23 @@ int phyhip_get_resident_stats(int instance, long long out[8]);
    those workgroups; they leave when the instance launches anything else, or after PHYHIP_RESIDENT_IDLE_US without a command. */
 int phyhip_get_big_resident_stats(int instance, long long out[4]);
 
+/* Virtual buffers.  A tip x tip partial vector ("cherry": both children of the node are tips, src/avx.c:527-549 Exex) is two
+   matrix columns and one product per pattern -- cheaper to recompute in registers than to write (C*S*8+4 bytes per pattern)
+   and read back.  A traversal launch of at least `minOperations` operations therefore does not STORE such results when every
+   reader of them sits later in the same launch: the defining operation is issued in front of each reader instead, its result
+   forwarded in registers, and the buffer's memory stays stale ("virtual").  Whatever reads such a buffer later -- a queued
+   operation, an evaluation edge, phyhip_update_eigen_lr, phyhip_get_partials / _scale_factors, a mixture evaluation -- first
+   gets the defining operation queued again, storing: every value that leaves through this interface is the double the reference
+   has in t_edge::p_lk_* at that point (tests/test_gpu_virtual.py).  A matrix or tip row the definition reads cannot change
+   under it: the setters materialise the dependants first.  minOperations = 0 switches the feature off (and materialises what
+   is virtual); the default is 16, so the short launches of a tree search never leave anything virtual.  Not on class-axis or
+   generic-loop instances.  Sharded instances: applied to every shard. */
+int phyhip_set_virtual_buffers(int instance, int minOperations);
+
+/* out[0] buffers virtual right now, out[1] stores skipped so far (operations that left their result virtual), out[2] non-storing
+   re-issues in front of readers, out[3] storing re-issues (materialisations).  Sharded instances: the first shard's counters. */
+int phyhip_get_virtual_stats(int instance, long long out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,7 @@ SYMBOLS = [
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
     "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
-    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_profile_read_eigen", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats", "phyhip_calculate_class_mixture_log_likelihood",
+    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_profile_read_eigen", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats", "phyhip_set_virtual_buffers", "phyhip_get_virtual_stats", "phyhip_calculate_class_mixture_log_likelihood",
     "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors", "phyhip_set_mixture_invariant_sites",
 ]
 
@@ -309,6 +309,17 @@ class Instance:
         out = (C.c_longlong * 8)()
         _chk(self.L.phyhip_get_resident_stats(self.id, out))
         return tuple(int(v) for v in out[4 * which:4 * which + 4])
+
+    def set_virtual_buffers(self, min_operations):
+        """phyhip_set_virtual_buffers: traversal launches of at least this many operations leave tip x tip results virtual
+        (0: never, and what is virtual is stored)"""
+        _chk(self.L.phyhip_set_virtual_buffers(self.id, int(min_operations)))
+
+    def virtual_stats(self):
+        """(buffers virtual now, stores skipped, non-storing re-issues, storing re-issues)"""
+        out = (C.c_longlong * 4)()
+        _chk(self.L.phyhip_get_virtual_stats(self.id, out))
+        return tuple(int(v) for v in out)
 
     def profile_read_eigen(self):
         """(ms, launches) of eigen_lr_kernel and of dlk_kernel since profile(1)"""

@@ -95,7 +95,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   if (categoryCount > 8) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "categoryCount %d > 8", categoryCount);
   if ((double)patternCount * categoryCount * stateCount * 8.0 >= 2147483648.0)
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "one partials buffer must stay below 2 GiB (shard the patterns across devices)");
-  if ((double)matrixBufferCount * categoryCount * stateCount * stateCount * 8.0 >= 2147483648.0)
+  if ((double)(matrixBufferCount + 2 * (partialsBufferCount - tipCount)) * categoryCount * stateCount * stateCount * 8.0 >= 2147483648.0)
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "transition-matrix table must stay below 2 GiB");
 
   int ndev = 0;
@@ -130,6 +130,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->class_axis = class_axis; I->NE = class_axis ? categoryCount : 1;
   I->dev = dev; I->tips = tipCount; I->nbuf = partialsBufferCount; I->S = stateCount; I->C = categoryCount;
   I->CP = next_pow2(categoryCount); I->P = patternCount; I->nmat = matrixBufferCount;
+  I->nmat_all = matrixBufferCount + 2 * (partialsBufferCount - tipCount);
   {
     const int rc = build_instance(I, prop);
     if (rc < 0)
@@ -193,7 +194,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   HIPCHK(hipMemset(I->d_scales, 0, n_int * scale_elems(I) * sizeof(int)));
   if (I->perm)
   {
-    const size_t fb = (size_t)I->nmat * kAaMat * sizeof(double);
+    const size_t fb = (size_t)I->nmat_all * kAaMat * sizeof(double);
     HIPCHK(hipMalloc((void **)&I->d_afrag, fb));
     HIPCHK(hipMemset(I->d_afrag, 0, fb));
     // one consumer wave per wave-tile (16 / aa_cb(C) patterns x all categories) + one loader wave per workgroup; enough
@@ -212,8 +213,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     HIPCHK(hipMemset(I->d_tipmasks, 0, (size_t)I->tips * I->Ppad * sizeof(uint32_t)));
   }
   HIPCHK(hipMalloc((void **)&I->d_masks, 256 * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void **)&I->d_pmats, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
-  HIPCHK(hipMemset(I->d_pmats, 0, (size_t)I->nmat * I->C * I->S * I->S * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&I->d_pmats, (size_t)I->nmat_all * I->C * I->S * I->S * sizeof(double)));
+  HIPCHK(hipMemset(I->d_pmats, 0, (size_t)I->nmat_all * I->C * I->S * I->S * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_wght, I->P * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_invar, I->P * sizeof(short)));
   HIPCHK(hipMemset(I->d_invar, 0xff, I->P * sizeof(short)));
@@ -265,7 +266,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     const long long waves = ((long long)I->P * I->CP + 63) / 64, simds = 4LL * prop.multiProcessorCount;
     if (!diag_env("PHYHIP_DIST") && waves > 3 * simds && waves <= 4 * simds) I->prefetch_dist = 1;
     if (I->soa) I->prefetch_dist = I->nt2_dist;
-    if (I->perm) I->prefetch_dist = 1; // the 20-state kernels forward only the previous result
+    if (I->perm) I->prefetch_dist = 2; // (the 20-state kernel loads one operation ahead, but forwards the last TWO results in registers)
   }
   HIPCHK(hipMalloc((void **)&I->d_block,
                    (size_t)2 * std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2)) * sizeof(double)));
@@ -300,14 +301,18 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->pm_scratch_cap = std::min(std::max(I->nmat, 16), 4096);
   HIPCHK(hipMalloc(&I->d_pmscratch, (size_t)I->pm_scratch_cap * 16 + 64));
   I->ops_cap = 2 * I->nbuf + 8;
-  I->ops_slot_bytes = (size_t)(I->ops_cap + 2) * (sizeof(IssueRec) + sizeof(ExecRec));
+  // (a launched list may be longer than the queue: operations that read a virtual buffer get its definition in front of them,
+  // at most two per operation -- rewrite_pending)
+  I->ops_slot_bytes = (size_t)(3 * I->ops_cap + 2) * (sizeof(IssueRec) + sizeof(ExecRec));
+  I->virt.assign(I->nbuf, 0);
+  I->vdef.assign(I->nbuf, DevOp{0, 0, 0, 0, 0, 0});
   HIPCHK(hipMalloc((void **)&I->d_ops, (size_t)I->ops_slots * I->ops_slot_bytes));
   size_t chunk = std::max<size_t>(64 * 1024, std::max(I->ops_slot_bytes,
                                                        (size_t)I->C * I->S * I->S * sizeof(double) * 4));
   rc = I->ring.init(chunk);
   if (rc) return rc;
   I->ring.before_rotate = [I]() { return I->up_idx.empty() ? 0 : flush_uploads(I); };
-  I->mat_in_queue.assign(I->nmat, 0);
+  I->mat_in_queue.assign(I->nmat_all, 0);
   I->up_slot.assign(I->nmat, -1);
   I->pm_slot.assign(I->nmat, -1);
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
@@ -386,6 +391,7 @@ int phyhip_finalize_instance(int instance)
 
 static int set_tip_codes(Instance *I, int tip, const std::vector<uint8_t> &codes)
 {
+  devirtualise_tip(I, tip); // (virtual buffers defined on the old row are stored first)
   int rc = flush_sync(I);
   if (rc) return rc;
   HIPCHK(hipMemcpy(I->d_tipcodes + (size_t)tip * I->Ppad, codes.data(), (size_t)I->P, hipMemcpyHostToDevice));
@@ -470,6 +476,7 @@ int phyhip_set_tip_partials_at_pattern(int instance, int tipIndex, int pattern, 
   int code = (int)m; // S <= 8: the byte stored on the device is the allowed-state mask itself
   int rc   = 0;
   if (I->S > 8 && (rc = code_for_mask(I, m, &code))) return rc;
+  devirtualise_tip(I, tipIndex);
   if ((rc = flush(I, nullptr))) return rc; // queued operations read the old state
   void *st = nullptr;
   if ((rc = I->ring.alloc(16, I->stream, &st))) return rc;
@@ -514,6 +521,7 @@ int phyhip_set_partials(int instance, int bufferIndex, const double *inPartials)
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
+  devirtualise(I, bufferIndex); // (the scale vector of the last update stays what the reference has)
   rc = flush_sync(I);
   if (rc) return rc;
   if (!I->perm && !I->soa)
@@ -623,6 +631,7 @@ int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br
   GET_INST(I, instance);
   const int sc = apply_lk_scaling ? 1 : 0;
   if (I->l_min == l_min && I->l_max == l_max && I->br_len_mult == br_len_mult && I->apply_scaling == sc) return PHYHIP_SUCCESS;
+  if (I->apply_scaling != sc) devirtualise_all(I); // (the rescaling rule is part of a virtual buffer's definition)
   int rc = flush(I, nullptr);
   if (rc) return rc;
   I->l_min = l_min; I->l_max = l_max; I->br_len_mult = br_len_mult; I->apply_scaling = sc;
@@ -652,11 +661,56 @@ int phyhip_set_invariant_sites(int instance, int invar_model, double pinvar, con
 
 // ---- transition matrices ---------------------------------------------------------------------------
 
-static int matrices_touch(Instance *I, const int *idx, int count)
+// shadow (whole-tree batches of device-built matrices): [count] slots that receive the old values instead, filled here
+static int matrices_touch(Instance *I, const int *idx, int count, std::vector<int> *shadow = nullptr)
 {
   for (int i = 0; i < count; ++i)
-  {
     if (idx[i] < 0 || idx[i] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", idx[i]);
+  // A virtual buffer is defined on the matrices as they are.  Before one of them changes: a whole-tree batch -- Update_All_PMat in
+  // front of a full traversal that recomputes every buffer anyway -- has pmat_kernel move the old value into the buffer's own
+  // snapshot slot, and the definition reads it there from now on; anything else stores the buffer first (queued, launched below).
+  if (I->n_virtual > 0 && shadow)
+  {
+    std::vector<int> where; // matrix -> position in idx (the last one wins, as in the queue); short lists are searched instead
+    if (count > 4)
+    {
+      where.assign(I->nmat, -1);
+      for (int i = 0; i < count; ++i) where[idx[i]] = i;
+    }
+    auto pos = [&](int pm) {
+      if (pm >= I->nmat) return -1; // (already a snapshot slot)
+      if (count > 4) return where[pm];
+      for (int i = count - 1; i >= 0; --i)
+        if (idx[i] == pm) return i;
+      return -1;
+    };
+    bool any = false;
+    for (int b = I->tips; b < I->nbuf && !any; ++b) any = I->virt[b] && (pos(I->vdef[b].pm1) >= 0 || pos(I->vdef[b].pm2) >= 0);
+    if (any && !I->pending.empty())
+    { // (queued operations may read a virtual buffer through its definition: launched before the definition moves to a slot
+      // that is only filled by the rebuild / upload queued below)
+      int rc = flush(I, nullptr);
+      if (rc) return rc;
+    }
+    if (any) shadow->assign(count, -1);
+    for (int b = I->tips; b < I->nbuf && any; ++b)
+    {
+      if (!I->virt[b]) continue;
+      DevOp &d = I->vdef[b];
+      const int  i1 = pos(d.pm1), i2 = pos(d.pm2);
+      if (i1 < 0 && i2 < 0) continue;
+      // (one snapshot per matrix and call; a second dependant of a matrix, or a definition that reads it twice, is stored instead)
+      const bool free1 = i1 < 0 || ((*shadow)[i1] < 0 && I->pm_slot[d.pm1] < 0 && I->up_slot[d.pm1] < 0);
+      const bool free2 = i2 < 0 || ((*shadow)[i2] < 0 && I->pm_slot[d.pm2] < 0 && I->up_slot[d.pm2] < 0);
+      if (!free1 || !free2 || (i1 >= 0 && i2 >= 0 && d.pm1 == d.pm2)) { devirtualise(I, b); continue; }
+      if (i1 >= 0) { (*shadow)[i1] = shadow_slot(I, b, 0); d.pm1 = shadow_slot(I, b, 0); }
+      if (i2 >= 0) { (*shadow)[i2] = shadow_slot(I, b, 1); d.pm2 = shadow_slot(I, b, 1); }
+    }
+  }
+  else
+    for (int i = 0; i < count && I->n_virtual > 0; ++i) devirtualise_matrix(I, idx[i]);
+  for (int i = 0; i < count; ++i)
+  {
     if (I->mat_in_queue[idx[i]])
     { // a queued operation still reads the old matrix: launch the queue first (stream order does the rest)
       int rc = flush(I, nullptr);
@@ -681,7 +735,9 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
   if (firstDerivativeIndices || secondDerivativeIndices)
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "derivative matrices are not used by PhyML's path (see phyhip_calculate_eigen_lnl_dlnl)");
   if (count <= 0) return PHYHIP_SUCCESS;
-  int rc = matrices_touch(I, probabilityIndices, count);
+  std::vector<int> shadow;
+  const bool batch = count >= kEagerPmBatch;
+  int rc = matrices_touch(I, probabilityIndices, count, batch ? &shadow : nullptr);
   if (rc) return rc;
   // Deferred like the partial updates: SPR refreshes three matrices per regraft candidate (src/spr.c:643-646);
   // they are rebuilt by ONE pmat_kernel launch right before the traversal kernel that reads them.
@@ -700,7 +756,9 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
       I->pm_slot[m] = (int)I->pm_idx.size();
       I->pm_idx.push_back(m);
       I->pm_len.push_back(edgeLengths[i]);
+      I->pm_shadow.push_back(-1);
     }
+    if (!shadow.empty() && shadow[i] >= 0) { I->pm_shadow[I->pm_slot[m]] = shadow[i]; ++I->n_pm_shadow; }
   }
   // A whole-tree batch (Update_All_PMat, src/lk.c:500-512) is launched now rather than with the traversal: the device
   // rebuilds the matrices while the host walks the tree and fills the operation list.
@@ -715,7 +773,10 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
     return group_each(G, [&](int id, long long, long long) { return phyhip_set_transition_matrix(id, matrixIndex, inMatrix, paddedValue); });
   (void)paddedValue;
   GET_INST_RES(I, instance);
-  int rc = matrices_touch(I, &matrixIndex, 1);
+  // (a virtual buffer defined on the old value: the upload kernel moves that into the buffer's snapshot slot first -- the host
+  // route rewrites a whole tree's matrices one call at a time, and a stored buffer per call would be a launch per call)
+  std::vector<int> shadow;
+  int rc = matrices_touch(I, &matrixIndex, 1, I->n_virtual > 0 ? &shadow : nullptr);
   if (rc) return rc;
   if (I->pm_slot[matrixIndex] >= 0 && (rc = flush_pmats(I))) return rc; // keep rebuild-then-upload order
   const size_t bytes = (size_t)I->C * I->S * I->S * sizeof(double);
@@ -730,7 +791,9 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
     I->up_slot[matrixIndex] = (int)I->up_idx.size();
     I->up_idx.push_back(matrixIndex);
     I->up_src.push_back((const double *)st);
+    I->up_shadow.push_back(-1);
   }
+  if (!shadow.empty() && shadow[0] >= 0) { I->up_shadow[I->up_slot[matrixIndex]] = shadow[0]; ++I->n_up_shadow; }
   if ((int)I->up_idx.size() >= 4 * kUploadBatch && (rc = flush_uploads(I))) return rc;
   return PHYHIP_SUCCESS;
 }
@@ -867,6 +930,7 @@ int phyhip_get_partials(int instance, int bufferIndex, int scaleIndex, double *o
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
+  devirtualise(I, bufferIndex);
   if ((rc = flush_sync(I))) return rc;
   if (!I->perm && !I->soa)
   {
@@ -891,6 +955,7 @@ int phyhip_get_class_scale_factors(int instance, int bufferIndex, int classIndex
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
   if (classIndex < 0 || classIndex >= (I->class_axis ? I->C : 1)) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "class index %d", classIndex);
+  devirtualise(I, bufferIndex);
   if ((rc = flush_sync(I))) return rc;
   HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * scale_elems(I) + (size_t)classIndex * I->Ppad, I->P * sizeof(int),
                    hipMemcpyDeviceToHost));
@@ -904,6 +969,7 @@ int phyhip_get_scale_factors(int instance, int bufferIndex, int *out)
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
+  devirtualise(I, bufferIndex);
   if ((rc = flush_sync(I))) return rc;
   HIPCHK(hipMemcpy(out, I->d_scales + (size_t)(bufferIndex - I->tips) * scale_elems(I), I->P * sizeof(int), hipMemcpyDeviceToHost));
   return PHYHIP_SUCCESS;
@@ -916,6 +982,7 @@ int phyhip_set_scale_factors(int instance, int bufferIndex, const int *in)
   GET_INST(I, instance);
   int rc = check_partial_index(I, bufferIndex, false);
   if (rc) return rc;
+  devirtualise(I, bufferIndex);
   if ((rc = flush_sync(I))) return rc;
   HIPCHK(hipMemcpy(I->d_scales + (size_t)(bufferIndex - I->tips) * scale_elems(I), in, I->P * sizeof(int), hipMemcpyHostToDevice));
   return PHYHIP_SUCCESS;
@@ -1055,6 +1122,29 @@ int phyhip_get_big_resident_stats(int instance, long long out[4])
   I_call.leave_query();
   const Resident *R = &I->rb;
   out[0] = (long long)R->n_cmd; out[1] = (long long)R->n_launch; out[2] = (long long)R->n_silent; out[3] = (long long)R->n_busy;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_set_virtual_buffers(int instance, int minOperations)
+{
+  if (Group *G = get_group(instance)) return group_each(G, [&](int id, long long, long long) { return phyhip_set_virtual_buffers(id, minOperations); });
+  GET_INST(I, instance);
+  if (minOperations < 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "minOperations %d", minOperations);
+  I->virt_min_ops = minOperations;
+  if (minOperations == 0 && I->n_virtual > 0)
+  {
+    devirtualise_all(I);
+    return flush(I, nullptr);
+  }
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_get_virtual_stats(int instance, long long out[4])
+{
+  if (Group *G = get_group(instance)) return phyhip_get_virtual_stats(G->sub_id[0], out);
+  GET_INST_RES(I, instance);
+  I_call.leave_query();
+  out[0] = I->n_virtual; out[1] = (long long)I->n_virt_skipped; out[2] = (long long)I->n_virt_recomputed; out[3] = (long long)I->n_virt_material;
   return PHYHIP_SUCCESS;
 }
 

@@ -106,6 +106,7 @@ struct MatUploadParams
 {
   int           count, S, C;
   int           idx[kUploadBatch];
+  int           shadow[kUploadBatch]; // slot that receives the matrix's OLD value first, or -1 (virtual buffers, phyhip_host.hpp)
   const double *src[kUploadBatch]; // host-pinned, device-accessible
   double       *pmats;
   double       *afrag;             // nullptr unless 20 states
@@ -114,12 +115,18 @@ struct MatUploadParams
 static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUploadParams q)
 {
   extern __shared__ __attribute__((aligned(16))) double mat[]; // [C][S][S]
-  int           m   = q.idx[0];
+  int           m   = q.idx[0], shd = q.shadow[0];
   const double *src = q.src[0];
 #pragma unroll
   for (int k = 1; k < kUploadBatch; ++k)
-    if ((int)blockIdx.x == k) { m = q.idx[k]; src = q.src[k]; }
+    if ((int)blockIdx.x == k) { m = q.idx[k]; src = q.src[k]; shd = q.shadow[k]; }
   const int n = q.C * q.S * q.S;
+  if (shd >= 0)
+  { // (as in pmat_kernel: the old value moves to the snapshot slot before anything of the matrix is overwritten)
+    for (int e = threadIdx.x; e < n; e += blockDim.x) q.pmats[(size_t)shd * n + e] = q.pmats[(size_t)m * n + e];
+    if (q.afrag)
+      for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) q.afrag[(size_t)shd * kAaMat + e] = q.afrag[(size_t)m * kAaMat + e];
+  }
   for (int e = threadIdx.x; e < n; e += blockDim.x) mat[e] = src[e];
   __syncthreads();
   double *out = q.pmats + (size_t)m * n;
@@ -391,8 +398,10 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         u[0] = a01.x; u[1] = a01.y; u[2] = a23.x; u[3] = a23.y; u[4] = At[256 + la];
       };
 
-      double   prev[T] = {0., 0., 0., 0., 0.}; // result of the previous operation (this lane's D fragments)
-      unsigned prev_sc = 0;
+      // results of the last two operations (this lane's D fragments), alternating: step k finds the result of k-1 in one set and
+      // writes its own over the result of k-2 in the other (a result that stays virtual -- phyhip_host.hpp -- exists only here)
+      double   FA[T] = {0., 0., 0., 0., 0.}, FB[T] = {0., 0., 0., 0., 0.};
+      unsigned scA = 0, scB = 0;
 
       if (n_ops > 0)
       {
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           __builtin_amdgcn_raw_buffer_store_b32(0u, none, 4096, 0, 0);
         }
 
-        auto step = [&](const int k, Raw &R, Raw &Rn) {
+        auto step = [&](const int k, Raw &R, Raw &Rn, double (&Fout)[T], unsigned &scout, const double (&Fprev)[T], const unsigned scprev) {
           const unsigned fl = cur.dst_data.x;
           double         x1[T], x2[T], o[T];
           unsigned       s1, s2;
@@ -443,16 +452,28 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           else if (fl & kOpF11)
           {
 #pragma unroll
-            for (int t = 0; t < T; ++t) x1[t] = prev[t];
-            s1 = prev_sc;
+            for (int t = 0; t < T; ++t) x1[t] = Fprev[t];
+            s1 = scprev;
+          }
+          else if (fl & kOpF12)
+          {
+#pragma unroll
+            for (int t = 0; t < T; ++t) x1[t] = Fout[t];
+            s1 = scout;
           }
           else { unpack(R.a, x1); s1 = R.xa; }
           if (fl & kOpTip2) { if (!hot2) tip_vec(m2, x2); s2 = 0; }
           else if (fl & kOpF21)
           {
 #pragma unroll
-            for (int t = 0; t < T; ++t) x2[t] = prev[t];
-            s2 = prev_sc;
+            for (int t = 0; t < T; ++t) x2[t] = Fprev[t];
+            s2 = scprev;
+          }
+          else if (fl & kOpF22)
+          {
+#pragma unroll
+            for (int t = 0; t < T; ++t) x2[t] = Fout[t];
+            s2 = scout;
           }
           else { unpack(R.b, x2); s2 = R.xb; }
           PHY_STAMP(k, 1)
@@ -525,22 +546,28 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           }
           PHY_STAMP(k, 6)
 #pragma unroll
-          for (int t = 0; t < T; ++t) prev[t] = o[t];
-          prev_sc = sc;
-          cur     = nxe;
-          nx1     = nx2;
+          for (int t = 0; t < T; ++t) Fout[t] = o[t];
+          scout = sc;
+          cur   = nxe;
+          nx1   = nx2;
         };
         if constexpr (ARGS)
         {
-          step(0, RA, RB);
-          if (n_ops > 1) step(1, RB, RA);
+          step(0, RA, RB, FA, scA, FB, scB);
+          if (n_ops > 1) step(1, RB, RA, FB, scB, FA, scA);
+          else
+          { // the evaluation below expects the last result in the second set
+#pragma unroll
+            for (int t = 0; t < T; ++t) FB[t] = FA[t];
+            scB = scA;
+          }
         }
         else
-        {
+        { // (the list form is padded to an even length: the last result ends up in the second set)
           for (int k = 0; k < n_ops; k += 2)
           {
-            step(k, RA, RB);
-            step(k + 1, RB, RA);
+            step(k, RA, RB, FA, scA, FB, scB);
+            step(k + 1, RB, RA, FB, scB, FA, scA);
           }
         }
       }
@@ -560,8 +587,8 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           else if (idx == q.last_dest)
           {
 #pragma unroll
-            for (int t = 0; t < T; ++t) v[t] = prev[t];
-            sc = prev_sc;
+            for (int t = 0; t < T; ++t) v[t] = FB[t];
+            sc = scB;
           }
           else
           {

@@ -27,6 +27,10 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
   if ((rc = check_partial_index(I, rght, true))) return rc;
+  // virtual buffers the products (or the queued updates in front of them) read are stored first: the decisions below see the
+  // queue as it will be launched
+  devirtualise(I, left); devirtualise(I, rght);
+  rewrite_pending(I, nullptr, false);
   // Small nucleotide alignments (the resident short-launch evaluator's range, 2 048 patterns): the queued partial update(s) and
   // the products are ONE launch of the lane-per-pattern kernel (TreeParams::edge_eval 2) -- or, mostly, one command of the
   // resident workgroups.  Measured by chain (1 Update_Eigen_Lr + 5 dLk, tools/gpu_fuse_eigen_cross.sh): 40.3 vs 43.8 us at 382

@@ -164,6 +164,7 @@ struct Instance
   hipStream_t stream     = nullptr;
   bool        own_stream = true;
   int         tips = 0, nbuf = 0, S = 0, C = 0, CP = 0, nmat = 0;
+  int         nmat_all = 0;    // nmat + two snapshot slots per internal buffer (virtual buffers: shadow_slot)
   long long   P = 0, Ppad = 0; // Ppad: patterns per buffer as allocated (P, or P rounded up to 16 when perm)
   bool        class_axis = false; // categories are the classes of a mixture (PHYHIP_FLAG_CLASS_AXIS; TreeParams::class_axis)
   bool        generic_loop = false; // PHYHIP_FLAG_GENERIC_LOOP: the reference's generic loop (`--cov`): plain kernel, no all-ones shortcut
@@ -257,15 +258,29 @@ struct Instance
   int       grid = 0, grid_nt = 0, block_nt = 64;
 
   std::vector<DevOp>                     pending;
+  // Virtual buffers: a whole-tree traversal does not STORE the results of its tip x tip operations -- each
+  // is recomputed in registers right in front of the operation that consumes it (two matrix columns and a product per
+  // pattern: cheaper than the 16-byte-per-entry write and the read back) -- so the buffer's memory is stale until something
+  // needs it: then the defining operation is queued again, storing (devirtualise).  virt[b] != 0 says so, vdef[b] is that
+  // operation; the tips and the two matrices it reads may not change while virt[b] (matrices_touch, the tip setters).
+  int                                    virt_min_ops = 16; // lists at least this long leave tip x tip results virtual (0: never)
+  int                                    n_virtual = 0;
+  std::vector<unsigned char>             virt;              // [nbuf]
+  std::vector<DevOp>                     vdef;              // [nbuf]
+  unsigned long long                     n_virt_skipped = 0, n_virt_recomputed = 0, n_virt_material = 0; // phyhip_get_virtual_stats
   std::vector<int>                       pm_idx;    // queued device-side matrix rebuilds (index, edge length)
   std::vector<double>                    pm_len;
   std::vector<int>                       pm_slot;   // matrix index -> position in pm_idx, or -1
+  std::vector<int>                       pm_shadow; // per queued rebuild: slot that receives the matrix's OLD value first, or -1
+  int                                    n_pm_shadow = 0; // ... how many of them ask for one (such a list is rebuilt by pmat_kernel)
   std::vector<std::vector<DevOp>>        slot_ops;  // what each device ring slot currently holds (content cache)
   std::vector<int>                       slot_kind; // 0 slim, 1 fat dist 1, 2 fat dist 2
   std::vector<unsigned char>             mat_in_queue; // matrix index referenced by a queued op
   std::vector<int>                       up_idx;       // host-computed matrices waiting for their upload launch
   std::vector<const double *>            up_src;       // ... their copies in pinned staging memory
   std::vector<int>                       up_slot;      // per matrix: position in up_idx or -1
+  std::vector<int>                       up_shadow;    // per queued upload: slot that receives the old value first, or -1
+  int                                    n_up_shadow = 0; // ... how many ask for one (such uploads go through upload_matrices_kernel)
   std::vector<uint32_t>                  masks;
   std::unordered_map<uint32_t, int>      mask_code;
   bool                                   masks_dirty = false;
@@ -510,6 +525,13 @@ int  wait_host_sum(Instance *I);
 int  wait_result(Instance *I);
 int  wait_result_impl(Instance *I);
 int  collect_profile(Instance *I);
+void devirtualise(Instance *I, int buf);       // queue (in front) the storing operation that makes buffer `buf` real again
+void devirtualise_all(Instance *I);
+void devirtualise_matrix(Instance *I, int m);  // ... for every virtual buffer whose definition reads matrix m
+void devirtualise_tip(Instance *I, int tip);   // ... reads tip row `tip`
+// snapshot slot w (0: the definition's first matrix, 1: its second) of internal buffer b in the matrix tables
+inline int shadow_slot(const Instance *I, int b, int w) { return I->nmat + 2 * (b - I->tips) + w; }
+void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise);
 
 // ---- resident evaluators: host side -----------------------------------------------------------------------------
 constexpr int kResidentMaxGrid = 64;   // resident evaluator: alignments of up to this many dLk workgroups

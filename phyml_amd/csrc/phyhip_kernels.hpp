@@ -1792,6 +1792,8 @@ struct PmatParams
   const double *lengths; // [count] raw edge lengths b->l->v
   int           small_idx[kSmallPm];
   double        small_len[kSmallPm];
+  const int    *shadow;  // [count] or nullptr: slot that receives the matrix's OLD value before it is overwritten (-1: none) --
+  int           small_shadow[kSmallPm]; // a virtual buffer defined on the old matrix keeps reading it there (phyhip_host.hpp)
   int           count;
   int           S, C;
   const double *U, *V, *R;   // r_e_vect, l_e_vect, e_val
@@ -1816,14 +1818,22 @@ __global__ __launch_bounds__(ST == 4 ? 64 : 1024) void pmat_kernel(const PmatPar
   const int    C = q.C;
   // SPR refreshes three matrices per candidate: such short lists ride in the kernel arguments (no H2D copy)
   double l;
-  int    mat;
-  if (q.indices) { l = q.lengths[m]; mat = q.indices[m]; }
+  int    mat, shd;
+  if (q.indices) { l = q.lengths[m]; mat = q.indices[m]; shd = q.shadow ? q.shadow[m] : -1; }
   else
   {
-    l = q.small_len[0]; mat = q.small_idx[0];
+    l = q.small_len[0]; mat = q.small_idx[0]; shd = q.small_shadow[0];
 #pragma unroll
     for (int k = 1; k < kSmallPm; ++k)
-      if (m == k) { l = q.small_len[k]; mat = q.small_idx[k]; }
+      if (m == k) { l = q.small_len[k]; mat = q.small_idx[k]; shd = q.small_shadow[k]; }
+  }
+  if (shd >= 0)
+  { // the old value first (the loads complete before this thread's stores issue, the barriers below come before any overwrite)
+    const double *src = q.pmats + (size_t)mat * q.C * S * S;
+    double       *dst = q.pmats + (size_t)shd * q.C * S * S;
+    for (int e = threadIdx.x; e < q.C * S * S; e += blockDim.x) dst[e] = src[e];
+    if (ST == 20 && q.afrag)
+      for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) q.afrag[(size_t)shd * kAaMat + e] = q.afrag[(size_t)mat * kAaMat + e];
   }
   double *tmp  = expt + C * S;         // [C][S][S] floored, un-normalised entries
   double *rsum = tmp + C * S * S;      // [C][S]

@@ -102,6 +102,7 @@ static int mixture_dlnl_impl(const int *instances, int count, const int *left, c
     int rc = check_partial_index(I, left[k], true);
     if (rc) return rc;
     if ((rc = check_partial_index(I, right[k], true))) return rc;
+    devirtualise(I, left[k]); devirtualise(I, right[k]); // (the combination kernel reads their scale vectors)
     if ((rc = flush(I, nullptr))) return rc; // queued partial updates write the scale vectors read below
     // src/mixt.c:3056-3114
     const double rr  = 1.0 * I->br_len_mult * I->h_rates[0];

@@ -5,6 +5,113 @@
 namespace phyhip_host
 {
 
+// ---- virtual buffers (Instance::virt) ---------------------------------------------------------------------------------------
+constexpr int kOpNoStore = 1; // DevOp::pad bit 0: the operation's result is forwarded in registers only (descriptors of size 0)
+
+void devirtualise(Instance *I, int buf)
+{
+  if (I->n_virtual == 0 || buf < I->tips || buf >= I->nbuf || !I->virt[buf]) return;
+  DevOp op = I->vdef[buf];
+  op.pad   = 0;
+  // in FRONT of what is queued: it reads tips and matrices only (unchanged since the launch that left it virtual), and a queued
+  // operation may read it
+  I->pending.insert(I->pending.begin(), op);
+  I->mat_in_queue[op.pm1] = 1; I->mat_in_queue[op.pm2] = 1;
+  I->virt[buf] = 0;
+  --I->n_virtual;
+  ++I->n_virt_material;
+}
+
+void devirtualise_all(Instance *I)
+{
+  for (int b = I->tips; b < I->nbuf && I->n_virtual > 0; ++b) devirtualise(I, b);
+}
+
+void devirtualise_matrix(Instance *I, int m)
+{
+  for (int b = I->tips; b < I->nbuf && I->n_virtual > 0; ++b)
+    if (I->virt[b] && (I->vdef[b].pm1 == m || I->vdef[b].pm2 == m)) devirtualise(I, b);
+}
+
+void devirtualise_tip(Instance *I, int tip)
+{
+  for (int b = I->tips; b < I->nbuf && I->n_virtual > 0; ++b)
+    if (I->virt[b] && (I->vdef[b].c1 == tip || I->vdef[b].c2 == tip)) devirtualise(I, b);
+}
+
+// The queue as it will be launched.  (1) Every queued operation (and the evaluation edge) that reads a virtual buffer gets the
+// buffer's defining operation in front of it -- not storing when the list is a long one that leaves such results virtual anyway,
+// storing (the buffer is real afterwards) otherwise.  (2) may_virtualise, long lists: a tip x tip operation whose result is
+// written once in this list, read only later in it and not by the evaluation leaves its place -- it is re-issued, not storing,
+// in front of each of its consumers (the kernels forward the results of the previous two operations in registers).
+void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
+{
+  const int n0 = (int)I->pending.size();
+  const bool virtualise = may_virtualise && I->virt_min_ops > 0 && n0 >= I->virt_min_ops;
+  if (!virtualise && I->n_virtual == 0) return;
+  std::vector<unsigned char> skip;
+  if (virtualise)
+  {
+    std::vector<int> n_dest(I->nbuf, 0), first_read(I->nbuf, -1);
+    for (int k = 0; k < n0; ++k)
+    {
+      const DevOp &o = I->pending[k];
+      ++n_dest[o.dest];
+      for (int c : {o.c1, o.c2})
+        if (c >= I->tips && first_read[c] < 0) first_read[c] = k;
+    }
+    skip.assign(n0, 0);
+    for (int k = 0; k < n0; ++k)
+    {
+      const DevOp &o = I->pending[k];
+      if (o.c1 < I->tips && o.c2 < I->tips && n_dest[o.dest] == 1 && first_read[o.dest] > k &&
+          !(ee && (ee->parent == o.dest || ee->child == o.dest)))
+        skip[k] = 1;
+    }
+  }
+  std::vector<DevOp> L;
+  L.reserve((size_t)n0 + (size_t)I->n_virtual + 8);
+  auto before_read = [&](int c) {
+    if (c < I->tips || !I->virt[c]) return;
+    DevOp d = I->vdef[c];
+    if (virtualise) { d.pad = kOpNoStore; ++I->n_virt_recomputed; }
+    else
+    {
+      d.pad = 0;
+      I->virt[c] = 0; --I->n_virtual; ++I->n_virt_material;
+    }
+    I->mat_in_queue[d.pm1] = 1; I->mat_in_queue[d.pm2] = 1;
+    L.push_back(d);
+  };
+  for (int k = 0; k < n0; ++k)
+  {
+    DevOp o = I->pending[k];
+    if (virtualise && skip[k])
+    { // from here on the buffer is what this operation says; nothing is launched for it until somebody reads it
+      if (!I->virt[o.dest]) { I->virt[o.dest] = 1; ++I->n_virtual; }
+      o.pad = 0;
+      I->vdef[o.dest] = o;
+      ++I->n_virt_skipped;
+      continue;
+    }
+    before_read(o.c1);
+    if (o.c2 != o.c1) before_read(o.c2);
+    L.push_back(o);
+    if (I->virt[o.dest]) { I->virt[o.dest] = 0; --I->n_virtual; } // (a storing operation: the buffer is real again)
+  }
+  if (ee)
+    for (int side : {ee->parent, ee->child})
+      if (side >= I->tips && I->virt[side])
+      { // the evaluation reads memory (or the last result): stored
+        DevOp d = I->vdef[side];
+        d.pad = 0;
+        I->virt[side] = 0; --I->n_virtual; ++I->n_virt_material;
+        I->mat_in_queue[d.pm1] = 1; I->mat_in_queue[d.pm2] = 1;
+        L.push_back(d);
+      }
+  I->pending.swap(L);
+}
+
 // Host-computed matrices queued by phyhip_set_transition_matrix: one launch per kUploadBatch of them.
 int flush_uploads(Instance *I)
 {
@@ -16,7 +123,8 @@ int flush_uploads(Instance *I)
     MatUploadParams q;
     memset(&q, 0, sizeof q);
     q.count = n; q.S = I->S; q.C = I->C; q.pmats = I->d_pmats; q.afrag = I->perm ? I->d_afrag : nullptr;
-    for (int k = 0; k < n; ++k) { q.idx[k] = I->up_idx[done + k]; q.src[k] = I->up_src[done + k]; }
+    for (int k = 0; k < kUploadBatch; ++k) q.shadow[k] = -1;
+    for (int k = 0; k < n; ++k) { q.idx[k] = I->up_idx[done + k]; q.src[k] = I->up_src[done + k]; q.shadow[k] = I->up_shadow[done + k]; }
     hipLaunchKernelGGL(upload_matrices_kernel, dim3(n), dim3(256), sizeof(double) * (size_t)I->C * I->S * I->S, I->stream, q);
     HIPCHK(hipGetLastError());
     done += n;
@@ -24,6 +132,8 @@ int flush_uploads(Instance *I)
   for (int m : I->up_idx) I->up_slot[m] = -1;
   I->up_idx.clear();
   I->up_src.clear();
+  I->up_shadow.clear();
+  I->n_up_shadow = 0;
   return 0;
 }
 
@@ -43,20 +153,24 @@ int flush_pmats(Instance *I)
     memset(&q, 0, sizeof q);
     if (small)
     {
+      for (int k = 0; k < kSmallPm; ++k) q.small_shadow[k] = -1;
       for (int k = 0; k < n; ++k)
       {
         q.small_idx[k] = I->pm_idx[done + k];
         q.small_len[k] = I->pm_len[done + k];
+        q.small_shadow[k] = I->pm_shadow[done + k];
       }
     }
     else
     {
       void        *st = nullptr;
+      const bool   sh = I->n_pm_shadow > 0; // (snapshots of old values for virtual buffers: a third array)
       const size_t bi = (sizeof(int) * n + 15) & ~size_t(15), bl = sizeof(double) * n;
-      rc = I->ring.alloc(bi + bl, I->stream, &st);
+      rc = I->ring.alloc(bi + bl + (sh ? bi : 0), I->stream, &st);
       if (rc) return rc;
       memcpy(st, I->pm_idx.data() + done, sizeof(int) * n);
       memcpy((char *)st + bi, I->pm_len.data() + done, bl);
+      if (sh) memcpy((char *)st + bi + bl, I->pm_shadow.data() + done, sizeof(int) * n);
       if (I->pm_copy)
       {
         HIPCHK(hipMemcpyAsync(I->d_pmscratch, st, bi + bl, hipMemcpyHostToDevice, I->stream));
@@ -69,6 +183,7 @@ int flush_pmats(Instance *I)
         q.indices = (const int *)st;
         q.lengths = (const double *)((char *)st + bi);
       }
+      if (sh) q.shadow = (const int *)((char *)st + bi + bl); // (always read from the staging chunk)
     }
     q.count = n;
     q.S = I->S; q.C = I->C; q.U = I->d_evec; q.V = I->d_ivec; q.R = I->d_eval; q.rates = I->d_catr;
@@ -93,6 +208,8 @@ int flush_pmats(Instance *I)
   for (int m : I->pm_idx) I->pm_slot[m] = -1;
   I->pm_idx.clear();
   I->pm_len.clear();
+  I->pm_shadow.clear();
+  I->n_pm_shadow = 0;
   return 0;
 }
 
@@ -113,6 +230,11 @@ bool fuse_reduce(const Instance *I, int nblocks)
 int flush_impl(Instance *I, const EdgeEval *ee)
 {
   const unsigned long long hp0 = hp_now();
+  const int n_queued = (int)I->pending.size(); // (what the caller asked for: the unit of phyhip_profile_read's update count)
+  // virtual buffers: what the queue reads of them is (re)computed in front of its reader; a long list of the two pipelined
+  // kernels with two-deep register forwarding leaves its own tip x tip results virtual (rewrite_pending)
+  rewrite_pending(I, ee, (I->soa || I->perm) && !I->generic_nt && I->prefetch_dist == 2 && !I->class_axis && !I->generic_loop &&
+                             !I->ablate && !I->no_loads);
   const int n_ops = (int)I->pending.size();
   int rc = 0;
   if (n_ops > 0 || ee || !I->pm_idx.empty() || !I->up_idx.empty()) I->stream_dirty = true;
@@ -149,11 +271,11 @@ int flush_impl(Instance *I, const EdgeEval *ee)
             (int)I->touched_call, I->clean_after, *reinterpret_cast<volatile unsigned long long *>(I->h_result + 3), I->big_streak, (int)I->rb.launched,
             (void *)g_big_owner[I->dev < 64 ? I->dev : 0].load(), (void *)I);
   const bool fold_pm = I->soa && I->fold_pmats && (I->grid_nt2 <= fold_grid_max || big_try || one_shot) && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
-                       I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
+                       I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8) && I->n_pm_shadow == 0;
   // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
   // (TreeParams::n_up): no upload kernel in front of the traversal
   const bool arg_up = I->soa && I->arg_uploads && !I->up_idx.empty() && (int)I->up_idx.size() <= kArgUp && I->pm_idx.empty() &&
-                      (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8);
+                      (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8) && I->n_up_shadow == 0;
   if (!fold_pm && !arg_up && (!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
   if (n_ops == 0 && !ee) return 0;
   rc = upload_masks(I);
@@ -174,6 +296,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     for (int m : I->up_idx) I->up_slot[m] = -1;
     I->up_idx.clear();
     I->up_src.clear();
+    I->up_shadow.clear();
   }
   if (fold_pm)
   {
@@ -286,8 +409,9 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes);
         child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);
         const size_t b = (size_t)(o.dest - I->tips);
-        xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), bufbytes, fl);
-        xr[k].dst_scale = desc(I->d_scales + b * scale_elems(I), scale_elems(I) * 4, 0);
+        const bool   st_on = !(o.pad & kOpNoStore); // (a result that stays virtual: stores through descriptors of size 0 are dropped)
+        xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), st_on ? bufbytes : 0, fl);
+        xr[k].dst_scale = desc(I->d_scales + b * scale_elems(I), st_on ? scale_elems(I) * 4 : 0, 0);
       }
       // (reading short lists straight from the pinned staging memory instead was measured: no gain)
       if (in_args)
@@ -469,6 +593,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         for (int m : I->pm_idx) I->pm_slot[m] = -1;
         I->pm_idx.clear();
         I->pm_len.clear();
+        I->pm_shadow.clear();
       }
       I->pending.clear();
       std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
@@ -527,7 +652,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         {
           HIPCHK(hipEventRecord(p1, I->stream));
           I->prof_pairs.emplace_back(p0, p1);
-          I->prof_updates += (double)n_ops * (double)I->P;
+          I->prof_updates += (double)n_queued * (double)I->P;
         }
         I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
       }
@@ -544,6 +669,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         for (int m : I->pm_idx) I->pm_slot[m] = -1;
         I->pm_idx.clear();
         I->pm_len.clear();
+        I->pm_shadow.clear();
       }
       I->pending.clear();
       std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
@@ -663,15 +789,15 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   case c_:                                                                                                                  \
     if (q.recs_in_args)                                                                                                     \
       hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,    \
-                         (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
+                         (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
     else                                                                                                                    \
     hipLaunchKernelGGL((traverse_aa_kernel<c_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,                      \
-                       (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
+                       (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
     return 0;
 #ifdef PHYHIP_DIAG
         if (I->C == 4 && I->ablate >= 256)
         { // PHYHIP_ABLATE = 256 + bits: timing-only ablations of the 20-state kernel (results invalid)
-#define AAABL(a_) case a_: hipLaunchKernelGGL((traverse_aa_kernel<4, false, a_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec, (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); return 0;
+#define AAABL(a_) case a_: hipLaunchKernelGGL((traverse_aa_kernel<4, false, a_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec, (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); return 0;
           switch (I->ablate - 256)
           {
             AAABL(1) AAABL(2) AAABL(4) AAABL(8) AAABL(9) AAABL(16) AAABL(18) AAABL(5) AAABL(13) AAABL(31) AAABL(27)
@@ -685,10 +811,10 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           if (!d_dbg) HIPCHK(hipMalloc((void **)&d_dbg, 64 * 8 * 8));
           if (I->ablate & 128) // (stamps of the bare skeleton: every ablation on)
             hipLaunchKernelGGL((traverse_aa_kernel<4, true, 31>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,
-                               (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, d_dbg);
+                               (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, d_dbg);
           else
           hipLaunchKernelGGL((traverse_aa_kernel<4, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,
-                             (const double *)I->d_afrag, I->nmat, (const uint32_t *)I->d_tipmasks, d_dbg);
+                             (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, d_dbg);
           static int printed = 0;
           if (printed++ == 5)
           {
@@ -723,16 +849,17 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   {
     HIPCHK(hipEventRecord(e1, I->stream));
     I->prof_pairs.emplace_back(e0, e1);
-    I->prof_updates += (double)n_ops * (double)I->P;
+    I->prof_updates += (double)n_queued * (double)I->P;
     // Minimum traffic of this launch if nothing but the kernel's own register forwarding saved a byte: every result is
     // written once; a child is read unless it is a tip (1 byte per pattern) or the result of one of the previous two
     // operations (forwarded in registers -- exactly the flags computed for the operation records above).
     {
       const double rec = (double)I->C * I->S * 8.0 + 4.0;
-      double       rd = 0.0, wr = (double)n_ops * rec;
+      double       rd = 0.0, wr = 0.0;
       for (int k = 0; k < n_ops; ++k)
       {
         const DevOp &o  = I->pending[k];
+        if (!(o.pad & kOpNoStore)) wr += rec;
         const int    e1 = k >= 1 ? I->pending[k - 1].dest : -1;
         const int    e2 = (k >= 2 && fat && I->prefetch_dist == 2) ? I->pending[k - 2].dest : -1;
         for (int c : {o.c1, o.c2})
@@ -766,6 +893,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     for (int m : I->pm_idx) I->pm_slot[m] = -1;
     I->pm_idx.clear();
     I->pm_len.clear();
+    I->pm_shadow.clear();
   }
   I->pending.clear();
   std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
@@ -962,6 +1090,7 @@ int flush_and_wait(Instance *I, EdgeEval &ee, bool flushed)
         I->pm_slot[I->rt_pm_idx[k]] = (int)I->pm_idx.size();
         I->pm_idx.push_back(I->rt_pm_idx[k]);
         I->pm_len.push_back(I->rt_pm_len[k]);
+        I->pm_shadow.push_back(-1);
       }
     I->rt_skip = true;
     rc = flush(I, &ee);

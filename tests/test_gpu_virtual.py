@@ -1,0 +1,187 @@
+"""Virtual buffers (include/phyhip.h: phyhip_set_virtual_buffers): a whole-tree traversal does not store its tip x tip results,
+every reader gets them recomputed in registers, and whatever LEAVES through the interface is still the double the reference
+holds in t_edge::p_lk_* at that point -- including the values computed with matrices that have changed since.
+
+Oracle: tests/orc.py (the pinned CPU restatement, host-computed matrices: bit-exact route) and the same device tree with the
+feature switched off."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from gpu_common import synthetic_pair
+
+SHAPES = [(4, 4, 700), (4, 1, 300), (4, 2, 513), (4, 3, 200), (20, 4, 130), (20, 1, 90), (20, 2, 70)]
+
+
+def cherry_keys(ot):
+    """(edge, side) of every buffer whose two children are tips"""
+    out = []
+    for (e, side) in ot.plk:
+        d = int(ot.el[e] if side == 0 else ot.er[e])
+        kids = [v for (v, be) in ot.adj[d] if be != e]
+        if all(v < ot.n for v in kids):
+            out.append((e, side))
+    return out
+
+
+def all_buffers(t, ot):
+    return {k: (t.partials(*k).copy(), t.scale_factors(*k).copy()) for k in ot.plk}
+
+
+@pytest.mark.parametrize("ns,C,P", SHAPES)
+@pytest.mark.parametrize("both", [False, True])
+def test_full_traversal_virtual_buffers_read_back_bit_equal(ns, C, P, both):
+    t, ot, tree, st = synthetic_pair(40, P, ns, C, seed=11 + ns + C, ambiguous_every=17)
+    t0, _, _, _ = synthetic_pair(40, P, ns, C, seed=11 + ns + C, ambiguous_every=17)
+    try:
+        t0.inst.set_virtual_buffers(0)
+        for x in (t, t0):
+            x.Set_Both_Sides(both)
+        lnl, lnl0 = t.Lk(None), t0.Lk(None)
+        ref = ot.lk(None, both_sides=both)
+        assert lnl == lnl0                      # the same doubles whether the stores were skipped or not
+        assert abs(lnl - ref) / abs(ref) < 1e-12
+        now, skipped, reissued, stored = t.inst.virtual_stats()
+        n_cherry = len(cherry_keys(ot))
+        assert now > 0 and skipped == now and stored == 0, (now, skipped, reissued, stored)
+        assert now <= n_cherry
+        assert t0.inst.virtual_stats() == (0, 0, 0, 0)
+        # a second traversal of the same tree: again nothing stored for them
+        assert t.Lk(None) == lnl
+        assert t.inst.virtual_stats()[0] == now and t.inst.virtual_stats()[3] == 0
+        # reading back materialises: every buffer (cherries included) bit-equal to the oracle and to the storing run
+        keys = [k for k in ot.plk if both or np.any(ot.plk[k] != 0)]
+        for k in keys:
+            got, sc = t.partials(*k), t.scale_factors(*k)
+            assert np.array_equal(got, ot.plk[k]), k
+            assert np.array_equal(sc, ot.scale[k]), k
+            assert np.array_equal(got, t0.partials(*k)), k
+        assert t.inst.virtual_stats()[0] == 0 and t.inst.virtual_stats()[3] == now
+        # and the evaluation at every edge afterwards (both sides of every edge are up to date only then)
+        if both:
+            assert t.Lk(None) == t0.Lk(None)   # (virtual again)
+            for e in range(t.ne):
+                assert t.Lk(e) == t0.Lk(e)
+    finally:
+        t.close(); t0.close()
+
+
+@pytest.mark.parametrize("ns,C,P", [(4, 4, 333), (20, 4, 77)])
+@pytest.mark.parametrize("host_pmat", [True, False])
+def test_a_virtual_buffer_keeps_the_old_matrix_value(ns, C, P, host_pmat):
+    """The reference's p_lk of a cherry stays what the last Update_Partial_Lk wrote, whatever happens to the pendant edges'
+    matrices afterwards.  One matrix changed (stored first, or snapshot by the upload), and a whole-tree batch (snapshots by
+    pmat_kernel)."""
+    t, ot, tree, st = synthetic_pair(30, P, ns, C, seed=5, host_pmat=host_pmat)
+    t0, _, _, _ = synthetic_pair(30, P, ns, C, seed=5, host_pmat=host_pmat)
+    try:
+        t0.inst.set_virtual_buffers(0)
+        assert t.Lk(None) == t0.Lk(None)
+        ck = cherry_keys(ot)
+        n_virtual = t.inst.virtual_stats()[0]
+        assert n_virtual > 0
+        before = {k: (t0.partials(*k).copy(), t0.scale_factors(*k).copy()) for k in ck}
+        # (1) one pendant edge of one cherry gets a new length and a new matrix -- nothing is recomputed
+        e0, s0 = ck[0]
+        d = int(ot.el[e0] if s0 == 0 else ot.er[e0])
+        pend = [be for (v, be) in ot.adj[d] if be != e0][0]
+        for x in (t, t0):
+            x.edge(pend).contents.l = 0.37
+            x.Update_PMat_At_Given_Edge(pend)
+        for k in ck:
+            assert np.array_equal(t.partials(*k), before[k][0]), k
+            assert np.array_equal(t.scale_factors(*k), before[k][1]), k
+        # (2) again virtual, then EVERY matrix changes in one batch (Update_All_PMat) without a traversal
+        assert t.Lk(None) == t0.Lk(None)
+        assert t.inst.virtual_stats()[0] == n_virtual
+        before = {k: (t0.partials(*k).copy(), t0.scale_factors(*k).copy()) for k in ck}
+        idx = np.array([t.edge(e).contents.Pij_rr_idx for e in range(t.ne)], dtype=np.int32)
+        lens = np.linspace(0.01, 0.5, t.ne)
+        if host_pmat:
+            for e in range(t.ne):
+                for x in (t, t0):
+                    x.edge(e).contents.l = float(lens[e])
+                    x.Update_PMat_At_Given_Edge(e)
+        else:
+            for x in (t, t0):
+                x.inst.update_transition_matrices(idx, lens)
+        assert t.inst.virtual_stats()[0] > 0    # snapshots, not stores
+        for k in ck:
+            assert np.array_equal(t.partials(*k), before[k][0]), k
+            assert np.array_equal(t.scale_factors(*k), before[k][1]), k
+        # the new matrices are what the next evaluation uses
+        if not host_pmat:
+            for x in (t, t0):
+                for e in range(t.ne):
+                    x.edge(e).contents.l = float(lens[e])
+        assert t.Lk(None) == t0.Lk(None)
+    finally:
+        t.close(); t0.close()
+
+
+@pytest.mark.parametrize("ns,C,P", [(4, 4, 450), (20, 4, 60)])
+def test_search_like_stream_after_a_virtualising_traversal(ns, C, P):
+    """Lk(NULL) leaves the cherries virtual; then the call pattern of a search: Lk(b) at every edge, partial updates along
+    paths, Update_Eigen_Lr + dLk at edges whose sides are cherries, tip rewrites -- every scalar the storing run's."""
+    t, ot, tree, st = synthetic_pair(36, P, ns, C, seed=3, host_pmat=False)
+    t0, _, _, _ = synthetic_pair(36, P, ns, C, seed=3, host_pmat=False)
+    try:
+        t0.inst.set_virtual_buffers(0)
+        for x in (t, t0):
+            x.Set_Both_Sides(True)
+        assert t.Lk(None) == t0.Lk(None)
+        assert t.inst.virtual_stats()[0] > 0
+        ck = cherry_keys(ot)
+        rng = np.random.default_rng(1)
+        for rep in range(3):
+            for (e, side) in ck[:6]:
+                d = int(ot.el[e] if side == 0 else ot.er[e])
+                pend = [be for (v, be) in ot.adj[d] if be != e]
+                for b in (e, pend[0], pend[1]):
+                    got, ref = [], []
+                    for x, out in ((t, got), (t0, ref)):
+                        x.Set_Update_Eigen_Lr(True); x.Set_Use_Eigen_Lr(False)
+                        out.append(x.Lk(b))
+                        x.Set_Update_Eigen_Lr(False); x.Set_Use_Eigen_Lr(True)
+                        for l in (0.05, 0.21):
+                            out.append(x.dLk(l, b)[1]); out.append(x.c_dlnL)
+                        x.Set_Use_Eigen_Lr(False)
+                        x.edge(b).contents.l = float(0.03 + 0.1 * rep)
+                        x.Update_PMat_At_Given_Edge(b)
+                        out.append(x.Lk(b))
+                    assert got == ref, (rep, e, b)
+            # a full traversal in between makes them virtual again
+            assert t.Lk(None) == t0.Lk(None)
+            assert t.inst.virtual_stats()[0] > 0
+            # one character of a cherry's tip hidden and restored (src/cv.c): stored on the old row first
+            (e, side) = ck[rep % len(ck)]
+            d = int(ot.el[e] if side == 0 else ot.er[e])
+            tip = [v for (v, be) in ot.adj[d] if be != e][0]
+            keep = t0.partials(e, side).copy()
+            for x in (t, t0):
+                x.inst.set_tip_partials_at_pattern(tip, int(rng.integers(0, P)), np.ones(ns))
+            assert np.array_equal(t.partials(e, side), keep)
+            assert t.Lk(None) == t0.Lk(None)
+    finally:
+        t.close(); t0.close()
+
+
+def test_short_lists_store_everything():
+    """Below the threshold (16 operations by default) nothing is left virtual; the threshold is the instance's to set."""
+    t, ot, tree, st = synthetic_pair(12, 200, 4, 4, seed=2)
+    try:
+        t.Lk(None)
+        assert t.inst.virtual_stats() == (0, 0, 0, 0)
+        t.inst.set_virtual_buffers(2)
+        lnl = t.Lk(None)
+        assert t.inst.virtual_stats()[0] > 0
+        ref = ot.lk(None)
+        assert abs(lnl - ref) / abs(ref) < 1e-12
+        t.inst.set_virtual_buffers(0)
+        assert t.inst.virtual_stats()[0] == 0
+        for k in ot.plk:
+            if np.any(ot.plk[k] != 0):
+                assert np.array_equal(t.partials(*k), ot.plk[k]), k
+    finally:
+        t.close()
