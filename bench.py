@@ -269,7 +269,8 @@ def run_single(args, torch):
     if exp and P == exp["n_pattern"]:
         out["lnL_reference_avx"] = exp["lnL"]
         out["lnL_rel_err"] = abs(lnl - exp["lnL"]) / abs(exp["lnL"])
-        out["input_checksum_ok"] = bool(synth.states_checksum(st) == exp["checksum"])
+        if "checksum" in exp:
+            out["input_checksum_ok"] = bool(synth.states_checksum(st) == exp["checksum"])
     t.close()
     if not args.no_extra and args.workload == "cfg2_nt_100x50k" and args.patterns is None:
         out["extra"] = {"cfg3_aa_200x10k": extra_line("cfg3_aa_200x10k", args, torch)}

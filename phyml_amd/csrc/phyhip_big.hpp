@@ -47,7 +47,7 @@ enum : unsigned long long
 // same additions, same double; no per-tile stores to memory, no wait for their acknowledgement, no dependent atomics (two
 // round trips to memory), one load per thread instead of thirteen (3 126 tiles).  At most kBigGroupTiles tiles per workgroup.
 constexpr int kBigGroupTiles = 8 * 16; // (16 rounds of the smallest workgroup fit every staging area twice over)
-constexpr unsigned long long kBigGroupPatience = 20000; // wall-clock ticks (200 us) the watching workgroup waits for a record
+constexpr unsigned long long kBigGroupPatience = 20000; // wall-clock ticks (200 us) the watching workgroup waits for a record, + 8 per tile (a command is ~1 tick per tile)
 
 struct BigCtl
 {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
               asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(rec) : "v"(b.wg_recs + sidx * kBigGroupWgs + tid) : "memory");
               if (rec.y == tag) break;
               // (a resident workgroup that left: nobody answers, the host launches; the workgroups of a launch all come)
-              if (!n_one_shot && wall_clock64() - t_poll > kBigGroupPatience) { sh_late = 1; break; }
+              if (!n_one_shot && wall_clock64() - t_poll > kBigGroupPatience + 8ull * (unsigned long long)b.n_tiles) { sh_late = 1; break; }
             }
             double d;
             const unsigned long long bits = rec.x;

@@ -581,7 +581,12 @@ inline bool big_shape(const Instance *I)
   return I->host_sum && I->soa && !I->co && !I->class_axis && I->grid_nt2 > kResidentMaxGrid && I->nt_groups <= 2 && !I->ablate;
 }
 // ... and whether those workgroups may serve it
-inline bool big_eligible(const Instance *I) { return big_shape(I) && I->resident && I->spin_wait && I->dev >= 0 && I->dev < 64; }
+// (an instance whose commands keep going unanswered -- more than 16 and more than a quarter of them -- stops asking: every such
+// command costs the wait, the workgroups' exit and a launch)
+inline bool big_eligible(const Instance *I)
+{
+  return big_shape(I) && I->resident && I->spin_wait && I->dev >= 0 && I->dev < 64 && !(I->rb.n_silent > 16 && I->rb.n_silent * 4 > I->rb.n_cmd);
+}
 
 // The final sum through one partial sum per workgroup (phyhip_big.hpp, kBigGroupSum): the tiles of a workgroup are one
 // accumulator of final_reduce_kernel's order only when there are exactly as many workgroups as accumulators

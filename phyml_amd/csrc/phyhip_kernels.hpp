@@ -596,9 +596,12 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
     {
       const size_t b   = (size_t)(op.dest - q.tip_count);
       double2     *dst = reinterpret_cast<double2 *>(q.partials + (b * q.P + p) * (size_t)CS + (size_t)c * S);
+      // the reference's generic loop writes zeros for a pattern without weight and leaves its scale exponent alone
+      // (src/lk.c:1405,1581-1584); the SIMD kernels leave such a pattern untouched (src/avx.c:399) -- its values are never used
+      const bool zero_w = q.generic_loop && !(q.wght[p] > kSmall);
 #pragma unroll
-      for (int j = 0; j < S / 2; ++j) dst[j] = make_double2(o[2 * j], o[2 * j + 1]);
-      if (c == 0) q.scales[b * q.Ppad + p] = sc;
+      for (int j = 0; j < S / 2; ++j) dst[j] = zero_w ? make_double2(0.0, 0.0) : make_double2(o[2 * j], o[2 * j + 1]);
+      if (c == 0 && !zero_w) q.scales[b * q.Ppad + p] = sc;
     }
   }
 

@@ -115,7 +115,12 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
 // Host-computed matrices queued by phyhip_set_transition_matrix: one launch per kUploadBatch of them.
 int flush_uploads(Instance *I)
 {
-  if (!I->up_idx.empty()) I->touched_call = true;
+  if (!I->up_idx.empty())
+  { // (the upload kernel writes the matrix table: behind the exit of the large-grid resident workgroups, whose own rebuilt
+    // matrices sit in their L2s until they leave -- reachable from entry points that keep them, phyhip.hip)
+    big_release(I);
+    I->touched_call = true;
+  }
   size_t done = 0;
   while (done < I->up_idx.size())
   {
@@ -964,7 +969,10 @@ int wait_host_sum(Instance *I)
         { // no answer from the resident workgroups (they may have left just before the command arrived): the caller
           // retires them and launches the evaluation the ordinary way
           if (waited > 30000L && resident_gone(*I->r_inflight)) return kResidentSilent; // they left as the command arrived
-          if (waited > 100000L && ns_since(I->r_inflight->t_launch) > 20e6) return kResidentSilent; // (a first launch loads code: ms)
+          // (a healthy command of the large-grid evaluator takes ~8 ns per tile and operation -- 25 us at 3 126 tiles -- so the
+          // give-up time grows with the grid: 100 us + 80 ns per tile)
+          const long patience = 100000L + (I->r_inflight == &I->rb ? 80L * (long)I->grid_nt2 : 0L);
+          if (waited > patience && ns_since(I->r_inflight->t_launch) > 20e6) return kResidentSilent; // (a first launch loads code: ms)
           continue;
         }
         if (waited > 2000000L || !I->spin_wait)

@@ -110,14 +110,18 @@ int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned l
                                        : hipExtMallocWithFlags((void **)&R.cmd, bytes, I->push_cmds == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
       if (e == hipSuccess && posix_memalign((void **)&R.shadow, 64, bytes) == 0)
       {
-        HIPCHK(hipMemset(R.cmd, 0, bytes));
-        HIPCHK(hipDeviceSynchronize());
+        // (zeroed on the instance's own stream and waited for THERE: a device-wide synchronisation would also wait for other
+        // instances' resident workgroups, which only leave after their idle time -- a mixture of 64 class instances met that
+        // stall on every instance's first use)
+        HIPCHK(hipMemsetAsync(R.cmd, 0, bytes, I->stream));
+        HIPCHK(hipStreamSynchronize(I->stream));
         memset(R.shadow, 0, bytes);
         R.pushed = true;
       }
       else
       {
         if (e == hipSuccess) (void)hipFree(R.cmd);
+        else (void)hipGetLastError(); // (the record falls back to host memory: no stale error for the next launch check to report)
         R.cmd = nullptr; R.shadow = nullptr;
       }
     }
@@ -129,7 +133,8 @@ int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned l
     HIPCHK(hipHostMalloc((void **)&R.report, 64, hipHostMallocMapped | hipHostMallocCoherent));
     memset(R.report, 0, 64);
     HIPCHK(hipMalloc((void **)&R.mail, sizeof(ResidentCmd)));
-    HIPCHK(hipMemset(R.mail, 0, sizeof(ResidentCmd)));
+    HIPCHK(hipMemsetAsync(R.mail, 0, sizeof(ResidentCmd), I->stream));
+    HIPCHK(hipStreamSynchronize(I->stream));
     for (hipStream_t &s2 : R.stream) HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   }
   ++R.n_launch;

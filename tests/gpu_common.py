@@ -23,7 +23,7 @@ def device_tree_from_golden(d, host_pmat=True, devices=None, force_sharded=False
 
 
 def synthetic_pair(n_otu, P, ns, C, seed, lmin=0.02, lmax=0.3, wght=None, apply_scaling=1, host_pmat=True, ambiguous_every=0,
-                   devices=None, force_sharded=False):
+                   devices=None, force_sharded=False, use_m4mod=False, arith=1):
     """Device tree + oracle tree on a seeded synthetic alignment with C rate classes (rates/weights made up,
     normalised) and the committed model block's eigen system."""
     from phyml_amd import synth, workloads
@@ -46,9 +46,9 @@ def synthetic_pair(n_otu, P, ns, C, seed, lmin=0.02, lmax=0.3, wght=None, apply_
     for t in range(n_otu):
         v, s, a = orc.init_tip(m.datatype, chars[t])
         tv.append(v); ds.append(s); amb_.append(a)
-    ot = orc.OracleTree(m, n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, wg, tv, ds, amb_, apply_scaling=apply_scaling)
+    ot = orc.OracleTree(m, n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, wg, tv, ds, amb_, apply_scaling=apply_scaling, arith=arith)
     t = lktree.LkTree(n_otu, tree.edge_left, tree.edge_rght, tree.edge_len, P, ns, C, host_pmat=host_pmat, devices=devices,
-                      force_sharded=force_sharded)
+                      force_sharded=force_sharded, use_m4mod=use_m4mod)
     t.set_model(m.pi, m.gamma_rr, m.gamma_r_proba, m.e_val, m.r_e_vect, m.l_e_vect, m.l_min, m.l_max, 1.0, apply_scaling)
     t.Make_Tree_For_Lk(wg)
     t.set_tips(tip_partials=tv)

@@ -59,8 +59,12 @@ def main():
         b, b2 = t.Replay_Surface_Trace(trb)
     finally:
         t.close()
-    res["stream_host"] = [float.hex(float(x)) for x in list(h) + list(h2)]
-    res["stream_big"] = [float.hex(float(x)) for x in list(b) + list(b2)]
+    # (first outputs: the lnL of every scalar-returning call; second outputs: dlnL of the dLk calls -- compared separately)
+    res["stream_host"] = [float.hex(float(x)) for x in h]
+    res["stream_host_d"] = [float.hex(float(x)) for x in h2]
+    res["stream_big"] = [float.hex(float(x)) for x in b]
+    res["stream_big_d"] = [float.hex(float(x)) for x in b2]
+    res["sum_w"] = {"stream": 900.0, "stream_host": 900.0, "stream_big": 9000.0}
     # 20 states: the golden proteic fixture (generic kernel against the MFMA kernel)
     d = phyg.load(os.path.join(ROOT, "tests", "golden", "proteic_lg_g4.phyg"))
     t, ot = device_tree_from_golden(d)

@@ -180,6 +180,13 @@ def test_resident_choke_point():
     for helper, allowed in REVIEWED.items():
         users = {name for name, body in bodies.items() if "." + helper + "(" in body}
         assert users == allowed, (helper, sorted(users ^ allowed))
+    # the kernels that write the matrix table outside the traversal launches run behind the large-grid resident workgroups' exit --
+    # both are reachable from entry points that keep those workgroups (GET_INST_RES: the two matrix setters)
+    q = open(os.path.join(csrc, "phyhip_queue.hip")).read()
+    for fn in ("flush_uploads", "flush_pmats"):
+        body = q[q.index("int %s(Instance *I)" % fn):]
+        body = body[:body.index("\n}\n")]
+        assert "big_release(I);" in body, fn
     # the table is reachable through the class only, and nobody restores the flag by hand
     assert len(re.findall(r"tab_\[", src)) == len(re.findall(r"tab_\[", src[src.index("class InstanceTable"):src.index("template <bool KeepsResidents> class Entered\n")]))
     assert len(re.findall(r"stream_dirty\s*=\s*I_?->dirty_prev", src)) == 3  # the three members themselves

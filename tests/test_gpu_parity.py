@@ -156,8 +156,10 @@ def test_generic_loop_door(golden):
         assert np.array_equal(t.partials(0, 0)[w], np.asarray(d["p_lk_left_0"])[w])
         assert np.array_equal(t.scale_factors(0, 0)[w], np.asarray(d["sum_scale_left_0"])[w])
         for (e, side), p in ot.plk.items():
-            assert np.array_equal(t.partials(e, side)[w], p[w]), (e, side)
+            # (every pattern: the generic loop writes zeros where the weight is zero, src/lk.c:1581-1584, and so does the device)
+            assert np.array_equal(t.partials(e, side), p), (e, side)
             assert np.array_equal(t.scale_factors(e, side)[w], ot.scale[(e, side)][w]), (e, side)
+        assert np.array_equal(t.partials(0, 0), np.asarray(d["p_lk_left_0"]))
         c_lnL_sorted, cur_site_lk, unscaled, fact = t.inst.site_outputs()
         assert np.array_equal(fact, d["fact_sum_scale"])
         assert np.max(np.abs(c_lnL_sorted[w] - d["c_lnL_sorted"][w]) / np.abs(d["c_lnL_sorted"][w])) < 1e-10
@@ -169,5 +171,27 @@ def test_generic_loop_door(golden):
             assert (t2.partials(0, 0)[w] != t.partials(0, 0)[w]).any(axis=1).sum() == 51
         finally:
             t2.close()
+    finally:
+        t.close()
+
+
+def test_generic_loop_zero_weight_patterns():
+    """The reference's generic loop zeroes the partial vector of a pattern without weight and leaves its scale exponent alone
+    (src/lk.c:1405,1581-1584; the restatement with arith = 2 does the same): the device's generic-loop instances too -- every
+    pattern of every buffer, not only the weighted ones."""
+    from gpu_common import synthetic_pair
+    rng = np.random.default_rng(4)
+    wght = rng.integers(0, 3, 257).astype(np.float64)
+    assert (wght == 0).sum() > 20
+    t, ot, *_ = synthetic_pair(18, 257, 4, 4, seed=8, wght=wght, ambiguous_every=9, use_m4mod=True, arith=2)
+    try:
+        t.Set_Both_Sides(True)
+        lnl, ref = t.Lk(None), ot.lk(None, both_sides=True)
+        assert abs(lnl - ref) / abs(ref) < 1e-12
+        for (e, side), p in ot.plk.items():
+            got = t.partials(e, side)
+            assert np.array_equal(got, p), (e, side)
+            assert not got[wght == 0].any()
+            assert np.array_equal(t.scale_factors(e, side), ot.scale[(e, side)]), (e, side)
     finally:
         t.close()

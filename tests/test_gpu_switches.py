@@ -50,14 +50,20 @@ def _check(libdir, sw):
     a2, b2 = [float.fromhex(x) for x in res["stream2"]], [float.fromhex(x) for x in base["stream2"]]
     reorder = ("PHYHIP_GENERIC_NT" in sw or "PHYHIP_HOST_SUM" in sw or "PHYHIP_SPLIT_REDUCE" in sw or "PHYHIP_DLK_GRID" in sw or
                sw.get("PHYHIP_NT_GROUPS") in ("1", "4"))
-    extra = [([float.fromhex(x) for x in res[k]], [float.fromhex(x) for x in base[k]]) for k in ("stream_host", "stream_big")]
+    hexl = lambda r, k: [float.fromhex(x) for x in r[k]]
+    lnl_lists = [(a, b)] + [(hexl(res, k), hexl(base, k)) for k in ("stream_host", "stream_big")]
+    dl_lists = [(a2, b2, res["sum_w"]["stream"])] + [(hexl(res, k + "_d"), hexl(base, k + "_d"), res["sum_w"][k]) for k in ("stream_host", "stream_big")]
     if reorder:  # another kernel shape / another final sum adds the patterns' contributions in another order
-        for u, v in [(a, b)] + extra:
-            assert max(abs(x - y) / max(1.0, abs(y)) for x, y in zip(u, v)) < 1e-11
+        for u, v in lnl_lists:   # log-likelihoods (|lnL| ~ 1e4): relative, the bar of the parity tests
+            assert max(abs(x - y) / abs(y) for x, y in zip(u, v) if y != 0.0) < 1e-12
+        for u, v, sw_ in dl_lists:
+            # derivatives: a sum of sum(w) per-pattern terms of either sign, each O(1) to O(100) -- reordering it moves the result
+            # by rounding errors of the partial sums, not of the (possibly tiny) total: an absolute bar of 1e-13 per unit of weight
+            assert max(abs(x - y) for x, y in zip(u, v)) <= 1e-13 * sw_
     else:
         assert a == b and a2 == b2
-        for u, v in extra:
-            assert u == v
+        for (u, v), (ud, vd, _) in zip(lnl_lists[1:], dl_lists[1:]):
+            assert u == v and ud == vd
 
 
 @pytest.mark.parametrize("sw", DIAG, ids=_ids)

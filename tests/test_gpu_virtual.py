@@ -159,8 +159,9 @@ def test_search_like_stream_after_a_virtualising_traversal(ns, C, P):
             d = int(ot.el[e] if side == 0 else ot.er[e])
             tip = [v for (v, be) in ot.adj[d] if be != e][0]
             keep = t0.partials(e, side).copy()
+            pat = int(rng.integers(0, P))
             for x in (t, t0):
-                x.inst.set_tip_partials_at_pattern(tip, int(rng.integers(0, P)), np.ones(ns))
+                x.inst.set_tip_partials_at_pattern(tip, pat, np.ones(ns))
             assert np.array_equal(t.partials(e, side), keep)
             assert t.Lk(None) == t0.Lk(None)
     finally:
