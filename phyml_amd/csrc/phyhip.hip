@@ -316,6 +316,8 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->up_slot.assign(I->nmat, -1);
   I->pm_slot.assign(I->nmat, -1);
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
+  I->slot_inl.assign(I->ops_slots, std::vector<InlineDef>());
+  if (const char *e = diag_env("PHYHIP_VIRT_INLINE")) I->virt_inline = atoi(e) != 0;
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = diag_env("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (I->generic_loop) I->generic_nt = true;

@@ -156,6 +156,14 @@ struct Resident
   double              ns_wait = 0.0;   // PHYHIP_RESIDENT_STATS: host time from a command's last word to its answer, summed
 };
 
+// The in-step child of a queued operation (DevOp::pad bits 1 / 2, phyhip_nt2.hpp INL): the virtual tip x tip result it reads is
+// computed inside its own step from tips a, b and matrices pmA, pmB (a < 0: the operation has none)
+struct InlineDef
+{
+  int a, b, pmA, pmB;
+  bool operator==(const InlineDef &o) const { return a == o.a && b == o.b && pmA == o.pmA && pmB == o.pmB; }
+};
+
 struct Instance
 {
   Collective *co         = nullptr; // one-process-per-GPU mode: communicator attached by phyhip_comm_init_rank
@@ -265,6 +273,9 @@ struct Instance
   // operation; the tips and the two matrices it reads may not change while virt[b] (matrices_touch, the tip setters).
   int                                    virt_min_ops = 16; // lists at least this long leave tip x tip results virtual (0: never)
   int                                    n_virtual = 0;
+  bool                                   virt_inline = true; // (diag: PHYHIP_VIRT_INLINE=0 re-issues every virtual child as a step of its own)
+  std::vector<InlineDef>                 pending_inl;        // per entry of `pending` as rewrite_pending left it (or empty: none has one)
+  std::vector<std::vector<InlineDef>>    slot_inl;           // ... of the lists the device ring slots hold (content cache)
   std::vector<unsigned char>             virt;              // [nbuf]
   std::vector<DevOp>                     vdef;              // [nbuf]
   unsigned long long                     n_virt_skipped = 0, n_virt_recomputed = 0, n_virt_material = 0; // phyhip_get_virtual_stats

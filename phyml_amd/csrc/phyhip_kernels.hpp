@@ -70,7 +70,12 @@ enum : unsigned
 {
   kOpTip1 = 1u, kOpTip2 = 2u,   // child is a tip: expand its state byte
   kOpF11 = 4u, kOpF12 = 8u,     // child 1 is the result of the previous / second-previous operation
-  kOpF21 = 16u, kOpF22 = 32u    // child 2 likewise
+  kOpF21 = 16u, kOpF22 = 32u,   // child 2 likewise
+  // child 1 / child 2 is a VIRTUAL tip x tip result (phyhip_host.hpp) computed inside this operation's step from its two tips
+  // and matrices (lane-per-pattern nucleotide kernel, list form; at most one such child per operation).  Its record slots:
+  // data.base = byte offsets of its two matrices (low | high word), data.bytes = 0, scale = its first tip's row, tip = its
+  // second tip's row with x = 1
+  kOpCh1 = 64u, kOpCh2 = 128u
 };
 
 // Everything a traversal launch needs.  Passed by value (fits the 4 KiB kernarg segment easily).

@@ -65,7 +65,11 @@ struct NtFresh
 // LREC (with ARGS != 0): the one or two records are read through irec / xrec -- LDS, where the resident evaluator put the
 // command's -- each time they are needed, instead of living in scalar registers from the command's arrival to their use
 // (the records of a launched kernel sit in its argument segment and cost no register until they are loaded).
-template <int C, int G, bool DBG, int ARGS, int DIST = 2, int NW = 1, bool LREC = false>
+// INL (list form only): operations may carry ONE child that is a virtual tip x tip result (kOpCh1 / kOpCh2): the step computes it
+// from its two tips and two matrices -- exactly the step the defining operation would have been (column look-ups or row sums,
+// the all-ones rule, the product, the rescaling rule) -- instead of that operation occupying a pipeline step of its own.  Costs
+// every step one more auxiliary dword and one more 16-byte matrix piece per lane; launched only for lists that have such children.
+template <int C, int G, bool DBG, int ARGS, int DIST = 2, int NW = 1, bool LREC = false, bool INL = false>
 __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__restrict__ irec, const ExecRec *__restrict__ xrec,
                                         const double *pmats, // (not restrict: the prologue may rewrite entries)
                                         const uint8_t *__restrict__ tip_codes, unsigned long long *dbg, const NtFresh fr,
@@ -82,8 +86,10 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   }
   static_assert(C % G == 0 && 64 % G == 0, "category groups must divide the categories and the wave");
   constexpr int S = 4, CL = C / G, CS = CL * S, PW = 64 / G; // categories per lane, entries per lane, patterns per wave
-  __shared__ __attribute__((aligned(16))) double lds_all[NW][2][2 * C * 16]; // [wave][buffer][matrix][c][i][j]
-  double (&lds_p)[2][2 * C * 16] = lds_all[NW > 1 ? (tid >> 6) : 0];
+  static_assert(!INL || (ARGS == 0 && DIST == 2 && NW == 1 && !LREC), "in-step tip x tip children: list form only");
+  constexpr int NM = INL ? 4 : 2; // matrices staged per step: the operation's two (+ the two of its in-step child)
+  __shared__ __attribute__((aligned(16))) double lds_all[NW][2][NM * C * 16]; // [wave][buffer][matrix][c][i][j]
+  double (&lds_p)[2][NM * C * 16] = lds_all[NW > 1 ? (tid >> 6) : 0];
 
   const int      lane = NW > 1 ? (int)(tid & 63) : (int)tid;
   const int      grp  = lane / PW, pl = lane % PW;        // category group, pattern within the wave
@@ -100,6 +106,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   {
     u32x4    a[HP], b[HP]; // child 1 / child 2 entries, as state pairs
     unsigned sa, sb;       // internal child: scale exponent; tip child: the aligned 4 bytes that hold its state byte
+    unsigned tx;           // INL: the aligned 4 bytes that hold the state byte of the in-step child's SECOND tip
   };
   const __amdgpu_buffer_rsrc_t pm_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(pmats), 0, 0x7fffffff, 0x00020000);
@@ -123,17 +130,31 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
     for (int e = 0; e < HP; ++e) r.b[e] = __builtin_amdgcn_raw_buffer_load_b128(d2r, voff16, (unsigned)e * rowb, PHYHIP_LOAD_AUX);
     r.sa = __builtin_amdgcn_raw_buffer_load_b32(g1r, uni(o.c1_scale.x) ? (p & ~3u) : voff4, 0, 0);
     r.sb = __builtin_amdgcn_raw_buffer_load_b32(g2r, uni(o.c2_scale.x) ? (p & ~3u) : voff4, 0, 0);
+    if constexpr (INL)
+    { // the in-step child's second tip row (size 0 when the operation has no such child: the load is dropped)
+      const bool second = uni(o.c2_tip.x) != 0;
+      Desc       ct;
+      ct.base = second ? o.c2_tip.base : o.c1_tip.base; ct.bytes = second ? o.c2_tip.bytes : o.c1_tip.bytes; ct.x = 0;
+      r.tx = __builtin_amdgcn_raw_buffer_load_b32(rsrc(ct), p & ~3u, 0, 0);
+    }
   };
-  auto issue_pm = [&](const IssueRec &o, u32x4 &pc) {
+  auto issue_pm = [&](const IssueRec &o, u32x4 &pc, u32x4 &pc2) {
     // this lane's 16-byte piece of [matrix 1 | matrix 2] (C*16 doubles each)
     int ch = (lane < 16 * C) ? lane : 0;
     const int      mat = ch / (8 * C), within = ch - mat * 8 * C;
     const unsigned off = (mat ? uni(o.c2_data.x) : uni(o.c1_data.x)) + (unsigned)within * 16u;
     pc = __builtin_amdgcn_raw_buffer_load_b128(pm_rsrc, off, 0, 0);
+    if constexpr (INL)
+    { // ... and of the in-step child's two matrices (matrix 0 when there is none: read, staged and never used)
+      const bool               c1 = uni(o.c1_tip.x) != 0, c2 = uni(o.c2_tip.x) != 0;
+      const unsigned long long ab = c2 ? o.c2_data.base : (c1 ? o.c1_data.base : 0ull);
+      const unsigned           off2 = (mat ? uni((unsigned)(ab >> 32)) : uni((unsigned)ab)) + (unsigned)within * 16u;
+      pc2 = __builtin_amdgcn_raw_buffer_load_b128(pm_rsrc, off2, 0, 0);
+    }
   };
-  auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc) {
+  auto issue = [&](const IssueRec &o, Raw &r, u32x4 &pc, u32x4 &pc2) {
     issue_data(o, r);
-    issue_pm(o, pc);
+    issue_pm(o, pc, pc2);
   };
 
   // u[c*4+i] = sum_j P[c][i][j] * x[c*4+j]: first product, then the FMA chain (src/avx.c:593-616);
@@ -199,7 +220,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   };
   const int last = ARGS ? 1 : q.n_ops - 1; // host pads the list to an even length
   Raw       RA, RB;
-  u32x4     PA, PB;
+  u32x4     PA, PB, PA2, PB2; // (PA2 / PB2: INL only)
   // The children of the first two operations do not depend on the matrices rebuilt below: their loads go out first and
   // travel while the prologue computes (a launch of one or two operations is a chain of dependent round trips --
   // kernel arguments, matrices, children, evaluation edge -- and every one taken off the chain is ~1 us of ~9).
@@ -289,14 +310,14 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
 
   if (has_ops)
   {
-    issue_pm(IR(0), PA);
-    if constexpr (!single && DIST == 2) issue_pm(IR((1 < last) ? 1 : last), PB);
+    issue_pm(IR(0), PA, PA2);
+    if constexpr (!single && DIST == 2) issue_pm(IR((1 < last) ? 1 : last), PB, PB2);
     ExecRec  cur = XR(0);
     IssueRec nx2 = IR((DIST < last) ? DIST : last); // the next operation whose loads go out
 
     // One pipeline step: operation k; its loads are in (R, PC); Fprev = result of k-1, Fout = result of k-2
     // on entry and the result of k on exit.
-    auto step = [&](const int k, const int parity, Raw &R, u32x4 &PC, double (&Fout)[CS], unsigned &scout,
+    auto step = [&](const int k, const int parity, Raw &R, u32x4 &PC, u32x4 &PC2, double (&Fout)[CS], unsigned &scout,
                     const double (&Fprev)[CS], const unsigned scprev) {
       PHY_STAMP(k, 0)
       // the execute record of operation k+1 is the first thing the next step needs (its flags steer the operand
@@ -307,6 +328,11 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         double2 v;
         __builtin_memcpy(&v, &PC, 16);
         buf[(lane < 16 * C) ? lane : 0] = v;
+        if constexpr (INL)
+        {
+          __builtin_memcpy(&v, &PC2, 16);
+          buf[16 * C + ((lane < 16 * C) ? lane : 0)] = v;
+        }
       }
       __builtin_amdgcn_wave_barrier();
       const double *bufd = &lds_p[parity][0];
@@ -317,8 +343,56 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
       bool           one1, one2; // first-entry test of the all-ones shortcut
       const unsigned tsh = (p & 3u) * 8u; // position of this pattern's byte inside a tip row's dword
       const unsigned tca = (R.sa >> tsh) & 255u, tcb = (R.sb >> tsh) & 255u;
+      // in-step child (INL): the step its defining operation would have been -- both children tips (tip_u), the all-ones rule
+      // (both tips fully ambiguous: exactly 1.0), the product, the rescaling rule over all categories of the pattern
+      double   XC[INL ? CS : 1];
+      unsigned scx = 0;
+      auto     cherry = [&](const unsigned t1, const unsigned t2) {
+        if constexpr (INL)
+        {
+          double ua[CS], ub[CS];
+          tip_u(bufd + 2 * C * 16, buf + 2 * C * 8, t1, ua);
+          tip_u(bufd + 3 * C * 16, buf + 3 * C * 8, t2, ub);
+          const bool all1 = (t1 == 15u) && (t2 == 15u);
+          unsigned   mx = 0;
+#pragma unroll
+          for (int e = 0; e < CS; ++e)
+          {
+            const double v = all1 ? 1.0 : ua[e] * ub[e];
+            XC[e] = v;
+            mx    = max(mx, hi32(v));
+          }
+          if constexpr (G > 1)
+          {
+            if (!cls)
+            {
+#pragma unroll
+              for (int d = PW; d < 64; d <<= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d, 64));
+            }
+          }
+          if (mx < kHiInvTwoToLarge && q.apply_scaling)
+          {
+#pragma unroll
+            for (int e = 0; e < CS; ++e) XC[e] *= kTwoToLarge;
+            scx = kLarge;
+          }
+        }
+      };
+      const unsigned tcx = INL ? ((R.tx >> tsh) & 255u) : 0u;
+      bool in1 = false, in2 = false;
+      if constexpr (INL) { in1 = (fl & kOpCh1) != 0; in2 = (fl & kOpCh2) != 0; }
       // ---- child 1 ----
-      if (fl & kOpTip1)
+      if constexpr (INL)
+      {
+        if (in1)
+        {
+          cherry(tca, tcx);
+          matvec_x(buf, XC, u1);
+          s1 = scx; one1 = (XC[0] == 1.0);
+        }
+      }
+      if (in1) {}
+      else if (fl & kOpTip1)
       {
         tip_u(bufd, buf, tca, u1);
         s1 = 0; one1 = (tca == 15u);
@@ -328,7 +402,17 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
       else { matvec_r(buf, R.a, u1); s1 = R.sa; one1 = (first_d(R.a[0]) == 1.0); }
       PHY_STAMP(k, 1)
       // ---- child 2 ----
-      if (fl & kOpTip2)
+      if constexpr (INL)
+      {
+        if (in2)
+        {
+          cherry(tcb, tcx);
+          matvec_x(buf + C * 8, XC, u2);
+          s2 = scx; one2 = (XC[0] == 1.0);
+        }
+      }
+      if (in2) {}
+      else if (fl & kOpTip2)
       {
         tip_u(bufd + C * 16, buf + C * 8, tcb, u2);
         s2 = 0; one2 = (tcb == 15u);
@@ -356,7 +440,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
             a1 = true;
 #pragma unroll
             for (int j = 0; j < S; ++j)
-              a1 = a1 && (((fl & kOpF11) ? Fprev[c * 4 + j] : (fl & kOpF12) ? Fout[c * 4 + j] : ra[c * 4 + j]) == 1.0);
+              a1 = a1 && ((in1 ? XC[INL ? c * 4 + j : 0] : (fl & kOpF11) ? Fprev[c * 4 + j] : (fl & kOpF12) ? Fout[c * 4 + j] : ra[c * 4 + j]) == 1.0);
           }
           if (fl & kOpTip2) a2 = (tcb == 15u);
           else
@@ -364,7 +448,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
             a2 = true;
 #pragma unroll
             for (int j = 0; j < S; ++j)
-              a2 = a2 && (((fl & kOpF21) ? Fprev[c * 4 + j] : (fl & kOpF22) ? Fout[c * 4 + j] : rb[c * 4 + j]) == 1.0);
+              a2 = a2 && ((in2 ? XC[INL ? c * 4 + j : 0] : (fl & kOpF21) ? Fprev[c * 4 + j] : (fl & kOpF22) ? Fout[c * 4 + j] : rb[c * 4 + j]) == 1.0);
           }
           ones_mask |= (a1 && a2) ? (1u << c) : 0u;
         }
@@ -372,7 +456,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
 
       PHY_STAMP(k, 3)
       // prefetch operation k+2 into the registers just freed; then the scalar records of the next step
-      if constexpr (!ARGS) issue(nx2, R, PC); // (records in the arguments: at most two operations, nothing to prefetch)
+      if constexpr (!ARGS) issue(nx2, R, PC, PC2); // (records in the arguments: at most two operations, nothing to prefetch)
       PHY_STAMP(k, 7)
       const IssueRec nx3 = IR((k + 1 + DIST < last) ? k + 1 + DIST : last);
       __builtin_amdgcn_wave_barrier();
@@ -422,21 +506,21 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
 
     if constexpr (ARGS != 0)
     {
-      step(0, 0, RA, PA, FA, scA, FB, scB);
+      step(0, 0, RA, PA, PA2, FA, scA, FB, scB);
       if constexpr (single)
       { // the evaluation below expects the last result in the second register set
 #pragma unroll
         for (int e = 0; e < CS; ++e) FB[e] = FA[e];
         scB = scA;
       }
-      else step(1, 1, RB, PB, FB, scB, FA, scA);
+      else step(1, 1, RB, PB, PB2, FB, scB, FA, scA);
     }
     else
       for (int k = 0; k < q.n_ops; k += 2)
       {
-        step(k, 0, RA, PA, FA, scA, FB, scB);
-        if constexpr (DIST == 2) step(k + 1, 1, RB, PB, FB, scB, FA, scA);
-        else step(k + 1, 1, RA, PA, FB, scB, FA, scA);
+        step(k, 0, RA, PA, PA2, FA, scA, FB, scB);
+        if constexpr (DIST == 2) step(k + 1, 1, RB, PB, PB2, FB, scB, FA, scA);
+        else step(k + 1, 1, RA, PA, PA2, FB, scB, FA, scA);
       }
   }
 
@@ -612,7 +696,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   publish_block_sum(q, contrib, lane, tile);
 }
 
-template <int C, int G = 1, bool DBG = false, int ARGS = 0, int DIST = 2>
+template <int C, int G = 1, bool DBG = false, int ARGS = 0, int DIST = 2, bool INL = false>
 __global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                              const ExecRec *__restrict__ xrec, const double *pmats,
                                                              const uint8_t *__restrict__ tip_codes,
@@ -630,7 +714,7 @@ __global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel
   fr.up_idx = reinterpret_cast<const int *>(ka + offsetof(TreeParams, up_idx));
   fr.up_val = reinterpret_cast<const double *>(ka + offsetof(TreeParams, up_val));
   __shared__ __attribute__((aligned(16))) double lds_dot[(64 / G) * C * 4];
-  nt2_run<C, G, DBG, ARGS, DIST>(q, irec, xrec, pmats, tip_codes, dbg, fr, blockIdx.x, threadIdx.x, lds_dot);
+  nt2_run<C, G, DBG, ARGS, DIST, 1, false, INL>(q, irec, xrec, pmats, tip_codes, dbg, fr, blockIdx.x, threadIdx.x, lds_dot);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@ namespace phyhip_host
 
 // ---- virtual buffers (Instance::virt) ---------------------------------------------------------------------------------------
 constexpr int kOpNoStore = 1; // DevOp::pad bit 0: the operation's result is forwarded in registers only (descriptors of size 0)
+constexpr int kOpInl1 = 2, kOpInl2 = 4; // DevOp::pad bits 1, 2: child 1 / child 2 is computed inside the operation's own step (Instance::pending_inl)
 
 void devirtualise(Instance *I, int buf)
 {
@@ -46,6 +47,7 @@ void devirtualise_tip(Instance *I, int tip)
 // in front of each of its consumers (the kernels forward the results of the previous two operations in registers).
 void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
 {
+  I->pending_inl.clear();
   const int n0 = (int)I->pending.size();
   const bool virtualise = may_virtualise && I->virt_min_ops > 0 && n0 >= I->virt_min_ops;
   if (!virtualise && I->n_virtual == 0) return;
@@ -69,19 +71,34 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
         skip[k] = 1;
     }
   }
-  std::vector<DevOp> L;
+  std::vector<DevOp>     L;
+  std::vector<InlineDef> LI; // (parallel to L)
   L.reserve((size_t)n0 + (size_t)I->n_virtual + 8);
-  auto before_read = [&](int c) {
+  LI.reserve(L.capacity());
+  const InlineDef none{-1, -1, -1, -1};
+  // the lane-per-pattern nucleotide kernel computes ONE virtual child inside its reader's step (phyhip_nt2.hpp, INL); a second
+  // one -- and every one of the 20-state kernel -- is re-issued as a non-storing operation in front of the reader
+  const bool in_step = virtualise && I->soa && I->virt_inline;
+  bool       any_inl = false;
+  auto before_read = [&](int c, DevOp &reader, InlineDef &rin, int bit) {
     if (c < I->tips || !I->virt[c]) return;
     DevOp d = I->vdef[c];
+    I->mat_in_queue[d.pm1] = 1; I->mat_in_queue[d.pm2] = 1;
+    if (in_step && rin.a < 0 && reader.c1 != reader.c2)
+    {
+      rin = InlineDef{d.c1, d.c2, d.pm1, d.pm2};
+      reader.pad |= bit;
+      any_inl = true;
+      ++I->n_virt_recomputed;
+      return;
+    }
     if (virtualise) { d.pad = kOpNoStore; ++I->n_virt_recomputed; }
     else
     {
       d.pad = 0;
       I->virt[c] = 0; --I->n_virtual; ++I->n_virt_material;
     }
-    I->mat_in_queue[d.pm1] = 1; I->mat_in_queue[d.pm2] = 1;
-    L.push_back(d);
+    L.push_back(d); LI.push_back(none);
   };
   for (int k = 0; k < n0; ++k)
   {
@@ -94,9 +111,10 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
       ++I->n_virt_skipped;
       continue;
     }
-    before_read(o.c1);
-    if (o.c2 != o.c1) before_read(o.c2);
-    L.push_back(o);
+    InlineDef in = none;
+    before_read(o.c1, o, in, kOpInl1);
+    if (o.c2 != o.c1) before_read(o.c2, o, in, kOpInl2);
+    L.push_back(o); LI.push_back(in);
     if (I->virt[o.dest]) { I->virt[o.dest] = 0; --I->n_virtual; } // (a storing operation: the buffer is real again)
   }
   if (ee)
@@ -107,9 +125,10 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
         d.pad = 0;
         I->virt[side] = 0; --I->n_virtual; ++I->n_virt_material;
         I->mat_in_queue[d.pm1] = 1; I->mat_in_queue[d.pm2] = 1;
-        L.push_back(d);
+        L.push_back(d); LI.push_back(none);
       }
   I->pending.swap(L);
+  if (any_inl) I->pending_inl.swap(LI);
 }
 
 // Host-computed matrices queued by phyhip_set_transition_matrix: one launch per kUploadBatch of them.
@@ -325,7 +344,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     // neither rebuilt nor re-uploaded
     for (int sl = 0; sl < I->ops_slots && hit < 0; ++sl)
       if (I->slot_kind[sl] == kind && I->slot_ops[sl].size() == (size_t)n_ops &&
-          memcmp(I->slot_ops[sl].data(), I->pending.data(), sizeof(DevOp) * n_ops) == 0)
+          memcmp(I->slot_ops[sl].data(), I->pending.data(), sizeof(DevOp) * n_ops) == 0 && I->slot_inl[sl] == I->pending_inl)
         hit = sl;
   }
   if (n_ops > 0 && hit >= 0)
@@ -393,8 +412,19 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         const int    e1 = (k >= 1 && !big_cmd) ? at(k - 1).dest : -1;
         const int    e2 = (k >= 2 && I->prefetch_dist == 2) ? at(k - 2).dest : -1;
         unsigned     fl = 0;
+        const InlineDef *inl = (o.pad & (kOpInl1 | kOpInl2)) ? &I->pending_inl[std::min(k, n_ops - 1)] : nullptr;
         auto child = [&](int c, unsigned tipbit, unsigned f1bit, unsigned f2bit, Desc &data, Desc &scale, Desc &tip,
-                         unsigned pmoff) {
+                         unsigned pmoff, bool in_step) {
+          if (in_step)
+          { // a virtual tip x tip result computed inside this operation's step (kOpCh1 / kOpCh2, phyhip_kernels.hpp): no load of
+            // its own -- its two matrices' offsets, its first tip's row in the auxiliary slot, its second tip's row in the tip slot
+            fl |= (tipbit == kOpTip1) ? kOpCh1 : kOpCh2;
+            const unsigned long long ab = (unsigned long long)((unsigned)inl->pmA * matbytes) | ((unsigned long long)((unsigned)inl->pmB * matbytes) << 32);
+            data  = desc(reinterpret_cast<const void *>((uintptr_t)ab), 0, pmoff);
+            scale = desc(I->d_tipcodes + (size_t)inl->a * I->Ppad, (size_t)I->Ppad, 1);
+            tip   = desc(I->d_tipcodes + (size_t)inl->b * I->Ppad, (size_t)I->Ppad, 1);
+            return;
+          }
           const bool t = c < I->tips;
           const bool f1 = !t && c == e1, f2 = !t && !f1 && c == e2;
           const bool ld = !t && !f1 && !f2 && !I->no_loads;
@@ -404,15 +434,15 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           const size_t b = ld ? (size_t)(c - I->tips) : 0;
           data  = desc(I->d_partials + b * buf_elems(I), ld ? bufbytes : 0, pmoff);
           scale = desc(I->d_scales + b * scale_elems(I), ld ? scale_elems(I) * 4 : 0, 0);
-          tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->Ppad, t ? (size_t)I->Ppad : 0, 0);
+          tip   = desc(I->d_tipcodes + (size_t)(t ? c : 0) * I->Ppad, (t && !I->soa) ? (size_t)I->Ppad : 0, 0); // (lane-per-pattern kernel: only an in-step child uses this slot)
           // lane-per-pattern nucleotide kernel and the 20-state kernel: ONE auxiliary dword load per child -- the scale
           // descriptor of a tip child points at its tip row instead (spare word 1: the kernel then reads the aligned dword
           // holding the byte)
           if (I->soa && t) scale = desc(I->d_tipcodes + (size_t)c * I->Ppad, (size_t)I->Ppad, 1);
           if (I->perm && t) scale = desc(I->d_tipmasks + (size_t)c * I->Ppad, (size_t)I->Ppad * 4, 1); // (the mask itself)
         };
-        child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes);
-        child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes);
+        child(o.c1, kOpTip1, kOpF11, kOpF12, ir[k].c1_data, ir[k].c1_scale, ir[k].c1_tip, (unsigned)o.pm1 * matbytes, (o.pad & kOpInl1) != 0);
+        child(o.c2, kOpTip2, kOpF21, kOpF22, ir[k].c2_data, ir[k].c2_scale, ir[k].c2_tip, (unsigned)o.pm2 * matbytes, (o.pad & kOpInl2) != 0);
         const size_t b = (size_t)(o.dest - I->tips);
         const bool   st_on = !(o.pad & kOpNoStore); // (a result that stays virtual: stores through descriptors of size 0 are dropped)
         xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), st_on ? bufbytes : 0, fl);
@@ -437,6 +467,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     if (new_slot >= 0)
     {
       I->slot_ops[new_slot]  = I->pending;
+      I->slot_inl[new_slot]  = I->pending_inl;
       I->slot_kind[new_slot] = kind;
       I->ops_slot = (new_slot + 1) % I->ops_slots;
     }
@@ -696,6 +727,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     HIPCHK(hipEventRecord(e0, I->stream));
   }
   const unsigned long long hp1 = hp_now();
+  const bool has_inl = !I->pending_inl.empty();
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     if constexpr (S_ == 4 && CP_ <= 4)
@@ -736,6 +768,11 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   if (!q.recs_in_args && I->prefetch_dist == 1)                                                                             \
   {                                                                                                                         \
     hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, 0, 1>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
+                       ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
+  }                                                                                                                         \
+  else if (!q.recs_in_args && has_inl && g_ <= 2)                                                                           \
+  { /* a list with in-step tip x tip children: the instantiation that stages four matrices per step */                      \
+    hipLaunchKernelGGL((traverse_nt2_kernel<c_, (g_ <= 2 ? g_ : 1), false, 0, 2, true>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
                        ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
   }                                                                                                                         \
   else if (!q.recs_in_args) { NT2LAUNCH(c_, g_, 0) }                                                                        \
@@ -867,8 +904,12 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         if (!(o.pad & kOpNoStore)) wr += rec;
         const int    e1 = k >= 1 ? I->pending[k - 1].dest : -1;
         const int    e2 = (k >= 2 && fat && I->prefetch_dist == 2) ? I->pending[k - 2].dest : -1;
-        for (int c : {o.c1, o.c2})
-          rd += c < I->tips ? 1.0 : ((fat && (c == e1 || c == e2)) ? 0.0 : rec);
+        for (int w = 0; w < 2; ++w)
+        {
+          const int c = w ? o.c2 : o.c1;
+          if (o.pad & (w ? kOpInl2 : kOpInl1)) rd += 2.0; // (an in-step child: its two tip bytes)
+          else rd += c < I->tips ? 1.0 : ((fat && (c == e1 || c == e2)) ? 0.0 : rec);
+        }
       }
       if (ee)
       { // root edge: both sides unless just produced, pattern weight in; per-pattern outputs out

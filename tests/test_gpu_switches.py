@@ -20,7 +20,7 @@ DIAG = [{}, {"PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_NT_GROUPS": "2"}, {"PHYHIP_NT_GR
         {"PHYHIP_FUSE_EIGEN": "0"}, {"PHYHIP_FOLD_GRID": "8"}, {"PHYHIP_DLK_GRID": "7"}, {"PHYHIP_BIG_DEVICE_SUM": "100000000"},
         {"PHYHIP_BIG_GROUP_SUM": "0"}, {"PHYHIP_BIG_ONE_SHOT": "0"}, {"PHYHIP_PUSH_CMDS": "0"}, {"PHYHIP_PUSH_CMDS": "2"},
         {"PHYHIP_PUSH_NO_MOVDIR": "1"},
-        {"PHYHIP_PMAT_THREADS": "1024"}, {"PHYHIP_RESIDENT_DIRECT": "4"}]
+        {"PHYHIP_PMAT_THREADS": "1024"}, {"PHYHIP_RESIDENT_DIRECT": "4"}, {"PHYHIP_VIRT_INLINE": "0"}]
 PRODUCT = [{}, {"PHYHIP_RESIDENT": "0"}, {"PHYHIP_HOST_SUM": "0"}]
 _cache = {}
 

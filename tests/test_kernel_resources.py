@@ -56,7 +56,7 @@ def test_no_hot_kernel_uses_scratch(product):
     assert len(hot) > 60
     # (the one-operation-ahead form of the lane-per-pattern kernel, DIST = 1, is selected by a diag-build switch only -- the product
     # never launches it; its <4 categories, 4 lane groups> shape spills 48 bytes under a launch bound of five waves per SIMD)
-    hot = [n for n in hot if not re.search(r"traverse_nt2_kernelILi\dELi\dELb0ELi0ELi1EEEv", n)]
+    hot = [n for n in hot if not re.search(r"traverse_nt2_kernelILi\dELi\dELb0ELi0ELi1ELb0EEEv", n)]
     for n in hot:
         k = product[n]
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (n, k)
@@ -65,9 +65,11 @@ def test_no_hot_kernel_uses_scratch(product):
 def test_default_traversal_kernels_keep_their_occupancy(product):
     # traverse_nt2_kernel<C, G, DBG=false, ARGS=0, DIST=2>: G waves per SIMD is what __launch_bounds__(64, G) asks for and what
     # the choice of G = 2 below ~100 k patterns rests on
+    # ... <..., INL>: the instantiation for lists with in-step tip x tip children (four matrices staged per step) as well
     for c, g in ((4, 2), (4, 1), (2, 2), (2, 1), (1, 1), (3, 1)):
-        n = f"_ZN6phyhip19traverse_nt2_kernelILi{c}ELi{g}ELb0ELi0ELi2EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdPKhPy"
-        assert waves_per_simd(product[n]["vgpr_count"]) >= g, (n, product[n]["vgpr_count"])
+        for inl in (0, 1):
+            n = f"_ZN6phyhip19traverse_nt2_kernelILi{c}ELi{g}ELb0ELi0ELi2ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdPKhPy"
+            assert waves_per_simd(product[n]["vgpr_count"]) >= g, (n, product[n]["vgpr_count"])
     # the 20-state kernel: 1 loader + 15 consumer waves per workgroup = four per SIMD
     for c in (1, 2, 3, 4):
         for args in (0, 1):
