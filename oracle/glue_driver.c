@@ -124,6 +124,21 @@ static void die(const char *what)
 }
 #define OK(call) do { if ((call) < 0) die(#call); } while (0)
 
+/* GLUE_HOSTPROF=1: where the HOST's time goes in a device-driven run -- cycles (rdtsc) inside each call of the C ABI and inside
+   the interposed surface functions around them (pointer look-ups, Set_All_Partial_Lk, the reference's own PMat), reported per
+   call and as a share of the run in the GLUE_DRIVER line (tools/host_share.py, profiles/r05_host_share.md).  The evaluation
+   slots include the wait for the device. */
+enum { HP_ABI_UPDATE_PARTIALS, HP_WRAP_UPDATE_PARTIAL_LK, HP_ABI_MATRIX, HP_HOST_PMAT, HP_WRAP_UPDATE_PMAT, HP_ABI_EDGE_LNL, HP_ABI_EIGEN_EVAL,
+       HP_ABI_UPDATE_EIGEN_LR, HP_ABI_WARNING, HP_PUSH_MODEL, HP_SLOTS };
+static const char *const hp_name[HP_SLOTS] = {"phyhip_update_partials", "Update_Partial_Lk wrapper (incl. the call)", "phyhip_set_transition_matrix / update_transition_matrices",
+                                              "reference PMat on the host", "Update_PMat_At_Given_Edge wrapper (incl. both)", "phyhip_calculate_edge_log_likelihoods (incl. wait)",
+                                              "phyhip_calculate_eigen_lnl[_dlnl] (incl. wait)", "phyhip_update_eigen_lr", "phyhip_get_numerical_warning", "push_model"};
+static int                g_hp_on = 0;
+static unsigned long long g_hp_cyc[HP_SLOTS], g_hp_n[HP_SLOTS], g_hp_c0 = 0;
+static inline unsigned long long hp_tick(void) { return g_hp_on ? __builtin_ia32_rdtsc() : 0ull; }
+static inline void hp_add(int slot, unsigned long long t0) { if (g_hp_on) { g_hp_cyc[slot] += __builtin_ia32_rdtsc() - t0; ++g_hp_n[slot]; } }
+#define TOK(slot, call) do { const unsigned long long t_ = hp_tick(); OK(call); hp_add(slot, t_); } while (0)
+
 /* one device instance per tree object that reaches the surface: the tree of an ordinary run, or every class tree of a
    mixture (src/mixt.c:2603-2640); pointer -> device index tables per instance */
 #define MAXID 2048
@@ -423,6 +438,7 @@ void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
   ++g_n_pmat;
   if (g_host || tree->is_mixt_tree) { real(b_fcus, tree); return; } /* mixture tree: the original loops over the class trees */
   if (tree->mixt_tree && tree->mod->ras->invar == YES) { real(b_fcus, tree); return; } /* invariant class: not on the device */
+  const unsigned long long hp_w = hp_tick();
   ctx_t *c = ensure_instance(tree);
   if (b_fcus->has_zero_br_len == YES) { fprintf(stderr, "glue_driver: zero-length edge flag not supported\n"); exit(5); }
   if (c->K > 0)
@@ -456,11 +472,17 @@ void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
   if (g_device_pmat && !g_check)
   { /* src/lk.c:2344: matrices built on the device from (U, lambda, U^-1, length) */
     const double len = b_fcus->l->v;
-    OK(phyhip_update_transition_matrices(c->inst, 0, &m, NULL, NULL, &len, 1));
+    TOK(HP_ABI_MATRIX, phyhip_update_transition_matrices(c->inst, 0, &m, NULL, NULL, &len, 1));
+    hp_add(HP_WRAP_UPDATE_PMAT, hp_w);
     return;
   }
-  real(b_fcus, tree); /* host PMat (src/models.c:257-373) into b->Pij_rr ... */
-  OK(phyhip_set_transition_matrix(c->inst, m, b_fcus->Pij_rr, -1.0)); /* ... and the upload of src/lk.c:2360 */
+  {
+    const unsigned long long t_ = hp_tick();
+    real(b_fcus, tree); /* host PMat (src/models.c:257-373) into b->Pij_rr ... */
+    hp_add(HP_HOST_PMAT, t_);
+  }
+  TOK(HP_ABI_MATRIX, phyhip_set_transition_matrix(c->inst, m, b_fcus->Pij_rr, -1.0)); /* ... and the upload of src/lk.c:2360 */
+  hp_add(HP_WRAP_UPDATE_PMAT, hp_w);
 }
 
 void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
@@ -480,6 +502,7 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   if (d->tax) return;
   ++g_n_upd;
   if (g_host || (tree->mixt_tree && tree->mod->ras->invar == YES)) { real(tree, b, d); return; }
+  const unsigned long long hp_w = hp_tick();
   ctx_t *c = ensure_instance(tree);
   t_node *n_v1 = NULL, *n_v2 = NULL;
   phydbl *p_lk = NULL, *p_lk_v1 = NULL, *p_lk_v2 = NULL, *Pij1 = NULL, *Pij2 = NULL, *tPij1 = NULL, *tPij2 = NULL;
@@ -509,7 +532,8 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   op.child1TransitionMatrix = mat_id(c, Pij1);
   op.child2Partials = n_v2->tax ? n_v2->num : buf_id(c, p_lk_v2);
   op.child2TransitionMatrix = mat_id(c, Pij2);
-  OK(phyhip_update_partials(c->inst, &op, 1, PHYHIP_OP_NONE));
+  TOK(HP_ABI_UPDATE_PARTIALS, phyhip_update_partials(c->inst, &op, 1, PHYHIP_OP_NONE));
+  hp_add(HP_WRAP_UPDATE_PARTIAL_LK, hp_w);
   if (c->K > 0)
   {
     clsbatch_t *q = (clsbatch_t *)c->batch;
@@ -529,7 +553,7 @@ void Update_Eigen_Lr(t_edge *b, t_tree *tree)
   if (c->K > 0 && c->cls > 0) { if (g_check) real(b, tree); return; } /* class axis: class 0's call covered every class */
   int l, r;
   edge_sides(c, b, &l, &r);
-  OK(phyhip_update_eigen_lr(c->inst, l, r));
+  TOK(HP_ABI_UPDATE_EIGEN_LR, phyhip_update_eigen_lr(c->inst, l, r));
   if (g_check) real(b, tree);
 }
 
@@ -560,12 +584,12 @@ static double device_edge_value(t_tree *tree, const t_edge *b)
 {
   ctx_t *c = ensure_instance(tree);
   double lnl = 0.0;
-  if (tree->use_eigen_lr == YES) OK(phyhip_calculate_eigen_lnl(c->inst, b->l->v, &lnl)); /* src/lk.c:592-603 */
+  if (tree->use_eigen_lr == YES) TOK(HP_ABI_EIGEN_EVAL, phyhip_calculate_eigen_lnl(c->inst, b->l->v, &lnl)); /* src/lk.c:592-603 */
   else
   {
     int l, r, pm = mat_id(c, b->Pij_rr), zero = 0;
     edge_sides(c, b, &l, &r);
-    OK(phyhip_calculate_edge_log_likelihoods(c->inst, &l, &r, &pm, NULL, NULL, &zero, &zero, NULL, 1, &lnl, NULL, NULL));
+    TOK(HP_ABI_EDGE_LNL, phyhip_calculate_edge_log_likelihoods(c->inst, &l, &r, &pm, NULL, NULL, &zero, &zero, NULL, 1, &lnl, NULL, NULL));
     if (g_site_outputs) site_outputs(tree, c);
   }
   return lnl;
@@ -830,7 +854,7 @@ phydbl Lk(t_edge *b, t_tree *tree)
     Update_Efrq(tree->mod);
     Update_Eigen(tree->mod);
   }
-  if (!b) push_model(ensure_instance(tree));
+  if (!b) { const unsigned long long t_ = hp_tick(); push_model(ensure_instance(tree)); hp_add(HP_PUSH_MODEL, t_); }
   if (tree->mod->s_opt->skip_tree_traversal == NO)
   {
     if (!b)
@@ -848,7 +872,7 @@ phydbl Lk(t_edge *b, t_tree *tree)
   tree->c_lnL = device_edge_value(tree, b);
   {
     int w = 0;
-    OK(phyhip_get_numerical_warning(ensure_instance(tree)->inst, &w));
+    TOK(HP_ABI_WARNING, phyhip_get_numerical_warning(ensure_instance(tree)->inst, &w));
     if (w) tree->numerical_warning = YES;
   }
   return tree->c_lnL;
@@ -874,7 +898,7 @@ phydbl dLk(phydbl *l, t_edge *b, t_tree *tree)
   tree->numerical_warning = NO;
   if (tree->update_eigen_lr == YES) Update_Eigen_Lr(b, tree);
   double lnl = 0.0, dlnl = 0.0;
-  OK(phyhip_calculate_eigen_lnl_dlnl(c->inst, l, &lnl, &dlnl)); /* clamps *l like src/lk.c:672-673 */
+  TOK(HP_ABI_EIGEN_EVAL, phyhip_calculate_eigen_lnl_dlnl(c->inst, l, &lnl, &dlnl)); /* clamps *l like src/lk.c:672-673 */
   tree->c_dlnL = dlnl;
   tree->c_lnL  = lnl;
   return tree->c_lnL;
@@ -943,8 +967,10 @@ int main(int argc, char **argv)
   g_device_pmat = getenv("GLUE_DEVICE_PMAT") && atoi(getenv("GLUE_DEVICE_PMAT"));
   g_class_axis  = getenv("GLUE_CLASS_AXIS") && atoi(getenv("GLUE_CLASS_AXIS"));
 
+  g_hp_on = getenv("GLUE_HOSTPROF") && atoi(getenv("GLUE_HOSTPROF"));
   const double t0 = now_s();
   g_t0 = t0;
+  g_hp_c0 = g_hp_on ? __builtin_ia32_rdtsc() : 0ull;
   if (getenv("GLUE_MAX_MIXT")) g_max_mixt = atol(getenv("GLUE_MAX_MIXT"));
   for (int k = 1; k < pargc; ++k)
     if (!strncmp(pargv[k], "--xml", 5))
@@ -988,6 +1014,16 @@ int main(int argc, char **argv)
     support_nwk = aLRT_From_String(Write_Tree(tree), tree->data, tree->mod, tree->io);
   }
   const double dt = now_s() - t0;
+  if (g_hp_on)
+  { /* one line of its own, in front of the result line */
+    const double cyc_per_ns = (double)(__builtin_ia32_rdtsc() - g_hp_c0) / (dt * 1e9);
+    printf("\nGLUE_HOSTPROF {\"seconds\": %.3f, \"cycles_per_ns\": %.4f, \"slots\": {", dt, cyc_per_ns);
+    for (int k = 0; k < HP_SLOTS; ++k)
+      printf("%s\"%s\": {\"calls\": %llu, \"ns_per_call\": %.1f, \"seconds\": %.4f, \"share\": %.4f}", k ? ", " : "", hp_name[k], g_hp_n[k],
+             g_hp_n[k] ? (double)g_hp_cyc[k] / cyc_per_ns / (double)g_hp_n[k] : 0.0, (double)g_hp_cyc[k] / cyc_per_ns * 1e-9,
+             (double)g_hp_cyc[k] / cyc_per_ns * 1e-9 / dt);
+    printf("}}\n");
+  }
   printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"device_pmat\": %d, \"lnL_init\": %.17g, \"lnL_final\": %.17g, \"seconds\": %.3f, "
          "\"calls\": {\"Lk\": %ld, \"Lk_full\": %ld, \"Update_Partial_Lk\": %ld, \"dLk\": %ld, \"Update_PMat\": %ld, "
          "\"Update_Eigen_Lr\": %ld}, \"worst_rel_lnL\": %.3g, \"worst_rel_dlnL\": %.3g, \"buffers\": %d, \"matrices\": %d, "

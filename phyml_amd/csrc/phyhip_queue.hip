@@ -78,7 +78,7 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
   const InlineDef none{-1, -1, -1, -1};
   // the lane-per-pattern nucleotide kernel computes ONE virtual child inside its reader's step (phyhip_nt2.hpp, INL); a second
   // one -- and every one of the 20-state kernel -- is re-issued as a non-storing operation in front of the reader
-  const bool in_step = virtualise && I->soa && I->virt_inline;
+  const bool in_step = virtualise && I->soa && I->virt_inline && I->nt_groups <= 2; // (the instantiations that exist: flush_impl)
   bool       any_inl = false;
   auto before_read = [&](int c, DevOp &reader, InlineDef &rin, int bit) {
     if (c < I->tips || !I->virt[c]) return;
