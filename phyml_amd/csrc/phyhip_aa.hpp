@@ -149,7 +149,13 @@ static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUp
 // (TreeParams::arg_ir / arg_xr, as the nucleotide kernel's short launches do): no staged copy in front of the launch.  A
 // separate instantiation: the records of the list form must stay provably uniform (scalar loads through the noalias
 // parameters) -- selecting between two pointers at run time turned every record load into a vector load (+35 % kernel time).
-template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false>
+// INL (list form only): an operation may carry ONE child that is a virtual tip x tip result (kOpCh1 / kOpCh2, phyhip_host.hpp):
+// its two matrix tables ride in the operation's ring item (four tables instead of two; the host hands out the table slots of
+// the 8-table ring and says what must have been released before an item is written), its tips' mask words come with the
+// operation's children, and the consumer computes it inside the step -- exactly the step its defining operation would have
+// been (matrix columns for one-state tips, products through the matrix cores otherwise, the all-ones rule, the rescaling
+// rule) -- instead of that operation occupying a pipeline step of its own.
+template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false, bool INL = false>
 __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                                             const ExecRec *__restrict__ xrec,
                                                                             const double *__restrict__ afrag, int n_frag_mats,
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
   constexpr int CB  = C_ == 1 ? 1 : (C_ == 2 ? 2 : 4); // blocks (categories) per pattern
   constexpr int NPW = 16 / CB;                          // patterns per wave-tile
   static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");
+  static_assert(!INL || (!ARGS && !DBG && ABL == 0), "in-step tip x tip children: list form only");
 
   __shared__ __attribute__((aligned(16))) double ring[kAaRing][2][kAaMat];
   // (read and written with relaxed workgroup-scope atomics: those stay plain ds_read / ds_write instructions, whereas a
@@ -232,11 +239,26 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
     };
     for (int j = 0; j < ((ABL & 8) ? 0 : n_items); ++j)
     {
-      unsigned off1, off2;
-      if (j < n_ops) { const IssueRec rj = IR(j); off1 = rj.c1_data.x; off2 = rj.c2_data.x; }
-      else off1 = off2 = (unsigned)q.e_pm * kMatB;
-      // the slot is free once every consumer has finished item j - kAaRing
-      const int need = j - kAaRing + 1;
+      unsigned off1, off2, off3 = 0, off4 = 0;
+      int      need = j - kAaRing + 1, tslot = (j % kAaRing) * 2; // (two tables per item: the slot is free once every consumer has finished item j - kAaRing)
+      bool     four = false;
+      if (j < n_ops)
+      {
+        const IssueRec rj = IR(j);
+        off1 = rj.c1_data.x; off2 = rj.c2_data.x;
+        if constexpr (INL)
+        { // the host's plan for this item (flush_impl): table slot, what must be released first, and -- with an in-step child --
+          // the two more tables
+          four = rj.c1_tip.x != 0;
+          off3 = (unsigned)rj.c1_tip.base; off4 = (unsigned)(rj.c1_tip.base >> 32);
+          need = (int)rj.c1_tip.bytes; tslot = (int)rj.c2_tip.x;
+        }
+      }
+      else
+      {
+        off1 = off2 = (unsigned)q.e_pm * kMatB;
+        if constexpr (INL) { need = q.aa_e_need; tslot = q.aa_e_slot; }
+      }
       if (!slot_free(need))
       { // the consumers may be waiting for what is still in flight: publish it before waiting for them
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
@@ -245,19 +267,24 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         while (!slot_free(need)) __builtin_amdgcn_s_sleep(2);
       }
       asm volatile("" ::: "memory");
-      char *slot = reinterpret_cast<char *>(&ring[j % kAaRing][0][0]);
+      char *slot = reinterpret_cast<char *>(&ring[0][0][0]) + (size_t)tslot * kMatB;
+      auto pair = [&](char *to, const unsigned oa, const unsigned ob) { // two tables = 25 pieces of 1 KiB
 #pragma unroll
-      for (int g = 0; g < kPieces; ++g)
-      {
-        const unsigned b = (unsigned)g * 1024u + (unsigned)lane * 16u; // byte inside the item
-        lds_ptr dst = (lds_ptr)(slot + g * 1024);
-        if (g * 1024 + 1024 <= (int)kMatB) __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b, off1, 0, 0);
-        else if (g * 1024 >= (int)kMatB) __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b - kMatB, off2, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b < kMatB ? b + off1 : b - kMatB + off2, 0, 0, 0);
-      }
+        for (int g = 0; g < kPieces; ++g)
+        {
+          const unsigned b = (unsigned)g * 1024u + (unsigned)lane * 16u; // byte inside the pair
+          lds_ptr dst = (lds_ptr)(to + g * 1024);
+          if (g * 1024 + 1024 <= (int)kMatB) __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b, oa, 0, 0);
+          else if (g * 1024 >= (int)kMatB) __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b - kMatB, ob, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, dst, 16, b < kMatB ? b + oa : b - kMatB + ob, 0, 0, 0);
+        }
+      };
+      pair(slot, off1, off2);
+      if (INL && four) pair(slot + 2 * kMatB, off3, off4);
       if (flagged < j)
-      {
-        __builtin_amdgcn_s_waitcnt(0x4F79); // vmcnt(25): everything but the item just issued has landed
+      { // everything but the item just issued has landed
+        if (INL && four) __builtin_amdgcn_s_waitcnt(0xCF72); // vmcnt(50)
+        else __builtin_amdgcn_s_waitcnt(0x4F79);             // vmcnt(25)
         asm volatile("" ::: "memory");
         publish(j);
       }
@@ -297,6 +324,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
       {
         Frag     a, b;
         unsigned xa, xb; // scale word, or the dword holding the tip code
+        unsigned xt;     // INL: the mask word of the in-step child's SECOND tip
       };
       auto rsrc = [](const Desc &d) {
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (ABL & 4) ? 0 : (int)d.bytes, 0x00020000);
@@ -321,6 +349,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         load_frag(r.b, rsrc(o.c2_data), voff_d16, voff_d8);
         r.xa = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c1_scale), o.c1_scale.x ? voff_t : voff_s, 0, 0);
         r.xb = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_scale), o.c2_scale.x ? voff_t : voff_s, 0, 0);
+        if constexpr (INL) r.xt = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_tip), voff_t, 0, 0); // (size 0 without such a child)
       };
       // cross-lane helpers.  Lanes that share a (pattern, category) differ in bits 4-5 (the state residue): the two
       // half-exchange instructions of gfx950 put both partners' values side by side without an LDS round trip.
@@ -363,14 +392,15 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
       };
       // wait until the ring holds item k; returns the item's first A table
       int ready_seen = 0;
-      auto wait_item = [&](int k) -> const double * {
+      auto wait_item = [&](int k, int tslot) -> const double * { // tslot (INL): the item's first table slot
         while (!(ABL & 8) && ready_seen <= k)
         {
           ready_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           if (ready_seen <= k) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
-        return &ring[k % kAaRing][0][0];
+        if constexpr (INL) return &ring[0][0][0] + (size_t)tslot * kAaMat;
+        else return &ring[k % kAaRing][0][0];
       };
       auto release_item = [&](int k) {
         asm volatile("" ::: "memory");
@@ -438,6 +468,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           // cores the result would be the same doubles -- the other 19 products are exact zeros -- at 25 MFMAs.)
           unsigned m1 = 0, m2 = 0;
           bool     hot1 = false, hot2 = false;
+          const bool in1 = INL && (fl & kOpCh1), in2 = INL && (fl & kOpCh2); // (this child is computed below, from the ring)
           if (fl & kOpTip1)
           {
             m1   = R.xa ? R.xa : 1u; // (padding patterns carry no state: any column will do)
@@ -448,7 +479,8 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
             m2   = R.xb ? R.xb : 1u;
             hot2 = __builtin_amdgcn_ballot_w64((m2 & (m2 - 1u)) != 0u) == 0;
           }
-          if (fl & kOpTip1) { if (!hot1) tip_vec(m1, x1); s1 = 0; }
+          if (in1) s1 = 0;
+          else if (fl & kOpTip1) { if (!hot1) tip_vec(m1, x1); s1 = 0; }
           else if (fl & kOpF11)
           {
 #pragma unroll
@@ -462,7 +494,8 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
             s1 = scout;
           }
           else { unpack(R.a, x1); s1 = R.xa; }
-          if (fl & kOpTip2) { if (!hot2) tip_vec(m2, x2); s2 = 0; }
+          if (in2) s2 = 0;
+          else if (fl & kOpTip2) { if (!hot2) tip_vec(m2, x2); s2 = 0; }
           else if (fl & kOpF21)
           {
 #pragma unroll
@@ -479,18 +512,70 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           PHY_STAMP(k, 1)
           // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587 (never with a one-state tip)
           unsigned ones = 0;
-          if (!hot1 && !hot2)
-          {
+          auto all_ones = [&]() {
             ones = 1;
 #pragma unroll
             for (int t = 0; t < T; ++t) ones &= (unsigned)((x1[t] == 1.0) & (x2[t] == 1.0));
             if (!(ABL & 16)) ones = and_states(ones);
-          }
+          };
+          if (!hot1 && !hot2 && !in1 && !in2) all_ones();
           PHY_STAMP(k, 2)
           double u1[T] = {0., 0., 0., 0., 0.}, u2[T] = {0., 0., 0., 0., 0.};
           {
-            const double *A = wait_item(k);
+            const double *A = wait_item(k, (int)cur.dst_scale.x);
             PHY_STAMP(k, 3)
+            if constexpr (INL)
+            {
+              if (in1 || in2)
+              { // the in-step child: the step of its defining operation (tips a, b through tables 2 and 3 of this item)
+                const unsigned ma = (in1 ? R.xa : R.xb) ? (in1 ? R.xa : R.xb) : 1u, mb = R.xt ? R.xt : 1u;
+                const bool     hota = __builtin_amdgcn_ballot_w64((ma & (ma - 1u)) != 0u) == 0;
+                const bool     hotb = __builtin_amdgcn_ballot_w64((mb & (mb - 1u)) != 0u) == 0;
+                double         ua[T] = {0., 0., 0., 0., 0.}, ub[T] = {0., 0., 0., 0., 0.}, va[T], vb[T];
+                if (hota) tip_column(A + 2 * kAaMat, ma, ua);
+                else
+                {
+                  tip_vec(ma, va);
+#pragma unroll
+                  for (int t = 0; t < T; ++t) mfma_chunk(A + 2 * kAaMat, t, va[t], ua);
+                }
+                if (hotb) tip_column(A + 3 * kAaMat, mb, ub);
+                else
+                {
+                  tip_vec(mb, vb);
+#pragma unroll
+                  for (int t = 0; t < T; ++t) mfma_chunk(A + 3 * kAaMat, t, vb[t], ub);
+                }
+                unsigned cones = 0;
+                if (!hota && !hotb)
+                {
+                  cones = 1;
+#pragma unroll
+                  for (int t = 0; t < T; ++t) cones &= (unsigned)((va[t] == 1.0) & (vb[t] == 1.0));
+                  cones = and_states(cones);
+                }
+                double  (&xc)[T] = in1 ? x1 : x2;
+                unsigned cm = 0;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                {
+                  xc[t] = cones ? 1.0 : ua[t] * ub[t];
+                  cm    = max(cm, hi32(xc[t]));
+                }
+                if (C_ == 3 && idle) cm = 0;
+                cm = max_states(cm);
+                if (!cls) cm = max_cats(cm);
+                unsigned csc = 0;
+                if (cm < kHiInvTwoToLarge && q.apply_scaling)
+                {
+#pragma unroll
+                  for (int t = 0; t < T; ++t) xc[t] *= kTwoToLarge;
+                  csc = kLarge;
+                }
+                if (in1) s1 = csc; else s2 = csc;
+                if (!hot1 && !hot2) all_ones(); // (the operation's own all-ones test, now that both children are there)
+              }
+            }
             if (ABL & 1)
             {
 #pragma unroll
@@ -601,7 +686,7 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         side(q.e_parent, x, sl);
         side(q.e_child, y, sr);
         {
-          const double *A = wait_item(n_ops);
+          const double *A = wait_item(n_ops, q.aa_e_slot);
 #pragma unroll
           for (int t = 0; t < T; ++t) mfma_chunk(A, t, x[t], u); // rows: right-side state
           release_item(n_ops);

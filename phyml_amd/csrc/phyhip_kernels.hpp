@@ -159,6 +159,9 @@ struct TreeParams
   // PHYHIP_FLAG_GENERIC_LOOP: the arithmetic of Update_Partial_Lk_Generic under mod->use_m4mod (`phyml --cov`): no all-ones
   // shortcut (src/lk.c:1463-1528 has none; src/avx.c:575-587 does)
   int             generic_loop;
+  // 20-state kernel, lists with in-step tip x tip children (traverse_aa_kernel<..., INL>): where the evaluation edge's matrix
+  // tables sit in the LDS ring (first table slot) and how many items must have been released before they may be written
+  int             aa_e_slot, aa_e_need;
 };
 
 constexpr int kBigGroupWgs = 256; // workgroups of the large-grid resident evaluator when it adds per workgroup (phyhip_big.hpp)

@@ -76,9 +76,9 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
   L.reserve((size_t)n0 + (size_t)I->n_virtual + 8);
   LI.reserve(L.capacity());
   const InlineDef none{-1, -1, -1, -1};
-  // the lane-per-pattern nucleotide kernel computes ONE virtual child inside its reader's step (phyhip_nt2.hpp, INL); a second
-  // one -- and every one of the 20-state kernel -- is re-issued as a non-storing operation in front of the reader
-  const bool in_step = virtualise && I->soa && I->virt_inline && I->nt_groups <= 2; // (the instantiations that exist: flush_impl)
+  // both pipelined kernels compute ONE virtual child inside its reader's step (phyhip_nt2.hpp / phyhip_aa.hpp, INL); a second
+  // one is re-issued as a non-storing operation in front of the reader
+  const bool in_step = virtualise && I->virt_inline && ((I->soa && I->nt_groups <= 2) || I->perm); // (the instantiations that exist: flush_impl)
   bool       any_inl = false;
   auto before_read = [&](int c, DevOp &reader, InlineDef &rin, int bit) {
     if (c < I->tips || !I->virt[c]) return;
@@ -334,6 +334,28 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     // (the matrix queue is cleared only after the launch that rebuilds it has been issued, see below)
   }
   const bool fat = ((I->S == 4) && !I->generic_nt) || I->perm;
+  const bool has_inl = !I->pending_inl.empty(); // (some operation of this list computes a virtual child inside its own step)
+  // 20-state kernel, such a list: an item of its LDS ring is two matrix tables or -- with an in-step child -- four.  The host
+  // hands out the table slots (8 tables; an item never wraps) and says, per item, how many items every consumer must have
+  // released before the loader may overwrite them (phyhip_aa.hpp)
+  std::vector<int> aa_slot, aa_need;
+  if (I->perm && has_inl)
+  {
+    const int n_rec = n_ops + (n_ops & 1), n_items = n_rec + (ee ? 1 : 0);
+    aa_slot.resize(n_items); aa_need.resize(n_items);
+    int cur = 0, owner[2 * kAaRing];
+    for (int &x : owner) x = -1;
+    for (int k = 0; k < n_items; ++k)
+    {
+      const int nt = (k < n_rec && (I->pending[std::min(k, n_ops - 1)].pad & (kOpInl1 | kOpInl2))) ? 4 : 2;
+      if (cur + nt > 2 * kAaRing) cur = 0;
+      int need = 0;
+      for (int t = cur; t < cur + nt; ++t) { need = std::max(need, owner[t] + 1); owner[t] = k; }
+      aa_slot[k] = cur; aa_need[k] = need;
+      cur = (cur + nt) % (2 * kAaRing);
+    }
+    if (ee) { q.aa_e_slot = aa_slot[n_rec]; q.aa_e_need = aa_need[n_rec]; }
+  }
   const IssueRec *d_irec = nullptr;
   const ExecRec  *d_xrec = nullptr;
   q.last_dest = -1;
@@ -420,6 +442,12 @@ int flush_impl(Instance *I, const EdgeEval *ee)
             // its own -- its two matrices' offsets, its first tip's row in the auxiliary slot, its second tip's row in the tip slot
             fl |= (tipbit == kOpTip1) ? kOpCh1 : kOpCh2;
             const unsigned long long ab = (unsigned long long)((unsigned)inl->pmA * matbytes) | ((unsigned long long)((unsigned)inl->pmB * matbytes) << 32);
+            if (I->perm)
+            { // (20 states: the operation's two tip slots carry the plan of its ring item and the second tip's mask row -- below)
+              data  = desc(nullptr, 0, pmoff);
+              scale = desc(I->d_tipmasks + (size_t)inl->a * I->Ppad, (size_t)I->Ppad * 4, 1);
+              return;
+            }
             data  = desc(reinterpret_cast<const void *>((uintptr_t)ab), 0, pmoff);
             scale = desc(I->d_tipcodes + (size_t)inl->a * I->Ppad, (size_t)I->Ppad, 1);
             tip   = desc(I->d_tipcodes + (size_t)inl->b * I->Ppad, (size_t)I->Ppad, 1);
@@ -447,6 +475,14 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         const bool   st_on = !(o.pad & kOpNoStore); // (a result that stays virtual: stores through descriptors of size 0 are dropped)
         xr[k].dst_data  = desc(I->d_partials + b * buf_elems(I), st_on ? bufbytes : 0, fl);
         xr[k].dst_scale = desc(I->d_scales + b * scale_elems(I), st_on ? scale_elems(I) * 4 : 0, 0);
+        if (I->perm && has_inl)
+        { // the ring item of this operation: first table slot (consumers: dst_scale.x; loader: c2_tip.x), what must be released
+          // before it is written (c1_tip.bytes), and -- with an in-step child -- its two tables' offsets and its second tip's masks
+          const unsigned long long ab = inl ? ((unsigned long long)((unsigned)inl->pmA * matbytes) | ((unsigned long long)((unsigned)inl->pmB * matbytes) << 32)) : 0ull;
+          ir[k].c1_tip = desc(reinterpret_cast<const void *>((uintptr_t)ab), (size_t)aa_need[k], inl ? ((o.pad & kOpInl1) ? 1u : 2u) : 0u);
+          ir[k].c2_tip = desc(I->d_tipmasks + (size_t)(inl ? inl->b : 0) * I->Ppad, inl ? (size_t)I->Ppad * 4 : 0, (unsigned)aa_slot[k]);
+          xr[k].dst_scale.x = (unsigned)aa_slot[k];
+        }
       }
       // (reading short lists straight from the pinned staging memory instead was measured: no gain)
       if (in_args)
@@ -727,7 +763,6 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     HIPCHK(hipEventRecord(e0, I->stream));
   }
   const unsigned long long hp1 = hp_now();
-  const bool has_inl = !I->pending_inl.empty();
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     if constexpr (S_ == 4 && CP_ <= 4)
@@ -831,6 +866,9 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   case c_:                                                                                                                  \
     if (q.recs_in_args)                                                                                                     \
       hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,    \
+                         (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
+    else if (has_inl)                                                                                                       \
+      hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, false, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec, \
                          (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
     else                                                                                                                    \
     hipLaunchKernelGGL((traverse_aa_kernel<c_>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,                      \

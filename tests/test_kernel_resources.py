@@ -71,9 +71,10 @@ def test_default_traversal_kernels_keep_their_occupancy(product):
             n = f"_ZN6phyhip19traverse_nt2_kernelILi{c}ELi{g}ELb0ELi0ELi2ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdPKhPy"
             assert waves_per_simd(product[n]["vgpr_count"]) >= g, (n, product[n]["vgpr_count"])
     # the 20-state kernel: 1 loader + 15 consumer waves per workgroup = four per SIMD
+    # (<C, DBG, ABL, ARGS, INL>: list form, argument form, and the list form with in-step tip x tip children)
     for c in (1, 2, 3, 4):
-        for args in (0, 1):
-            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb{args}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
+        for args, inl in ((0, 0), (1, 0), (0, 1)):
+            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb{args}ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
             assert product[n]["vgpr_count"] <= 128, (n, product[n]["vgpr_count"])
 
 
