@@ -234,7 +234,13 @@ int phyhip_get_numerical_warning(int instance, int *outWarning);
    sumProbas (src/mixt.c:1048-1053), DBL_MIN floor, log, pattern weights of the FIRST instance.  All instances must sit
    on the same device with the same pattern count and one category; up to 64 classes (profile mixtures of the C10-C60 kind:
    one class tree per profile), PHYHIP_ERROR_OUT_OF_RANGE beyond.  The per-pattern log-likelihoods
-   (mixt_tree->c_lnL_sorted) are left in the first instance (phyhip_get_site_log_likelihoods). */
+   (mixt_tree->c_lnL_sorted) are left in the first instance (phyhip_get_site_log_likelihoods).
+   GROUPS OF CLASSES: an entry of `instances` may also be an instance created with PHYHIP_FLAG_CLASS_AXIS (below): it stands for
+   its C classes, in category order, evaluated by ONE traversal launch; parent / child / matrix indices stay per ENTRY, the
+   per-class tables (classProba, rMatWeight, eFrqWeight) run over all classes in list order (entry 0's classes, then entry
+   1's, ...; 64 in total).  A mixture of K classes is then ceil(K / 4) traversal launches per evaluation instead of K -- e.g.
+   4 + 4 + 2 for ten classes, 4 + 1 for five; with three nucleotide classes 2 + 1 (the nucleotide class axis holds 1, 2 or 4).
+   phyhip_calculate_mixture_eigen_lnl_dlnl takes the same lists. */
 int phyhip_calculate_mixture_log_likelihood(const int *instances, int count, const int *parentBufferIndices,
                                             const int *childBufferIndices, const int *probabilityIndices,
                                             const double *classProba, const double *rMatWeight, const double *eFrqWeight,
@@ -352,9 +358,11 @@ int phyhip_get_big_resident_stats(int instance, long long out[4]);
    operation, an evaluation edge, phyhip_update_eigen_lr, phyhip_get_partials / _scale_factors, a mixture evaluation -- first
    gets the defining operation queued again, storing: every value that leaves through this interface is the double the reference
    has in t_edge::p_lk_* at that point (tests/test_gpu_virtual.py).  A matrix or tip row the definition reads cannot change
-   under it: the setters materialise the dependants first.  minOperations = 0 switches the feature off (and materialises what
-   is virtual); the default is 16, so the short launches of a tree search never leave anything virtual.  Not on class-axis or
-   generic-loop instances.  Sharded instances: applied to every shard. */
+   under it: before one changes, its old value is moved to a snapshot slot of the buffer (whole-tree batches of device-built
+   matrices, uploaded matrices) or the dependants are stored first.  minOperations = 0 switches the feature off (and stores what
+   is virtual); the default is 16, so the short launches of a tree search never leave anything virtual -- and the first of
+   them that reads a virtual buffer stores them all, in its own launch.  Not on class-axis or generic-loop instances.  Sharded
+   instances: applied to every shard. */
 int phyhip_set_virtual_buffers(int instance, int minOperations);
 
 /* out[0] buffers virtual right now, out[1] stores skipped so far (operations that left their result virtual), out[2] non-storing

@@ -346,6 +346,20 @@ def mixture_log_likelihood(instance_ids, parents, children, matrices, proba, r_m
     return out.value
 
 
+def mixture_log_likelihood_classes(instance_ids, parents, children, matrices, proba, r_mat_weight, e_frq_weight, r_sum, e_sum, sum_probas):
+    """phyhip_calculate_mixture_log_likelihood with class-axis instances among the entries: the per-class tables are longer than
+    the instance list (an entry stands for its C classes)."""
+    L = load()
+    n = len(instance_ids)
+    ia = lambda v: (C.c_int * len(v))(*[int(x) for x in v])
+    da = lambda v: (C.c_double * len(v))(*[float(x) for x in v])
+    out = C.c_double(0.0)
+    _chk(L.phyhip_calculate_mixture_log_likelihood(ia(instance_ids), n, ia(parents), ia(children), ia(matrices), da(proba),
+                                                   da(r_mat_weight), da(e_frq_weight), C.c_double(r_sum), C.c_double(e_sum),
+                                                   C.c_double(sum_probas), C.byref(out)))
+    return out.value
+
+
 def mixture_eigen_lnl_dlnl(instance_ids, lefts, rights, l, proba, r_mat_weight, e_frq_weight, r_sum, e_sum, sum_probas):
     """phyhip_calculate_mixture_eigen_lnl_dlnl: MIXT_dLk over class instances; returns (clamped l, lnL, dlnL)."""
     L = load()

@@ -1650,9 +1650,9 @@ struct MixParams
 {
   int           count;
   long long     P;
-  const double *site_cat[kMaxMixClasses]; // per class: [P] (C = 1), or base + class with cat_stride = C (class axis)
+  const double *site_cat[kMaxMixClasses]; // per class: [P] (C = 1: cat_stride 1), or base + class with cat_stride = C (a class of a class-axis instance)
   const int    *fact[kMaxMixClasses];
-  int           cat_stride;
+  unsigned short cat_stride[kMaxMixClasses]; // (per class: a mixture may be spread over several instances of different shapes)
   // +I mixture (src/mixt.c:1079-1112): the invariant class is not a class tree of the device; its share enters here
   int           invar_model;
   double        pinvar;
@@ -1676,7 +1676,7 @@ static __global__ __launch_bounds__(256) void mixture_combine_kernel(const MixPa
     {
       int s = q.fact[k][p];
       if (s > 1024) { s = 1023; raise_warn(q.fin.warn); }
-      const double x = ldexp(q.site_cat[k][(size_t)p * q.cat_stride], -s); // == site_lk_cat / pow(2, sum): exact power-of-two scaling
+      const double x = ldexp(q.site_cat[k][(size_t)p * q.cat_stride[k]], -s); // == site_lk_cat / pow(2, sum): exact power-of-two scaling
       site_lk += x * q.proba[k] * q.r_w[k] / q.r_sum * q.e_w[k] / q.e_sum / q.sum_probas;
     }
     if (q.invar_model)
@@ -1713,7 +1713,7 @@ template <int S> struct MixDlkParams
   int           count;
   long long     P;
   const double *dot[kMaxMixClasses];                 // per class: dot_prod [P][S] (dot_stride = S), or base + class * S with dot_stride = C * S
-  int           dot_stride;
+  unsigned short dot_stride[kMaxMixClasses];
   const int    *scale_l[kMaxMixClasses], *scale_r[kMaxMixClasses]; // scale exponents of the two edge sides (nullptr: tip)
   double        proba[kMaxMixClasses], r_w[kMaxMixClasses], e_w[kMaxMixClasses];
   double        r_sum, e_sum, sum_probas;
@@ -1739,7 +1739,7 @@ template <int S> __global__ __launch_bounds__(256) void mixture_dlk_kernel(const
     double       site_lk = 0.0, site_dlk = 0.0;
     for (int k = 0; k < q.count; ++k)
     {
-      const double2 *s2 = reinterpret_cast<const double2 *>(q.dot[k] + (size_t)p * q.dot_stride);
+      const double2 *s2 = reinterpret_cast<const double2 *>(q.dot[k] + (size_t)p * q.dot_stride[k]);
       const double  *ex = q.expl + (size_t)k * 2 * S;
       double         z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
 #pragma unroll

@@ -14,29 +14,38 @@ static int mixture_lnl_impl(const int *instances, int count, const int *parent, 
   Instance *I0 = nullptr;
   MixParams q;
   memset(&q, 0, sizeof q);
+  // An entry of the list is ONE class (an instance with one category) or a GROUP of classes on the category axis of one
+  // instance (PHYHIP_FLAG_CLASS_AXIS: its C classes, in category order): a mixture of K classes is ceil(K / 4) traversal
+  // launches instead of K.  The per-class tables (classProba, ...) run over the classes in list order.
+  int nc = 0;
   for (int k = 0; k < count; ++k)
   {
     GET_INST(I, instances[k]);
     if (k == 0) I0 = I;
-    if (I->C != 1 || I->P != I0->P || I->dev != I0->dev)
-      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture class %d: needs one category, the same pattern count and the same device", k);
+    const int Ck = I->class_axis ? I->C : 1;
+    if ((!I->class_axis && I->C != 1) || I->P != I0->P || I->dev != I0->dev)
+      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture entry %d: needs one category (or the class axis), the same pattern count and the same device", k);
+    if (nc + Ck > kMaxMixClasses) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "more than %d mixture classes", kMaxMixClasses);
     int rc = check_partial_index(I, parent[k], true);
     if (rc) return rc;
     if ((rc = check_partial_index(I, child[k], true))) return rc;
     if (pm[k] < 0 || pm[k] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", pm[k]);
-    // the class's own edge evaluation: leaves unscaled_site_lk_cat and fact_sum_scale in its device arrays, no host sync
-    EdgeEval ee{parent[k], child[k], pm[k], I->d_result, false, nullptr};
+    // the entry's own edge evaluation: leaves unscaled_site_lk_cat and fact_sum_scale (per class) in its device arrays, no host sync
+    EdgeEval ee{parent[k], child[k], pm[k], I->class_axis ? nullptr : I->d_result, false, nullptr};
     if ((rc = flush(I, &ee))) return rc;
     if (I != I0)
     { // the combination runs on the first instance's stream, after every class stream
       HIPCHK(hipEventRecord(I->ev_sync, I->stream));
       HIPCHK(hipStreamWaitEvent(I0->stream, I->ev_sync, 0));
     }
-    q.site_cat[k] = I->d_site_cat; q.fact[k] = I->d_fact;
-    q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
+    for (int c = 0; c < Ck; ++c, ++nc)
+    {
+      q.site_cat[nc] = I->d_site_cat + c; q.cat_stride[nc] = (unsigned short)Ck; q.fact[nc] = I->d_fact + (size_t)c * I->P;
+      q.proba[nc] = classProba[nc]; q.r_w[nc] = rMatWeight[nc]; q.e_w[nc] = eFrqWeight[nc];
+    }
   }
-  q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
-  q.wght = I0->d_wght; q.site_lnl = I0->d_site_lnl; q.cat_stride = 1;
+  q.count = nc; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
+  q.wght = I0->d_wght; q.site_lnl = I0->d_site_lnl;
   fill_mixture_invariant(I0, q);
   const int grid = (int)((I0->P + 255) / 256);
   mix_finish_setup(I0, q.fin, grid, 1, mo);
@@ -87,6 +96,7 @@ static int mixture_dlnl_impl(const int *instances, int count, const int *left, c
   Instance *I0 = nullptr;
   std::vector<double> expl;
   std::vector<Instance *> cls;
+  int nc = 0; // classes so far (an entry of the list is one class, or the C classes of a class-axis instance: mixture_lnl_impl)
   for (int k = 0; k < count; ++k)
   {
     GET_INST(I, instances[k]);
@@ -95,28 +105,33 @@ static int mixture_dlnl_impl(const int *instances, int count, const int *left, c
       I0 = I;
       if (*l < I->l_min) *l = I->l_min; // src/lk.c:672-673 (dLk clamps before diverting to MIXT_dLk)
       else if (*l > I->l_max) *l = I->l_max;
-      expl.assign((size_t)count * 2 * I->S, 0.0);
+      expl.assign((size_t)kMaxMixClasses * 2 * I->S, 0.0);
     }
-    if (I->C != 1 || I->P != I0->P || I->dev != I0->dev || I->S != I0->S)
-      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture class %d: needs one category, the same shape and the same device", k);
+    const int Ck = I->class_axis ? I->C : 1;
+    if ((!I->class_axis && I->C != 1) || I->P != I0->P || I->dev != I0->dev || I->S != I0->S)
+      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "mixture entry %d: needs one category (or the class axis), the same shape and the same device", k);
+    if (nc + Ck > kMaxMixClasses) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "more than %d mixture classes", kMaxMixClasses);
     int rc = check_partial_index(I, left[k], true);
     if (rc) return rc;
     if ((rc = check_partial_index(I, right[k], true))) return rc;
     devirtualise(I, left[k]); devirtualise(I, right[k]); // (the combination kernel reads their scale vectors)
     if ((rc = flush(I, nullptr))) return rc; // queued partial updates write the scale vectors read below
-    // src/mixt.c:3056-3114
-    const double rr  = 1.0 * I->br_len_mult * I->h_rates[0];
-    double       len = (*l) * rr;
-    if (len < I->l_min) len = I->l_min;
-    else if (len > I->l_max) len = I->l_max;
-    for (int s = 0; s < I->S; ++s)
-    {
-      const double ev = I->h_eval[s], ex = exp(ev * len);
-      expl[(size_t)k * 2 * I->S + 2 * s]     = ex;
-      expl[(size_t)k * 2 * I->S + 2 * s + 1] = ex * ev * rr;
+    for (int c = 0; c < Ck; ++c, ++nc)
+    { // src/mixt.c:3056-3114
+      const double rr  = 1.0 * I->br_len_mult * I->h_rates[c];
+      double       len = (*l) * rr;
+      if (len < I->l_min) len = I->l_min;
+      else if (len > I->l_max) len = I->l_max;
+      for (int s = 0; s < I->S; ++s)
+      {
+        const double ev = I->h_eval[(size_t)(I->class_axis ? c : 0) * I->S + s], ex = exp(ev * len);
+        expl[(size_t)nc * 2 * I->S + 2 * s]     = ex;
+        expl[(size_t)nc * 2 * I->S + 2 * s + 1] = ex * ev * rr;
+      }
     }
     cls.push_back(I);
   }
+  expl.resize((size_t)nc * 2 * I0->S);
   // expl pairs of all classes: staged copy into the first instance's matrix scratch area
   void        *st = nullptr;
   const size_t eb = expl.size() * sizeof(double);
@@ -128,6 +143,7 @@ static int mixture_dlnl_impl(const int *instances, int count, const int *left, c
     constexpr int S_ = decltype(s_)::value;
     MixDlkParams<S_> q;
     memset(&q, 0, sizeof q);
+    int n = 0;
     for (int k = 0; k < count; ++k)
     {
       Instance *I = cls[k];
@@ -136,13 +152,17 @@ static int mixture_dlnl_impl(const int *instances, int count, const int *left, c
         HIPCHK(hipEventRecord(I->ev_sync, I->stream));
         HIPCHK(hipStreamWaitEvent(I0->stream, I->ev_sync, 0));
       }
-      q.dot[k] = I->d_dot;
-      q.scale_l[k] = left[k] < I->tips ? nullptr : I->d_scales + (size_t)(left[k] - I->tips) * I->Ppad;
-      q.scale_r[k] = right[k] < I->tips ? nullptr : I->d_scales + (size_t)(right[k] - I->tips) * I->Ppad;
-      q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
+      const int Ck = I->class_axis ? I->C : 1;
+      for (int c = 0; c < Ck; ++c, ++n)
+      {
+        q.dot[n] = I->d_dot + (size_t)c * S_; q.dot_stride[n] = (unsigned short)(Ck * S_);
+        q.scale_l[n] = left[k] < I->tips ? nullptr : I->d_scales + (size_t)(left[k] - I->tips) * scale_elems(I) + (size_t)c * I->Ppad;
+        q.scale_r[n] = right[k] < I->tips ? nullptr : I->d_scales + (size_t)(right[k] - I->tips) * scale_elems(I) + (size_t)c * I->Ppad;
+        q.proba[n] = classProba[n]; q.r_w[n] = rMatWeight[n]; q.e_w[n] = eFrqWeight[n];
+      }
     }
-    q.count = count; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
-    q.expl = I0->d_mixexpl; q.wght = I0->d_wght; q.dot_stride = S_;
+    q.count = n; q.P = I0->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
+    q.expl = I0->d_mixexpl; q.wght = I0->d_wght;
     fill_mixture_invariant(I0, q);
     const int grid = (int)((I0->P + 255) / 256);
     mix_finish_setup(I0, q.fin, grid, 2, mo);
@@ -237,11 +257,11 @@ static int class_mixture_lnl_impl(int instance, int parent, int child, int pm, c
   memset(&q, 0, sizeof q);
   for (int k = 0; k < I->C; ++k)
   {
-    q.site_cat[k] = I->d_site_cat + k; q.fact[k] = I->d_fact + (size_t)k * I->P;
+    q.site_cat[k] = I->d_site_cat + k; q.fact[k] = I->d_fact + (size_t)k * I->P; q.cat_stride[k] = (unsigned short)I->C;
     q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
   }
   q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
-  q.wght = I->d_wght; q.site_lnl = I->d_site_lnl; q.cat_stride = I->C;
+  q.wght = I->d_wght; q.site_lnl = I->d_site_lnl;
   fill_mixture_invariant(I, q);
   const int grid = (int)((I->P + 255) / 256);
   mix_finish_setup(I, q.fin, grid, 1, mo);
@@ -314,13 +334,13 @@ static int class_mixture_dlnl_impl(int instance, int left, int right, double *l,
     memset(&q, 0, sizeof q);
     for (int k = 0; k < I->C; ++k)
     {
-      q.dot[k]     = I->d_dot + (size_t)k * I->S;
+      q.dot[k]     = I->d_dot + (size_t)k * I->S; q.dot_stride[k] = (unsigned short)(I->C * I->S);
       q.scale_l[k] = left < I->tips ? nullptr : I->d_scales + (size_t)(left - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
       q.scale_r[k] = right < I->tips ? nullptr : I->d_scales + (size_t)(right - I->tips) * scale_elems(I) + (size_t)k * I->Ppad;
       q.proba[k] = classProba[k]; q.r_w[k] = rMatWeight[k]; q.e_w[k] = eFrqWeight[k];
     }
     q.count = I->C; q.P = I->P; q.r_sum = rMatWeightSum; q.e_sum = eFrqWeightSum; q.sum_probas = sumProbas;
-    q.expl = I->d_mixexpl; q.wght = I->d_wght; q.dot_stride = I->C * I->S;
+    q.expl = I->d_mixexpl; q.wght = I->d_wght;
     fill_mixture_invariant(I, q);
     const int grid = (int)((I->P + 255) / 256);
     mix_finish_setup(I, q.fin, grid, 2, mo);

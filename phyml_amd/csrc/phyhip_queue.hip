@@ -40,19 +40,30 @@ void devirtualise_tip(Instance *I, int tip)
     if (I->virt[b] && (I->vdef[b].c1 == tip || I->vdef[b].c2 == tip)) devirtualise(I, b);
 }
 
-// The queue as it will be launched.  (1) Every queued operation (and the evaluation edge) that reads a virtual buffer gets the
-// buffer's defining operation in front of it -- not storing when the list is a long one that leaves such results virtual anyway,
-// storing (the buffer is real afterwards) otherwise.  (2) may_virtualise, long lists: a tip x tip operation whose result is
-// written once in this list, read only later in it and not by the evaluation leaves its place -- it is re-issued, not storing,
-// in front of each of its consumers (the kernels forward the results of the previous two operations in registers).
+// The queue as it will be launched.  Short lists (or kernels without two-deep forwarding): the first one that reads a virtual
+// buffer gets the storing definitions of ALL virtual buffers in front of it.  Long lists (may_virtualise): a tip x tip operation
+// whose result is written once in this list, read only later in it and not by the evaluation leaves its place; every reader of a
+// virtual buffer -- one left virtual by this list or by an earlier one -- computes it inside its own step (one per operation:
+// DevOp::pad bits 1-2, pending_inl) or gets the definition re-issued in front of it, not storing (the kernels forward the
+// results of the previous two operations in registers); what the evaluation edge reads is stored.
 void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
 {
   I->pending_inl.clear();
   const int n0 = (int)I->pending.size();
   const bool virtualise = may_virtualise && I->virt_min_ops > 0 && n0 >= I->virt_min_ops;
   if (!virtualise && I->n_virtual == 0) return;
+  if (!virtualise)
+  { // A short launch.  If it reads a virtual buffer, EVERY virtual buffer is stored now, in this one launch: the short launches
+    // of a tree search (SPR candidates, Lk(b), Br_Len_Opt) come in long runs after a full traversal, and one list of tip x tip
+    // operations in front of the first of them costs less than a launch of three operations -- instead of a resident command
+    // -- at each buffer's first use.
+    bool reads = false;
+    for (const DevOp &o : I->pending) reads = reads || (o.c1 >= I->tips && I->virt[o.c1]) || (o.c2 >= I->tips && I->virt[o.c2]);
+    if (ee) reads = reads || (ee->parent >= I->tips && I->virt[ee->parent]) || (ee->child >= I->tips && I->virt[ee->child]);
+    if (reads) devirtualise_all(I);
+    return;
+  }
   std::vector<unsigned char> skip;
-  if (virtualise)
   {
     std::vector<int> n_dest(I->nbuf, 0), first_read(I->nbuf, -1);
     for (int k = 0; k < n0; ++k)
@@ -78,7 +89,7 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
   const InlineDef none{-1, -1, -1, -1};
   // both pipelined kernels compute ONE virtual child inside its reader's step (phyhip_nt2.hpp / phyhip_aa.hpp, INL); a second
   // one is re-issued as a non-storing operation in front of the reader
-  const bool in_step = virtualise && I->virt_inline && ((I->soa && I->nt_groups <= 2) || I->perm); // (the instantiations that exist: flush_impl)
+  const bool in_step = I->virt_inline && ((I->soa && I->nt_groups <= 2) || I->perm); // (the instantiations that exist: flush_impl)
   bool       any_inl = false;
   auto before_read = [&](int c, DevOp &reader, InlineDef &rin, int bit) {
     if (c < I->tips || !I->virt[c]) return;
@@ -92,18 +103,13 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
       ++I->n_virt_recomputed;
       return;
     }
-    if (virtualise) { d.pad = kOpNoStore; ++I->n_virt_recomputed; }
-    else
-    {
-      d.pad = 0;
-      I->virt[c] = 0; --I->n_virtual; ++I->n_virt_material;
-    }
+    d.pad = kOpNoStore; ++I->n_virt_recomputed;
     L.push_back(d); LI.push_back(none);
   };
   for (int k = 0; k < n0; ++k)
   {
     DevOp o = I->pending[k];
-    if (virtualise && skip[k])
+    if (skip[k])
     { // from here on the buffer is what this operation says; nothing is launched for it until somebody reads it
       if (!I->virt[o.dest]) { I->virt[o.dest] = 1; ++I->n_virtual; }
       o.pad = 0;

@@ -279,3 +279,77 @@ def test_many_class_mixture_against_the_oracle(fx, K):
     finally:
         for t in trees:
             t.close()
+
+
+def _class_groups(K, S):
+    """group sizes the class axis holds: up to 4 classes (20 states: 1-4; nucleotides: 1, 2 or 4)"""
+    sizes, left = [], K
+    while left > 0:
+        g = min(4, left)
+        if S == 4 and g == 3:
+            g = 2
+        sizes.append(g); left -= g
+    return sizes
+
+
+@pytest.mark.parametrize("fx,K", [("nt4", 3), ("nt4", 5), ("nt4", 10), ("nt4", 24), ("lg4x", 3), ("lg4x", 5), ("lg4x", 10), ("lg4x", 24),
+                                  ("lg4x", 60)])
+def test_many_class_mixture_in_groups_on_the_class_axis(fx, K):
+    """Any class count on the class axis: the K classes ride in groups of up to four on the category axes of ceil(K / 4)
+    instances (phyhip_calculate_mixture_* take class-axis instances as list entries) -- MIXT_Lk and MIXT_dLk against the oracle's
+    per-class evaluation + the restated combinations, as for the one-instance-per-class form above."""
+    from test_mixture_oracle import class_tree
+    d = phyg.load(os.path.join(GOLDEN, f"mixture_{fx}_dlk.phyg"))
+    models, factors = _many_classes(d, K)
+    S = int(d["ns"][0])
+    tv, _, _ = replay.tips_from_masks(d["tip_mask"], S)
+    e = int(d["eval_edge"][0])
+    l = float(d["dlk_l"][0])
+    unscaled, fact, dots = [], [], []
+    for md in models:
+        ot = class_tree(d, md)
+        ot.lk(both_sides=True)
+        ot.lk(e)
+        unscaled.append(ot.unscaled_site_lk_cat[:, 0].copy()); fact.append(ot.fact_sum_scale.copy())
+        ot.update_eigen_lr(e)
+        dots.append(ot.dot_prod.copy())
+    ref_lnl, ref_logs = replay.mixture_combine(unscaled, fact, factors, float(K), float(K), 1.0, d["wght"])
+    ref_l2, ref_dlnl = replay.mixture_dlk(dots, fact, models, factors, float(K), float(K), 1.0, d["wght"], l)
+    sizes = _class_groups(K, S)
+    assert sum(sizes) == K and len(sizes) == (K + 3) // 4 + (1 if (S == 4 and K % 4 == 3) else 0)
+    trees, at = [], 0
+    try:
+        for g in sizes:
+            t = _class_axis_tree(d, models[at:at + g], tv, True)
+            at += g
+            root = t.node(0).contents.v[0].contents.num
+            t.Post_Order_Lk(0, root)
+            t.Pre_Order_Lk(0, root)
+            trees.append(t)
+        ids = [t.tree.contents.b_inst for t in trees]
+        par = [t.side_buffer(e, 0) for t in trees]; chi = [t.side_buffer(e, 1) for t in trees]
+        pms = [t.edge(e).contents.Pij_rr_idx for t in trees]
+        L = capi.load()
+        import ctypes as C
+        ia = lambda v: (C.c_int * len(v))(*[int(x) for x in v])
+        da = lambda v: (C.c_double * len(v))(*[float(x) for x in v])
+        out = C.c_double(0.0)
+        rc = L.phyhip_calculate_mixture_log_likelihood(ia(ids), len(ids), ia(par), ia(chi), ia(pms), da([f[0] for f in factors]),
+                                                       da([f[1] for f in factors]), da([f[2] for f in factors]), C.c_double(float(K)),
+                                                       C.c_double(float(K)), C.c_double(1.0), C.byref(out))
+        assert rc >= 0, L.phyhip_get_last_error()
+        lnl = out.value
+        assert abs(lnl - ref_lnl) <= 1e-12 * abs(ref_lnl), (lnl, ref_lnl)
+        assert np.max(np.abs(trees[0].inst.site_log_likelihoods() - ref_logs)) < 1e-10
+        for t in trees:
+            t.Update_Eigen_Lr(e)
+        lv, o1, o2 = C.c_double(l), C.c_double(0.0), C.c_double(0.0)
+        rc = L.phyhip_calculate_mixture_eigen_lnl_dlnl(ia(ids), len(ids), ia(par), ia(chi), C.byref(lv), da([f[0] for f in factors]),
+                                                       da([f[1] for f in factors]), da([f[2] for f in factors]), C.c_double(float(K)),
+                                                       C.c_double(float(K)), C.c_double(1.0), C.byref(o1), C.byref(o2))
+        assert rc >= 0, L.phyhip_get_last_error()
+        assert abs(o1.value - ref_l2) <= 1e-12 * abs(ref_l2), (o1.value, ref_l2)
+        assert abs(o2.value - ref_dlnl) <= 1e-8 * max(1.0, abs(ref_dlnl)), (o2.value, ref_dlnl)
+    finally:
+        for t in trees:
+            t.close()

@@ -229,8 +229,8 @@ def test_large_grid_resident_evaluator_spr_and_brlen_call_pattern(taxa, patterns
     served, launches, silent, busy = stats["1"]
     n_scalar = int(np.isin(tr["kind"], (replay.EDGE_LNL, replay.DLK, replay.EIGEN_LR)).sum())
     # (the both-sides traversal in front of the stream leaves the tip x tip buffers virtual, include/phyhip.h: the first evaluation
-    # that reads one stores it first -- a launch of three operations instead of a resident command, once per such buffer)
-    assert served >= n_scalar - 8 - taxa // 2 and silent == 0 and launches <= 3, (stats["1"], n_scalar)
+    # that reads one stores them all -- one launch instead of a resident command)
+    assert served >= n_scalar - 9 and silent == 0 and launches <= 3, (stats["1"], n_scalar)
 
 
 def test_large_grid_resident_evaluator_brlen_chains_weights_and_invariant_sites(monkeypatch):
