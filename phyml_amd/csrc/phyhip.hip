@@ -393,9 +393,12 @@ int phyhip_finalize_instance(int instance)
 
 static int set_tip_codes(Instance *I, int tip, const std::vector<uint8_t> &codes)
 {
-  devirtualise_tip(I, tip); // (virtual buffers defined on the old row are stored first)
-  int rc = flush_sync(I);
+  // what is queued runs on the old row -- and may leave tip x tip results virtual; those, and the ones that already are, are
+  // stored before the row changes
+  int rc = flush(I, nullptr);
   if (rc) return rc;
+  devirtualise_tip(I, tip);
+  if ((rc = flush_sync(I))) return rc;
   HIPCHK(hipMemcpy(I->d_tipcodes + (size_t)tip * I->Ppad, codes.data(), (size_t)I->P, hipMemcpyHostToDevice));
   if (I->d_tipmasks)
   {
@@ -478,8 +481,9 @@ int phyhip_set_tip_partials_at_pattern(int instance, int tipIndex, int pattern, 
   int code = (int)m; // S <= 8: the byte stored on the device is the allowed-state mask itself
   int rc   = 0;
   if (I->S > 8 && (rc = code_for_mask(I, m, &code))) return rc;
-  devirtualise_tip(I, tipIndex);
   if ((rc = flush(I, nullptr))) return rc; // queued operations read the old state
+  devirtualise_tip(I, tipIndex);           // ... and virtual buffers defined on it are stored before it changes
+  if ((rc = flush(I, nullptr))) return rc;
   void *st = nullptr;
   if ((rc = I->ring.alloc(16, I->stream, &st))) return rc;
   *reinterpret_cast<uint8_t *>(st) = (uint8_t)code;
@@ -633,9 +637,13 @@ int phyhip_set_phyml_options(int instance, double l_min, double l_max, double br
   GET_INST(I, instance);
   const int sc = apply_lk_scaling ? 1 : 0;
   if (I->l_min == l_min && I->l_max == l_max && I->br_len_mult == br_len_mult && I->apply_scaling == sc) return PHYHIP_SUCCESS;
-  if (I->apply_scaling != sc) devirtualise_all(I); // (the rescaling rule is part of a virtual buffer's definition)
   int rc = flush(I, nullptr);
   if (rc) return rc;
+  if (I->apply_scaling != sc)
+  { // (the rescaling rule is part of a virtual buffer's definition)
+    devirtualise_all(I);
+    if ((rc = flush(I, nullptr))) return rc;
+  }
   I->l_min = l_min; I->l_max = l_max; I->br_len_mult = br_len_mult; I->apply_scaling = sc;
   return PHYHIP_SUCCESS;
 }
@@ -663,15 +671,27 @@ int phyhip_set_invariant_sites(int instance, int invar_model, double pinvar, con
 
 // ---- transition matrices ---------------------------------------------------------------------------
 
-// shadow (whole-tree batches of device-built matrices): [count] slots that receive the old values instead, filled here
+// Called before the matrices idx[0..count) change.  shadow != nullptr: the caller's rebuild / upload can move a matrix's old value
+// into a snapshot slot first ([count] slots, filled here; -1: none) -- whole-tree batches of device-built matrices and uploads.
 static int matrices_touch(Instance *I, const int *idx, int count, std::vector<int> *shadow = nullptr)
 {
   for (int i = 0; i < count; ++i)
     if (idx[i] < 0 || idx[i] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", idx[i]);
-  // A virtual buffer is defined on the matrices as they are.  Before one of them changes: a whole-tree batch -- Update_All_PMat in
-  // front of a full traversal that recomputes every buffer anyway -- has pmat_kernel move the old value into the buffer's own
-  // snapshot slot, and the definition reads it there from now on; anything else stores the buffer first (queued, launched below).
-  if (I->n_virtual > 0 && shadow)
+  bool queued_reader = false;
+  for (int i = 0; i < count && !queued_reader; ++i) queued_reader = I->mat_in_queue[idx[i]] != 0;
+  // a queued operation still reads an old matrix -- or (virtual buffers around, definitions about to move) may read a virtual
+  // buffer through its definition: launch the queue first (stream order does the rest).  That launch may itself leave tip x tip
+  // results virtual that are defined on the old values: they are looked at below, after it.
+  if (queued_reader || (I->n_virtual > 0 && shadow && !I->pending.empty()))
+  {
+    int rc = flush(I, nullptr);
+    if (rc) return rc;
+  }
+  if (I->n_virtual == 0) return 0;
+  // A virtual buffer is defined on the matrices as they are.  Before one changes: pmat_kernel / upload_matrices_kernel move the
+  // old value into the buffer's own snapshot slot, and the definition reads it there from now on (a full traversal that follows
+  // recomputes every buffer anyway; the host route rewrites a tree's matrices one call at a time) -- or the buffer is stored first.
+  if (shadow)
   {
     std::vector<int> where; // matrix -> position in idx (the last one wins, as in the queue); short lists are searched instead
     if (count > 4)
@@ -686,21 +706,13 @@ static int matrices_touch(Instance *I, const int *idx, int count, std::vector<in
         if (idx[i] == pm) return i;
       return -1;
     };
-    bool any = false;
-    for (int b = I->tips; b < I->nbuf && !any; ++b) any = I->virt[b] && (pos(I->vdef[b].pm1) >= 0 || pos(I->vdef[b].pm2) >= 0);
-    if (any && !I->pending.empty())
-    { // (queued operations may read a virtual buffer through its definition: launched before the definition moves to a slot
-      // that is only filled by the rebuild / upload queued below)
-      int rc = flush(I, nullptr);
-      if (rc) return rc;
-    }
-    if (any) shadow->assign(count, -1);
-    for (int b = I->tips; b < I->nbuf && any; ++b)
+    for (int b = I->tips; b < I->nbuf && I->n_virtual > 0; ++b)
     {
       if (!I->virt[b]) continue;
       DevOp &d = I->vdef[b];
       const int  i1 = pos(d.pm1), i2 = pos(d.pm2);
       if (i1 < 0 && i2 < 0) continue;
+      if (shadow->empty()) shadow->assign(count, -1);
       // (one snapshot per matrix and call; a second dependant of a matrix, or a definition that reads it twice, is stored instead)
       const bool free1 = i1 < 0 || ((*shadow)[i1] < 0 && I->pm_slot[d.pm1] < 0 && I->up_slot[d.pm1] < 0);
       const bool free2 = i2 < 0 || ((*shadow)[i2] < 0 && I->pm_slot[d.pm2] < 0 && I->up_slot[d.pm2] < 0);
@@ -711,14 +723,10 @@ static int matrices_touch(Instance *I, const int *idx, int count, std::vector<in
   }
   else
     for (int i = 0; i < count && I->n_virtual > 0; ++i) devirtualise_matrix(I, idx[i]);
-  for (int i = 0; i < count; ++i)
-  {
-    if (I->mat_in_queue[idx[i]])
-    { // a queued operation still reads the old matrix: launch the queue first (stream order does the rest)
-      int rc = flush(I, nullptr);
-      if (rc) return rc;
-      break;
-    }
+  if (!I->pending.empty())
+  { // (stored on the old values: now)
+    int rc = flush(I, nullptr);
+    if (rc) return rc;
   }
   return 0;
 }
@@ -778,7 +786,7 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
   // (a virtual buffer defined on the old value: the upload kernel moves that into the buffer's snapshot slot first -- the host
   // route rewrites a whole tree's matrices one call at a time, and a stored buffer per call would be a launch per call)
   std::vector<int> shadow;
-  int rc = matrices_touch(I, &matrixIndex, 1, I->n_virtual > 0 ? &shadow : nullptr);
+  int rc = matrices_touch(I, &matrixIndex, 1, &shadow);
   if (rc) return rc;
   if (I->pm_slot[matrixIndex] >= 0 && (rc = flush_pmats(I))) return rc; // keep rebuild-then-upload order
   const size_t bytes = (size_t)I->C * I->S * I->S * sizeof(double);

@@ -278,6 +278,7 @@ struct Instance
   std::vector<std::vector<InlineDef>>    slot_inl;           // ... of the lists the device ring slots hold (content cache)
   std::vector<unsigned char>             virt;              // [nbuf]
   std::vector<DevOp>                     vdef;              // [nbuf]
+  std::vector<int>                       keep_real;         // buffers the caller reads from MEMORY right after the next launch (devirtualise): that launch leaves them stored
   unsigned long long                     n_virt_skipped = 0, n_virt_recomputed = 0, n_virt_material = 0; // phyhip_get_virtual_stats
   std::vector<int>                       pm_idx;    // queued device-side matrix rebuilds (index, edge length)
   std::vector<double>                    pm_len;

@@ -1,6 +1,7 @@
 // phyhip_queue.hip -- the deferred operation queue turned into launches, and the waits for their scalars
 // (libphyhip.so, gfx950 only; the units and what they share: phyhip_host.hpp)
 #include "phyhip_host.hpp"
+#include <algorithm>
 
 namespace phyhip_host
 {
@@ -11,6 +12,10 @@ constexpr int kOpInl1 = 2, kOpInl2 = 4; // DevOp::pad bits 1, 2: child 1 / child
 
 void devirtualise(Instance *I, int buf)
 {
+  // whoever asks is about to read the buffer from memory -- a kernel outside the traversal launch (eigen_lr_kernel, a mixture
+  // combination), a copy to the host, or a setter that changes what the buffer was computed from: the launch in between must not
+  // leave it virtual AGAIN (a long queue that writes it with a tip x tip operation and reads it later would: rewrite_pending)
+  if (buf >= I->tips && buf < I->nbuf && I->virt_min_ops > 0) I->keep_real.push_back(buf);
   if (I->n_virtual == 0 || buf < I->tips || buf >= I->nbuf || !I->virt[buf]) return;
   DevOp op = I->vdef[buf];
   op.pad   = 0;
@@ -25,7 +30,8 @@ void devirtualise(Instance *I, int buf)
 
 void devirtualise_all(Instance *I)
 {
-  for (int b = I->tips; b < I->nbuf && I->n_virtual > 0; ++b) devirtualise(I, b);
+  for (int b = I->tips; b < I->nbuf && I->n_virtual > 0; ++b)
+    if (I->virt[b]) devirtualise(I, b);
 }
 
 void devirtualise_matrix(Instance *I, int m)
@@ -78,7 +84,8 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
     {
       const DevOp &o = I->pending[k];
       if (o.c1 < I->tips && o.c2 < I->tips && n_dest[o.dest] == 1 && first_read[o.dest] > k &&
-          !(ee && (ee->parent == o.dest || ee->child == o.dest)))
+          !(ee && (ee->parent == o.dest || ee->child == o.dest)) &&
+          std::find(I->keep_real.begin(), I->keep_real.end(), o.dest) == I->keep_real.end())
         skip[k] = 1;
     }
   }
@@ -123,16 +130,17 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
     L.push_back(o); LI.push_back(in);
     if (I->virt[o.dest]) { I->virt[o.dest] = 0; --I->n_virtual; } // (a storing operation: the buffer is real again)
   }
+  auto store_now = [&](int b) { // what is read from memory behind this launch (or by its evaluation): stored
+    if (b < I->tips || !I->virt[b]) return;
+    DevOp d = I->vdef[b];
+    d.pad = 0;
+    I->virt[b] = 0; --I->n_virtual; ++I->n_virt_material;
+    I->mat_in_queue[d.pm1] = 1; I->mat_in_queue[d.pm2] = 1;
+    L.push_back(d); LI.push_back(none);
+  };
+  for (int b : I->keep_real) store_now(b);
   if (ee)
-    for (int side : {ee->parent, ee->child})
-      if (side >= I->tips && I->virt[side])
-      { // the evaluation reads memory (or the last result): stored
-        DevOp d = I->vdef[side];
-        d.pad = 0;
-        I->virt[side] = 0; --I->n_virtual; ++I->n_virt_material;
-        I->mat_in_queue[d.pm1] = 1; I->mat_in_queue[d.pm2] = 1;
-        L.push_back(d); LI.push_back(none);
-      }
+    for (int side : {ee->parent, ee->child}) store_now(side);
   I->pending.swap(L);
   if (any_inl) I->pending_inl.swap(LI);
 }
@@ -265,6 +273,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // kernels with two-deep register forwarding leaves its own tip x tip results virtual (rewrite_pending)
   rewrite_pending(I, ee, (I->soa || I->perm) && !I->generic_nt && I->prefetch_dist == 2 && !I->class_axis && !I->generic_loop &&
                              !I->ablate && !I->no_loads);
+  I->keep_real.clear();
   const int n_ops = (int)I->pending.size();
   int rc = 0;
   if (n_ops > 0 || ee || !I->pm_idx.empty() || !I->up_idx.empty()) I->stream_dirty = true;

@@ -186,3 +186,111 @@ def test_short_lists_store_everything():
                 assert np.array_equal(t.partials(*k), ot.plk[k]), k
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("ns,C,P", [(20, 4, 90), (4, 4, 300), (20, 2, 50)])
+@pytest.mark.parametrize("host_pmat", [True, False])
+def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
+    """What a search does between two full traversals, at random: new lengths / matrices on random edges (pendant edges of cherries
+    among them), partial updates over whole subtrees (long lists that READ buffers an earlier launch left virtual, and lists
+    that re-virtualise them), evaluations at random edges, full traversals in between -- every scalar equal to the run that stores
+    every buffer, and every buffer read back at the end."""
+    t, ot, tree, st = synthetic_pair(34, P, ns, C, seed=21, host_pmat=host_pmat, ambiguous_every=13)
+    t0, _, _, _ = synthetic_pair(34, P, ns, C, seed=21, host_pmat=host_pmat, ambiguous_every=13)
+    try:
+        t0.inst.set_virtual_buffers(0)
+        for x in (t, t0):
+            x.Set_Both_Sides(True)
+        assert t.Lk(None) == t0.Lk(None)
+        rng = np.random.default_rng(17)
+        internal = [e for e in range(t.ne) if ot.el[e] >= ot.n and ot.er[e] >= ot.n]
+        for it in range(120):
+            act = int(rng.integers(0, 6))
+            if act == 0:
+                assert t.Lk(None) == t0.Lk(None), it
+            elif act in (1, 2):
+                for e in rng.choice(t.ne, size=int(rng.integers(1, 6)), replace=False):
+                    l = float(rng.uniform(0.005, 0.4))
+                    for x in (t, t0):
+                        x.edge(int(e)).contents.l = l
+                        x.Update_PMat_At_Given_Edge(int(e))
+            elif act == 3:
+                e = int(rng.choice(internal))
+                a, d = (int(ot.el[e]), int(ot.er[e])) if rng.integers(0, 2) else (int(ot.er[e]), int(ot.el[e]))
+                for x in (t, t0):
+                    x.Post_Order_Lk(a, d)      # the whole subtree behind d: a long list
+                assert t.Lk(e) == t0.Lk(e), it
+            elif act == 4:
+                e = int(rng.integers(0, t.ne))
+                assert t.Lk(e) == t0.Lk(e), it
+            else:
+                e = int(rng.choice(internal))
+                got, ref = [], []
+                for x, out in ((t, got), (t0, ref)):
+                    x.Set_Update_Eigen_Lr(True); x.Set_Use_Eigen_Lr(False)
+                    out.append(x.Lk(e))
+                    x.Set_Update_Eigen_Lr(False); x.Set_Use_Eigen_Lr(True)
+                    out.append(x.dLk(0.11, e)[1]); out.append(x.c_dlnL)
+                    x.Set_Use_Eigen_Lr(False)
+                assert got == ref, it
+        assert t.Lk(None) == t0.Lk(None)
+        for k in ot.plk:
+            assert np.array_equal(t.partials(*k), t0.partials(*k)), k
+            assert np.array_equal(t.scale_factors(*k), t0.scale_factors(*k)), k
+    finally:
+        t.close(); t0.close()
+
+
+@pytest.mark.parametrize("ns,C,P", [(20, 4, 70), (4, 4, 2600), (4, 4, 200)])
+def test_readers_and_setters_behind_a_long_queue(ns, C, P):
+    """A whole traversal QUEUED (nothing evaluated yet) and then something that reads a tip x tip buffer from memory, or changes
+    what it is computed from: the launch in between must leave that buffer stored, on the old values -- `phyhip_get_partials`,
+    `Update_Eigen_Lr` as a kernel of its own (20 states; nucleotides beyond the fused range), a pendant edge's matrix, a tip row."""
+    t, ot, tree, st = synthetic_pair(30, P, ns, C, seed=9, host_pmat=True, ambiguous_every=11)
+    t0, _, _, _ = synthetic_pair(30, P, ns, C, seed=9, host_pmat=True, ambiguous_every=11)
+    try:
+        t0.inst.set_virtual_buffers(0)
+        ck = cherry_keys(ot)
+        root = t.node(0).contents.v[0].contents.num
+
+        def queue_all():
+            for x in (t, t0):
+                x.Post_Order_Lk(0, root); x.Pre_Order_Lk(0, root)
+        for x in (t, t0):
+            x.Set_Both_Sides(True)
+        assert t.Lk(None) == t0.Lk(None)
+        # (1) read a cherry right behind the queued traversal
+        queue_all()
+        e, side = ck[0]
+        assert np.array_equal(t.partials(e, side), t0.partials(e, side))
+        assert np.array_equal(t.scale_factors(e, side), t0.scale_factors(e, side))
+        # (2) Update_Eigen_Lr + dLk at edges one of whose sides is a cherry, behind the queued traversal
+        for (e, side) in ck[:4]:
+            queue_all()
+            got, ref = [], []
+            for x, out in ((t, got), (t0, ref)):
+                x.Set_Update_Eigen_Lr(True); x.Update_Eigen_Lr(e); x.Set_Update_Eigen_Lr(False)
+                x.Set_Use_Eigen_Lr(True)
+                out.append(x.dLk(0.07, e)[1]); out.append(x.c_dlnL); out.append(x.Lk(e))
+                x.Set_Use_Eigen_Lr(False)
+            assert got == ref, e
+        # (3) a pendant edge's matrix changes behind the queued traversal: the cherry keeps the value of the queued update
+        e, side = ck[1]
+        d = int(ot.el[e] if side == 0 else ot.er[e])
+        pend = [be for (v, be) in ot.adj[d] if be != e][0]
+        queue_all()
+        for x in (t, t0):
+            x.edge(pend).contents.l = 0.29
+            x.Update_PMat_At_Given_Edge(pend)
+        assert np.array_equal(t.partials(e, side), t0.partials(e, side))
+        # (4) a tip row changes behind the queued traversal
+        tip = [v for (v, be) in ot.adj[d] if be != e][0]
+        queue_all()
+        for x in (t, t0):
+            x.inst.set_tip_partials_at_pattern(tip, 3, np.ones(ns))
+        assert np.array_equal(t.partials(e, side), t0.partials(e, side))
+        assert t.Lk(None) == t0.Lk(None)
+        for k in ot.plk:
+            assert np.array_equal(t.partials(*k), t0.partials(*k)), k
+    finally:
+        t.close(); t0.close()
