@@ -351,10 +351,37 @@ static ctx_t *ensure_instance(t_tree *tree)
   return c;
 }
 
+static void first_bad(double d, double dev, double ref); /* GLUE_FIRST_BAD=1 (below) */
 static void track(double *worst, double dev, double ref, double floor_)
 {
   const double d = fabs(dev - ref) / fmax(floor_, fabs(ref));
   if (d > *worst) *worst = d;
+  if (d > 1e-8) first_bad(d, dev, ref);
+}
+
+/* GLUE_FIRST_BAD=1 (check mode, developer aid): the first compared scalar that is off by more than 1e-8, with the call counts so far
+   and the instance's virtual-buffer counters */
+#define TRN 64
+static struct { char k; int a, b, c, d, e; double x; } g_tr[TRN];
+static unsigned long g_trn = 0;
+static void tr(char k, int a, int b, int c, int d, int e, double x)
+{
+  g_tr[g_trn % TRN].k = k; g_tr[g_trn % TRN].a = a; g_tr[g_trn % TRN].b = b; g_tr[g_trn % TRN].c = c; g_tr[g_trn % TRN].d = d;
+  g_tr[g_trn % TRN].e = e; g_tr[g_trn % TRN].x = x; ++g_trn;
+}
+static void first_bad(double d, double dev, double ref)
+{
+  static int done = 0;
+  if (done || !getenv("GLUE_FIRST_BAD")) return;
+  done = 1;
+  for (unsigned long i = g_trn > TRN ? g_trn - TRN : 0; i < g_trn; ++i)
+    fprintf(stderr, "GLUE_TRACE %lu %c %d %d %d %d %d %.6g\n", i, g_tr[i % TRN].k, g_tr[i % TRN].a, g_tr[i % TRN].b, g_tr[i % TRN].c, g_tr[i % TRN].d,
+            g_tr[i % TRN].e, g_tr[i % TRN].x);
+  long long vs[4] = {0, 0, 0, 0};
+  if (g_nctx > 0) phyhip_get_virtual_stats(g_ctx[0].inst, vs);
+  fprintf(stderr, "GLUE_FIRST_BAD rel %.3g device %.17g reference %.17g | calls so far: Lk %ld (full %ld) Update_Partial_Lk %ld dLk %ld Update_PMat %ld "
+                  "Update_Eigen_Lr %ld | virtual now %lld skipped %lld reissued %lld stored %lld\n",
+          d, dev, ref, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat, g_n_eig, vs[0], vs[1], vs[2], vs[3]);
 }
 
 /* ---- the interposed surface ---------------------------------------------------------------------------------- */
@@ -481,6 +508,7 @@ void Update_PMat_At_Given_Edge(t_edge *b_fcus, t_tree *tree)
     real(b_fcus, tree); /* host PMat (src/models.c:257-373) into b->Pij_rr ... */
     hp_add(HP_HOST_PMAT, t_);
   }
+  tr('P', m, 0, 0, 0, 0, b_fcus->l->v);
   TOK(HP_ABI_MATRIX, phyhip_set_transition_matrix(c->inst, m, b_fcus->Pij_rr, -1.0)); /* ... and the upload of src/lk.c:2360 */
   hp_add(HP_WRAP_UPDATE_PMAT, hp_w);
 }
@@ -532,6 +560,7 @@ void Update_Partial_Lk(t_tree *tree, t_edge *b, t_node *d)
   op.child1TransitionMatrix = mat_id(c, Pij1);
   op.child2Partials = n_v2->tax ? n_v2->num : buf_id(c, p_lk_v2);
   op.child2TransitionMatrix = mat_id(c, Pij2);
+  tr('U', op.destinationPartials, op.child1Partials, op.child2Partials, op.child1TransitionMatrix, op.child2TransitionMatrix, 0.0);
   TOK(HP_ABI_UPDATE_PARTIALS, phyhip_update_partials(c->inst, &op, 1, PHYHIP_OP_NONE));
   hp_add(HP_WRAP_UPDATE_PARTIAL_LK, hp_w);
   if (c->K > 0)
@@ -553,6 +582,7 @@ void Update_Eigen_Lr(t_edge *b, t_tree *tree)
   if (c->K > 0 && c->cls > 0) { if (g_check) real(b, tree); return; } /* class axis: class 0's call covered every class */
   int l, r;
   edge_sides(c, b, &l, &r);
+  tr('E', l, r, 0, 0, 0, 0.0);
   TOK(HP_ABI_UPDATE_EIGEN_LR, phyhip_update_eigen_lr(c->inst, l, r));
   if (g_check) real(b, tree);
 }
@@ -584,12 +614,13 @@ static double device_edge_value(t_tree *tree, const t_edge *b)
 {
   ctx_t *c = ensure_instance(tree);
   double lnl = 0.0;
-  if (tree->use_eigen_lr == YES) TOK(HP_ABI_EIGEN_EVAL, phyhip_calculate_eigen_lnl(c->inst, b->l->v, &lnl)); /* src/lk.c:592-603 */
+  if (tree->use_eigen_lr == YES) { TOK(HP_ABI_EIGEN_EVAL, phyhip_calculate_eigen_lnl(c->inst, b->l->v, &lnl)); tr('G', 0, 0, 0, 0, 0, lnl); } /* src/lk.c:592-603 */
   else
   {
     int l, r, pm = mat_id(c, b->Pij_rr), zero = 0;
     edge_sides(c, b, &l, &r);
     TOK(HP_ABI_EDGE_LNL, phyhip_calculate_edge_log_likelihoods(c->inst, &l, &r, &pm, NULL, NULL, &zero, &zero, NULL, 1, &lnl, NULL, NULL));
+    tr('L', l, r, pm, 0, 0, lnl);
     if (g_site_outputs) site_outputs(tree, c);
   }
   return lnl;
@@ -833,7 +864,7 @@ phydbl Lk(t_edge *b, t_tree *tree)
   static phydbl (*real)(t_edge *, t_tree *) = NULL;
   if (!real) real = (phydbl (*)(t_edge *, t_tree *))dlsym(RTLD_NEXT, "Lk");
   ++g_n_lk;
-  if (!b) ++g_n_lk_full;
+  if (!b) { ++g_n_lk_full; tr('F', 0, 0, 0, 0, 0, 0.0); }
   if (g_host || tree->is_mixt_tree) return real(b, tree); /* mixture: src/lk.c:465-472 diverts to MIXT_Lk (above) */
   if (tree->mixt_tree && tree->mod->ras->invar == YES) return real(b, tree); /* the invariant class of a +I mixture: host only */
   if (tree->mixt_tree && !g_check) { fprintf(stderr, "glue_driver: Lk() on a class tree outside MIXT_Lk is served in check mode only\n"); exit(5); }
@@ -890,6 +921,7 @@ phydbl dLk(phydbl *l, t_edge *b, t_tree *tree)
     double x = *l, lnl = 0.0, dlnl = 0.0;
     const phydbl ref = real(l, b, tree); /* its Update_Eigen_Lr (if any) reaches the device through the wrapper */
     OK(phyhip_calculate_eigen_lnl_dlnl(c->inst, &x, &lnl, &dlnl));
+    tr('D', 0, 0, 0, 0, 0, lnl);
     track(&g_worst_lnl, lnl, ref, 1.0);
     track(&g_worst_dlnl, dlnl, tree->c_dlnL, 1.0);
     return ref;

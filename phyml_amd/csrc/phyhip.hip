@@ -318,6 +318,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->slot_ops.assign(I->ops_slots, std::vector<DevOp>());
   I->slot_inl.assign(I->ops_slots, std::vector<InlineDef>());
   if (const char *e = diag_env("PHYHIP_VIRT_INLINE")) I->virt_inline = atoi(e) != 0;
+  if (const char *e = diag_env("PHYHIP_VIRT_MIN_OPS")) I->virt_min_ops = std::max(0, atoi(e)); // (diag: phyhip_set_virtual_buffers' threshold from the environment)
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = diag_env("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (I->generic_loop) I->generic_nt = true;
@@ -679,15 +680,24 @@ static int matrices_touch(Instance *I, const int *idx, int count, std::vector<in
     if (idx[i] < 0 || idx[i] >= I->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", idx[i]);
   bool queued_reader = false;
   for (int i = 0; i < count && !queued_reader; ++i) queued_reader = I->mat_in_queue[idx[i]] != 0;
-  // a queued operation still reads an old matrix -- or (virtual buffers around, definitions about to move) may read a virtual
-  // buffer through its definition: launch the queue first (stream order does the rest).  That launch may itself leave tip x tip
-  // results virtual that are defined on the old values: they are looked at below, after it.
-  if (queued_reader || (I->n_virtual > 0 && shadow && !I->pending.empty()))
+  // does a virtual buffer's definition read one of them?  (a scan of the buffer flags: only while some are virtual)
+  auto depends = [&]() {
+    for (int b = I->tips; b < I->nbuf && I->n_virtual > 0; ++b)
+      if (I->virt[b])
+        for (int i = 0; i < count; ++i)
+          if (I->vdef[b].pm1 == idx[i] || I->vdef[b].pm2 == idx[i]) return true;
+    return false;
+  };
+  // a queued operation still reads an old matrix -- or may read a virtual buffer through a definition that is about to move to
+  // a snapshot slot: launch the queue first (stream order does the rest).  That launch may itself leave tip x tip results
+  // virtual that are defined on the old values: they are looked at below, after it.
+  if (queued_reader || (shadow && !I->pending.empty() && depends()))
   {
     int rc = flush(I, nullptr);
     if (rc) return rc;
   }
   if (I->n_virtual == 0) return 0;
+  const unsigned long long stored_before = I->n_virt_material;
   // A virtual buffer is defined on the matrices as they are.  Before one changes: pmat_kernel / upload_matrices_kernel move the
   // old value into the buffer's own snapshot slot, and the definition reads it there from now on (a full traversal that follows
   // recomputes every buffer anyway; the host route rewrites a tree's matrices one call at a time) -- or the buffer is stored first.
@@ -723,7 +733,7 @@ static int matrices_touch(Instance *I, const int *idx, int count, std::vector<in
   }
   else
     for (int i = 0; i < count && I->n_virtual > 0; ++i) devirtualise_matrix(I, idx[i]);
-  if (!I->pending.empty())
+  if (I->n_virt_material != stored_before)
   { // (stored on the old values: now)
     int rc = flush(I, nullptr);
     if (rc) return rc;

@@ -67,6 +67,9 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
     for (const DevOp &o : I->pending) reads = reads || (o.c1 >= I->tips && I->virt[o.c1]) || (o.c2 >= I->tips && I->virt[o.c2]);
     if (ee) reads = reads || (ee->parent >= I->tips && I->virt[ee->parent]) || (ee->child >= I->tips && I->virt[ee->child]);
     if (reads) devirtualise_all(I);
+    // (a queued operation that WRITES a virtual buffer stores it: real again -- its old definition must never be stored over it)
+    for (const DevOp &o : I->pending)
+      if (I->virt[o.dest]) { I->virt[o.dest] = 0; --I->n_virtual; }
     return;
   }
   std::vector<unsigned char> skip;

@@ -204,8 +204,9 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
         assert t.Lk(None) == t0.Lk(None)
         rng = np.random.default_rng(17)
         internal = [e for e in range(t.ne) if ot.el[e] >= ot.n and ot.er[e] >= ot.n]
-        for it in range(120):
-            act = int(rng.integers(0, 6))
+        keys = list(ot.plk)
+        for it in range(300):
+            act = int(rng.integers(0, 10))
             if act == 0:
                 assert t.Lk(None) == t0.Lk(None), it
             elif act in (1, 2):
@@ -219,11 +220,24 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
                 a, d = (int(ot.el[e]), int(ot.er[e])) if rng.integers(0, 2) else (int(ot.er[e]), int(ot.el[e]))
                 for x in (t, t0):
                     x.Post_Order_Lk(a, d)      # the whole subtree behind d: a long list
+                if it % 2:
+                    # (the order of Lk(b) in a search, src/lk.c:513-528: partial updates queued, THEN the edge's matrix, then the evaluation)
+                    l = float(rng.uniform(0.005, 0.4))
+                    for x in (t, t0):
+                        x.edge(e).contents.l = l
+                        x.Update_PMat_At_Given_Edge(e)
                 assert t.Lk(e) == t0.Lk(e), it
             elif act == 4:
                 e = int(rng.integers(0, t.ne))
+                if it % 3 == 0 and ot.el[e] >= ot.n:
+                    # one partial update queued, a matrix set, then the evaluation (an SPR candidate's order, src/spr.c:643-646)
+                    l = float(rng.uniform(0.005, 0.4))
+                    for x in (t, t0):
+                        x.Update_Partial_Lk(e, int(ot.el[e]))
+                        x.edge(e).contents.l = l
+                        x.Update_PMat_At_Given_Edge(e)
                 assert t.Lk(e) == t0.Lk(e), it
-            else:
+            elif act == 5:
                 e = int(rng.choice(internal))
                 got, ref = [], []
                 for x, out in ((t, got), (t0, ref)):
@@ -233,6 +247,26 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
                     out.append(x.dLk(0.11, e)[1]); out.append(x.c_dlnL)
                     x.Set_Use_Eigen_Lr(False)
                 assert got == ref, it
+            elif act in (6, 7):
+                # single partial updates, left QUEUED (Br_Len_Opt / SPR rewrite one node at a time -- also nodes whose buffer an
+                # earlier traversal left virtual: a short launch that stores it)
+                for _ in range(int(rng.integers(1, 4))):
+                    e = int(rng.integers(0, t.ne))
+                    d = int(ot.el[e] if rng.integers(0, 2) else ot.er[e])
+                    if d >= ot.n:
+                        for x in (t, t0):
+                            x.Update_Partial_Lk(e, d)
+            elif act == 8:
+                k = keys[int(rng.integers(0, len(keys)))]     # a host reader at a random moment
+                assert np.array_equal(t.partials(*k), t0.partials(*k)), (it, k)
+                assert np.array_equal(t.scale_factors(*k), t0.scale_factors(*k)), (it, k)
+            else:
+                tip, pat = int(rng.integers(0, ot.n)), int(rng.integers(0, P))
+                v = np.zeros(ns); v[int(rng.integers(0, ns))] = 1.0
+                if rng.integers(0, 2):
+                    v[:] = 1.0
+                for x in (t, t0):
+                    x.inst.set_tip_partials_at_pattern(tip, pat, v)
         assert t.Lk(None) == t0.Lk(None)
         for k in ot.plk:
             assert np.array_equal(t.partials(*k), t0.partials(*k)), k
@@ -292,5 +326,37 @@ def test_readers_and_setters_behind_a_long_queue(ns, C, P):
         assert t.Lk(None) == t0.Lk(None)
         for k in ot.plk:
             assert np.array_equal(t.partials(*k), t0.partials(*k)), k
+    finally:
+        t.close(); t0.close()
+
+
+@pytest.mark.parametrize("ns,C,P", [(4, 4, 150), (20, 4, 40)])
+def test_a_short_update_of_a_virtual_buffer_makes_it_real(ns, C, P):
+    """A tip x tip buffer left virtual by a full traversal is rewritten by a SHORT launch (a new pendant length, then
+    Update_Partial_Lk of that node alone: what Br_Len_Opt does at a cherry): the buffer is what that update stored -- its old
+    definition is never stored over it later, whatever triggers the storing of the others."""
+    t, ot, tree, st = synthetic_pair(26, P, ns, C, seed=6, host_pmat=True)
+    t0, _, _, _ = synthetic_pair(26, P, ns, C, seed=6, host_pmat=True)
+    try:
+        t0.inst.set_virtual_buffers(0)
+        for x in (t, t0):
+            x.Set_Both_Sides(True)
+        assert t.Lk(None) == t0.Lk(None)
+        ck = cherry_keys(ot)
+        assert t.inst.virtual_stats()[0] >= len(ck) - 1
+        (e, side) = ck[0]
+        d = int(ot.el[e] if side == 0 else ot.er[e])
+        pend = [be for (v, be) in ot.adj[d] if be != e][0]
+        for x in (t, t0):
+            x.edge(pend).contents.l = 0.33
+            x.Update_PMat_At_Given_Edge(pend)
+            x.Update_Partial_Lk(e, d)          # one operation: stored
+        # something else makes the remaining virtual buffers real (an evaluation at another cherry's edge)
+        (e2, side2) = ck[1]
+        assert t.Lk(e2) == t0.Lk(e2)
+        assert t.inst.virtual_stats()[0] == 0
+        assert np.array_equal(t.partials(e, side), t0.partials(e, side))
+        for b in range(t.ne):
+            assert t.Lk(b) == t0.Lk(b), b
     finally:
         t.close(); t0.close()
