@@ -233,7 +233,7 @@ def run_single(args, torch):
     dt, lnl = timed_steps(t, args.steps, args.warmup, torch.cuda.synchronize)
     value = float(P) * (n - 2) * args.steps / dt / 1e6
     roof, kdur = roofline_block(t, n, P, S, C, args.workload, args.patterns is None)
-    if roof["virtual_buffers"]["virtual_after_launch"] > 0:
+    if roof["virtual_buffers"]["virtual_after_launch"] > 0 and not args.no_companion:
         roof["all_buffers_stored"] = all_stored_companion(wl, args, torch, n, P)
     # ("scaling": the N = 1 line is the cfg2 workload on one GPU -- neither weak nor strong; --gpus N > 1 is STRONG scaling of cfg4)
     out = {"metric": METRIC, "value": value, "unit": "M site-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -417,7 +417,7 @@ def extra_line(name, args, torch):
     t = build_tree(wl, device=0)
     dt, lnl = timed_steps(t, args.steps, args.warmup, torch.cuda.synchronize)
     roof, kdur = roofline_block(t, n, P, S, C, name, True)
-    if roof["virtual_buffers"]["virtual_after_launch"] > 0:
+    if roof["virtual_buffers"]["virtual_after_launch"] > 0 and not args.no_companion:
         roof["all_buffers_stored"] = all_stored_companion(wl, args, torch, n, P)
     exp = workloads.manifest()["expected"][name]
     line = {"value": float(P) * (n - 2) * args.steps / dt / 1e6, "unit": "M site-updates/s", "ms_per_step": dt / args.steps * 1e3,
@@ -530,6 +530,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3 line (N = 1) / the single-GPU reference (N > 1)")
     ap.add_argument("--virtual-buffers", type=int, default=None,
                     help="phyhip_set_virtual_buffers threshold (default: the library's, 16 operations; 0: every buffer stored)")
+    ap.add_argument("--no-companion", action="store_true",
+                    help="skip the all-buffers-stored companion run (counter profiles: its launches share the traversal kernel's name)")
     ap.add_argument("--cpu-sample", type=int, default=50000)
     ap.add_argument("--cpu-reps", type=int, default=30)
     args = ap.parse_args()

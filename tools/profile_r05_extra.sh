@@ -16,7 +16,7 @@ run() { # name, command...
   done
 }
 for kind in spr dlk eig; do run cfg5_$kind python $repo/tools/pmc_cfg5.py $kind --n 40; done
-run cfg4_1M python $repo/bench.py --workload cfg4_nt_100x1M --steps 3 --warmup 1 --no-cpu-baseline --no-extra
+run cfg4_1M python $repo/bench.py --workload cfg4_nt_100x1M --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-companion
 python3 - <<PY
 import csv,glob,collections,json,os,sys
 sys.path.insert(0,'$repo')
