@@ -186,6 +186,13 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   }
   if (I->soa && I->class_axis) I->nt_groups = I->C; // one class per lane: scaling and evaluation are per class
   I->grid_nt2 = (int)(I->Ppad / (64 / I->nt_groups));
+  if (I->soa && I->C == 4 && I->nt_groups == 2 && !I->class_axis && !(diag_env("PHYHIP_NT_MIXED") && atoi(diag_env("PHYHIP_NT_MIXED")) == 0))
+  { // two wave shapes for whole-tree traversals (phyhip_nt2.hpp): full rounds of two-lane waves, the rest in four-lane waves --
+    // where there is at least one full round and the rest fits one small wave per CU
+    const int       cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const long long n2 = (I->P / 32 / cus) * cus, rest = I->P - 32 * n2, n4 = (rest + 15) / 16;
+    if (n2 >= cus && rest > 0 && n4 <= cus) { I->mix_n2 = (int)n2; I->mix_n4 = (int)n4; }
+  }
   const size_t n_int = (size_t)(I->nbuf - I->tips);
   const size_t be    = buf_elems(I);
   HIPCHK(hipMalloc((void **)&I->d_partials, n_int * be * sizeof(double)));
@@ -269,7 +276,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     if (I->perm) I->prefetch_dist = 2; // (the 20-state kernel loads one operation ahead, but forwards the last TWO results in registers)
   }
   HIPCHK(hipMalloc((void **)&I->d_block,
-                   (size_t)2 * std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, I->grid_nt2)) * sizeof(double)));
+                   (size_t)2 * std::max(std::max(I->grid, I->grid_nt), std::max(I->grid_aa, std::max(I->grid_nt2, I->mix_n2 + I->mix_n4))) * sizeof(double)));
   HIPCHK(hipMalloc((void **)&I->d_result, 2 * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&I->h_result, 4 * sizeof(double), hipHostMallocMapped));
   memset(I->h_result, 0, 4 * sizeof(double));

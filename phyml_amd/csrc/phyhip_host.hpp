@@ -182,6 +182,9 @@ struct Instance
   bool        soa = false;     // 4-state buffers pattern-minor, lane-per-pattern kernel (phyhip_nt2.hpp)
   int         grid_nt2 = 0;
   int         nt_groups = 1; // lanes per pattern in the lane-per-pattern nucleotide kernel
+  // whole-tree traversals with two wave shapes (traverse_nt2_mixed_kernel): mix_n2 two-lane workgroups (a multiple of the CU
+  // count) + mix_n4 four-lane ones for the remaining patterns; 0: one shape
+  int         mix_n2 = 0, mix_n4 = 0;
   double     *d_afrag = nullptr;
   int         grid_aa = 0;
 

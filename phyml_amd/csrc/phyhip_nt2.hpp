@@ -73,8 +73,8 @@ template <int C, int G, bool DBG, int ARGS, int DIST = 2, int NW = 1, bool LREC 
 __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__restrict__ irec, const ExecRec *__restrict__ xrec,
                                         const double *pmats, // (not restrict: the prologue may rewrite entries)
                                         const uint8_t *__restrict__ tip_codes, unsigned long long *dbg, const NtFresh fr,
-                                        const unsigned tile, const unsigned tid, double *lds_dot)
-{ // lds_dot: this wave's LDS staging area for the eigen products of its tile, (64 / G) * C * 4 doubles (edge_eval == 2) // (tid: threadIdx.x -- handed in, so that a kernel that runs this body inside a loop can keep what derives from it inside too)
+                                        const unsigned tile, const unsigned tid, double *lds_dot, const unsigned rec_no = 0xffffffffu)
+{ // rec_no: which record the wave's sum is posted to (default: its tile's) -- traverse_nt2_mixed_kernel's four-lane waves // lds_dot: this wave's LDS staging area for the eigen products of its tile, (64 / G) * C * 4 doubles (edge_eval == 2) // (tid: threadIdx.x -- handed in, so that a kernel that runs this body inside a loop can keep what derives from it inside too)
   // DBG: cycle stamps of the first 64 steps of one wave (PHYHIP_ABLATE=8), kept in LDS until the end
   __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
   const bool stamper = DBG && tile == gridDim.x / 2 && tid == 0;
@@ -613,7 +613,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
       }
       // completion as an evaluation's (launched or resident): stores fenced, then an empty record per workgroup
       if (LREC && q.tile_sums == tile_sums_in_wave()) return; // (adding per workgroup: the workgroup reports, phyhip_big.hpp)
-      publish_block_sum(q, 0.0, lane, tile);
+      publish_block_sum(q, 0.0, lane, rec_no == 0xffffffffu ? tile : rec_no);
       return;
     }
     const double *__restrict__ M = pmats + (size_t)q.e_pm * (C * 16) + c0 * 16; // rows: right-side state
@@ -693,7 +693,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
     if (lane == 0) lds_dot[tile / (unsigned)(NW * kBigGroupWgs)] = contrib;
     return;
   }
-  publish_block_sum(q, contrib, lane, tile);
+  publish_block_sum(q, contrib, lane, rec_no == 0xffffffffu ? tile : rec_no);
 }
 
 template <int C, int G = 1, bool DBG = false, int ARGS = 0, int DIST = 2, bool INL = false>
@@ -715,6 +715,38 @@ __global__ __launch_bounds__(64, DIST == 1 ? G + 1 : G) void traverse_nt2_kernel
   fr.up_val = reinterpret_cast<const double *>(ka + offsetof(TreeParams, up_val));
   __shared__ __attribute__((aligned(16))) double lds_dot[(64 / G) * C * 4];
   nt2_run<C, G, DBG, ARGS, DIST, 1, false, INL>(q, irec, xrec, pmats, tip_codes, dbg, fr, blockIdx.x, threadIdx.x, lds_dot);
+}
+
+// Whole-tree traversals of mid-sized alignments with TWO wave shapes in one launch (four categories).  The two-lanes-per-pattern
+// wave covers 32 patterns; 50 000 patterns are 1 563 of them on 256 CUs: six per CU and a seventh on 27 CUs -- and the kernel ends
+// with those 27 (measured: 49 152 patterns = six per CU 127.6 us, 50 000 patterns 150 us, eight per CU 157 us).  So the first
+// n2 workgroups -- a multiple of the CU count -- are two-lane waves, and the remaining patterns go to four-lane waves of 16
+// patterns (one category per lane: about half a two-lane wave's work), one more SMALL wave on up to 256 CUs instead of one more
+// big wave on a few.  The buffer layout does not depend on the lane grouping; a four-lane wave's tile number is its first pattern
+// over 16, its record is its workgroup's.  The block sums are added in workgroup order like any launch's.
+template <int C, bool INL>
+__global__ __launch_bounds__(64, 2) void traverse_nt2_mixed_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+                                                                   const ExecRec *__restrict__ xrec, const double *pmats,
+                                                                   const uint8_t *__restrict__ tip_codes, const int n2)
+{
+  static_assert(C == 4, "four-lane waves: one category per lane");
+  typedef const __attribute__((address_space(4))) char karg_char;
+  const char *ka = (const char *)(karg_char *)__builtin_amdgcn_kernarg_segment_ptr(); // q is the first argument
+  NtFresh     fr;
+  fr.idx  = reinterpret_cast<const int *>(ka + offsetof(TreeParams, fresh_idx));
+  fr.len  = reinterpret_cast<const double *>(ka + offsetof(TreeParams, fresh_len));
+  fr.evec = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_evec));
+  fr.ivec = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_ivec));
+  fr.eval = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_eval));
+  fr.rates = reinterpret_cast<const double *>(ka + offsetof(TreeParams, m_rates));
+  fr.up_idx = reinterpret_cast<const int *>(ka + offsetof(TreeParams, up_idx));
+  fr.up_val = reinterpret_cast<const double *>(ka + offsetof(TreeParams, up_val));
+  __shared__ __attribute__((aligned(16))) double lds_dot[32 * C * 4];
+  if ((int)blockIdx.x < n2)
+    nt2_run<C, 2, false, 0, 2, 1, false, INL>(q, irec, xrec, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, lds_dot);
+  else
+    nt2_run<C, 4, false, 0, 2, 1, false, INL>(q, irec, xrec, pmats, tip_codes, nullptr, fr, 2u * (unsigned)n2 + (blockIdx.x - (unsigned)n2),
+                                              threadIdx.x, lds_dot, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

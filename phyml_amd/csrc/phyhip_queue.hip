@@ -528,6 +528,9 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   }
   // small nucleotide alignments: the resident short-launch evaluator (resident_nt2_kernel) may take the call
   const bool rt_grid = resident_short_eligible(I);
+  // (a list-form launch of an instance with two wave shapes: traverse_nt2_mixed_kernel's grid, one record per workgroup)
+  const bool mixed = I->mix_n4 > 0 && n_ops > 0 && !q.recs_in_args && I->prefetch_dist == 2 && !I->ablate;
+  const int  soa_grid = mixed ? I->mix_n2 + I->mix_n4 : I->grid_nt2;
   if (ee && ee->eigen)
   { // Update_Eigen_Lr fused behind the queued partial update(s): no sums, the products go to d_dot
     q.edge_eval = 2; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = 0; q.dot_out = I->d_dot;
@@ -547,7 +550,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     // stream is clean when phyhip_update_eigen_lr returns, and the resident workgroups can take the call (the only
     // instances that come here: phyhip_update_eigen_lr)
     q.host_blocks = I->h_blocks; q.host_tag = ++I->seq; q.warn = I->h_warn;
-    host_sum_n    = I->grid_nt2;
+    host_sum_n    = soa_grid;
   }
   else if (ee)
   {
@@ -564,7 +567,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       };
       q.e_prefetch = (untouched(ee->parent) ? 1 : 0) | (untouched(ee->child) ? 2 : 0);
     }
-    const int nblk = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
+    const int nblk = I->soa ? soa_grid : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     // (fusing on large grids was measured for one-operation launches too: 61.6 vs 41.9 us per SPR candidate at cfg5)
     fused_sum = !I->class_axis && fuse_reduce(I, nblk) && !(I->host_sum && ee->to_host && !ee->dev_out);
     if (fused_sum)
@@ -818,7 +821,16 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, a_>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec,  \
                      ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);
 #define NT2CASE(c_, g_)                                                                                                     \
-  if (!q.recs_in_args && I->prefetch_dist == 1)                                                                             \
+  if (mixed && c_ == 4 && g_ == 2)                                                                                          \
+  { /* two wave shapes in one launch (phyhip_nt2.hpp): full rounds of two-lane waves + four-lane waves for the rest */      \
+    if (has_inl)                                                                                                            \
+      hipLaunchKernelGGL((traverse_nt2_mixed_kernel<4, true>), dim3(soa_grid), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats,  \
+                         ro.tip_codes, I->mix_n2);                                                                          \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((traverse_nt2_mixed_kernel<4, false>), dim3(soa_grid), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats, \
+                         ro.tip_codes, I->mix_n2);                                                                          \
+  }                                                                                                                         \
+  else if (!q.recs_in_args && I->prefetch_dist == 1)                                                                        \
   {                                                                                                                         \
     hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, 0, 1>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
                        ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
@@ -984,7 +996,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   if (ee && !ee->eigen && !fused_sum && !host_sum_n && !I->class_axis) // (class axis: the combination kernel follows, no sum here)
   {
     double *out = ee->dev_out ? ee->dev_out : I->d_result;
-    const int nsum = I->soa ? I->grid_nt2 : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
+    const int nsum = I->soa ? soa_grid : (I->perm ? I->grid_aa : (fat ? I->grid_nt : I->grid));
     hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(256), 0, I->stream, (const double *)I->d_block, nsum, 1,
                        nsum, out, ee->to_host ? I->h_result : (double *)nullptr, I->d_warn, I->h_warn,
                        ee->to_host ? ++I->seq : 0ull, ee->warn_out);

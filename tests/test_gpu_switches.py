@@ -20,7 +20,7 @@ DIAG = [{}, {"PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_NT_GROUPS": "2"}, {"PHYHIP_NT_GR
         {"PHYHIP_FUSE_EIGEN": "0"}, {"PHYHIP_FOLD_GRID": "8"}, {"PHYHIP_DLK_GRID": "7"}, {"PHYHIP_BIG_DEVICE_SUM": "100000000"},
         {"PHYHIP_BIG_GROUP_SUM": "0"}, {"PHYHIP_BIG_ONE_SHOT": "0"}, {"PHYHIP_PUSH_CMDS": "0"}, {"PHYHIP_PUSH_CMDS": "2"},
         {"PHYHIP_PUSH_NO_MOVDIR": "1"},
-        {"PHYHIP_PMAT_THREADS": "1024"}, {"PHYHIP_RESIDENT_DIRECT": "4"}, {"PHYHIP_VIRT_INLINE": "0"}]
+        {"PHYHIP_PMAT_THREADS": "1024"}, {"PHYHIP_RESIDENT_DIRECT": "4"}, {"PHYHIP_VIRT_INLINE": "0"}, {"PHYHIP_VIRT_MIN_OPS": "0"}, {"PHYHIP_NT_MIXED": "0"}]
 PRODUCT = [{}, {"PHYHIP_RESIDENT": "0"}, {"PHYHIP_HOST_SUM": "0"}]
 _cache = {}
 
@@ -49,7 +49,7 @@ def _check(libdir, sw):
     a, b = [float.fromhex(x) for x in res["stream"]], [float.fromhex(x) for x in base["stream"]]
     a2, b2 = [float.fromhex(x) for x in res["stream2"]], [float.fromhex(x) for x in base["stream2"]]
     reorder = ("PHYHIP_GENERIC_NT" in sw or "PHYHIP_HOST_SUM" in sw or "PHYHIP_SPLIT_REDUCE" in sw or "PHYHIP_DLK_GRID" in sw or
-               sw.get("PHYHIP_NT_GROUPS") in ("1", "4"))
+               sw.get("PHYHIP_NT_GROUPS") in ("1", "4") or "PHYHIP_NT_MIXED" in sw)  # (one wave shape: the 9 000-pattern stream's full traversals sum other blocks)
     hexl = lambda r, k: [float.fromhex(x) for x in r[k]]
     lnl_lists = [(a, b)] + [(hexl(res, k), hexl(base, k)) for k in ("stream_host", "stream_big")]
     dl_lists = [(a2, b2, res["sum_w"]["stream"])] + [(hexl(res, k + "_d"), hexl(base, k + "_d"), res["sum_w"][k]) for k in ("stream_host", "stream_big")]

@@ -70,6 +70,10 @@ def test_default_traversal_kernels_keep_their_occupancy(product):
         for inl in (0, 1):
             n = f"_ZN6phyhip19traverse_nt2_kernelILi{c}ELi{g}ELb0ELi0ELi2ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdPKhPy"
             assert waves_per_simd(product[n]["vgpr_count"]) >= g, (n, product[n]["vgpr_count"])
+    # the launch with two wave shapes (two-lane waves + four-lane waves for the rest): two per SIMD like the two-lane kernel
+    for inl in (0, 1):
+        n = f"_ZN6phyhip25traverse_nt2_mixed_kernelILi4ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdPKhi"
+        assert waves_per_simd(product[n]["vgpr_count"]) >= 2 and product[n]["private_segment_fixed_size"] == 0, (n, product[n])
     # the 20-state kernel: 1 loader + 15 consumer waves per workgroup = four per SIMD
     # (<C, DBG, ABL, ARGS, INL>: list form, argument form, and the list form with in-step tip x tip children)
     for c in (1, 2, 3, 4):
