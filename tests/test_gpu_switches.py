@@ -49,7 +49,9 @@ def _check(libdir, sw):
     a, b = [float.fromhex(x) for x in res["stream"]], [float.fromhex(x) for x in base["stream"]]
     a2, b2 = [float.fromhex(x) for x in res["stream2"]], [float.fromhex(x) for x in base["stream2"]]
     reorder = ("PHYHIP_GENERIC_NT" in sw or "PHYHIP_HOST_SUM" in sw or "PHYHIP_SPLIT_REDUCE" in sw or "PHYHIP_DLK_GRID" in sw or
-               sw.get("PHYHIP_NT_GROUPS") in ("1", "4") or "PHYHIP_NT_MIXED" in sw)  # (one wave shape: the 9 000-pattern stream's full traversals sum other blocks)
+               sw.get("PHYHIP_NT_GROUPS") in ("1", "4") or "PHYHIP_NT_MIXED" in sw or "PHYHIP_ARGS_RECS" in sw)
+    # (PHYHIP_NT_MIXED=0: one wave shape -- the 9 000-pattern stream's full traversals sum other blocks; PHYHIP_ARGS_RECS=0: its
+    # short launches go through the list form, i.e. the two-shape launch, instead of the one-shape argument form)
     hexl = lambda r, k: [float.fromhex(x) for x in r[k]]
     lnl_lists = [(a, b)] + [(hexl(res, k), hexl(base, k)) for k in ("stream_host", "stream_big")]
     dl_lists = [(a2, b2, res["sum_w"]["stream"])] + [(hexl(res, k + "_d"), hexl(base, k + "_d"), res["sum_w"][k]) for k in ("stream_host", "stream_big")]
