@@ -140,6 +140,24 @@ def pmc_traffic(workload):
 VIRTUAL = None  # --virtual-buffers: threshold handed to phyhip_set_virtual_buffers (None: the library's default, 0: off)
 
 
+def pmc_kernel(profile, kernel_substr):
+    """HBM bytes per dispatch of one kernel from the counter profiles of the other call kinds (tools/profile_r05_extra.sh ->
+    profiles/rNN_pmc_<profile>.json: per-kernel averages, 2 x FETCH_SIZE + WRITE_SIZE), or None when no profile of these very
+    kernel sources is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{profile}.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if d.get("kernel_source_hash") != kernel_source_hash():
+                continue
+            for k, v in d.get("kernels", {}).items():
+                if kernel_substr in k and "hbm_bytes_per_dispatch" in v:
+                    return float(v["hbm_bytes_per_dispatch"])
+        except Exception:  # noqa: BLE001
+            pass
+    return None
+
+
 def build_tree(wl, device=None, devices=None, virtual="default"):
     from phyml_amd import lktree
     tree, st, blk, cfg = wl["tree"], wl["states"], wl["model"], wl["cfg"]
@@ -331,7 +349,14 @@ def call_latency():
         n_scalar = int(np.isin(k, (replay.EDGE_LNL, replay.DLK)).sum())
         if name == "spr_500x100k":
             brlen = brlen_block(t, taxa, P, 4, int(blk["ncatg"][0]))
-        rows[name] = {"us_per_candidate": dt / cand * 1e6, "us_per_scalar_returning_call": dt / n_scalar * 1e6, "candidates": cand,
+        extra = {}
+        if name == "spr_500x100k":
+            # what a candidate moves (counter profile of the large-grid kernel's one-shot form, the tile bodies the resident
+            # workgroups run: profiles/rNN_pmc_cfg5_spr.json) against what it takes end to end -- latency, not a streaming rate
+            b = pmc_kernel("cfg5_spr", "resident_big_kernel")
+            if b:
+                extra = {"hbm_bytes_per_candidate": b, "hbm_GBps_end_to_end": b / (dt / cand) / 1e9, "frac_real_end_to_end": b / (dt / cand) / 8e12}
+        rows[name] = {**extra, "us_per_candidate": dt / cand * 1e6, "us_per_scalar_returning_call": dt / n_scalar * 1e6, "candidates": cand,
                       "scalar_returning_calls": n_scalar, "dlk_calls": int((k == replay.DLK).sum()), "surface_calls": int(len(k)),
                       "finite": bool(np.isfinite(res).all()),
                       "served_by_resident_workgroups": {"dlk": t.inst.resident_stats(0)[0], "short_evaluations": t.inst.resident_stats(1)[0],
@@ -388,6 +413,7 @@ def brlen_block(t, taxa, P, S, C):
             "dlk_kernel": {"launches": k4_n, "avg_us": k4_us, "bytes": k4_bytes, "GBps": k4_bytes / (k4_us * 1e-6) / 1e9 if k4_us else 0.0,
                            "frac_of_8TBps": k4_bytes / (k4_us * 1e-6) / 8e12 if k4_us else 0.0},
             "us_per_chain_of_1_eigen_lr_and_5_dlk": wall / n_chain * 1e6, "us_per_dlk_call": dlk_wall,
+            "hbm_bytes_per_dlk_call": pmc_kernel("cfg5_dlk", "resident_big_kernel"), "hbm_bytes_per_eigen_lr_kernel": pmc_kernel("cfg5_eig", "eigen_lr_kernel"),
             "served_by_large_grid_resident_workgroups": t.inst.resident_stats(2)[0]}
 
 
@@ -401,10 +427,18 @@ def scaling_reference_line(args, torch):
     t = build_tree(wl, device=0)
     steps = max(5, min(args.steps, 20))
     dt, lnl = timed_steps(t, steps, min(args.warmup, 3), torch.cuda.synchronize)
+    kern_ms, kern_n, _ = t.inst.profile_read()
+    vnow = t.inst.virtual_stats()[0]
     t.close()
     exp = workloads.manifest()["expected"][name]
+    kdur = kern_ms / max(kern_n, 1) * 1e-3
+    alg = workloads.algorithmic_bytes_per_pattern(n, 4, 4) * float(P)
+    traffic = pmc_kernel("cfg4_1M", "traverse_nt2")
+    roof = {"bound": "hbm", "kernel_avg_us": kdur * 1e6, "achieved": alg / kdur / 1e9 if kdur > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+            "frac": alg / kdur / 8e12 if kdur > 0 else 0.0, "frac_is": "algorithmic (SURVEY 8d bytes / kernel time / peak); physical: frac_real",
+            "traffic": traffic, "frac_real": (traffic / kdur / 8e12) if (traffic and kdur > 0) else None, "virtual_buffers_after_launch": vnow}
     return {"value": float(P) * (n - 2) * steps / dt / 1e6, "unit": "M site-updates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "n_gpus": 1, "patterns": P, "lnL": lnl, "lnL_rel_err": abs(lnl - exp["lnL"]) / abs(exp["lnL"]),
+            "n_gpus": 1, "patterns": P, "lnL": lnl, "lnL_rel_err": abs(lnl - exp["lnL"]) / abs(exp["lnL"]), "roofline": roof,
             "note": "strong-scaling reference: bench.py --gpus N (N > 1) runs this workload in N pattern shards"}
 
 
