@@ -178,7 +178,9 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->nt_groups = 1;
   // measured (us per traversal, G=2 / G=1): 50 k 195 / 206, 75 k 301 / 363, 125 k 444 / 456, 250 k 837 / 848, 1 M 3293 / 3246
   // (round 3, non-temporal result stores: 50 k 165 / 198, 125 k 386 / 377, 1 M 3188 / 3186 -- the crossover moved to ~100 k)
-  if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 1600) I->nt_groups = 2;
+  // (round 5, virtual buffers + two wave shapes, tools/gpu_r5m.sh: 125 000 patterns 319 / 333, 250 000 650 / 622, 500 000 1275 / 1207 -- the
+  // crossover sits between two and four residency rounds of two-lane waves: up to 131 072 patterns)
+  if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 2048) I->nt_groups = 2;
   if (const char *e = diag_env("PHYHIP_NT_GROUPS"))
   {
     const int g = atoi(e);

@@ -190,14 +190,14 @@ def test_resident_protocol_under_stress(monkeypatch):
 # ---- the large-grid resident evaluator (phyml_amd/csrc/phyhip_big.hpp) ----------------------------------------------------
 
 @pytest.mark.parametrize("taxa,patterns,categories", [(16, 5000, 4), (12, 40000, 4), (12, 9000, 2), (12, 7000, 3), (12, 6000, 1),
-                                                      (8, 110000, 4), (12, 7200, 4), (10, 20000, 3)])
+                                                      (8, 140000, 4), (12, 7200, 4), (10, 20000, 3)])
 def test_large_grid_resident_evaluator_spr_and_brlen_call_pattern(taxa, patterns, categories, monkeypatch):
     """Beyond 64 pattern tiles the scalar-returning calls of a search are served by resident_big_kernel -- one persistent
     workgroup per compute unit, commands relayed through device memory, a wave walks several tiles, the tile sums added by the
     host (up to 200 tiles: 5 000 patterns), on the device through tickets (fewer than 256 workgroups: 7 200 patterns = 225 tiles)
     or on the device through one partial sum per workgroup (256 workgroups: the other sizes) -- the seeded SPR / Br_Len_Opt stream
     returns the launch path's doubles, scalar by scalar, and the oracle's values.  Covers every instantiation: two lanes per pattern (4 and 2 categories, eight waves per
-    workgroup), one lane per pattern (3 and 1 categories; 4 categories beyond 102 400 patterns)."""
+    workgroup), one lane per pattern (3 and 1 categories; 4 categories beyond 131 072 patterns)."""
     from phyml_amd import replay
     import replay_oracle
     res, stats = {}, {}
