@@ -1,0 +1,6 @@
+#!/bin/bash
+# the whole GPU suite + smoke (what the driver runs at round end, without the bench)
+export TMPDIR=/tmp
+o=gpurun_out/suite; mkdir -p $o
+timeout 1800 python -m pytest tests -q -m gpu > $o/full.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $o/full.log | tail -2; grep -E "^FAILED|^ERROR" $o/full.log | head -20
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
