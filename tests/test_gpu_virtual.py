@@ -25,10 +25,6 @@ def cherry_keys(ot):
     return out
 
 
-def all_buffers(t, ot):
-    return {k: (t.partials(*k).copy(), t.scale_factors(*k).copy()) for k in ot.plk}
-
-
 @pytest.mark.parametrize("ns,C,P", SHAPES)
 @pytest.mark.parametrize("both", [False, True])
 def test_full_traversal_virtual_buffers_read_back_bit_equal(ns, C, P, both):
