@@ -359,7 +359,8 @@ int phyhip_get_big_resident_stats(int instance, long long out[4]);
    gets the defining operation queued again, storing: every value that leaves through this interface is the double the reference
    has in t_edge::p_lk_* at that point (tests/test_gpu_virtual.py).  A matrix or tip row the definition reads cannot change
    under it: before one changes, its old value is moved to a snapshot slot of the buffer (whole-tree batches of device-built
-   matrices, uploaded matrices) or the dependants are stored first.  minOperations = 0 switches the feature off (and stores what
+   matrices, uploaded matrices) or the dependants are stored first.  Only launches of the list form take part (at least three operations stay in the launch, whatever
+   minOperations says).  minOperations = 0 switches the feature off (and stores what
    is virtual); the default is 16, so the short launches of a tree search never leave anything virtual -- and the first of
    them that reads a virtual buffer stores them all, in its own launch.  Not on class-axis or generic-loop instances.  Sharded
    instances: applied to every shard. */

@@ -56,7 +56,16 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
 {
   I->pending_inl.clear();
   const int n0 = (int)I->pending.size();
-  const bool virtualise = may_virtualise && I->virt_min_ops > 0 && n0 >= I->virt_min_ops;
+  // (only launches of the LIST form: one- and two-operation launches -- records in the kernel arguments, the resident evaluators --
+  // run kernels without in-step children and without the second forwarding level's guarantees: a list must keep three
+  // operations even if each of its tip x tip operations leaves its place)
+  bool virtualise = may_virtualise && I->virt_min_ops > 0 && n0 >= I->virt_min_ops && n0 >= 3;
+  if (virtualise)
+  {
+    int stay = 0;
+    for (const DevOp &o : I->pending) stay += !(o.c1 < I->tips && o.c2 < I->tips);
+    virtualise = stay >= 3;
+  }
   if (!virtualise && I->n_virtual == 0) return;
   if (!virtualise)
   { // A short launch.  If it reads a virtual buffer, EVERY virtual buffer is stored now, in this one launch: the short launches

@@ -184,27 +184,34 @@ def test_short_lists_store_everything():
         t.close()
 
 
-@pytest.mark.parametrize("ns,C,P", [(20, 4, 90), (4, 4, 300), (20, 2, 50)])
+@pytest.mark.parametrize("ns,C,P,devices", [(20, 4, 90, None), (4, 4, 300, None), (20, 2, 50, None), (4, 4, 9000, None), (4, 4, 700, (0, 0)),
+                                            (20, 4, 120, (0, 0, 0))])
 @pytest.mark.parametrize("host_pmat", [True, False])
-def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
+def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, devices, host_pmat):
     """What a search does between two full traversals, at random: new lengths / matrices on random edges (pendant edges of cherries
     among them), partial updates over whole subtrees (long lists that READ buffers an earlier launch left virtual, and lists
     that re-virtualise them), evaluations at random edges, full traversals in between -- every scalar equal to the run that stores
     every buffer, and every buffer read back at the end."""
-    t, ot, tree, st = synthetic_pair(34, P, ns, C, seed=21, host_pmat=host_pmat, ambiguous_every=13)
-    t0, _, _, _ = synthetic_pair(34, P, ns, C, seed=21, host_pmat=host_pmat, ambiguous_every=13)
+    # (9 000 patterns: two wave shapes and the large-grid resident evaluator; devices: pattern shards on device 0, every shard its own
+    # virtual buffers)
+    dev = None if devices is None else list(devices)
+    t, ot, tree, st = synthetic_pair(34, P, ns, C, seed=21, host_pmat=host_pmat, ambiguous_every=13, devices=dev)
+    t0, _, _, _ = synthetic_pair(34, P, ns, C, seed=21, host_pmat=host_pmat, ambiguous_every=13, devices=dev)
     try:
         t0.inst.set_virtual_buffers(0)
         for x in (t, t0):
             x.Set_Both_Sides(True)
-        assert t.Lk(None) == t0.Lk(None)
+        # (9 000 patterns: a list-form launch runs two wave shapes, a short one runs one -- other block sums, the same patterns: the two
+        # runs may take different forms for the same call once one of them stores a virtual buffer in front of it, so 1e-13 there)
+        same = (lambda a, b: a == b) if P < 8192 else (lambda a, b: abs(a - b) <= 1e-13 * abs(b))
+        assert same(t.Lk(None), t0.Lk(None))
         rng = np.random.default_rng(17)
         internal = [e for e in range(t.ne) if ot.el[e] >= ot.n and ot.er[e] >= ot.n]
         keys = list(ot.plk)
         for it in range(300):
             act = int(rng.integers(0, 10))
             if act == 0:
-                assert t.Lk(None) == t0.Lk(None), it
+                assert same(t.Lk(None), t0.Lk(None)), it
             elif act in (1, 2):
                 for e in rng.choice(t.ne, size=int(rng.integers(1, 6)), replace=False):
                     l = float(rng.uniform(0.005, 0.4))
@@ -222,7 +229,7 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
                     for x in (t, t0):
                         x.edge(e).contents.l = l
                         x.Update_PMat_At_Given_Edge(e)
-                assert t.Lk(e) == t0.Lk(e), it
+                assert same(t.Lk(e), t0.Lk(e)), it
             elif act == 4:
                 e = int(rng.integers(0, t.ne))
                 if it % 3 == 0 and ot.el[e] >= ot.n:
@@ -232,7 +239,7 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
                         x.Update_Partial_Lk(e, int(ot.el[e]))
                         x.edge(e).contents.l = l
                         x.Update_PMat_At_Given_Edge(e)
-                assert t.Lk(e) == t0.Lk(e), it
+                assert same(t.Lk(e), t0.Lk(e)), it
             elif act == 5:
                 e = int(rng.choice(internal))
                 got, ref = [], []
@@ -242,7 +249,7 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
                     x.Set_Update_Eigen_Lr(False); x.Set_Use_Eigen_Lr(True)
                     out.append(x.dLk(0.11, e)[1]); out.append(x.c_dlnL)
                     x.Set_Use_Eigen_Lr(False)
-                assert got == ref, it
+                assert all(same(u, v) or abs(u - v) <= 1e-9 * max(1.0, abs(v)) for u, v in zip(got, ref)) if P >= 8192 else got == ref, it
             elif act in (6, 7):
                 # single partial updates, left QUEUED (Br_Len_Opt / SPR rewrite one node at a time -- also nodes whose buffer an
                 # earlier traversal left virtual: a short launch that stores it)
@@ -256,6 +263,8 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
                 k = keys[int(rng.integers(0, len(keys)))]     # a host reader at a random moment
                 assert np.array_equal(t.partials(*k), t0.partials(*k)), (it, k)
                 assert np.array_equal(t.scale_factors(*k), t0.scale_factors(*k)), (it, k)
+            elif act == 9 and it % 4 == 0:
+                t.inst.set_virtual_buffers(int(rng.choice([0, 2, 16, 40])))   # (the threshold moves; 0 stores what is virtual)
             else:
                 tip, pat = int(rng.integers(0, ot.n)), int(rng.integers(0, P))
                 v = np.zeros(ns); v[int(rng.integers(0, ns))] = 1.0
@@ -263,7 +272,7 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, host_pmat):
                     v[:] = 1.0
                 for x in (t, t0):
                     x.inst.set_tip_partials_at_pattern(tip, pat, v)
-        assert t.Lk(None) == t0.Lk(None)
+        assert same(t.Lk(None), t0.Lk(None))
         for k in ot.plk:
             assert np.array_equal(t.partials(*k), t0.partials(*k)), k
             assert np.array_equal(t.scale_factors(*k), t0.scale_factors(*k)), k
