@@ -328,13 +328,16 @@ def call_latency():
     against the oracle in tests/test_gpu_cfg5.py / test_gpu_replay.py / test_gpu_resident.py; here it is only timed."""
     import numpy as np
     from phyml_amd import lktree, replay, synth, workloads
-    blk = workloads.model_block("model_gtr_g4")
     rows = {}
-    for name, taxa, P, cand, opt in (("spr_500x100k", 500, 100000, 600, 0), ("spr_54x382", 54, 382, 3000, 0),
-                                     ("spr_and_brlen_54x382", 54, 382, 1500, 4)):
+    # (the 20-state rows: the size of the reference's example protein alignment and cfg3's -- a launch per call, there is no
+    # resident evaluator for 20 states)
+    for name, taxa, P, cand, opt, S in (("spr_500x100k", 500, 100000, 600, 0, 4), ("spr_54x382", 54, 382, 3000, 0, 4),
+                                        ("spr_and_brlen_54x382", 54, 382, 1500, 4, 4), ("spr_37x429_aa", 37, 429, 1500, 0, 20),
+                                        ("spr_and_brlen_37x429_aa", 37, 429, 1000, 4, 20), ("spr_200x10k_aa", 200, 10000, 600, 0, 20)):
+        blk = workloads.model_block("model_gtr_g4" if S == 4 else "model_lg_g4")
         tree = synth.random_tree(taxa, 9, 0.02, 0.15)
-        st = synth.simulate_states(tree, P, 4, 9)
-        t = lktree.LkTree(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, P, 4, int(blk["ncatg"][0]))
+        st = synth.simulate_states(tree, P, S, 9)
+        t = lktree.LkTree(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, P, S, int(blk["ncatg"][0]))
         t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"])
         t.Make_Tree_For_Lk(np.ones(P))
         t.set_tips(tip_states=st.astype(np.int32))
