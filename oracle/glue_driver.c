@@ -1056,12 +1056,14 @@ int main(int argc, char **argv)
              (double)g_hp_cyc[k] / cyc_per_ns * 1e-9 / dt);
     printf("}}\n");
   }
-  printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"device_pmat\": %d, \"lnL_init\": %.17g, \"lnL_final\": %.17g, \"seconds\": %.3f, "
+  long long vs[4] = {0, 0, 0, 0}; /* virtual buffers of the (first) instance: now | stores skipped | recomputed for a reader | stored on demand */
+  if (!g_host && g_nctx > 0) phyhip_get_virtual_stats(g_ctx[0].inst, vs);
+  printf("\nGLUE_DRIVER {\"mode\": \"%s\", \"virtual_buffers\": [%lld, %lld, %lld, %lld], \"device_pmat\": %d, \"lnL_init\": %.17g, \"lnL_final\": %.17g, \"seconds\": %.3f, "
          "\"calls\": {\"Lk\": %ld, \"Lk_full\": %ld, \"Update_Partial_Lk\": %ld, \"dLk\": %ld, \"Update_PMat\": %ld, "
          "\"Update_Eigen_Lr\": %ld}, \"worst_rel_lnL\": %.3g, \"worst_rel_dlnL\": %.3g, \"buffers\": %d, \"matrices\": %d, "
          "\"site_output_downloads\": %ld, \"worst_rel_site_output\": %.3g, \"mirrored_buffers\": %ld, \"mirror_mismatches\": %ld, \"instances_created\": %ld, "
          "\"alias_one_subpatt_calls_made_here\": %ld, \"support_tree\": \"%s\", \"tree\": \"%s\"}\n",
-         g_host ? "host" : (g_check ? "check" : "device"), g_device_pmat, lnl_init, lnl_final, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
+         g_host ? "host" : (g_check ? "check" : "device"), vs[0], vs[1], vs[2], vs[3], g_device_pmat, lnl_init, lnl_final, dt, g_n_lk, g_n_lk_full, g_n_upd, g_n_dlk, g_n_pmat,
          g_n_eig, g_worst_lnl, g_worst_dlnl, g_nbuf, g_nmat, g_n_site_dl, g_worst_site_lnl, g_mirror_buffers, g_mirror_mismatch, g_n_created, g_n_alias, support_nwk ? support_nwk : "", nwk ? nwk : "");
   fflush(stdout);
   for (int k = 0; k < g_nctx; ++k) OK(phyhip_finalize_instance(g_ctx[k].inst));

@@ -26,6 +26,6 @@ r = subprocess.run([GLUE] + args, cwd=tmp, env=env, stdout=subprocess.PIPE, stde
 m = re.search(r"GLUE_DRIVER (\{.*\})", r.stdout)
 if not m:
     print(r.stdout[-1500:]); raise SystemExit(1)
-info = json.loads(m.group(1)); info.pop("tree", None); info.pop("support_tree", None)
+info = json.loads(m.group(1)); info.pop("tree", None); info.pop("support_tree", None)  # ("virtual_buffers": now | stores skipped | recomputed | stored on demand)
 bad = [l for l in r.stdout.splitlines() if "GLUE_FIRST_BAD" in l]
 print(json.dumps({"taxa": n, "patterns": P, "states": ns, "check": info, "first_bad": bad[:1]}))
