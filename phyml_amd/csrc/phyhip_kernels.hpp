@@ -1914,4 +1914,128 @@ __global__ __launch_bounds__(ST == 4 ? 64 : 1024) void pmat_kernel(const PmatPar
   }
 }
 
+// 20 states, register-blocked (round 5).  pmat_kernel<20> above takes every entry's twenty-term chain through LDS term by term
+// (two reads per term), the matrix through LDS twice more for the row sums and the division, and four workgroup barriers.  Here
+// a lane owns a 2 x 4 block of entries (rows i0, i0 + 1 of category c, columns 4 jq .. 4 jq + 3): per term one e[c][k], two U
+// words and four V words (two 16-byte reads) feed eight FMAs, the products U[i][k] e[c][k] are formed in registers, the five
+// lanes of a row pair sit side by side and pass the row sums along by shuffle in ascending j, the division happens in registers
+// and the natural-layout matrix is stored from them; the A-operand table is scattered into LDS and leaves in 16-byte pieces.
+// One workgroup of 256 threads per matrix, one barrier before the arithmetic (eigen system and exponentials staged in LDS), one
+// behind it for the table.  Every entry is the same chain of operations in the same order as above (src/models.c:275-298): (U e)
+// first, FMA over ascending k, the floor, the row sum over ascending j, the division -- the same bits
+// (tests/test_gpu_switches.py, PHYHIP_PMAT20).  Measured against pmat_kernel<20>: the three matrices of an SPR candidate 7.0
+// against 8.0 us (a short list is a chain of latencies either way: profiles/r05_aa_candidate.md), the 397 matrices of a
+// 200-taxon tree 15.2 against 16.8 us.
+static __global__ __launch_bounds__(256) void pmat20_kernel(const PmatParams q)
+{
+  constexpr int S = 20;
+  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S] | U [NE][S][S] | V [NE][S][S] | A-operand table [kAaMat]
+  const int m = blockIdx.x, C = q.C;
+  double l;
+  int    mat, shd;
+  if (q.indices) { l = q.lengths[m]; mat = q.indices[m]; shd = q.shadow ? q.shadow[m] : -1; }
+  else
+  {
+    l = q.small_len[0]; mat = q.small_idx[0]; shd = q.small_shadow[0];
+#pragma unroll
+    for (int k = 1; k < kSmallPm; ++k)
+      if (m == k) { l = q.small_len[k]; mat = q.small_idx[k]; shd = q.small_shadow[k]; }
+  }
+  if (shd >= 0)
+  { // the old value first (as in pmat_kernel: the barriers below come before any overwrite)
+    const double *src = q.pmats + (size_t)mat * C * S * S;
+    double       *dst = q.pmats + (size_t)shd * C * S * S;
+    for (int e = threadIdx.x; e < C * S * S; e += blockDim.x) dst[e] = src[e];
+    if (q.afrag)
+      for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) q.afrag[(size_t)shd * kAaMat + e] = q.afrag[(size_t)mat * kAaMat + e];
+  }
+  const bool cls = q.class_axis != 0;
+  const int  NE  = cls ? C : 1;
+  double *Us = expt + C * S, *Vs = Us + NE * S * S, *tab = q.afrag ? Vs + NE * S * S : nullptr;
+  for (int t = threadIdx.x; t < NE * S * S; t += blockDim.x)
+  {
+    Us[t] = q.U[t];
+    Vs[t] = q.V[t];
+  }
+  for (int t = threadIdx.x; t < C * S; t += blockDim.x)
+  {
+    const int c   = t / S, k = t % S;
+    double    len = (l > 0.0 ? l : 0.0) * q.rates[c]; // src/lk.c:2296
+    len *= q.br_len_mult;                             // :2297
+    if (len < q.l_min) len = q.l_min;                 // :2299-2300
+    else if (len > q.l_max) len = q.l_max;
+    expt[t] = exp(q.R[(cls ? c * S : 0) + k] * len);  // src/models.c:275
+  }
+  if (tab && C == 3) // (blocks beyond the category count -- C = 3: block 3 -- stay zero)
+    for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) tab[e] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const int jq = lane % 5, cb = aa_cb(C);
+  double   *out = q.pmats + (size_t)mat * C * S * S;
+  for (int g0 = wv * 12; g0 < C * 10; g0 += nwv * 12) // (uniform per wave: 12 row pairs of 5 lanes each, lanes 60-63 idle)
+  {
+    const int  grp  = g0 + lane / 5;
+    const bool live = lane < 60 && grp < C * 10;
+    const int  g = live ? grp : 0, c = g / 10, i0 = (g % 10) * 2;
+    const double *U0 = Us + (cls ? c * S * S : 0) + i0 * S, *U1 = U0 + S, *ec = expt + c * S;
+    const double *Vq = Vs + (cls ? c * S * S : 0) + 4 * jq;
+    double a0[4] = {0., 0., 0., 0.}, a1[4] = {0., 0., 0., 0.};
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+    {
+      const double e = ec[k], w0 = U0[k] * e, w1 = U1[k] * e; // src/models.c:278-292
+      const double2 va = *reinterpret_cast<const double2 *>(Vq + k * S), vb = *reinterpret_cast<const double2 *>(Vq + k * S + 2);
+      a0[0] = __builtin_fma(w0, va.x, a0[0]); a0[1] = __builtin_fma(w0, va.y, a0[1]);
+      a0[2] = __builtin_fma(w0, vb.x, a0[2]); a0[3] = __builtin_fma(w0, vb.y, a0[3]);
+      a1[0] = __builtin_fma(w1, va.x, a1[0]); a1[1] = __builtin_fma(w1, va.y, a1[1]);
+      a1[2] = __builtin_fma(w1, vb.x, a1[2]); a1[3] = __builtin_fma(w1, vb.y, a1[3]);
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+    { // :293
+      a0[x] = (a0[x] < kSmallPij) ? kSmallPij : a0[x];
+      a1[x] = (a1[x] < kSmallPij) ? kSmallPij : a1[x];
+    }
+    // row sums in ascending j (src/models.c:296-297): the lane of column quad jq continues the sum of the lane of jq - 1
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int step = 0; step < 5; ++step)
+    {
+      const double p0 = __shfl_up(s0, 1, 64), p1 = __shfl_up(s1, 1, 64);
+      const double b0 = step ? p0 : 0.0, b1 = step ? p1 : 0.0;
+      const double n0 = (((b0 + a0[0]) + a0[1]) + a0[2]) + a0[3], n1 = (((b1 + a1[0]) + a1[1]) + a1[2]) + a1[3];
+      if (jq == step) { s0 = n0; s1 = n1; }
+    }
+    const int    last = (lane / 5) * 5 + 4;
+    const double t0 = __shfl(s0, last < 64 ? last : 63, 64), t1 = __shfl(s1, last < 64 ? last : 63, 64);
+    if (live)
+    {
+      double r0[4], r1[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { r0[x] = a0[x] / t0; r1[x] = a1[x] / t1; } // :298
+      double2 *o0 = reinterpret_cast<double2 *>(out + (size_t)(c * S + i0) * S + 4 * jq), *o1 = o0 + S / 2;
+      o0[0] = double2{r0[0], r0[1]}; o0[1] = double2{r0[2], r0[3]};
+      o1[0] = double2{r1[0], r1[1]}; o1[1] = double2{r1[2], r1[3]};
+      if (tab)
+      { // A-operand order (phyhip_aa.hpp): lane (k, b, i) of row group r, k-chunk t holds P[category of block b][4r + i][4t + k]
+        const int r = i0 >> 2, il = i0 & 3;
+        for (int b = c; b < 4; b += cb)
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+          {
+            tab[aa_a_slot(jq, r, 16 * x + 4 * b + il)]     = r0[x];
+            tab[aa_a_slot(jq, r, 16 * x + 4 * b + il + 1)] = r1[x];
+          }
+      }
+    }
+  }
+  if (tab)
+  {
+    __syncthreads();
+    double2       *dst = reinterpret_cast<double2 *>(q.afrag + (size_t)mat * kAaMat);
+    const double2 *src = reinterpret_cast<const double2 *>(tab);
+    for (int e = threadIdx.x; e < kAaMat / 2; e += blockDim.x) dst[e] = src[e];
+  }
+}
+
 } // namespace phyhip

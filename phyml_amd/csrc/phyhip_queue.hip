@@ -249,7 +249,13 @@ int flush_pmats(Instance *I)
     q.afrag = I->perm ? I->d_afrag : nullptr; // 20 states: the MFMA A-operand fragments come out of the same kernel
     q.class_axis = I->class_axis ? 1 : 0;
     const size_t lds = sizeof(double) * ((size_t)2 * I->C * I->S + (size_t)2 * I->C * I->S * I->S + (size_t)2 * I->NE * I->S * I->S);
+    // 20 states: the register-blocked kernel (phyhip_kernels.hpp: pmat20_kernel).  PHYHIP_PMAT20 (diag) = 0: the LDS-staged
+    // pmat_kernel<20> builds every list, 1: it builds the lists of more than 16 matrices
+    static const int pmat20 = diag_env("PHYHIP_PMAT20") ? atoi(diag_env("PHYHIP_PMAT20")) : 2;
     if (I->S == 4) hipLaunchKernelGGL((pmat_kernel<4, true>), dim3(n), dim3(threads), lds, I->stream, q);
+    else if (pmat20 == 2 || (pmat20 == 1 && n <= 16))
+      hipLaunchKernelGGL(pmat20_kernel, dim3(n), dim3(256), sizeof(double) * ((size_t)I->C * 20 + (size_t)2 * I->NE * 400 + (q.afrag ? kAaMat : 0)),
+                         I->stream, q);
     else if (n <= 16) hipLaunchKernelGGL((pmat_kernel<20, true>), dim3(n), dim3(threads), lds, I->stream, q);
     else hipLaunchKernelGGL((pmat_kernel<20, false>), dim3(n), dim3(threads), lds, I->stream, q);
     HIPCHK(hipGetLastError());

@@ -20,7 +20,8 @@ DIAG = [{}, {"PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_NT_GROUPS": "2"}, {"PHYHIP_NT_GR
         {"PHYHIP_FUSE_EIGEN": "0"}, {"PHYHIP_FOLD_GRID": "8"}, {"PHYHIP_DLK_GRID": "7"}, {"PHYHIP_BIG_DEVICE_SUM": "100000000"},
         {"PHYHIP_BIG_GROUP_SUM": "0"}, {"PHYHIP_BIG_ONE_SHOT": "0"}, {"PHYHIP_PUSH_CMDS": "0"}, {"PHYHIP_PUSH_CMDS": "2"},
         {"PHYHIP_PUSH_NO_MOVDIR": "1"},
-        {"PHYHIP_PMAT_THREADS": "1024"}, {"PHYHIP_RESIDENT_DIRECT": "4"}, {"PHYHIP_VIRT_INLINE": "0"}, {"PHYHIP_VIRT_MIN_OPS": "0"}, {"PHYHIP_NT_MIXED": "0"}]
+        {"PHYHIP_PMAT_THREADS": "1024"}, {"PHYHIP_RESIDENT_DIRECT": "4"}, {"PHYHIP_VIRT_INLINE": "0"}, {"PHYHIP_VIRT_MIN_OPS": "0"}, {"PHYHIP_NT_MIXED": "0"},
+        {"PHYHIP_PMAT20": "0"}, {"PHYHIP_PMAT20": "1"}]
 PRODUCT = [{}, {"PHYHIP_RESIDENT": "0"}, {"PHYHIP_HOST_SUM": "0"}]
 _cache = {}
 
@@ -46,26 +47,30 @@ def _run(libdir, sw):
 def _check(libdir, sw):
     res, base = _run(libdir, sw), _run(libdir, {})
     assert res["lnl_rel"] < 1e-12 and res["vectors_bit_equal"] and res["aa_lnl_rel"] < 1e-12
-    a, b = [float.fromhex(x) for x in res["stream"]], [float.fromhex(x) for x in base["stream"]]
-    a2, b2 = [float.fromhex(x) for x in res["stream2"]], [float.fromhex(x) for x in base["stream2"]]
+    # device-built 20-state matrices: the same bits whichever kernel / block size builds them; the lnL on them as well unless the
+    # switch selects another 20-state traversal kernel or another grouping of its block sums
+    assert res["aa_device_matrices"]["sha256"] == base["aa_device_matrices"]["sha256"]
+    if "PHYHIP_GENERIC_AA" not in sw and "PHYHIP_AA_NW" not in sw and "PHYHIP_SPLIT_REDUCE" not in sw and "PHYHIP_HOST_SUM" not in sw:
+        assert res["aa_device_matrices"]["lnL"] == base["aa_device_matrices"]["lnL"], sw
     reorder = ("PHYHIP_GENERIC_NT" in sw or "PHYHIP_HOST_SUM" in sw or "PHYHIP_SPLIT_REDUCE" in sw or "PHYHIP_DLK_GRID" in sw or
                sw.get("PHYHIP_NT_GROUPS") in ("1", "4") or "PHYHIP_NT_MIXED" in sw or "PHYHIP_ARGS_RECS" in sw)
     # (PHYHIP_NT_MIXED=0: one wave shape -- the 9 000-pattern stream's full traversals sum other blocks; PHYHIP_ARGS_RECS=0: its
     # short launches go through the list form, i.e. the two-shape launch, instead of the one-shape argument form)
+    # ... and for the 20-state stream: another traversal kernel, another number of wave-tiles per workgroup, another final sum
+    reorder_aa = ("PHYHIP_GENERIC_AA" in sw or "PHYHIP_AA_NW" in sw or "PHYHIP_HOST_SUM" in sw or "PHYHIP_SPLIT_REDUCE" in sw or
+                  "PHYHIP_DLK_GRID" in sw)
     hexl = lambda r, k: [float.fromhex(x) for x in r[k]]
-    lnl_lists = [(a, b)] + [(hexl(res, k), hexl(base, k)) for k in ("stream_host", "stream_big")]
-    dl_lists = [(a2, b2, res["sum_w"]["stream"])] + [(hexl(res, k + "_d"), hexl(base, k + "_d"), res["sum_w"][k]) for k in ("stream_host", "stream_big")]
-    if reorder:  # another kernel shape / another final sum adds the patterns' contributions in another order
-        for u, v in lnl_lists:   # log-likelihoods (|lnL| ~ 1e4): relative, the bar of the parity tests
-            assert max(abs(x - y) / abs(y) for x, y in zip(u, v) if y != 0.0) < 1e-12
-        for u, v, sw_ in dl_lists:
+    for k, ro in (("stream", reorder), ("stream_host", reorder), ("stream_big", reorder), ("stream_aa", reorder_aa)):
+        u, v = hexl(res, k), hexl(base, k)
+        ud, vd = hexl(res, k + "_d" if k != "stream" else "stream2"), hexl(base, k + "_d" if k != "stream" else "stream2")
+        if ro:  # another kernel shape / another final sum adds the patterns' contributions in another order
+            # log-likelihoods (|lnL| ~ 1e4): relative, the bar of the parity tests
+            assert max(abs(x - y) / abs(y) for x, y in zip(u, v) if y != 0.0) < 1e-12, (k, sw)
             # derivatives: a sum of sum(w) per-pattern terms of either sign, each O(1) to O(100) -- reordering it moves the result
             # by rounding errors of the partial sums, not of the (possibly tiny) total: an absolute bar of 1e-13 per unit of weight
-            assert max(abs(x - y) for x, y in zip(u, v)) <= 1e-13 * sw_
-    else:
-        assert a == b and a2 == b2
-        for (u, v), (ud, vd, _) in zip(lnl_lists[1:], dl_lists[1:]):
-            assert u == v and ud == vd
+            assert max(abs(x - y) for x, y in zip(ud, vd)) <= 1e-13 * res["sum_w"][k], (k, sw)
+        else:
+            assert u == v and ud == vd, (k, sw)
 
 
 @pytest.mark.parametrize("sw", DIAG, ids=_ids)
