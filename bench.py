@@ -429,7 +429,7 @@ def scaling_reference_line(args, torch):
     n, P = tree.n_otu, st.shape[1]
     t = build_tree(wl, device=0)
     steps = max(5, min(args.steps, 20))
-    dt, lnl = timed_steps(t, steps, min(args.warmup, 3), torch.cuda.synchronize)
+    dt, lnl = timed_steps(t, steps, max(3, min(args.warmup, 10)), torch.cuda.synchronize)
     kern_ms, kern_n, _ = t.inst.profile_read()
     vnow = t.inst.virtual_stats()[0]
     t.close()
