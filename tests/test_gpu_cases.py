@@ -51,6 +51,30 @@ def test_category_counts(ns, C):
     _check(t, ot)
 
 
+@pytest.mark.parametrize("ns,C", [(4, 3), (4, 8), (20, 1), (20, 2), (20, 3), (20, 4), (20, 5), (20, 8)])
+def test_device_built_matrices_at_every_category_count(ns, C):
+    """phyhip_update_transition_matrices (src/lk.c:2344 -> src/models.c:257-326 on the device) against the restatement's
+    matrices: only exp() differs (device libm against glibc).  20 states: pmat20_kernel's A-operand table with the categories
+    replicated over the four MFMA blocks (C = 1, 2), one block idle (C = 3), and -- more than four categories, the generic
+    traversal kernel -- two passes per wave and no table; the whole tree's list and a short one (the arguments route)."""
+    t, ot, *_ = synthetic_pair(10, 70, ns, C, seed=3 * C + ns, ambiguous_every=9, host_pmat=False)
+    try:
+        lnl = t.Lk(None)
+        ref = ot.lk(None)
+        assert abs(lnl - ref) / abs(ref) < 1e-11
+        for e in range(ot.ne):
+            assert np.allclose(t.inst.get_transition_matrix(e), ot.pm[e], rtol=1e-11, atol=1e-16), e
+        short = [1, 4, 6]
+        lens = [0.031, 0.4, 2.2]
+        t.inst.update_transition_matrices(np.array(short, np.int32), np.array(lens))
+        for e, l in zip(short, lens):
+            ot.len[e] = l
+            ot.update_pmat(e)
+            assert np.allclose(t.inst.get_transition_matrix(e), ot.pm[e], rtol=1e-11, atol=1e-16), e
+    finally:
+        t.close()
+
+
 @pytest.mark.parametrize("ns", [4, 20])
 def test_scaling_switched_off_and_zero_weights(ns):
     w = np.ones(90); w[::4] = 0.0
