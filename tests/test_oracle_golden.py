@@ -6,6 +6,8 @@ Known answers (reference AVX build):
 Everything else in tests/golden/*.phyg was produced by oracle/ref_driver.c linked against the
 reference's own objects (tests/golden/make_golden.py holds the commands).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -210,3 +212,22 @@ def test_alias_subpatt_changes_no_number_of_the_reference(tmp_path):
     a, b = out
     assert a["calls"] == b["calls"] and a["calls"]["Update_Partial_Lk"] > 100000
     assert a["lnL_init"] == b["lnL_init"] and a["lnL_final"] == b["lnL_final"] and a["tree"] == b["tree"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/m4.c") or not os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libphyml_ref.a")),
+                    reason="build container only: needs the reference's sources and oracle/_ref")
+def test_no_reference_behaviour_for_other_state_counts():
+    """SURVEY 8 f4, second half: the only code of the reference that sets a state count other than 4 / 20 is the covarion model
+    (mod->ns = n_o * n_h, src/init.c:6407).  oracle/probe_m4.sh tries its four doors -- the -DM4 build (src/cl.c does not compile),
+    src/main.c:151-153's call order, src/interface.c:110-118's allocation, the same with the state count restored for Init_Model --
+    and none reaches a likelihood function; the control (the generic loop on 4 states, which IS pinned) runs.  Should a later
+    reference make one of them run, this test fails and the row reopens."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run(["bash", os.path.join(root, "oracle", "probe_m4.sh")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+    assert "gcc exit status 1" in out and "opt_cov_alpha" in out, out
+    doors = [l for l in out.splitlines() if l.startswith("exit status")]
+    assert len(doors) == 3, out
+    for l in doors:
+        assert "exit status 139" in l and "likelihood functions in the backtrace: 0" in l and "REF_BENCH lines: 0" in l, out
+    assert 'REF_BENCH {"lnL": -5680.0376' in out, out
