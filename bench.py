@@ -188,6 +188,43 @@ def all_stored_companion(wl, args, torch, n, P):
             "write_bytes": wr / max(kern_n, 1), "lnL": lnl, "steps": steps}
 
 
+def materialise_after_traversal(wl, torch, reps=6):
+    """What the buffers a whole-tree traversal left virtual cost the search that follows it: Lk(NULL) (both sides), then Lk(b) on an
+    edge whose inner side is a tip x tip result -- the first SHORT launch that reads a virtual buffer, which stores them all
+    (include/phyhip.h: phyhip_set_virtual_buffers) -- against the same call repeated (nothing virtual any more).  Per call, wall
+    clock, the scalar on the host both times."""
+    tree = wl["tree"]
+    n = tree.n_otu
+    deg_tips = {}
+    for e, (a, b) in enumerate(zip(tree.edge_left, tree.edge_rght)):
+        for u, v in ((int(a), int(b)), (int(b), int(a))):
+            if u >= n and v < n:
+                deg_tips[u] = deg_tips.get(u, 0) + 1
+    cherry = next(u for u, k in sorted(deg_tips.items()) if k == 2)
+    e_c = next(e for e, (a, b) in enumerate(zip(tree.edge_left, tree.edge_rght))
+               if (int(a) == cherry and int(b) >= n) or (int(b) == cherry and int(a) >= n))
+    t = build_tree(wl, device=0)
+    t.Set_Both_Sides(True)
+    first, again, virt = [], [], []
+    for k in range(reps + 2):
+        ref = t.Lk(None)
+        torch.cuda.synchronize()
+        v0 = t.inst.virtual_stats()
+        t0 = time.perf_counter()
+        a = t.Lk(e_c)
+        t1 = time.perf_counter()
+        b = t.Lk(e_c)
+        t2 = time.perf_counter()
+        v1 = t.inst.virtual_stats()
+        assert abs(a - ref) <= 1e-9 * abs(ref) and a == b, (ref, a, b)
+        if k >= 2:  # (the first rounds load code objects)
+            first.append((t1 - t0) * 1e6); again.append((t2 - t1) * 1e6); virt.append((v0[0], v1[0], v1[3] - v0[3]))
+    t.close()
+    f, g = sum(first) / len(first), sum(again) / len(again)
+    return {"materialise_after_traversal_us": f - g, "first_short_call_after_traversal_us": f, "same_call_repeated_us": g,
+            "virtual_before_after_materialised": virt[-1], "edge": e_c, "both_sides": True, "reps": reps}
+
+
 def timed_steps(t, steps, warmup, sync, barrier=None):
     lnl = None
     for _ in range(warmup):
@@ -216,27 +253,34 @@ def roofline_block(t, n, P, S, C, workload_key, with_traffic, shards=1):
     alg_bytes = workloads.algorithmic_bytes_per_pattern(n, S, C) * float(P)
     achieved = alg_bytes / kdur / 1e9 if kdur > 0 else 0.0
     rd, wr = rd / max(kern_n, 1) / shards, wr / max(kern_n, 1) / shards  # per launch of ONE shard
-    traffic = pmc_traffic(workload_key) if with_traffic else None
+    pmc = pmc_traffic(workload_key) if with_traffic else None
+    # `traffic`: the HBM bytes of one launch -- the counters' (2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes of
+    # this very command) when a profile of these kernel sources is committed, else the launch's own count of what it must move
+    # (phyhip_profile_read_traffic: results stored once, children read unless forwarded in registers; the counters read 1.03 x
+    # that in round 5).  `frac` = traffic / kernel time / 8 TB/s: a PHYSICAL fraction, never above 1.  SURVEY 8(d)'s algorithmic
+    # bytes (every child read and result write of a post-order, also the ones a fused launch keeps in registers) are kept as
+    # `frac_algorithmic`: that figure is not a rate of the memory system and exceeds 1 at large sizes.
+    traffic = pmc if pmc else rd + wr
     vnow, vskip, vre, vstored = t.inst.virtual_stats()
-    r = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-         # `achieved` / `frac` are SURVEY 8(d)'s ALGORITHMIC figure: it charges every child read and every result write of a
-         # post-order, also the ones this launch keeps in registers, so it is not a physical rate and may exceed 1.  The physical
-         # one is `frac_real` (counter bytes of this very launch / kernel time / 8 TB/s), null without a counter profile of these sources.
-         "frac_is": "algorithmic (SURVEY 8d bytes / kernel time / peak); physical: frac_real",
-         "frac_real": (traffic / kdur / 8e12) if (traffic and kdur > 0) else None,
+    phys = traffic / kdur / 1e9 if kdur > 0 else 0.0
+    r = {"bound": "hbm", "achieved": phys, "peak": 8000.0, "unit": "GB/s", "frac": phys / 8000.0, "traffic": traffic,
+         "traffic_source": "rocprofv3 pmc (2*FETCH_SIZE+WRITE_SIZE, KiB)" if pmc else "launch byte model (no pmc profile of these kernel sources)",
+         "frac_is": "physical: traffic / kernel time / 8 TB/s",
+         "frac_algorithmic": achieved / 8000.0, "achieved_algorithmic": achieved,
+         "frac_real": (pmc / kdur / 8e12) if (pmc and kdur > 0) else None,
          # buffers whose tip x tip result the launch did NOT store (include/phyhip.h: phyhip_set_virtual_buffers) -- they are
          # recomputed in registers in front of their readers and stored on demand; `all_buffers_stored` is the same run without that
          "virtual_buffers": {"virtual_after_launch": vnow, "internal_buffers": n - 2, "stores_skipped": vskip,
                              "reissued_not_storing": vre, "materialised": vstored},
-         "kernel": ("traverse_nt2_kernel" if C <= 4 else "traverse_nt_kernel") if S == 4 else "traverse_aa_kernel",
+         "kernel": t.inst.profile_read_kernel(),
          "kernel_avg_us": kdur * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
          "algorithmic_bytes_per_site_update": alg_bytes / (float(P) * (n - 2)),
          "min_traffic_bytes": rd + wr, "min_read_bytes": rd, "write_bytes": wr,
          "frac_of_min_traffic": (rd + wr) / kdur / 8e12 if kdur > 0 else 0.0,
          "frac_of_write_stream": wr / kdur / 8e12 if kdur > 0 else 0.0}
-    if traffic:
-        r["hbm_achieved"] = traffic / kdur / 1e9
-        r["hbm_frac"] = traffic / kdur / 8e12
+    if pmc:
+        r["hbm_achieved"] = pmc / kdur / 1e9
+        r["hbm_frac"] = pmc / kdur / 8e12
     return r, kdur
 
 
@@ -253,6 +297,10 @@ def run_single(args, torch):
     roof, kdur = roofline_block(t, n, P, S, C, args.workload, args.patterns is None)
     if roof["virtual_buffers"]["virtual_after_launch"] > 0 and not args.no_companion:
         roof["all_buffers_stored"] = all_stored_companion(wl, args, torch, n, P)
+        try:
+            roof["materialise"] = materialise_after_traversal(wl, torch)
+        except Exception as e:  # (a companion must never cost the run its headline line)
+            roof["materialise"] = {"error": repr(e)}
     # ("scaling": the N = 1 line is the cfg2 workload on one GPU -- neither weak nor strong; --gpus N > 1 is STRONG scaling of cfg4)
     out = {"metric": METRIC, "value": value, "unit": "M site-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "none", "vs_baseline": None, "dtype": "f64",
@@ -277,7 +325,7 @@ def run_single(args, torch):
         best_write = max(mr.get("best_write_GBps", 0.0), mr.get("write_nt_GBps", 0.0), mr["write_GBps"])
         # SURVEY 8(d)'s unit over the measured read stream.  The algorithmic bytes charge every child of every operation; a
         # fused launch forwards most children in registers, so this can exceed 1 -- it is NOT a physical rate (those follow)
-        roof["algorithmic_frac_of_measured_read"] = roof["achieved"] / max(mr["read_GBps"], mr.get("best_read_GBps", 0.0))
+        roof["algorithmic_frac_of_measured_read"] = roof["achieved_algorithmic"] / max(mr["read_GBps"], mr.get("best_read_GBps", 0.0))
         roof["write_stream_frac_of_measured_write"] = roof["write_bytes"] / kdur / 1e9 / best_write
         if roof.get("hbm_achieved") and mixed > 0:
             roof["frac_real_bytes_of_measured_mixed"] = roof["hbm_achieved"] / mixed
@@ -431,15 +479,20 @@ def scaling_reference_line(args, torch):
     steps = max(5, min(args.steps, 20))
     dt, lnl = timed_steps(t, steps, max(3, min(args.warmup, 10)), torch.cuda.synchronize)
     kern_ms, kern_n, _ = t.inst.profile_read()
+    rd_, wr_ = t.inst.profile_read_traffic()
+    model_traffic = (rd_ + wr_) / max(kern_n, 1)
+    kname = t.inst.profile_read_kernel()
     vnow = t.inst.virtual_stats()[0]
     t.close()
     exp = workloads.manifest()["expected"][name]
     kdur = kern_ms / max(kern_n, 1) * 1e-3
     alg = workloads.algorithmic_bytes_per_pattern(n, 4, 4) * float(P)
-    traffic = pmc_kernel("cfg4_1M", "traverse_nt2")
-    roof = {"bound": "hbm", "kernel_avg_us": kdur * 1e6, "achieved": alg / kdur / 1e9 if kdur > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
-            "frac": alg / kdur / 8e12 if kdur > 0 else 0.0, "frac_is": "algorithmic (SURVEY 8d bytes / kernel time / peak); physical: frac_real",
-            "traffic": traffic, "frac_real": (traffic / kdur / 8e12) if (traffic and kdur > 0) else None, "virtual_buffers_after_launch": vnow}
+    pmc = pmc_kernel("cfg4_1M", "traverse_nt2")
+    traffic = pmc if pmc else model_traffic
+    roof = {"bound": "hbm", "kernel": kname, "kernel_avg_us": kdur * 1e6, "achieved": traffic / kdur / 1e9 if kdur > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+            "frac": traffic / kdur / 8e12 if kdur > 0 else 0.0, "frac_is": "physical: traffic / kernel time / 8 TB/s",
+            "traffic": traffic, "traffic_source": "rocprofv3 pmc" if pmc else "launch byte model",
+            "frac_algorithmic": alg / kdur / 8e12 if kdur > 0 else 0.0, "virtual_buffers_after_launch": vnow}
     return {"value": float(P) * (n - 2) * steps / dt / 1e6, "unit": "M site-updates/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "n_gpus": 1, "patterns": P, "lnL": lnl, "lnL_rel_err": abs(lnl - exp["lnL"]) / abs(exp["lnL"]), "roofline": roof,
             "note": "strong-scaling reference: bench.py --gpus N (N > 1) runs this workload in N pattern shards"}
@@ -522,6 +575,18 @@ def run_sharded(args, torch):
         dt = float(tt.item())
     P_local = wl["states"].shape[1] if multiproc else total // n_gpus
     roof, kdur = roofline_block(t, n, P_local, S, C, name, False, shards=1 if multiproc else n_gpus)
+    # what every rank saw: its traversal kernel (HIP events), the collective path behind it (local sum, ncclAllReduce, publish:
+    # HIP events on the rank's stream -- includes waiting for the slowest rank) and the size of the communicator RCCL built
+    coll_ms, coll_n, coll_ranks = t.inst.profile_read_collective()
+    mine = {"rank": rank, "kernel_us": round(kdur * 1e6, 2), "collective_us": round(coll_ms / max(coll_n, 1) * 1e3, 2), "comm_size": coll_ranks,
+            "patterns": int(P_local)}
+    if multiproc:
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+    else:
+        every = [mine]  # (one process, sharded instance: the slowest shard's kernel, the first device's collective path)
+    per_rank = {"kernel_us": [e["kernel_us"] for e in every], "collective_us": [e["collective_us"] for e in every],
+                "comm_size": [e["comm_size"] for e in every], "patterns": [e["patterns"] for e in every]}
     t.close()
     out = None
     if rank == 0:
@@ -534,7 +599,7 @@ def run_sharded(args, torch):
                                       "all-reduce of {warning, lnL} per evaluation",
                           "patterns_total": total, "patterns_per_gpu": total // n_gpus, "taxa": n, "states": S, "rate_categories": C,
                           "parallelism": f"pattern-shard x{n_gpus}", "mode": mode, "rccl_ranks": ranks_seen},
-               "lnL": lnl, "roofline": roof}
+               "lnL": lnl, "roofline": roof, "per_rank": per_rank}
         roof["note"] = "per-GPU figures of rank 0's shard"
         if exp and total == exp["n_pattern"]:
             out["lnL_reference_avx"] = exp["lnL"]
@@ -552,6 +617,87 @@ def run_sharded(args, torch):
         dist.barrier()
         dist.destroy_process_group()
     return out, True   # RCCL was used in this process (either form): see the exit note in main()
+
+
+def _r(x, n=4):
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    x = float(x)
+    return round(x, n) if abs(x) < 1e6 else float(f"{x:.7g}")
+
+
+def _roof_short(roof):
+    """The roofline block of the printed line: the contract's keys (physical figures) + kernel name and time, the algorithmic
+    companion, and -- where buffers stayed virtual -- the all-stored run and what materialising them costs the next short call."""
+    o = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    o["traffic_is"] = "pmc" if roof.get("frac_real") is not None or "pmc" in str(roof.get("traffic_source", "")) else "model"
+    o["kernel"] = roof.get("kernel")
+    o["kernel_avg_us"] = _r(roof.get("kernel_avg_us"), 2)
+    o["frac_algorithmic"] = _r(roof.get("frac_algorithmic"))
+    vb = roof.get("virtual_buffers") or {}
+    if "virtual_after_launch" in vb:
+        o["virtual_buffers"] = vb["virtual_after_launch"]
+    elif "virtual_buffers_after_launch" in roof:
+        o["virtual_buffers"] = roof["virtual_buffers_after_launch"]
+    a = roof.get("all_buffers_stored")
+    if a:
+        o["all_stored_kernel_us"] = _r(a["kernel_avg_us"], 2)
+        o["all_stored_value"] = _r(a["value"], 1)
+    m = roof.get("materialise")
+    if m and "materialise_after_traversal_us" in m:
+        o["materialise_after_traversal_us"] = _r(m["materialise_after_traversal_us"], 2)
+    return o
+
+
+def compact_line(out):
+    """The printed line: the contract's keys, `roofline` and `cpu_baseline` in short, one short block per further configuration."""
+    line = {k: out[k] for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"] = _r(out["value"], 1)
+    line["ms_per_step"] = _r(out["ms_per_step"], 5)
+    cfg = out["config"]
+    line["config"] = {"workload": cfg["workload"].split(":")[0], **{k: cfg[k] for k in ("taxa", "states", "rate_categories", "patterns_per_gpu", "patterns_total", "parallelism", "rccl_ranks") if k in cfg}}
+    if "lnL_rel_err" in out:
+        line["lnL_rel_err"] = float(f"{out['lnL_rel_err']:.2g}")
+    line["roofline"] = _roof_short(out["roofline"])
+    if "cpu_baseline" in out:
+        c = out["cpu_baseline"]
+        line["cpu_baseline"] = {"value": _r(c["value"], 2), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                                "sample": c["sample"].replace(" of the same workload", "")}
+    ex = out.get("extra", {})
+    c3 = ex.get("cfg3_aa_200x10k")
+    if c3 and "value" in c3:
+        r3 = _roof_short(c3["roofline"])
+        line["cfg3_aa_200x10k"] = {"value": _r(c3["value"], 1), "ms_per_step": _r(c3["ms_per_step"], 5), "lnL_rel_err": float(f"{c3['lnL_rel_err']:.2g}"),
+                                   **{k: r3[k] for k in ("kernel", "kernel_avg_us", "frac", "traffic", "traffic_is", "frac_algorithmic", "all_stored_kernel_us") if k in r3},
+                                   "mfma_frac": _r(c3["mfma"]["frac"])}
+    c4 = ex.get("cfg4_nt_100x1M_one_gpu")
+    if c4 and "value" in c4:
+        r4 = _roof_short(c4["roofline"])
+        line["cfg4_nt_100x1M_one_gpu"] = {"value": _r(c4["value"], 1), "ms_per_step": _r(c4["ms_per_step"], 4), "lnL_rel_err": float(f"{c4['lnL_rel_err']:.2g}"),
+                                          **{k: r4[k] for k in ("kernel_avg_us", "frac", "traffic_is", "frac_algorithmic") if k in r4}}
+    cl = ex.get("call_latency")
+    if cl and "error" not in cl:
+        us = {}
+        for name, short in (("spr_500x100k", "spr_500x100k"), ("spr_54x382", "spr_54x382"), ("spr_37x429_aa", "spr_37x429_aa"), ("spr_200x10k_aa", "spr_200x10k_aa")):
+            if name in cl:
+                us[short] = _r(cl[name]["us_per_candidate"], 2)
+        for name, short in (("spr_and_brlen_54x382", "call_54x382"), ("spr_and_brlen_37x429_aa", "call_37x429_aa")):
+            if name in cl:
+                us[short] = _r(cl[name]["us_per_scalar_returning_call"], 2)
+        b = cl.get("brlen_500x100k")
+        if b:
+            us["dlk_500x100k"] = _r(b["us_per_dlk_call"], 2)
+            us["chain_1eig_5dlk_500x100k"] = _r(b["us_per_chain_of_1_eigen_lr_and_5_dlk"], 2)
+        aa = [cl[k]["served_by_resident_workgroups"] for k in cl if k.endswith("_aa") and "served_by_resident_workgroups" in cl[k]]
+        us["resident_served_aa"] = int(sum(sum(v.values()) for v in aa))
+        line["call_us"] = us
+    if "strong_scaling" in out:
+        ss = out["strong_scaling"]
+        line["strong_scaling"] = {"single_gpu_value": _r(ss["single_gpu_value"], 1), "speedup": _r(ss["speedup"], 3)}
+    if "per_rank" in out:
+        line["per_rank"] = out["per_rank"]
+    line["detail"] = "bench_detail.json"
+    return line
 
 
 def main():
@@ -585,9 +731,21 @@ def main():
     else:
         out, used_rccl = run_sharded(args, torch)
     if out is not None:
+        # Everything measured goes to a side file (and stderr); the ONE JSON line on stdout is the compact form of it -- the
+        # contract's keys plus the few figures a reader needs, under 2 000 characters so that a log tail holds all of it
+        detail = json.dumps(out)
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            try:
+                if os.path.isdir(d):
+                    open(os.path.join(d, "bench_detail.json"), "w").write(detail + "\n")
+            except OSError:
+                pass
+        sys.stderr.write("[bench detail] " + detail + "\n")
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        assert len(line) < 2000, len(line)
         # the ONE JSON line goes out last, after RCCL has finished any chatter of its own on stdout
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        print(line, flush=True)
     # RCCL prints a version banner on stdout while the interpreter shuts down; leave before that so the JSON
     # line stays the last (and, single-GPU, the only) line on stdout
     sys.stdout.flush(); sys.stderr.flush()

@@ -323,6 +323,15 @@ int phyhip_synchronize(int instance);
    enable != 0 starts (and resets) accumulation. */
 int phyhip_profile(int instance, int enable);
 int phyhip_profile_read(int instance, double *outTraversalMs, int *outLaunches, double *outSiteUpdates);
+/* The collective path of the evaluations profiled since phyhip_profile(instance, 1) on a sharded instance or on a rank of
+   phyhip_comm_init_rank: HIP events on the first shard's stream around {per-device local sum, ncclAllReduce, publish kernel} --
+   the time from this rank's traversal kernel having ended to the reduced scalar being on its way to the host, which includes
+   waiting for the slowest rank.  outRanks: the communicator's size (1: no communicator, nothing measured). */
+int phyhip_profile_read_collective(int instance, double *outMs, int *outCount, int *outRanks);
+/* Name of the traversal kernel of the last launch profiled since phyhip_profile(instance, 1), template arguments included, as
+   rocprofv3 --kernel-trace shows it without the namespace (bench.py: `roofline.kernel`); empty before the first such launch.
+   Sharded instances: the first shard's. */
+int phyhip_profile_read_kernel(int instance, char *outName, int capacity);
 /* Traffic model of the launches profiled since phyhip_profile(instance, 1): the bytes those traversal launches had to
    move if nothing but the kernel's own register forwarding saved any -- every result written once, every child read
    unless it is a tip (1 byte) or one of the two previous results.  The honest floor under the algorithmic byte count of

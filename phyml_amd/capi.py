@@ -45,7 +45,7 @@ SYMBOLS = [
     "phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl", "phyhip_get_dot_prod", "phyhip_set_stream",
     "phyhip_synchronize", "phyhip_profile", "phyhip_profile_read", "phyhip_calculate_mixture_log_likelihood",
     "phyhip_calculate_mixture_eigen_lnl_dlnl", "phyhip_comm_get_unique_id", "phyhip_comm_init_rank", "phyhip_comm_size",
-    "phyhip_get_shard_range", "phyhip_profile_read_traffic", "phyhip_profile_read_eigen", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats", "phyhip_set_virtual_buffers", "phyhip_get_virtual_stats", "phyhip_calculate_class_mixture_log_likelihood",
+    "phyhip_get_shard_range", "phyhip_profile_read_kernel", "phyhip_profile_read_collective", "phyhip_profile_read_traffic", "phyhip_profile_read_eigen", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats", "phyhip_set_virtual_buffers", "phyhip_get_virtual_stats", "phyhip_calculate_class_mixture_log_likelihood",
     "phyhip_calculate_class_mixture_eigen_lnl_dlnl", "phyhip_get_class_scale_factors", "phyhip_set_mixture_invariant_sites",
 ]
 
@@ -326,6 +326,18 @@ class Instance:
         a = C.c_double(0); an = C.c_int(0); b = C.c_double(0); bn = C.c_int(0)
         _chk(self.L.phyhip_profile_read_eigen(self.id, C.byref(a), C.byref(an), C.byref(b), C.byref(bn)))
         return (a.value, an.value), (b.value, bn.value)
+
+    def profile_read_collective(self):
+        """(ms, evaluations, ranks) of the collective path (local sum, all-reduce, publish) since profile(1)"""
+        ms = C.c_double(0); n = C.c_int(0); r = C.c_int(0)
+        _chk(self.L.phyhip_profile_read_collective(self.id, C.byref(ms), C.byref(n), C.byref(r)))
+        return ms.value, n.value, r.value
+
+    def profile_read_kernel(self):
+        """name of the traversal kernel of the last profiled launch (template arguments included)"""
+        buf = C.create_string_buffer(128)
+        _chk(self.L.phyhip_profile_read_kernel(self.id, buf, 128))
+        return buf.value.decode()
 
     def profile_read_traffic(self):
         r = C.c_double(0); w = C.c_double(0)

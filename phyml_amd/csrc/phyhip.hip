@@ -92,7 +92,8 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "bad instance dimensions");
   if (stateCount != 4 && stateCount != 20)
     return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "stateCount %d: only 4 (nt) and 20 (aa) are built", stateCount);
-  if (categoryCount > 8) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "categoryCount %d > 8", categoryCount);
+  // (src/cl.c:1262-1263 accepts any -c n >= 1; the lane = (pattern, category) kernels hold a pattern's categories in one wave)
+  if (categoryCount > kMaxCategories) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "categoryCount %d > %d", categoryCount, kMaxCategories);
   if ((double)patternCount * categoryCount * stateCount * 8.0 >= 2147483648.0)
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "one partials buffer must stay below 2 GiB (shard the patterns across devices)");
   if ((double)(matrixBufferCount + 2 * (partialsBufferCount - tipCount)) * categoryCount * stateCount * stateCount * 8.0 >= 2147483648.0)
@@ -331,6 +332,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->slot_kind.assign(I->ops_slots, -1);
   if (const char *e = diag_env("PHYHIP_GENERIC_NT")) I->generic_nt = atoi(e) != 0;
   if (I->generic_loop) I->generic_nt = true;
+  if (I->C > 8) I->generic_nt = true; // (9 .. 64 categories: the plain lane = (pattern, category) kernel for either state count)
 #ifdef PHYHIP_DIAG
   if (const char *e = diag_env("PHYHIP_ABLATE")) I->ablate = atoi(e);
   if (const char *e = diag_env("PHYHIP_NOLOADS")) I->no_loads = atoi(e) != 0;
@@ -1077,8 +1079,8 @@ int phyhip_profile(int instance, int enable)
     HIPCHK(hipEventCreate(&e));
     I->prof_spare.push_back(e);
   }
-  I->prof_ms = 0.0; I->prof_n = 0; I->prof_updates = 0.0; I->prof_rd_bytes = 0.0; I->prof_wr_bytes = 0.0;
-  I->prof_aux_ms[0] = I->prof_aux_ms[1] = 0.0; I->prof_aux_n[0] = I->prof_aux_n[1] = 0;
+  I->prof_ms = 0.0; I->prof_n = 0; I->prof_updates = 0.0; I->prof_rd_bytes = 0.0; I->prof_wr_bytes = 0.0; I->prof_kernel[0] = 0;
+  for (int k = 0; k < 3; ++k) { I->prof_aux_ms[k] = 0.0; I->prof_aux_n[k] = 0; }
   return PHYHIP_SUCCESS;
 }
 
@@ -1174,6 +1176,30 @@ int phyhip_get_virtual_stats(int instance, long long out[4])
   GET_INST_RES(I, instance);
   I_call.leave_query();
   out[0] = I->n_virtual; out[1] = (long long)I->n_virt_skipped; out[2] = (long long)I->n_virt_recomputed; out[3] = (long long)I->n_virt_material;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_profile_read_collective(int instance, double *outMs, int *outCount, int *outRanks)
+{
+  Group *G = get_group(instance);
+  GET_INST(I, G ? G->sub_id[0] : instance);
+  int rc = flush_sync(I);
+  if (rc) return rc;
+  if ((rc = collect_profile(I))) return rc;
+  if (outMs) *outMs = I->prof_aux_ms[2];
+  if (outCount) *outCount = I->prof_aux_n[2];
+  const Collective *co = G ? G->co : I->co;
+  if (outRanks) *outRanks = co ? co->nranks : 1;
+  return PHYHIP_SUCCESS;
+}
+
+int phyhip_profile_read_kernel(int instance, char *outName, int capacity)
+{
+  Group *G = get_group(instance);
+  GET_INST_RES(I, G ? G->sub_id[0] : instance);
+  I_call.leave_query();
+  if (!outName || capacity < 1) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "no room for the kernel name");
+  snprintf(outName, (size_t)capacity, "%s", I->prof_kernel);
   return PHYHIP_SUCCESS;
 }
 

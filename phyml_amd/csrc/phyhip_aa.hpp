@@ -127,9 +127,15 @@ static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUp
     if (q.afrag)
       for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) q.afrag[(size_t)shd * kAaMat + e] = q.afrag[(size_t)m * kAaMat + e];
   }
+  double *out = q.pmats + (size_t)m * n;
+  if (!q.afrag)
+  { // (no A-operand table to derive: straight from the staging memory to the slot, element e by the thread that moved its old
+    // value -- no LDS, so any category count fits)
+    for (int e = threadIdx.x; e < n; e += blockDim.x) out[e] = src[e];
+    return;
+  }
   for (int e = threadIdx.x; e < n; e += blockDim.x) mat[e] = src[e];
   __syncthreads();
-  double *out = q.pmats + (size_t)m * n;
   for (int e = threadIdx.x; e < n; e += blockDim.x) out[e] = mat[e];
   if (q.afrag)
     aa_fill_atable(q.afrag + (size_t)m * kAaMat, q.C, [&](int c, int i, int j) { return mat[(size_t)c * 400 + i * 20 + j]; });

@@ -83,7 +83,10 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
 static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dlnl, double *dev_out = nullptr,
                       double *warn_out = nullptr)
 {
-  if ((size_t)I->C * 2 * I->S > (size_t)kMaxExpl) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "expl table too large");
+  // the expl table: in the kernel arguments up to 8 categories, staged into device memory beyond (C <= kMaxCategories)
+  const bool          expl_in_args = (size_t)I->C * 2 * I->S <= (size_t)kMaxExpl;
+  std::vector<double> expl_big;
+  if (!expl_in_args) expl_big.assign((size_t)I->C * 2 * I->S, 0.0);
   int rc = flush(I, nullptr);
   if (rc) return rc;
   DlkParams q;
@@ -114,6 +117,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
     q.fin.result_host = dev_out ? nullptr : I->h_result; q.fin.warn_host = I->h_warn;
     q.fin.seq = dev_out ? 0ull : ++I->seq; q.fin.warn_out = warn_out;
   }
+  double *const xp = expl_in_args ? q.expl : expl_big.data();
   for (int c = 0; c < I->C; ++c)
   {
     if (deriv)
@@ -125,8 +129,8 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       for (int s = 0; s < I->S; ++s)
       {
         const double ev = I->h_eval[s], ex = exp(ev * len);
-        q.expl[c * 2 * I->S + 2 * s]     = ex;
-        q.expl[c * 2 * I->S + 2 * s + 1] = ex * ev * rr;
+        xp[c * 2 * I->S + 2 * s]     = ex;
+        xp[c * 2 * I->S + 2 * s + 1] = ex * ev * rr;
       }
     }
     else
@@ -135,8 +139,19 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
       len *= I->br_len_mult;
       if (len < I->l_min) len = I->l_min;
       else if (len > I->l_max) len = I->l_max;
-      for (int s = 0; s < I->S; ++s) q.expl[c * I->S + s] = exp(I->h_eval[s] * len);
+      for (int s = 0; s < I->S; ++s) xp[c * I->S + s] = exp(I->h_eval[s] * len);
     }
+  }
+  if (!expl_in_args)
+  { // (the mixture evaluations' table area, kMaxMixClasses x 2 x 20 doubles: stream order keeps the two apart)
+    void        *st = nullptr;
+    const size_t eb = expl_big.size() * sizeof(double);
+    if ((rc = I->ring.alloc(eb, I->stream, &st))) return rc;
+    memcpy(st, expl_big.data(), eb);
+    big_release(I, false);
+    I->touched_call = true;
+    HIPCHK(hipMemcpyAsync(I->d_mixexpl, st, eb, hipMemcpyHostToDevice, I->stream));
+    q.expl_dev = I->d_mixexpl;
   }
   // Small alignment, scalar wanted on the host: hand the evaluation to the resident workgroups (resident_dlk_kernel) when
   // nothing of this instance is still running on its stream -- they are not ordered with it.  Right after Update_Eigen_Lr
@@ -191,7 +206,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   // (20 states, re-measured in round 4 with compact commands -- exp() values only, two 512-byte reads instead of four, ONE
   // polling workgroup, the others on the device-memory mailbox: 10.7 us from command to answer on the recorded proteic search,
   // 18.2 against 17.5 us per scalar-returning call, 13.2 against 13.4 us per dLk at 2 000 patterns -- still no gain: removed)
-  if (!big && hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait)
+  if (!big && hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait && expl_in_args)
   {
     bool idle = !I->stream_dirty;
     if (idle && I->clean_after)

@@ -332,12 +332,13 @@ struct Instance
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pairs;
   struct ProfPair { hipEvent_t a, b; int kind; };
   std::vector<hipEvent_t> prof_spare;      // events of collected launches, reused (creating one costs more than recording it)
-  std::vector<ProfPair> prof_aux;          // eigen-basis kernels while profiling: kind 0 eigen_lr_kernel (K3), 1 dlk_kernel (K4)
-  double     prof_aux_ms[2] = {0.0, 0.0};
-  int        prof_aux_n[2]  = {0, 0};
+  std::vector<ProfPair> prof_aux;          // while profiling: kind 0 eigen_lr_kernel (K3), 1 dlk_kernel (K4), 2 the collective path (local sum, all-reduce, publish)
+  double     prof_aux_ms[3] = {0.0, 0.0, 0.0};
+  int        prof_aux_n[3]  = {0, 0, 0};
   double     prof_ms = 0.0, prof_updates = 0.0;
   double     prof_rd_bytes = 0.0, prof_wr_bytes = 0.0; // traffic model of the profiled launches (phyhip_profile_read_traffic)
   int        prof_n = 0;
+  char       prof_kernel[96] = {0}; // the traversal kernel of the last profiled launch, as a profiler names it (phyhip_profile_read_kernel)
 };
 
 // The calling thread's current device is ASKED, not remembered: a host application (or another library in its process) may
@@ -504,6 +505,7 @@ template <typename F> int dispatch_shape(const Instance *I, F &&f)
 #define CASE(S_, CP_)                                                                                        \
   if (I->S == S_ && I->CP == CP_) return f(std::integral_constant<int, S_>(), std::integral_constant<int, CP_>());
   CASE(4, 1) CASE(4, 2) CASE(4, 4) CASE(4, 8) CASE(20, 1) CASE(20, 2) CASE(20, 4) CASE(20, 8)
+  CASE(4, 16) CASE(4, 32) CASE(4, 64) CASE(20, 16) CASE(20, 32) CASE(20, 64) // (more than 8 categories: the plain kernels only)
 #undef CASE
   return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "no kernel for %d states x %d categories", I->S, I->C);
 }

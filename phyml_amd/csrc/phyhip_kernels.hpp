@@ -27,7 +27,8 @@ constexpr double kSmall         = 2.2250738585072014e-308;     // SMALL = DBL_MI
 constexpr double kLog2          = 0.69314718055994528623;      // LOG2, src/utilities.h:267
 constexpr double kSmallPij      = 1.E-100;                     // SMALL_PIJ, src/utilities.h:478
 constexpr int    kArgUp         = 3;                           // host-computed matrices per launch in the kernel arguments
-constexpr int    kMaxExpl       = 2 * 8 * 20;                  // dLk's expl table: [C<=8][2][S<=20]
+constexpr int    kMaxExpl       = 2 * 8 * 20;                  // dLk's expl table in the kernel arguments: [C<=8][2][S<=20]
+constexpr int    kMaxCategories = 64;                          // a pattern's categories sit in the lanes of one wave
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct HostBlock
@@ -1220,6 +1221,7 @@ struct DlkParams
   double        pinvar;
   FinishParams  fin;             // block_sums [2][stride], warn, and (optionally) the fused final sum
   double        expl[kMaxExpl];
+  const double *expl_dev;        // more than 8 categories: the table in device memory instead (kernel arguments hold 4 KiB)
 };
 
 // What varies from one evaluation to the next on one edge (the rest of DlkParams is fixed while the instance lives)
@@ -1443,7 +1445,7 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
 {
   const DlkCall k = {q.with_derivative, q.invar_model, q.apply_scaling, q.pinvar};
   double        v[2];
-  if (dlk_block<S, CP>(q, k, q.expl, q.fin.warn, v)) finish_sums<2>(q.fin, v, (int)(threadIdx.x & 63));
+  if (dlk_block<S, CP>(q, k, q.expl_dev ? q.expl_dev : q.expl, q.fin.warn, v)) finish_sums<2>(q.fin, v, (int)(threadIdx.x & 63));
 }
 
 // One tile (dlk_tile) per one-wave workgroup: the launched form of what the large-grid resident evaluator serves

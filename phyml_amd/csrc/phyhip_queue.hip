@@ -175,7 +175,7 @@ int flush_uploads(Instance *I)
     q.count = n; q.S = I->S; q.C = I->C; q.pmats = I->d_pmats; q.afrag = I->perm ? I->d_afrag : nullptr;
     for (int k = 0; k < kUploadBatch; ++k) q.shadow[k] = -1;
     for (int k = 0; k < n; ++k) { q.idx[k] = I->up_idx[done + k]; q.src[k] = I->up_src[done + k]; q.shadow[k] = I->up_shadow[done + k]; }
-    hipLaunchKernelGGL(upload_matrices_kernel, dim3(n), dim3(256), sizeof(double) * (size_t)I->C * I->S * I->S, I->stream, q);
+    hipLaunchKernelGGL(upload_matrices_kernel, dim3(n), dim3(256), q.afrag ? sizeof(double) * (size_t)I->C * I->S * I->S : 0, I->stream, q);
     HIPCHK(hipGetLastError());
     done += n;
   }
@@ -756,6 +756,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
           HIPCHK(hipEventRecord(p0, I->stream));
         }
         if ((rc = big_one_shot(I, words, kBigWords))) return rc;
+        if (timed) snprintf(I->prof_kernel, sizeof I->prof_kernel, "resident_big_kernel<%d, %d> (launched for one evaluation)", I->C, I->nt_groups);
         if (timed)
         {
           HIPCHK(hipEventRecord(p1, I->stream));
@@ -799,6 +800,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     HIPCHK(hipEventRecord(e0, I->stream));
   }
   const unsigned long long hp1 = hp_now();
+  auto named = [&](const char *fmt, auto... a) { if (I->prof) snprintf(I->prof_kernel, sizeof I->prof_kernel, fmt, a...); };
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;
     if constexpr (S_ == 4 && CP_ <= 4)
@@ -838,6 +840,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
 #define NT2CASE(c_, g_)                                                                                                     \
   if (mixed && c_ == 4 && g_ == 2)                                                                                          \
   { /* two wave shapes in one launch (phyhip_nt2.hpp): full rounds of two-lane waves + four-lane waves for the rest */      \
+    named("traverse_nt2_mixed_kernel<4, %s>", has_inl ? "true" : "false");                                                  \
     if (has_inl)                                                                                                            \
       hipLaunchKernelGGL((traverse_nt2_mixed_kernel<4, true>), dim3(soa_grid), dim3(64), 0, I->stream, q, d_irec, d_xrec, ro.pmats,  \
                          ro.tip_codes, I->mix_n2);                                                                          \
@@ -847,18 +850,20 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   }                                                                                                                         \
   else if (!q.recs_in_args && I->prefetch_dist == 1)                                                                        \
   {                                                                                                                         \
+    named("traverse_nt2_kernel<%d, %d, false, 0, 1>", c_, g_);                                                              \
     hipLaunchKernelGGL((traverse_nt2_kernel<c_, g_, false, 0, 1>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
                        ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
   }                                                                                                                         \
   else if (!q.recs_in_args && has_inl && g_ <= 2)                                                                           \
   { /* a list with in-step tip x tip children: the instantiation that stages four matrices per step */                      \
+    named("traverse_nt2_kernel<%d, %d, false, 0, 2, true>", c_, (g_ <= 2 ? g_ : 1));                                        \
     hipLaunchKernelGGL((traverse_nt2_kernel<c_, (g_ <= 2 ? g_ : 1), false, 0, 2, true>), dim3(I->grid_nt2), dim3(64), 0, I->stream, q, d_irec, d_xrec, \
                        ro.pmats, ro.tip_codes, (unsigned long long *)nullptr);                                              \
   }                                                                                                                         \
-  else if (!q.recs_in_args) { NT2LAUNCH(c_, g_, 0) }                                                                        \
-  else if (q.n_real_ops == 1) { NT2LAUNCH(c_, g_, 1) }                                                                      \
-  else if (q.n_real_ops == 2) { NT2LAUNCH(c_, g_, 2) }                                                                      \
-  else { NT2LAUNCH(c_, g_, 3) }                                                                                             \
+  else if (!q.recs_in_args) { named("traverse_nt2_kernel<%d, %d, false, 0>", c_, g_); NT2LAUNCH(c_, g_, 0) }                \
+  else if (q.n_real_ops == 1) { named("traverse_nt2_kernel<%d, %d, false, 1>", c_, g_); NT2LAUNCH(c_, g_, 1) }              \
+  else if (q.n_real_ops == 2) { named("traverse_nt2_kernel<%d, %d, false, 2>", c_, g_); NT2LAUNCH(c_, g_, 2) }              \
+  else { named("traverse_nt2_kernel<%d, %d, false, 3>", c_, g_); NT2LAUNCH(c_, g_, 3) }                                     \
   return 0;
         switch (I->C * 8 + I->nt_groups)
         {
@@ -875,10 +880,11 @@ int flush_impl(Instance *I, const EdgeEval *ee)
 #undef NT2LAUNCH
       }
     }
-    if constexpr (S_ == 4 && (CP_ == 8 || kDiag))
+    if constexpr (S_ == 4 && CP_ <= 8 && (CP_ == 8 || kDiag))
     { // first-generation lane = (pattern, category) pipeline: the production kernel for 5..8 categories
       if (!I->generic_nt)
       {
+        named("traverse_nt_kernel<%d, 0, %d>", CP_, I->prefetch_dist == 1 ? 1 : 2);
         if (I->prefetch_dist == 1)
         {
           hipLaunchKernelGGL((traverse_nt_kernel<CP_, 0, 1>), dim3(I->grid_nt), dim3(I->block_nt), 0, I->stream, q, d_irec, d_xrec, ro.pmats,
@@ -909,6 +915,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         const dim3 blk(64 * (I->aa_nw + 1));
 #define AACASE(c_)                                                                                                          \
   case c_:                                                                                                                  \
+    named("traverse_aa_kernel<%d, false, 0, %s, %s>", c_, q.recs_in_args ? "true" : "false", (!q.recs_in_args && has_inl) ? "true" : "false"); \
     if (q.recs_in_args)                                                                                                     \
       hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec,    \
                          (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
@@ -965,6 +972,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
 #undef AACASE
       }
     }
+    named("traverse_kernel<%d, %d>", S_, CP_);
     hipLaunchKernelGGL((traverse_kernel<S_, CP_>), dim3(I->grid), dim3(256), 0, I->stream, q, ro.ops, ro.pmats, ro.tip_codes,
                        ro.code_masks);
     return 0;

@@ -39,6 +39,13 @@ __global__ void shard_publish_kernel(const double *red, double *result_host, int
 int reduce_and_publish(Collective &co, int count, Instance *I0)
 {
   int rc = 0;
+  hipEvent_t pa = nullptr, pb = nullptr; // (profiled instance: HIP events around the whole collective path on the first device's stream)
+  if (I0->prof)
+  {
+    if ((rc = set_dev(co.ctx[0].dev))) return rc;
+    if (hipEventCreate(&pa) != hipSuccess || hipEventCreate(&pb) != hipSuccess) pa = pb = nullptr;
+    if (pa) (void)hipEventRecord(pa, co.ctx[0].stream);
+  }
   for (auto &c : co.ctx)
     if (c.nsub > 1)
     {
@@ -58,6 +65,11 @@ int reduce_and_publish(Collective &co, int count, Instance *I0)
   hipLaunchKernelGGL(shard_publish_kernel, dim3(1), dim3(64), 0, co.ctx[0].stream, (const double *)co.ctx[0].d_red, I0->h_result,
                      I0->h_warn, ++I0->seq);
   HIPCHK(hipGetLastError());
+  if (pa)
+  {
+    (void)hipEventRecord(pb, co.ctx[0].stream);
+    I0->prof_aux.push_back({pa, pb, 2});
+  }
   return wait_result(I0);
 }
 

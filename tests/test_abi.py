@@ -172,11 +172,11 @@ def test_resident_choke_point():
     assert keepers == {"phyhip_update_transition_matrices", "phyhip_set_transition_matrix", "phyhip_update_partials",
                        "phyhip_update_eigen_lr", "phyhip_calculate_edge_log_likelihoods", "phyhip_calculate_eigen_lnl_dlnl",
                        "phyhip_calculate_eigen_lnl", "phyhip_get_numerical_warning", "phyhip_get_resident_stats",
-                       "phyhip_get_big_resident_stats", "phyhip_get_virtual_stats"}, sorted(keepers)
+                       "phyhip_get_big_resident_stats", "phyhip_get_virtual_stats", "phyhip_profile_read_kernel"}, sorted(keepers)
     REVIEWED = {"leave_queued_only": {"phyhip_update_transition_matrices", "phyhip_update_partials"},
                 "leave_untouched": {"phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl"},
                 "leave_query": {"phyhip_get_numerical_warning", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats",
-                                "phyhip_get_virtual_stats"}}
+                                "phyhip_get_virtual_stats", "phyhip_profile_read_kernel"}}
     for helper, allowed in REVIEWED.items():
         users = {name for name, body in bodies.items() if "." + helper + "(" in body}
         assert users == allowed, (helper, sorted(users ^ allowed))

@@ -37,25 +37,47 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config")
 
 
+def _detail():
+    """everything the run measured (bench.py writes it next to itself; the printed line is its compact form)"""
+    return json.load(open(os.path.join(ROOT, "bench_detail.json")))
+
+
+def _physical(r):
+    """a roofline block of the printed line: physical figures only -- nothing above 1, and reproducible from its own keys"""
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-4
+    assert abs(r["achieved"] - r["traffic"] / (r["kernel_avg_us"] * 1e-6) / 1e9) < 2e-3 * r["achieved"]
+    assert r["traffic_is"] in ("pmc", "model") and r["frac_algorithmic"] > r["frac"]
+
+
 def test_default_single_gpu_line():
-    d, lines = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-call-latency"], {})
-    assert len(lines) == 1  # N = 1: nothing but the JSON line on stdout
+    d, lines = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert len(lines) == 1 and len(lines[0]) < 2000  # N = 1: nothing but the JSON line on stdout, short enough for a log tail
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "none" and d["dtype"] == "f64" and d["higher_is_better"] is True
-    assert d["config"]["workload"].startswith("cfg2_nt_100x50k")
-    assert d["lnL_rel_err"] < 1e-6 and d["input_checksum_ok"]
+    assert d["config"]["workload"] == "cfg2_nt_100x50k" and d["lnL_rel_err"] < 1e-6
     r = d["roofline"]
-    # `frac` is SURVEY 8(d)'s ALGORITHMIC figure (it also charges what the launch keeps in registers or leaves virtual: it passes 1
-    # and says so); the physical one -- counter bytes of these very kernel sources, or null -- can not
-    assert r["bound"] == "hbm" and 0.0 < r["frac"] < 2.0 and r["kernel"] == "traverse_nt2_kernel" and "algorithmic" in r["frac_is"]
-    assert r["frac_real"] is None or 0.0 < r["frac_real"] < 1.0
-    vb = r["virtual_buffers"]
-    assert 0 < vb["virtual_after_launch"] < vb["internal_buffers"] and r["all_buffers_stored"]["kernel_avg_us"] > r["kernel_avg_us"]
-    assert r["all_buffers_stored"]["lnL"] == d["lnL"]   # the same double, stored or not
-    x = d["extra"]["cfg3_aa_200x10k"]
-    assert x["lnL_rel_err"] < 1e-6 and x["roofline"]["kernel"] == "traverse_aa_kernel" and 0.0 < x["roofline"]["frac"] < 2.0
-    assert x["roofline"]["frac_real"] is None or 0.0 < x["roofline"]["frac_real"] < 1.0
+    _physical(r)
+    # the kernel rocprofv3 shows for this launch: the two-wave-shape list form with in-step tip x tip children
+    assert r["kernel"] == "traverse_nt2_mixed_kernel<4, true>"
+    assert 0 < r["virtual_buffers"] < 98 and r["all_stored_kernel_us"] > r["kernel_avg_us"] and r["all_stored_value"] < d["value"]
+    assert r["materialise_after_traversal_us"] > 0.0
+    x = d["cfg3_aa_200x10k"]
+    assert x["lnL_rel_err"] < 1e-6 and x["kernel"].startswith("traverse_aa_kernel<4") and 0.0 < x["frac"] < 1.0 and 0.0 < x["mfma_frac"] < 1.0
+    y = d["cfg4_nt_100x1M_one_gpu"]
+    assert y["lnL_rel_err"] < 1e-6 and 0.0 < y["frac"] < 1.0 and y["value"] > 0
+    c = d["call_us"]
+    for k in ("spr_500x100k", "dlk_500x100k", "chain_1eig_5dlk_500x100k", "spr_54x382", "call_54x382", "spr_37x429_aa", "call_37x429_aa"):
+        assert c[k] > 0.0, k
+    full = _detail()
+    assert full["input_checksum_ok"] and full["value"] == pytest.approx(d["value"], rel=1e-4)
+    fr = full["roofline"]
+    assert fr["all_buffers_stored"]["lnL"] == full["lnL"]   # the same double, stored or not
+    m = fr["materialise"]
+    assert m["virtual_before_after_materialised"][0] > 0 and m["virtual_before_after_materialised"][1] == 0
+    assert m["first_short_call_after_traversal_us"] > m["same_call_repeated_us"]
+    assert full["extra"]["call_latency"]["spr_37x429_aa"]["finite"]
 
 
 def test_bare_multi_gpu_command_with_two_shards_on_device_0():
@@ -66,9 +88,12 @@ def test_bare_multi_gpu_command_with_two_shards_on_device_0():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
     assert d["config"]["rccl_ranks"] == 1            # two shards on ONE device share its (one-rank) communicator
     assert d["config"]["patterns_per_gpu"] == 100000
-    ss = d["strong_scaling"]
-    assert abs(d["lnL"] - ss["single_gpu_lnL"]) / abs(d["lnL"]) < 1e-10   # the sharded sum against the whole alignment on one GPU
-    assert d["value"] > 0 and ss["single_gpu_value"] > 0
+    pr = d["per_rank"]
+    assert pr["comm_size"] == [1] and pr["kernel_us"][0] > 0 and pr["collective_us"][0] > 0
+    full = _detail()
+    ss = full["strong_scaling"]
+    assert abs(full["lnL"] - ss["single_gpu_lnL"]) / abs(full["lnL"]) < 1e-10   # the sharded sum against the whole alignment on one GPU
+    assert d["value"] > 0 and d["strong_scaling"]["single_gpu_value"] > 0
 
 
 def test_torchrun_form_one_rank():
@@ -79,9 +104,13 @@ def test_torchrun_form_one_rank():
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "strong"
-    assert d["config"]["rccl_ranks"] == 1 and "phyhip_comm_init_rank" in d["config"]["mode"]
-    ss = d["strong_scaling"]
-    assert abs(d["lnL"] - ss["single_gpu_lnL"]) / abs(d["lnL"]) < 1e-10
+    assert d["config"]["rccl_ranks"] == 1
+    pr = d["per_rank"]
+    assert pr["comm_size"] == [1] and pr["patterns"] == [200000] and pr["kernel_us"][0] > 0 and pr["collective_us"][0] > 0
+    full = _detail()
+    assert "phyhip_comm_init_rank" in full["config"]["mode"]
+    ss = full["strong_scaling"]
+    assert abs(full["lnL"] - ss["single_gpu_lnL"]) / abs(full["lnL"]) < 1e-10
 
 
 def test_full_size_sharded_line_matches_the_reference_shard_sum():

@@ -45,13 +45,14 @@ def test_ragged_pattern_counts_aa(P):
     _check(t, ot)
 
 
-@pytest.mark.parametrize("ns,C", [(4, 1), (4, 2), (4, 3), (4, 5), (4, 8), (20, 1), (20, 2), (20, 3), (20, 5), (20, 8)])
+@pytest.mark.parametrize("ns,C", [(4, 1), (4, 2), (4, 3), (4, 5), (4, 8), (20, 1), (20, 2), (20, 3), (20, 5), (20, 8),
+                                   (4, 9), (4, 12), (4, 16), (4, 33), (4, 64), (20, 12), (20, 16), (20, 40), (20, 64)])
 def test_category_counts(ns, C):
     t, ot, *_ = synthetic_pair(10, 70, ns, C, seed=3 * C + ns, ambiguous_every=9)
     _check(t, ot)
 
 
-@pytest.mark.parametrize("ns,C", [(4, 3), (4, 8), (20, 1), (20, 2), (20, 3), (20, 4), (20, 5), (20, 8)])
+@pytest.mark.parametrize("ns,C", [(4, 3), (4, 8), (20, 1), (20, 2), (20, 3), (20, 4), (20, 5), (20, 8), (4, 12), (4, 64), (20, 16), (20, 64)])
 def test_device_built_matrices_at_every_category_count(ns, C):
     """phyhip_update_transition_matrices (src/lk.c:2344 -> src/models.c:257-326 on the device) against the restatement's
     matrices: only exp() differs (device libm against glibc).  20 states: pmat20_kernel's A-operand table with the categories
@@ -71,6 +72,43 @@ def test_device_built_matrices_at_every_category_count(ns, C):
             ot.len[e] = l
             ot.update_pmat(e)
             assert np.allclose(t.inst.get_transition_matrix(e), ot.pm[e], rtol=1e-11, atol=1e-16), e
+    finally:
+        t.close()
+
+
+@pytest.mark.parametrize("ns,C", [(4, 12), (4, 16), (4, 40), (20, 12), (20, 16), (20, 40)])
+def test_more_than_eight_categories_whole_surface(ns, C):
+    """`phyml -c 12` is a legal command line (src/cl.c:1262-1263 takes any n >= 1).  Beyond 8 categories the plain lane =
+    (pattern, category) kernels serve both state counts (a pattern's categories in up to 64 lanes of one wave), dLk's expl
+    table no longer fits the kernel arguments and travels through device memory: the whole surface against the restatement --
+    partials and scale vectors bit-equal on a tree deep enough to rescale, zero weights, ambiguity codes, Lk(b), Update_Eigen_Lr, dLk,
+    the eigen-basis Lk."""
+    n, P = (40, 150) if ns == 4 else (24, 70)
+    w = np.ones(P); w[::7] = 0.0
+    t, ot, tree, st = synthetic_pair(n, P, ns, C, seed=11 * C + ns, lmin=0.05, lmax=0.6, wght=w, ambiguous_every=8)
+    try:
+        t.Set_Both_Sides(True)
+        lnl, ref = t.Lk(None), ot.lk(None, both_sides=True)
+        assert abs(lnl - ref) / abs(ref) < 1e-12, (lnl, ref)
+        ww = w > 0
+        for (e, side), p in ot.plk.items():
+            assert np.array_equal(t.partials(e, side)[ww], p[ww]), (e, side)
+            assert np.array_equal(t.scale_factors(e, side)[ww], ot.scale[(e, side)][ww])
+        assert np.array_equal(t.inst.site_outputs()[3][ww], ot.fact_sum_scale[ww])
+        for e in (0, ot.ne // 2, ot.ne - 1):
+            l0 = float(ot.len[e])
+            assert abs(t.Lk(e) - ot.lk(e)) / abs(ref) < 1e-12
+            t.Set_Update_Eigen_Lr(True); t.Set_Use_Eigen_Lr(False)
+            t.Lk(e)
+            ot.lk(e); ot.update_eigen_lr(e)
+            t.Set_Update_Eigen_Lr(False); t.Set_Use_Eigen_Lr(True)
+            assert np.allclose(t.inst.get_dot_prod()[ww], ot.dot_prod.reshape(P, -1)[ww], rtol=1e-12, atol=1e-300)
+            for l in (0.5 * l0, l0, 3.0 * l0):
+                l_out, v = t.dLk(l, e)
+                lr, vr, dr = ot.dlk(l)
+                assert l_out == lr and abs(v - vr) / abs(vr) < 1e-12 and abs(t.c_dlnL - dr) <= 1e-8 * max(1.0, abs(dr)), (e, l)
+            assert abs(t.Lk(e) - ot.lk_eigen(l0)) / abs(ref) < 1e-12
+            t.Set_Use_Eigen_Lr(False)
     finally:
         t.close()
 
