@@ -630,7 +630,7 @@ def _roof_short(roof):
     """The roofline block of the printed line: the contract's keys (physical figures) + kernel name and time, the algorithmic
     companion, and -- where buffers stayed virtual -- the all-stored run and what materialising them costs the next short call."""
     o = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    o["traffic_is"] = "pmc" if roof.get("frac_real") is not None or "pmc" in str(roof.get("traffic_source", "")) else "model"
+    o["traffic_is"] = "pmc" if str(roof.get("traffic_source", "")).startswith("rocprofv3") else "model"
     o["kernel"] = roof.get("kernel")
     o["kernel_avg_us"] = _r(roof.get("kernel_avg_us"), 2)
     o["frac_algorithmic"] = _r(roof.get("frac_algorithmic"))

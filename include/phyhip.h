@@ -183,7 +183,8 @@ int phyhip_get_transition_matrix(int instance, int matrixIndex, double *outMatri
 
 /* replaces beagleUpdatePartials, src/beagle_utils.c:245 (i.e. the body of Update_Partial_Lk,
    src/lk.c:1300-1302 -> src/avx.c:301-522).  Operations are executed in order; an operation may read
-   the destination of an earlier one.  cumulativeScaleIndex is ignored. */
+   the destination of an earlier one, but not its own (PHYHIP_ERROR_OUT_OF_RANGE: Update_Partial_Lk never
+   updates in place).  cumulativeScaleIndex is ignored. */
 int phyhip_update_partials(int instance, const phyhip_operation *operations, int operationCount,
                            int cumulativeScaleIndex);
 

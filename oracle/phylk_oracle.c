@@ -483,7 +483,7 @@ void orc_dlk(double *l, int P, int C, int S, const double *wght, const double *d
              double *lnL, double *dlnL)
 {
   const int CS = C * S;
-  double expl[2 * 64 * ORC_MAX_NS / 8 + 2 * 4 * ORC_MAX_NS];
+  double expl[2 * CS]; /* [category][state][value, derivative] */
   *l = clamp(*l, l_min, l_max);                                  /* src/lk.c:673-674 */
   for (int c = 0; c < C; ++c)
   {
@@ -542,7 +542,7 @@ double orc_lk_eigen(double l, int P, int C, int S, const double *wght, const dou
                     const short *invar, const double *pi, const int *fact_sum_scale, int apply_scaling)
 {
   const int CS = C * S;
-  double expl[64 * ORC_MAX_NS / 4];
+  double expl[CS];
   for (int c = 0; c < C; ++c)
   { /* src/lk.c:594-602 */
     double len = (l > 0.0 ? l : 0.0) * gamma_rr[c];

@@ -96,7 +96,10 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   if (categoryCount > kMaxCategories) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "categoryCount %d > %d", categoryCount, kMaxCategories);
   if ((double)patternCount * categoryCount * stateCount * 8.0 >= 2147483648.0)
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "one partials buffer must stay below 2 GiB (shard the patterns across devices)");
-  if ((double)(matrixBufferCount + 2 * (partialsBufferCount - tipCount)) * categoryCount * stateCount * stateCount * 8.0 >= 2147483648.0)
+  // (instances whose buffers can be virtual carry two snapshot slots per internal buffer behind the caller's matrices)
+  const bool can_virtualise = categoryCount <= 4 && !(requirementFlags & (PHYHIP_FLAG_CLASS_AXIS | PHYHIP_FLAG_GENERIC_LOOP));
+  const int  matrixSlots = matrixBufferCount + (can_virtualise ? 2 * (partialsBufferCount - tipCount) : 0);
+  if ((double)matrixSlots * categoryCount * stateCount * stateCount * 8.0 >= 2147483648.0)
     return fail(PHYHIP_ERROR_OUT_OF_RANGE, "transition-matrix table must stay below 2 GiB");
 
   int ndev = 0;
@@ -131,7 +134,7 @@ int phyhip_create_instance(int tipCount, int partialsBufferCount, int compactBuf
   I->class_axis = class_axis; I->NE = class_axis ? categoryCount : 1;
   I->dev = dev; I->tips = tipCount; I->nbuf = partialsBufferCount; I->S = stateCount; I->C = categoryCount;
   I->CP = next_pow2(categoryCount); I->P = patternCount; I->nmat = matrixBufferCount;
-  I->nmat_all = matrixBufferCount + 2 * (partialsBufferCount - tipCount);
+  I->nmat_all = matrixSlots;
   {
     const int rc = build_instance(I, prop);
     if (rc < 0)
@@ -179,7 +182,7 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->nt_groups = 1;
   // measured (us per traversal, G=2 / G=1): 50 k 195 / 206, 75 k 301 / 363, 125 k 444 / 456, 250 k 837 / 848, 1 M 3293 / 3246
   // (round 3, non-temporal result stores: 50 k 165 / 198, 125 k 386 / 377, 1 M 3188 / 3186 -- the crossover moved to ~100 k)
-  // (round 5, virtual buffers + two wave shapes, tools/gpu_r5m.sh: 125 000 patterns 319 / 333, 250 000 650 / 622, 500 000 1275 / 1207 -- the
+  // (round 5, virtual buffers + two wave shapes, docs/history/tools/gpu_r5m.sh: 125 000 patterns 319 / 333, 250 000 650 / 622, 500 000 1275 / 1207 -- the
   // crossover sits between two and four residency rounds of two-lane waves: up to 131 072 patterns)
   if (I->soa && I->C % 2 == 0 && I->Ppad / 64 <= 2048) I->nt_groups = 2;
   if (const char *e = diag_env("PHYHIP_NT_GROUPS"))
@@ -313,8 +316,11 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
   I->ops_cap = 2 * I->nbuf + 8;
   // (a launched list may be longer than the queue: operations that read a virtual buffer get its definition in front of them,
   // at most two per operation -- rewrite_pending)
-  I->ops_slot_bytes = (size_t)(3 * I->ops_cap + 2) * (sizeof(IssueRec) + sizeof(ExecRec));
+  // ... and devirtualise() puts up to one storing definition per internal buffer in front of the queue: 3 x (queue + internal
+  // buffers) records bound every rewritten list (flush_impl refuses a longer one instead of overrunning the slot)
+  I->ops_slot_bytes = (size_t)(3 * (I->ops_cap + (I->nbuf - I->tips)) + 2) * (sizeof(IssueRec) + sizeof(ExecRec));
   I->virt.assign(I->nbuf, 0);
+  I->keep_real_flag.assign(I->nbuf, 0);
   I->vdef.assign(I->nbuf, DevOp{0, 0, 0, 0, 0, 0});
   HIPCHK(hipMalloc((void **)&I->d_ops, (size_t)I->ops_slots * I->ops_slot_bytes));
   size_t chunk = std::max<size_t>(64 * 1024, std::max(I->ops_slot_bytes,
@@ -859,6 +865,10 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
     if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= I->nmat || o.child2TransitionMatrix < 0 ||
         o.child2TransitionMatrix >= I->nmat)
       return fail(PHYHIP_ERROR_OUT_OF_RANGE, "operation %d: matrix index out of range", i);
+    // (Update_Partial_Lk writes one side of an edge from the two OTHER edges at that node, src/lk.c:1282: never in place.  The
+    // pipelined kernels rely on it: an odd list runs its last operation twice, which must give the same result)
+    if (o.destinationPartials == o.child1Partials || o.destinationPartials == o.child2Partials)
+      return fail(PHYHIP_ERROR_OUT_OF_RANGE, "operation %d: buffer %d is both destination and child", i, o.destinationPartials);
     if ((int)I->pending.size() >= I->ops_cap)
     {
       rc = flush(I, nullptr);

@@ -33,7 +33,7 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   rewrite_pending(I, nullptr, false);
   // Small nucleotide alignments (the resident short-launch evaluator's range, 2 048 patterns): the queued partial update(s) and
   // the products are ONE launch of the lane-per-pattern kernel (TreeParams::edge_eval 2) -- or, mostly, one command of the
-  // resident workgroups.  Measured by chain (1 Update_Eigen_Lr + 5 dLk, tools/gpu_fuse_eigen_cross.sh): 40.3 vs 43.8 us at 382
+  // resident workgroups.  Measured by chain (1 Update_Eigen_Lr + 5 dLk, docs/history/tools/gpu_fuse_eigen_cross.sh): 40.3 vs 43.8 us at 382
   // patterns, 53.7 vs 56.2 at 2 048; WITHOUT the resident evaluator the fused launch loses to eigen_lr_kernel at every size
   // (+2 us: it stores dot_prod 16 bytes per lane at a 64-byte stride), beyond 4 096 patterns by 4-7 us -- so nowhere else.
   // Large alignments: the same, when the large-grid resident workgroups (phyhip_big.hpp) can take it -- launched, the fused form
@@ -157,7 +157,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   // nothing of this instance is still running on its stream -- they are not ordered with it.  Right after Update_Eigen_Lr
   // the products are a few microseconds away: poll the stream that long, else launch as usual.
   // (4 states only: a 20-state command takes four 512-byte reads per poll instead of one and the round trip loses to the launch, 14.1-14.9 against
-  // 12.4-12.5 us at 2 000 patterns -- measured, tools/gpu_resident_ab2.sh)
+  // 12.4-12.5 us at 2 000 patterns -- measured, docs/history/tools/gpu_resident_ab2.sh)
   if (kDiag && getenv("PHYHIP_RESIDENT_DEBUG") && big)
     fprintf(stderr, "big dLk: eligible %d | dirty %d dirty_prev %d touched %d clean_after %llu stamp %llu streak %d launched %d\n", (int)big_eligible(I),
             (int)I->stream_dirty, (int)I->dirty_prev, (int)I->touched_call, I->clean_after, *reinterpret_cast<volatile unsigned long long *>(I->h_result + 3),

@@ -133,7 +133,7 @@ struct StagingRing
 struct Collective;
 
 constexpr int kPushCmdsDefault = 3;    // uncached device memory (see Instance::push_cmds; measured against 1 / 2 / host memory, profiles/r04_latency.md)
-constexpr int kResidentDirect = 16;    // up to this many resident workgroups poll the host themselves, above that workgroup 0 relays (measured: 8 / 16 / 32, tools/gpu_direct_ab.sh)
+constexpr int kResidentDirect = 16;    // up to this many resident workgroups poll the host themselves, above that workgroup 0 relays (measured: 8 / 16 / 32, docs/history/tools/gpu_direct_ab.sh)
 // Host side of one set of resident workgroups (see resident_dlk_kernel / resident_nt2_kernel)
 struct Resident
 {
@@ -281,6 +281,7 @@ struct Instance
   std::vector<std::vector<InlineDef>>    slot_inl;           // ... of the lists the device ring slots hold (content cache)
   std::vector<unsigned char>             virt;              // [nbuf]
   std::vector<DevOp>                     vdef;              // [nbuf]
+  std::vector<unsigned char>             keep_real_flag;    // [nbuf]: buffer is in keep_real
   std::vector<int>                       keep_real;         // buffers the caller reads from MEMORY right after the next launch (devirtualise): that launch leaves them stored
   unsigned long long                     n_virt_skipped = 0, n_virt_recomputed = 0, n_virt_material = 0; // phyhip_get_virtual_stats
   std::vector<int>                       pm_idx;    // queued device-side matrix rebuilds (index, edge length)
@@ -547,6 +548,12 @@ void devirtualise_all(Instance *I);
 void devirtualise_matrix(Instance *I, int m);  // ... for every virtual buffer whose definition reads matrix m
 void devirtualise_tip(Instance *I, int tip);   // ... reads tip row `tip`
 // snapshot slot w (0: the definition's first matrix, 1: its second) of internal buffer b in the matrix tables
+// (the launch in between has happened: nothing is asked to stay stored any more)
+inline void keep_real_clear(Instance *I)
+{
+  for (int b : I->keep_real) I->keep_real_flag[b] = 0;
+  I->keep_real.clear();
+}
 inline int shadow_slot(const Instance *I, int b, int w) { return I->nmat + 2 * (b - I->tips) + w; }
 void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise);
 

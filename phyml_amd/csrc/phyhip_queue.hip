@@ -15,7 +15,11 @@ void devirtualise(Instance *I, int buf)
   // whoever asks is about to read the buffer from memory -- a kernel outside the traversal launch (eigen_lr_kernel, a mixture
   // combination), a copy to the host, or a setter that changes what the buffer was computed from: the launch in between must not
   // leave it virtual AGAIN (a long queue that writes it with a tip x tip operation and reads it later would: rewrite_pending)
-  if (buf >= I->tips && buf < I->nbuf && I->virt_min_ops > 0) I->keep_real.push_back(buf);
+  if (buf >= I->tips && buf < I->nbuf && I->virt_min_ops > 0 && !I->keep_real_flag[buf])
+  { // (a flag per buffer + the list of the flagged ones: constant-time lookup in rewrite_pending, no duplicates)
+    I->keep_real_flag[buf] = 1;
+    I->keep_real.push_back(buf);
+  }
   if (I->n_virtual == 0 || buf < I->tips || buf >= I->nbuf || !I->virt[buf]) return;
   DevOp op = I->vdef[buf];
   op.pad   = 0;
@@ -97,7 +101,7 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
       const DevOp &o = I->pending[k];
       if (o.c1 < I->tips && o.c2 < I->tips && n_dest[o.dest] == 1 && first_read[o.dest] > k &&
           !(ee && (ee->parent == o.dest || ee->child == o.dest)) &&
-          std::find(I->keep_real.begin(), I->keep_real.end(), o.dest) == I->keep_real.end())
+          !I->keep_real_flag[o.dest])
         skip[k] = 1;
     }
   }
@@ -153,6 +157,19 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise)
   for (int b : I->keep_real) store_now(b);
   if (ee)
     for (int side : {ee->parent, ee->child}) store_now(side);
+  // The pipelined kernels pad an odd list by running its last operation once more (flush_impl), at a position where the result
+  // of the operation THREE steps back is no longer in registers: a child of the last operation produced there is then read from
+  // memory -- so it must have been stored (two non-storing re-issues in front of a reader; reachable without in-step children)
+  if ((L.size() & 1) && L.size() >= 3)
+  {
+    DevOp       &d1 = L[L.size() - 3];
+    const DevOp &rd = L.back();
+    if ((d1.pad & kOpNoStore) && (rd.c1 == d1.dest || rd.c2 == d1.dest))
+    {
+      d1.pad &= ~kOpNoStore;
+      if (I->virt[d1.dest]) { I->virt[d1.dest] = 0; --I->n_virtual; ++I->n_virt_material; }
+    }
+  }
   I->pending.swap(L);
   if (any_inl) I->pending_inl.swap(LI);
 }
@@ -270,7 +287,7 @@ int flush_pmats(Instance *I)
 }
 
 // Final sum inside the producing kernel (last workgroup) or as a separate 1-block kernel?  Measured on MI355X (round 2,
-// tools/gpu_step_ab.sh, with PHYHIP_SPLIT_REDUCE actually honoured): fused saves the second launch (~3.4 us + gap)
+// docs/history/tools/gpu_step_ab.sh, with PHYHIP_SPLIT_REDUCE actually honoured): fused saves the second launch (~3.4 us + gap)
 // whenever the grid is small -- every SPR / Br_Len_Opt call on small and mid-sized alignments.  On large grids it costs
 // the traversal kernel ~6-10 % (cfg2 198 vs 186 us, 125 000 patterns 469 vs 414, 1 M 3.54 vs 3.22 ms, cfg3 574 vs 553):
 // a workgroup must see its block sum acknowledged by memory before it draws its ticket, i.e. it waits for ALL its
@@ -291,7 +308,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // kernels with two-deep register forwarding leaves its own tip x tip results virtual (rewrite_pending)
   rewrite_pending(I, ee, (I->soa || I->perm) && !I->generic_nt && I->prefetch_dist == 2 && !I->class_axis && !I->generic_loop &&
                              !I->ablate && !I->no_loads);
-  I->keep_real.clear();
+  keep_real_clear(I);
   const int n_ops = (int)I->pending.size();
   int rc = 0;
   if (n_ops > 0 || ee || !I->pm_idx.empty() || !I->up_idx.empty()) I->stream_dirty = true;
@@ -430,6 +447,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     void *st = nullptr;
     if (!fat)
     {
+      if (sizeof(DevOp) * (size_t)n_ops > I->ops_slot_bytes)
+        return fail(PHYHIP_ERROR_OUT_OF_RANGE, "a launch of %d operations does not fit a device slot of %zu bytes", n_ops, I->ops_slot_bytes);
       rc = I->ring.alloc(sizeof(DevOp) * n_ops, I->stream, &st);
       if (rc) return rc;
       memcpy(st, I->pending.data(), sizeof(DevOp) * n_ops);
@@ -443,6 +462,8 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       // inputs, same output, same address) whose forwarding flags are computed for its own position.
       const int    n_rec = n_ops + (n_ops & 1);
       const size_t ib = sizeof(IssueRec) * n_rec, xb = sizeof(ExecRec) * n_rec;
+      if (!in_args && ib + xb > I->ops_slot_bytes)
+        return fail(PHYHIP_ERROR_OUT_OF_RANGE, "a launch of %d operation records does not fit a device slot of %zu bytes", n_rec, I->ops_slot_bytes);
       if (!in_args)
       {
         rc = I->ring.alloc(ib + xb, I->stream, &st);

@@ -207,7 +207,7 @@ def test_random_call_streams_keep_the_stored_runs_scalars(ns, C, P, devices, hos
         # runs may take different forms for the same call once one of them stores a virtual buffer in front of it, so 1e-13 there)
         same = (lambda a, b: a == b) if P < 8192 else (lambda a, b: abs(a - b) <= 1e-13 * abs(b))
         assert same(t.Lk(None), t0.Lk(None))
-        # (tools/gpu_fuzz_virtual.sh runs this test over more seeds and longer streams: PHYHIP_FUZZ_SEED / PHYHIP_FUZZ_ITERS)
+        # (docs/history/tools/gpu_fuzz_virtual.sh runs this test over more seeds and longer streams: PHYHIP_FUZZ_SEED / PHYHIP_FUZZ_ITERS)
         rng = np.random.default_rng(int(os.environ.get("PHYHIP_FUZZ_SEED", "17")))
         internal = [e for e in range(t.ne) if ot.el[e] >= ot.n and ot.er[e] >= ot.n]
         keys = list(ot.plk)

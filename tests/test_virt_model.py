@@ -42,8 +42,8 @@ def model(tmp_path_factory):
     return d, obj, exe
 
 
-def run(exe, seed, events, tips, soa):
-    return subprocess.run([exe, str(seed), str(events), str(tips), str(soa)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+def run(exe, seed, events, tips, soa, in_step=1):
+    return subprocess.run([exe, str(seed), str(events), str(tips), str(soa), str(in_step)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                           timeout=300)
 
 
@@ -58,6 +58,55 @@ def test_rewritten_queues_keep_the_plain_semantics(model, soa):
         f = r.stdout.split(":")[1].split(",")
         launches, skipped, in_step = (int(x.split()[0]) for x in f[:3])
         assert launches > 1000 and skipped > 50 and in_step > 100, r.stdout
+
+
+def test_without_in_step_children(model):
+    """Every virtual child re-issued as a non-storing step of its own (the diag build's PHYHIP_VIRT_INLINE=0): two such steps in
+    front of the last reader of an odd list put the first of them three steps behind the list's padding re-run."""
+    _, _, exe = model
+    for seed, tips in ((11, 12), (12, 6), (13, 20)):
+        r = run(exe, seed, 3000, tips, 1, in_step=0)
+        assert r.returncode == 0 and "VIRT_MODEL OK" in r.stdout, (seed, tips, r.stdout[-300:], r.stderr[-600:])
+        assert int(r.stdout.split(",")[-1].split()[0]) > 100, r.stdout  # odd lists did occur
+
+
+def _variant(model, name, edit):
+    """the bookkeeping functions of phyhip_queue.hip with `edit` applied, linked in front of the library"""
+    d, obj, _ = model
+    src = open(os.path.join(CSRC, "phyhip_queue.hip")).read()
+    end = src.index("\n// Host-computed matrices queued")
+    head = src[:end].replace('#include "phyhip_host.hpp"', '#include "%s"' % os.path.join(CSRC, "phyhip_host.hpp")) + "\n}\n"
+    text = edit(head)
+    p = os.path.join(d, name + ".hip")
+    open(p, "w").write(text)
+    o = os.path.join(d, name + ".o")
+    compile_host(p, o, d)
+    exe = os.path.join(d, "vm_" + name)
+    link([obj, o], exe, d)
+    return exe
+
+
+def test_the_model_sees_the_unstored_child_of_a_padded_list(model):
+    """Control: the rewriting WITHOUT the statement that stores the first of two re-issued children of an odd list's last reader."""
+    def edit(head):
+        fix = "      d1.pad &= ~kOpNoStore;\n"
+        assert fix in head
+        return head.replace(fix, "")
+    exe = _variant(model, "pad_defect", edit)
+    runs = [run(exe, seed, 3000, 12, 1, in_step=0) for seed in (11, 12, 13)]
+    assert sum(r.returncode != 0 and "re-run of an odd list" in r.stderr for r in runs) >= 2, [(r.stdout[-200:], r.stderr[-200:]) for r in runs]
+
+
+def test_the_model_sees_a_reader_left_virtual(model):
+    """Control: devirtualise() without the keep-real request (round 5's second defect: a long queue that rewrites the buffer with a
+    tip x tip operation left it virtual again under the reader that was about to copy it from memory)."""
+    def edit(head):
+        keep = "    I->keep_real_flag[buf] = 1;\n    I->keep_real.push_back(buf);\n"
+        assert keep in head
+        return head.replace(keep, "")
+    exe = _variant(model, "keep_defect", edit)
+    runs = [run(exe, seed, 3000, 12, 1) for seed in (1, 2, 3)]
+    assert any(r.returncode != 0 and "VIRT_MODEL FAIL" in r.stderr for r in runs), [(r.stdout[-200:], r.stderr[-200:]) for r in runs]
 
 
 def test_the_model_sees_a_stale_definition(model):

@@ -8,7 +8,7 @@
 //   * the evaluation edge sees the plain semantics' values.
 // Matrices and tip rows change through the store-first route (devirtualise_matrix / devirtualise_tip + a launch); the snapshot
 // route of the matrix setters needs a device and is covered by tests/test_gpu_virtual.py.
-// Built and run by tests/test_virt_model.py:  virt_model <seed> <events> <tips> <soa 0|1>
+// Built and run by tests/test_virt_model.py:  virt_model <seed> <events> <tips> <soa 0|1> [in-step children 1|0]
 #include "../phyml_amd/csrc/phyhip_host.hpp"
 
 #include <cstdint>
@@ -35,7 +35,7 @@ struct Model
   std::vector<uint64_t> ref, dev;       // plain semantics / device memory per buffer
   std::vector<char>     written;        // the buffer has been the destination of a queued operation
   std::vector<DevOp>    queued;         // what the caller queued since the last launch (plain semantics are applied at launch)
-  long                  n_launch = 0, n_instep = 0, n_nostore = 0;
+  long                  n_launch = 0, n_instep = 0, n_nostore = 0, n_pad = 0;
 
   uint64_t tipval(int t) const { return H(1, (uint64_t)t, tipv[t], 0); }
   uint64_t def_value(const DevOp &d) const { return H(tipval(d.c1), tipval(d.c2), matv[d.pm1], matv[d.pm2]); }
@@ -62,7 +62,7 @@ struct Model
       }
     };
     rewrite_pending(I, ee, true);
-    I->keep_real.clear(); // (as flush_impl does)
+    keep_real_clear(I); // (as flush_impl does)
     const std::vector<DevOp> &L = I->pending;
     const bool has_inl = !I->pending_inl.empty();
     if (has_inl && I->pending_inl.size() != L.size()) die("pending_inl is not parallel to pending");
@@ -113,6 +113,31 @@ struct Model
       d2 = d1; r2 = r1; d1 = o.dest; r1 = v;
     }
     plain(queued.size());
+    if ((L.size() & 1) && L.size() >= 3)
+    { // The pipelined kernels alternate two register sets: an odd LIST (three operations or more; shorter ones travel in the kernel
+      // arguments and are not padded) runs its last operation once more, one position later -- its own result is now the newest
+      // register, the previous operation's the second, and what was two steps back is gone: read from memory
+      const size_t k = L.size() - 1;
+      const DevOp &o = L[k];
+      ++n_pad;
+      auto child = [&](int c, int bit) -> uint64_t {
+        uint64_t v;
+        if (o.pad & bit)
+        {
+          const InlineDef &d = I->pending_inl[k];
+          v = H(tipval(d.a), tipval(d.b), matv[d.pmA], matv[d.pmB]);
+        }
+        else if (c < I->tips) return tipval(c);
+        else if (c == d2) v = r2; // (the operation in front of the last one)
+        else v = dev[c];
+        if (v != cur[c]) die("the re-run of an odd list's last operation reads a stale value", c, (int)k);
+        return v;
+      };
+      const uint64_t v = H(child(o.c1, 2), child(o.c2, 4), matv[o.pm1], matv[o.pm2]);
+      if (v != cur[o.dest]) die("the re-run of an odd list's last operation computes another value", o.dest, (int)k);
+      if (!(o.pad & 1)) dev[o.dest] = v;
+      r1 = v;
+    }
     if (ee)
       for (int side : {ee->parent, ee->child})
       {
@@ -147,6 +172,7 @@ int main(int argc, char **argv)
   const unsigned seed = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
   const int      events = argc > 2 ? atoi(argv[2]) : 2000, tips = argc > 3 ? atoi(argv[3]) : 12;
   const bool     soa = argc > 4 ? atoi(argv[4]) != 0 : true;
+  const bool     in_step = argc > 5 ? atoi(argv[5]) != 0 : true; // 0: every virtual child re-issued as a step of its own (diag: PHYHIP_VIRT_INLINE=0)
   std::mt19937   rng(seed);
   auto rnd = [&](int n) { return (int)(rng() % (unsigned)n); };
 
@@ -154,9 +180,11 @@ int main(int argc, char **argv)
   I->tips = tips; I->nbuf = 3 * tips; I->nmat = 2 * tips; I->nmat_all = I->nmat + 2 * (I->nbuf - I->tips);
   I->S = soa ? 4 : 20; I->C = 4; I->soa = soa; I->perm = !soa; I->nt_groups = 2; I->prefetch_dist = 2;
   I->virt.assign(I->nbuf, 0);
+  I->keep_real_flag.assign(I->nbuf, 0);
   I->vdef.assign(I->nbuf, DevOp{0, 0, 0, 0, 0, 0});
   I->mat_in_queue.assign(I->nmat_all, 0);
   I->virt_min_ops = 3 + rnd(6);
+  I->virt_inline = in_step;
 
   Model M;
   M.I = I;
@@ -187,9 +215,12 @@ int main(int argc, char **argv)
     {
       const int dest = tips + rnd(I->nbuf - tips);
       const int kind = rnd(4);
-      if (kind == 0 || made.empty()) queue_op(dest, rnd(tips), rnd(tips));
-      else if (kind == 1) queue_op(dest, made[rnd((int)made.size())], rnd(tips));
-      else queue_op(dest, made[rnd((int)made.size())], any_child(dest));
+      // (an operation never reads its own destination: phyhip_update_partials refuses it)
+      int from = made.empty() ? -1 : made[rnd((int)made.size())];
+      if (from == dest) from = -1;
+      if (kind == 0 || from < 0) queue_op(dest, rnd(tips), rnd(tips));
+      else if (kind == 1) queue_op(dest, from, rnd(tips));
+      else queue_op(dest, from, any_child(dest));
       if (std::find(made.begin(), made.end(), dest) == made.end()) made.push_back(dest);
     }
   };
@@ -251,7 +282,7 @@ int main(int argc, char **argv)
     }
   }
   M.launch(nullptr);
-  printf("VIRT_MODEL OK seed %u: %ld launches, %llu stores skipped, %ld in-step children, %ld non-storing re-issues, %llu stored on demand\n", seed,
-         M.n_launch, (unsigned long long)I->n_virt_skipped, M.n_instep, M.n_nostore, (unsigned long long)I->n_virt_material);
+  printf("VIRT_MODEL OK seed %u: %ld launches, %llu stores skipped, %ld in-step children, %ld non-storing re-issues, %llu stored on demand, %ld odd lists re-ran their last operation\n", seed,
+         M.n_launch, (unsigned long long)I->n_virt_skipped, M.n_instep, M.n_nostore, (unsigned long long)I->n_virt_material, M.n_pad);
   return 0;
 }
