@@ -216,6 +216,11 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     const long long cus    = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     I->aa_nw = (int)std::min<long long>(kAaMaxCons, std::max<long long>(1, (ntiles + cus - 1) / cus));
     if (const char *e = diag_env("PHYHIP_AA_NW")) { const int v = atoi(e); if (v >= 1 && v <= kAaMaxCons) I->aa_nw = v; }
+    // list-form launches of alignments with at least two consumer waves per SIMD: two wave-tiles per consumer wave (phyhip_aa.hpp:
+    // one read of the A operand and one set of per-step scalar work for both) -- at most 2 x kAaMaxCons2 tiles per workgroup then
+    I->aa_nt = I->aa_nw >= 8 ? 2 : 1;
+    if (const char *e = diag_env("PHYHIP_AA_NT")) { const int v = atoi(e); if (v == 1 || v == 2) I->aa_nt = v; }
+    if (I->aa_nt == 2) I->aa_nw = std::min(I->aa_nw, 2 * kAaMaxCons2);
     I->grid_aa = (int)((ntiles + I->aa_nw - 1) / I->aa_nw);
   }
   HIPCHK(hipMalloc((void **)&I->d_tipcodes, (size_t)I->tips * I->Ppad));

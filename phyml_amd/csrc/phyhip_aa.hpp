@@ -56,6 +56,7 @@ constexpr int kAaBlock  = 320;  // doubles per wave-tile block of a partials buf
 #endif
 constexpr int kAaRing   = AA_RING;    // operations whose matrices the LDS ring holds (2 x 12.8 KB each)
 constexpr int kAaMaxCons = 15;  // consumer waves per workgroup (+ 1 loader = 16 waves = 4 per SIMD at <= 128 VGPRs)
+constexpr int kAaMaxCons2 = 7;  // ... with two wave-tiles per consumer wave (+ 1 loader = 8 waves = 2 per SIMD at <= 256 VGPRs)
 
 
 // Write matrix `mat`'s A-operand table (kAaMat doubles) from its natural [c][i][j] entries: `get(c, i, j)`.
@@ -161,8 +162,10 @@ static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUp
 // operation's children, and the consumer computes it inside the step -- exactly the step its defining operation would have
 // been (matrix columns for one-state tips, products through the matrix cores otherwise, the all-ones rule, the rescaling
 // rule) -- instead of that operation occupying a pipeline step of its own.
-template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false, bool INL = false>
-__global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+// NT (list form only): wave-tiles per consumer wave, 1 or 2 (see the consumers below): at most kAaMaxCons2 consumer waves then -- eight
+// waves per workgroup, two per SIMD, 256 registers each.
+template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false, bool INL = false, int NT = 1>
+__global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2 + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                                             const ExecRec *__restrict__ xrec,
                                                                             const double *__restrict__ afrag, int n_frag_mats,
                                                                             const uint32_t *__restrict__ tip_masks,
@@ -181,18 +184,20 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
   constexpr int NPW = 16 / CB;                          // patterns per wave-tile
   static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");
   static_assert(!INL || (!ARGS && !DBG && ABL == 0), "in-step tip x tip children: list form only");
+  static_assert(NT == 1 || (NT == 2 && !ARGS && !DBG && ABL == 0), "two wave-tiles per wave: list form only");
 
   __shared__ __attribute__((aligned(16))) double ring[kAaRing][2][kAaMat];
   // (read and written with relaxed workgroup-scope atomics: those stay plain ds_read / ds_write instructions, whereas a
   // volatile access to LDS is compiled as a flat access behind a vmcnt(0) wait)
   __shared__ int      s_ready;             // operations (+ the evaluation edge) whose matrices are in the ring
   __shared__ int      s_done[16];          // per consumer wave: operations whose matrices it has finished reading
-  __shared__ double   s_wsum[16];          // per consumer wave: its share of the workgroup's sum
+  __shared__ double   s_wsum[16];          // per wave-tile of the workgroup: its share of the workgroup's sum
   __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw   = (int)(blockDim.x >> 6) - 1; // consumer waves
+  const int tpw  = NT == 1 ? nw : q.aa_tpw;     // wave-tiles per workgroup (the same in every form of an instance: the block sums are)
   const int C    = q.C;
   const size_t ntiles = (size_t)(q.Ppad / NPW);
   // (the list form is padded to an even length by the host -- the nucleotide kernel's convention; the argument form is not)
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
 
   if (threadIdx.x < 16)
   {
-    const size_t tl = (size_t)blockIdx.x * nw + threadIdx.x;
-    s_done[threadIdx.x] = ((int)threadIdx.x < nw && tl < ntiles) ? 0 : 0x7fffffff; // absent waves never hold a slot
+    const size_t tl = (size_t)blockIdx.x * tpw + threadIdx.x * NT; // (the wave's first tile)
+    s_done[threadIdx.x] = ((int)threadIdx.x < nw && (int)threadIdx.x * NT < tpw && tl < ntiles) ? 0 : 0x7fffffff; // absent waves never hold a slot
   }
   if (threadIdx.x == 0) s_ready = 0;
   __syncthreads();
@@ -302,24 +307,44 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
   else
   {
     // ---- consumers -------------------------------------------------------------------------------------------------
-    const int       w    = wave - 1;
-    const long long tile = (long long)blockIdx.x * nw + w;
-    if (tile < (long long)ntiles)
+    // A consumer wave owns NT wave-tiles (NT = 2: the list form of alignments with enough tiles, flush_impl): every phase of a
+    // step runs for both tiles back to back -- two independent chains of loads, matrix-core accumulations and cross-lane scans
+    // for the scheduler to interleave -- and the A operand (the same for every tile) is read from the ring ONCE per k-chunk for
+    // both tiles' MFMAs; the operation records, flag tests, descriptor set-up and the ring hand-shake are per STEP, not per tile.
+    const int w = wave - 1;
+    long long tile[NT];
+    bool      tact[NT]; // the tile exists (the last wave of a workgroup with an odd number of tiles, the end of the alignment)
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+    {
+      tile[i] = (long long)blockIdx.x * tpw + w * NT + i;
+      tact[i] = (w * NT + i < tpw) && tile[i] < (long long)ntiles;
+    }
+    if (tact[0])
     {
       const int kk = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3; // state residue / MFMA block / pattern within the group
       const int c  = b % CB;                                        // this lane's rate category
       const bool idle = c >= C_;                                    // C = 3: block 3 carries nothing
-      const long long p0 = tile * NPW + (b / CB) * 4 + jj;          // < Ppad
-      const bool      pact = p0 < q.P && !idle;
       const int       tips = q.tip_count;
       const bool      cls  = q.class_axis != 0;
-      const unsigned  blk_bytes = (unsigned)((size_t)tile * kAaBlock * 8);
-      const unsigned  voff_d16 = blk_bytes + lane * 16, voff_d8 = blk_bytes + 2048 + lane * 8; // chunk pairs | chunk 4
-      // class axis (mixture classes as categories): every class has its own scale vector, [buffer][class][pattern]
-      const unsigned  voff_s = ((cls ? (unsigned)(idle ? 0 : c) * (unsigned)q.Ppad : 0u) + (unsigned)p0) * 4u;
-      const unsigned  voff_t = (unsigned)p0 * 4u; // tip rows: one allowed-state mask (32 bits) per pattern
-      // the scale word of a pattern (of a (class, pattern)) is stored by ONE lane; the others aim past the end of the buffer
-      const unsigned  voff_sst = (kk == 0 && !idle && (cls || c == 0)) ? voff_s : 0x7ffffff0u;
+      constexpr unsigned kNowhere = 0x7fff0000u; // an offset beyond every buffer: loads through it return zeros, stores are dropped
+      long long p0[NT];
+      bool      pact[NT];
+      unsigned  voff_d16[NT], voff_d8[NT], voff_s[NT], voff_t[NT], voff_sst[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+      {
+        p0[i]   = tile[i] * NPW + (b / CB) * 4 + jj; // < Ppad when the tile exists
+        pact[i] = tact[i] && p0[i] < q.P && !idle;
+        const unsigned blk_bytes = (unsigned)((size_t)tile[i] * kAaBlock * 8);
+        voff_d16[i] = tact[i] ? blk_bytes + lane * 16 : kNowhere;        // chunk pairs
+        voff_d8[i]  = tact[i] ? blk_bytes + 2048 + lane * 8 : kNowhere;  // chunk 4
+        // class axis (mixture classes as categories): every class has its own scale vector, [buffer][class][pattern]
+        voff_s[i] = tact[i] ? ((cls ? (unsigned)(idle ? 0 : c) * (unsigned)q.Ppad : 0u) + (unsigned)p0[i]) * 4u : kNowhere;
+        voff_t[i] = tact[i] ? (unsigned)p0[i] * 4u : kNowhere; // tip rows: one allowed-state mask (32 bits) per pattern
+        // the scale word of a pattern (of a (class, pattern)) is stored by ONE lane; the others aim past the end of the buffer
+        voff_sst[i] = (tact[i] && kk == 0 && !idle && (cls || c == 0)) ? voff_s[i] : kNowhere;
+      }
 
       struct Frag
       { // a lane's five k-chunk values as they come from memory
@@ -350,12 +375,17 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         __builtin_memcpy(&f.p23, &x[2], 16);
         __builtin_memcpy(&f.p4, &x[4], 8);
       };
-      auto issue_children = [&](const IssueRec &o, Raw &r) {
-        load_frag(r.a, rsrc(o.c1_data), voff_d16, voff_d8);
-        load_frag(r.b, rsrc(o.c2_data), voff_d16, voff_d8);
-        r.xa = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c1_scale), o.c1_scale.x ? voff_t : voff_s, 0, 0);
-        r.xb = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_scale), o.c2_scale.x ? voff_t : voff_s, 0, 0);
-        if constexpr (INL) r.xt = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_tip), voff_t, 0, 0); // (size 0 without such a child)
+      auto issue_children = [&](const IssueRec &o, Raw (&r)[NT]) {
+        const __amdgpu_buffer_rsrc_t d1 = rsrc(o.c1_data), d2 = rsrc(o.c2_data), g1 = rsrc(o.c1_scale), g2 = rsrc(o.c2_scale);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+        {
+          load_frag(r[i].a, d1, voff_d16[i], voff_d8[i]);
+          load_frag(r[i].b, d2, voff_d16[i], voff_d8[i]);
+          r[i].xa = __builtin_amdgcn_raw_buffer_load_b32(g1, o.c1_scale.x ? voff_t[i] : voff_s[i], 0, 0);
+          r[i].xb = __builtin_amdgcn_raw_buffer_load_b32(g2, o.c2_scale.x ? voff_t[i] : voff_s[i], 0, 0);
+          if constexpr (INL) r[i].xt = __builtin_amdgcn_raw_buffer_load_b32(rsrc(o.c2_tip), voff_t[i], 0, 0); // (size 0 without such a child)
+        }
       };
       // cross-lane helpers.  Lanes that share a (pattern, category) differ in bits 4-5 (the state residue): the two
       // half-exchange instructions of gfx950 put both partners' values side by side without an LDS round trip.
@@ -385,6 +415,42 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         }
         else if (CB == 2) v = max(v, (unsigned)__shfl_xor((int)v, 4, 64));
         return v;
+      };
+      // The rescaling test (src/avx.c:498-506) only needs the high words' order (phyhip_kernels.hpp: kHiInvTwoToLarge).  Two
+      // tiles: both maxima travel through the cross-lane scans in ONE register -- the upper 16 bits of each high word (sign,
+      // exponent, four mantissa bits: 2^-256 = 0x2FF0 there, and v < 2^-256 <=> upper16(v) < 0x2FF0 for v >= 0), compared as
+      // packed halves
+      auto scan_max = [&](unsigned (&mx)[NT]) {
+        if constexpr (NT == 2)
+        {
+          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+          auto pmax = [](unsigned x, unsigned y) {
+            us2 a, bb;
+            __builtin_memcpy(&a, &x, 4); __builtin_memcpy(&bb, &y, 4);
+            const us2 m = __builtin_elementwise_max(a, bb);
+            unsigned  r;
+            __builtin_memcpy(&r, &m, 4);
+            return r;
+          };
+          unsigned v = (mx[0] >> 16) | (mx[1] & 0xFFFF0000u), a, bb;
+          xor16_pair(v, a, bb); v = pmax(a, bb);
+          xor32_pair(v, a, bb); v = pmax(a, bb);
+          if (!cls)
+          { // (a mixture class rescales alone)
+            if (CB == 4)
+            {
+              v = pmax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false)); // row_ror:4
+              v = pmax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false)); // row_ror:8
+            }
+            else if (CB == 2) v = pmax(v, (unsigned)__shfl_xor((int)v, 4, 64));
+          }
+          mx[0] = v << 16; mx[1] = v & 0xFFFF0000u; // (back as high words: the low bits play no part in the test)
+        }
+        else
+        {
+          mx[0] = max_states(mx[0]);
+          if (!cls) mx[0] = max_cats(mx[0]);
+        }
       };
       auto sum_states = [&](double v) { // (kk0 + kk1) + (kk2 + kk3), whichever lane asks
         v += __shfl_xor(v, 16, 64);
@@ -423,6 +489,39 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         u[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a23.y, xt, u[3], 0, 0, 0);
         u[4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xt, u[4], 0, 0, 0);
       };
+      // the same for the tiles of this wave that take the product (all of them: one read of the A operand feeds every tile)
+      auto mfma_tiles = [&](const double *A, const double (&x)[NT][T], double (&u)[NT][T], const bool (&take)[NT]) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) all = all && take[i];
+        if (NT > 1 && all)
+        {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+          {
+            const v2d   *pr = reinterpret_cast<const v2d *>(A + t * kAaBlock) + lane;
+            const v2d    a01 = pr[0], a23 = pr[64];
+            const double a4  = A[t * kAaBlock + 256 + lane];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+            {
+              u[i][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01.x, x[i][t], u[i][0], 0, 0, 0);
+              u[i][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01.y, x[i][t], u[i][1], 0, 0, 0);
+              u[i][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a23.x, x[i][t], u[i][2], 0, 0, 0);
+              u[i][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a23.y, x[i][t], u[i][3], 0, 0, 0);
+              u[i][4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, x[i][t], u[i][4], 0, 0, 0);
+            }
+          }
+          return;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          if (take[i])
+          {
+#pragma unroll
+            for (int t = 0; t < T; ++t) mfma_chunk(A, t, x[i][t], u[i]);
+          }
+      };
 
       // column `state` of a table, rows 4r + kk of this lane's category: the A lane that holds P[c][4r + i][4t + k] is
       // 16k + 4b + i, so this (D) lane kk reads lane 16 (state & 3) + 4b + kk of k-chunk state >> 2
@@ -433,36 +532,49 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
         const v2d     a01 = pr[0], a23 = pr[64];
         u[0] = a01.x; u[1] = a01.y; u[2] = a23.x; u[3] = a23.y; u[4] = At[256 + la];
       };
+      auto one_state = [](unsigned m) { return __builtin_amdgcn_ballot_w64((m & (m - 1u)) != 0u) == 0; }; // every lane's mask is one state
 
       // results of the last two operations (this lane's D fragments), alternating: step k finds the result of k-1 in one set and
       // writes its own over the result of k-2 in the other (a result that stays virtual -- phyhip_host.hpp -- exists only here)
-      double   FA[T] = {0., 0., 0., 0., 0.}, FB[T] = {0., 0., 0., 0., 0.};
-      unsigned scA = 0, scB = 0;
+      double   FA[NT][T], FB[NT][T];
+      unsigned scA[NT], scB[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+      {
+#pragma unroll
+        for (int t = 0; t < T; ++t) FA[i][t] = FB[i][t] = 0.0;
+        scA[i] = scB[i] = 0;
+      }
 
       if (n_ops > 0)
       {
         const int last = n_ops - 1;
-        Raw       RA, RB;
+        Raw       RA[NT], RB[NT];
         ExecRec   cur = XR(0);
         IssueRec  nx1 = IR((1 < last) ? 1 : last);
         issue_children(IR(0), RA);
         {
-          // The loop body sees [children loads of k+1][4 result stores of k] in flight when step k+1 starts.  Four stores
-          // through a zero-sized descriptor (dropped by the hardware, but counted) give the loop entry the same shape, so
+          // The loop body sees [children loads of k+1][4 result stores of k] in flight (per tile) when step k+1 starts.  As many
+          // stores through a zero-sized descriptor (dropped by the hardware, but counted) give the loop entry the same shape, so
           // the compiler's merged s_waitcnt counts never make a step wait for the previous step's stores.
           const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
           const u32x4                  z4   = {0u, 0u, 0u, 0u};
           const u32x2                  z2   = {0u, 0u};
-          __builtin_amdgcn_raw_buffer_store_b128(z4, none, 0, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(z4, none, 1024, 0, 0); // distinct offsets: identical stores would be merged
-          __builtin_amdgcn_raw_buffer_store_b64(z2, none, 2048, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(0u, none, 4096, 0, 0);
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+          {
+            __builtin_amdgcn_raw_buffer_store_b128(z4, none, 8192 * i, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(z4, none, 8192 * i + 1024, 0, 0); // distinct offsets: identical stores would be merged
+            __builtin_amdgcn_raw_buffer_store_b64(z2, none, 8192 * i + 2048, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(0u, none, 8192 * i + 4096, 0, 0);
+          }
         }
 
-        auto step = [&](const int k, Raw &R, Raw &Rn, double (&Fout)[T], unsigned &scout, const double (&Fprev)[T], const unsigned scprev) {
+        auto step = [&](const int k, Raw (&R)[NT], Raw (&Rn)[NT], double (&Fout)[NT][T], unsigned (&scout)[NT], const double (&Fprev)[NT][T],
+                        const unsigned (&scprev)[NT]) {
           const unsigned fl = cur.dst_data.x;
-          double         x1[T], x2[T], o[T];
-          unsigned       s1, s2;
+          double         x1[NT][T], x2[NT][T], o[NT][T];
+          unsigned       s1[NT], s2[NT];
           PHY_STAMP(k, 0)
           // The loads of operation k+1 go out first (their registers were consumed by step k-1), then the records of
           // k+2 / k+1 are requested into the scalar registers the issue just freed: both have the whole step to arrive.
@@ -472,61 +584,75 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           // A tip child whose patterns all carry ONE state contributes a column of its matrix (the reference's Exex / Exin
           // kernels, src/avx.c:527-564): five values per lane straight from the ring, no product.  (Through the matrix
           // cores the result would be the same doubles -- the other 19 products are exact zeros -- at 25 MFMAs.)
-          unsigned m1 = 0, m2 = 0;
-          bool     hot1 = false, hot2 = false;
+          unsigned m1[NT], m2[NT];
+          bool     hot1[NT], hot2[NT];
           const bool in1 = INL && (fl & kOpCh1), in2 = INL && (fl & kOpCh2); // (this child is computed below, from the ring)
-          if (fl & kOpTip1)
-          {
-            m1   = R.xa ? R.xa : 1u; // (padding patterns carry no state: any column will do)
-            hot1 = __builtin_amdgcn_ballot_w64((m1 & (m1 - 1u)) != 0u) == 0;
-          }
-          if (fl & kOpTip2)
-          {
-            m2   = R.xb ? R.xb : 1u;
-            hot2 = __builtin_amdgcn_ballot_w64((m2 & (m2 - 1u)) != 0u) == 0;
-          }
-          if (in1) s1 = 0;
-          else if (fl & kOpTip1) { if (!hot1) tip_vec(m1, x1); s1 = 0; }
-          else if (fl & kOpF11)
-          {
 #pragma unroll
-            for (int t = 0; t < T; ++t) x1[t] = Fprev[t];
-            s1 = scprev;
-          }
-          else if (fl & kOpF12)
+          for (int i = 0; i < NT; ++i)
           {
+            m1[i] = m2[i] = 0; hot1[i] = hot2[i] = false;
+            if (fl & kOpTip1)
+            {
+              m1[i]   = R[i].xa ? R[i].xa : 1u; // (padding patterns carry no state: any column will do)
+              hot1[i] = one_state(m1[i]);
+            }
+            if (fl & kOpTip2)
+            {
+              m2[i]   = R[i].xb ? R[i].xb : 1u;
+              hot2[i] = one_state(m2[i]);
+            }
+            if (in1) s1[i] = 0;
+            else if (fl & kOpTip1) { if (!hot1[i]) tip_vec(m1[i], x1[i]); s1[i] = 0; }
+            else if (fl & kOpF11)
+            {
 #pragma unroll
-            for (int t = 0; t < T; ++t) x1[t] = Fout[t];
-            s1 = scout;
-          }
-          else { unpack(R.a, x1); s1 = R.xa; }
-          if (in2) s2 = 0;
-          else if (fl & kOpTip2) { if (!hot2) tip_vec(m2, x2); s2 = 0; }
-          else if (fl & kOpF21)
-          {
+              for (int t = 0; t < T; ++t) x1[i][t] = Fprev[i][t];
+              s1[i] = scprev[i];
+            }
+            else if (fl & kOpF12)
+            {
 #pragma unroll
-            for (int t = 0; t < T; ++t) x2[t] = Fprev[t];
-            s2 = scprev;
-          }
-          else if (fl & kOpF22)
-          {
+              for (int t = 0; t < T; ++t) x1[i][t] = Fout[i][t];
+              s1[i] = scout[i];
+            }
+            else { unpack(R[i].a, x1[i]); s1[i] = R[i].xa; }
+            if (in2) s2[i] = 0;
+            else if (fl & kOpTip2) { if (!hot2[i]) tip_vec(m2[i], x2[i]); s2[i] = 0; }
+            else if (fl & kOpF21)
+            {
 #pragma unroll
-            for (int t = 0; t < T; ++t) x2[t] = Fout[t];
-            s2 = scout;
+              for (int t = 0; t < T; ++t) x2[i][t] = Fprev[i][t];
+              s2[i] = scprev[i];
+            }
+            else if (fl & kOpF22)
+            {
+#pragma unroll
+              for (int t = 0; t < T; ++t) x2[i][t] = Fout[i][t];
+              s2[i] = scout[i];
+            }
+            else { unpack(R[i].b, x2[i]); s2[i] = R[i].xb; }
           }
-          else { unpack(R.b, x2); s2 = R.xb; }
           PHY_STAMP(k, 1)
           // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587 (never with a one-state tip)
-          unsigned ones = 0;
-          auto all_ones = [&]() {
-            ones = 1;
+          unsigned ones[NT];
+          auto all_ones = [&](int i) {
+            ones[i] = 1;
 #pragma unroll
-            for (int t = 0; t < T; ++t) ones &= (unsigned)((x1[t] == 1.0) & (x2[t] == 1.0));
-            if (!(ABL & 16)) ones = and_states(ones);
+            for (int t = 0; t < T; ++t) ones[i] &= (unsigned)((x1[i][t] == 1.0) & (x2[i][t] == 1.0));
+            if (!(ABL & 16)) ones[i] = and_states(ones[i]);
           };
-          if (!hot1 && !hot2 && !in1 && !in2) all_ones();
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+          {
+            ones[i] = 0;
+            if (!hot1[i] && !hot2[i] && !in1 && !in2) all_ones(i);
+          }
           PHY_STAMP(k, 2)
-          double u1[T] = {0., 0., 0., 0., 0.}, u2[T] = {0., 0., 0., 0., 0.};
+          double u1[NT][T], u2[NT][T];
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int t = 0; t < T; ++t) u1[i][t] = u2[i][t] = 0.0;
           {
             const double *A = wait_item(k, (int)cur.dst_scale.x);
             PHY_STAMP(k, 3)
@@ -534,111 +660,146 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
             {
               if (in1 || in2)
               { // the in-step child: the step of its defining operation (tips a, b through tables 2 and 3 of this item)
-                const unsigned ma = (in1 ? R.xa : R.xb) ? (in1 ? R.xa : R.xb) : 1u, mb = R.xt ? R.xt : 1u;
-                const bool     hota = __builtin_amdgcn_ballot_w64((ma & (ma - 1u)) != 0u) == 0;
-                const bool     hotb = __builtin_amdgcn_ballot_w64((mb & (mb - 1u)) != 0u) == 0;
-                double         ua[T] = {0., 0., 0., 0., 0.}, ub[T] = {0., 0., 0., 0., 0.}, va[T], vb[T];
-                if (hota) tip_column(A + 2 * kAaMat, ma, ua);
-                else
+                // (one child after the other: its tip vector is dead once its products are issued; what the all-ones rule needs of
+                // it is one bit per lane)
+                bool     hota[NT], hotb[NT], tk[NT];
+                unsigned onesab[NT];
+                double   ua[NT][T], ub[NT][T];
                 {
-                  tip_vec(ma, va);
+                  double va[NT][T];
 #pragma unroll
-                  for (int t = 0; t < T; ++t) mfma_chunk(A + 2 * kAaMat, t, va[t], ua);
+                  for (int i = 0; i < NT; ++i)
+                  {
+                    const unsigned ma = (in1 ? R[i].xa : R[i].xb) ? (in1 ? R[i].xa : R[i].xb) : 1u;
+                    hota[i] = one_state(ma); tk[i] = !hota[i]; onesab[i] = 1;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) ua[i][t] = 0.0;
+                    if (hota[i]) tip_column(A + 2 * kAaMat, ma, ua[i]);
+                    else
+                    {
+                      tip_vec(ma, va[i]);
+#pragma unroll
+                      for (int t = 0; t < T; ++t) onesab[i] &= (unsigned)(va[i][t] == 1.0);
+                    }
+                  }
+                  mfma_tiles(A + 2 * kAaMat, va, ua, tk);
                 }
-                if (hotb) tip_column(A + 3 * kAaMat, mb, ub);
-                else
                 {
-                  tip_vec(mb, vb);
+                  double vb[NT][T];
 #pragma unroll
-                  for (int t = 0; t < T; ++t) mfma_chunk(A + 3 * kAaMat, t, vb[t], ub);
+                  for (int i = 0; i < NT; ++i)
+                  {
+                    const unsigned mb = R[i].xt ? R[i].xt : 1u;
+                    hotb[i] = one_state(mb); tk[i] = !hotb[i];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) ub[i][t] = 0.0;
+                    if (hotb[i]) tip_column(A + 3 * kAaMat, mb, ub[i]);
+                    else
+                    {
+                      tip_vec(mb, vb[i]);
+#pragma unroll
+                      for (int t = 0; t < T; ++t) onesab[i] &= (unsigned)(vb[i][t] == 1.0);
+                    }
+                  }
+                  mfma_tiles(A + 3 * kAaMat, vb, ub, tk);
                 }
-                unsigned cones = 0;
-                if (!hota && !hotb)
+                unsigned cm[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
                 {
-                  cones = 1;
+                  const unsigned cones = (!hota[i] && !hotb[i]) ? and_states(onesab[i]) : 0u;
+                  double (&xc)[T] = in1 ? x1[i] : x2[i];
+                  cm[i] = 0;
 #pragma unroll
-                  for (int t = 0; t < T; ++t) cones &= (unsigned)((va[t] == 1.0) & (vb[t] == 1.0));
-                  cones = and_states(cones);
+                  for (int t = 0; t < T; ++t)
+                  {
+                    xc[t] = cones ? 1.0 : ua[i][t] * ub[i][t];
+                    cm[i] = max(cm[i], hi32(xc[t]));
+                  }
+                  if (C_ == 3 && idle) cm[i] = 0;
                 }
-                double  (&xc)[T] = in1 ? x1 : x2;
-                unsigned cm = 0;
+                scan_max(cm);
 #pragma unroll
-                for (int t = 0; t < T; ++t)
+                for (int i = 0; i < NT; ++i)
                 {
-                  xc[t] = cones ? 1.0 : ua[t] * ub[t];
-                  cm    = max(cm, hi32(xc[t]));
-                }
-                if (C_ == 3 && idle) cm = 0;
-                cm = max_states(cm);
-                if (!cls) cm = max_cats(cm);
-                unsigned csc = 0;
-                if (cm < kHiInvTwoToLarge && q.apply_scaling)
-                {
+                  double (&xc)[T] = in1 ? x1[i] : x2[i];
+                  unsigned csc = 0;
+                  if (cm[i] < kHiInvTwoToLarge && q.apply_scaling)
+                  {
 #pragma unroll
-                  for (int t = 0; t < T; ++t) xc[t] *= kTwoToLarge;
-                  csc = kLarge;
+                    for (int t = 0; t < T; ++t) xc[t] *= kTwoToLarge;
+                    csc = kLarge;
+                  }
+                  if (in1) s1[i] = csc; else s2[i] = csc;
+                  if (!hot1[i] && !hot2[i]) all_ones(i); // (the operation's own all-ones test, now that both children are there)
                 }
-                if (in1) s1 = csc; else s2 = csc;
-                if (!hot1 && !hot2) all_ones(); // (the operation's own all-ones test, now that both children are there)
               }
             }
             if (ABL & 1)
             {
 #pragma unroll
-              for (int t = 0; t < T; ++t) { u1[t] = x1[t]; u2[t] = x2[t]; }
+              for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int t = 0; t < T; ++t) { u1[i][t] = x1[i][t]; u2[i][t] = x2[i][t]; }
             }
             else
             {
-              if (hot1) tip_column(A, m1, u1);
-              else
-              {
+              bool tk[NT];
 #pragma unroll
-                for (int t = 0; t < T; ++t) mfma_chunk(A, t, x1[t], u1);
-              }
-              if (hot2) tip_column(A + kAaMat, m2, u2);
-              else
+              for (int i = 0; i < NT; ++i)
               {
-#pragma unroll
-                for (int t = 0; t < T; ++t) mfma_chunk(A + kAaMat, t, x2[t], u2);
+                tk[i] = !hot1[i];
+                if (hot1[i]) tip_column(A, m1[i], u1[i]);
               }
+              mfma_tiles(A, x1, u1, tk);
+#pragma unroll
+              for (int i = 0; i < NT; ++i)
+              {
+                tk[i] = !hot2[i];
+                if (hot2[i]) tip_column(A + kAaMat, m2[i], u2[i]);
+              }
+              mfma_tiles(A + kAaMat, x2, u2, tk);
             }
             release_item(k);
           }
           PHY_STAMP(k, 4)
-          unsigned mxh = 0;
+          unsigned mxh[NT];
 #pragma unroll
-          for (int t = 0; t < T; ++t)
+          for (int i = 0; i < NT; ++i)
           {
-            o[t] = ones ? 1.0 : u1[t] * u2[t];
-            mxh  = max(mxh, hi32(o[t]));
+            mxh[i] = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+            {
+              o[i][t] = ones[i] ? 1.0 : u1[i][t] * u2[i][t];
+              mxh[i]  = max(mxh[i], hi32(o[i][t]));
+            }
+            if (C_ == 3 && idle) mxh[i] = 0;
           }
-          if (C_ == 3 && idle) mxh = 0;
-          if (!(ABL & 2))
-          {
-            mxh = max_states(mxh);
-            if (!cls) mxh = max_cats(mxh); // a mixture class rescales alone
-          }
+          if (!(ABL & 2)) scan_max(mxh);
           PHY_STAMP(k, 5)
-          unsigned sc = s1 + s2; // src/avx.c:462-464
-          if (mxh < kHiInvTwoToLarge && q.apply_scaling)
-          { // src/avx.c:504-510
+          const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
 #pragma unroll
-            for (int t = 0; t < T; ++t) o[t] *= kTwoToLarge;
-            sc += kLarge;
-          }
+          for (int i = 0; i < NT; ++i)
           {
-            const __amdgpu_buffer_rsrc_t dr = rsrc(cur.dst_data), gr = rsrc(cur.dst_scale);
+            unsigned sc = s1[i] + s2[i]; // src/avx.c:462-464
+            if (mxh[i] < kHiInvTwoToLarge && q.apply_scaling)
+            { // src/avx.c:504-510
+#pragma unroll
+              for (int t = 0; t < T; ++t) o[i][t] *= kTwoToLarge;
+              sc += kLarge;
+            }
             Frag wv;
-            pack(o, wv);
-            __builtin_amdgcn_raw_buffer_store_b128(wv.p01, dr, voff_d16, 0, PHYHIP_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(wv.p23, dr, voff_d16 + 1024, 0, PHYHIP_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b64(wv.p4, dr, voff_d8, 0, PHYHIP_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_sst, 0, 0);
+            pack(o[i], wv);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p01, dr, voff_d16[i], 0, PHYHIP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p23, dr, voff_d16[i] + 1024, 0, PHYHIP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(wv.p4, dr, voff_d8[i], 0, PHYHIP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_sst[i], 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) Fout[i][t] = o[i][t];
+            scout[i] = sc;
           }
           PHY_STAMP(k, 6)
-#pragma unroll
-          for (int t = 0; t < T; ++t) Fout[t] = o[t];
-          scout = sc;
           cur   = nxe;
           nx1   = nx2;
         };
@@ -649,8 +810,12 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
           else
           { // the evaluation below expects the last result in the second set
 #pragma unroll
-            for (int t = 0; t < T; ++t) FB[t] = FA[t];
-            scB = scA;
+            for (int i = 0; i < NT; ++i)
+            {
+#pragma unroll
+              for (int t = 0; t < T; ++t) FB[i][t] = FA[i][t];
+              scB[i] = scA[i];
+            }
           }
         }
         else
@@ -666,94 +831,111 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
       if (q.edge_eval)
       {
         // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861) -------------------------------
-        double contrib = 0.0;
-        double   x[T], y[T], u[T] = {0., 0., 0., 0., 0.};
-        unsigned sl, sr;
-        auto side = [&](int idx, double (&v)[T], unsigned &sc) {
-          if (idx < tips)
+        double   x[NT][T], y[NT][T], u[NT][T];
+        unsigned sl[NT], sr[NT];
+        bool     tk[NT];
+        auto side = [&](int i, int idx, double (&v)[T], unsigned &sc) {
+          if (!tact[i])
           {
-            tip_vec(tip_masks[(size_t)idx * q.Ppad + p0], v);
+#pragma unroll
+            for (int t = 0; t < T; ++t) v[t] = 0.0;
+            sc = 0;
+          }
+          else if (idx < tips)
+          {
+            tip_vec(tip_masks[(size_t)idx * q.Ppad + p0[i]], v);
             sc = 0;
           }
           else if (idx == q.last_dest)
           {
 #pragma unroll
-            for (int t = 0; t < T; ++t) v[t] = FB[t];
-            sc = scB;
+            for (int t = 0; t < T; ++t) v[t] = FB[i][t];
+            sc = scB[i];
           }
           else
           {
-            const double *src = q.partials + (size_t)(idx - tips) * (ntiles * kAaBlock) + (size_t)tile * kAaBlock;
+            const double *src = q.partials + (size_t)(idx - tips) * (ntiles * kAaBlock) + (size_t)tile[i] * kAaBlock;
 #pragma unroll
             for (int t = 0; t < T; ++t) v[t] = src[aa_slot(t, lane)];
-            sc = (unsigned)q.scales[(size_t)(idx - tips) * (cls ? C : 1) * q.Ppad + voff_s / 4];
+            sc = (unsigned)q.scales[(size_t)(idx - tips) * (cls ? C : 1) * q.Ppad + voff_s[i] / 4];
           }
         };
-        side(q.e_parent, x, sl);
-        side(q.e_child, y, sr);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+        {
+          side(i, q.e_parent, x[i], sl[i]);
+          side(i, q.e_child, y[i], sr[i]);
+          tk[i] = true;
+#pragma unroll
+          for (int t = 0; t < T; ++t) u[i][t] = 0.0;
+        }
         {
           const double *A = wait_item(n_ops, q.aa_e_slot);
-#pragma unroll
-          for (int t = 0; t < T; ++t) mfma_chunk(A, t, x[t], u); // rows: right-side state
+          mfma_tiles(A, x, u, tk); // rows: right-side state
           release_item(n_ops);
         }
         const double *pi_c = q.pi + ((cls && !idle) ? c * 20 : 0);
-        double part = 0.0;
 #pragma unroll
-        for (int t = 0; t < T; ++t) part += u[t] * (y[t] * pi_c[4 * t + kk]);
-        const double lkc = sum_states(part);
-        if (pact && kk == 0 && q.site_cat) q.site_cat[(size_t)p0 * C + c] = lkc;
-        if (cls)
-        { // per class: its likelihood (above) and its scale exponent; the mixture is combined by class_combine_kernel
-          if (pact && kk == 0) q.fact[(size_t)c * q.P + p0] = q.apply_scaling ? (int)(sl + sr) : 0;
-        }
-        else
+        for (int i = 0; i < NT; ++i)
         {
-          // the categories of this lane's pattern, in category order (src/lk.c:816-818)
-          double site = 0.0;
+          double contrib = 0.0;
+          double part = 0.0;
 #pragma unroll
-          for (int cc = 0; cc < C_; ++cc) site += __shfl(lkc, (lane & ~(3 << 2)) | (((b / CB) * CB + cc) << 2), 64) * q.cat_w[cc];
-          if (pact && kk == 0 && c == 0)
-          {
-            const double wt = q.wght[p0];
-            int          f  = q.apply_scaling ? (int)(sl + sr) : 0;
-            if (wt > kSmall)
-            {
-              if (q.invar_model)
-              { // src/lk.c:820-842, 1226-1273
-                const int iv  = q.invar[p0];
-                double    inv = 0.0;
-                bool      issue_ = false;
-                if (iv >= 0)
-                {
-                  inv = q.pi[iv];
-                  if (q.apply_scaling)
-                  {
-                    int e = f;
-                    do
-                    {
-                      const int piece = e < 63 ? e : 63;
-                      inv *= (double)(1ull << piece);
-                      e -= piece;
-                    } while (e != 0);
-                  }
-                  issue_ = isinf(inv);
-                }
-                if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
-                else site = site * (1. - q.pinvar) + inv * q.pinvar;
-              }
-              if (site < kSmall) { site = kSmall; raise_warn(q); }
-              const double lsl = log(site) - kLog2 * (double)f;
-              if (q.site_lnl) q.site_lnl[p0] = lsl;
-              if (q.site_lk) q.site_lk[p0] = exp(lsl);
-              contrib = wt * lsl;
-            }
-            q.fact[p0] = f;
+          for (int t = 0; t < T; ++t) part += u[i][t] * (y[i][t] * pi_c[4 * t + kk]);
+          const double lkc = sum_states(part);
+          if (pact[i] && kk == 0 && q.site_cat) q.site_cat[(size_t)p0[i] * C + c] = lkc;
+          if (cls)
+          { // per class: its likelihood (above) and its scale exponent; the mixture is combined by class_combine_kernel
+            if (pact[i] && kk == 0) q.fact[(size_t)c * q.P + p0[i]] = q.apply_scaling ? (int)(sl[i] + sr[i]) : 0;
           }
-          // this wave's share: fixed shuffle tree -> deterministic
+          else
+          {
+            // the categories of this lane's pattern, in category order (src/lk.c:816-818)
+            double site = 0.0;
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
-          if (lane == 0) s_wsum[w] = contrib;
+            for (int cc = 0; cc < C_; ++cc) site += __shfl(lkc, (lane & ~(3 << 2)) | (((b / CB) * CB + cc) << 2), 64) * q.cat_w[cc];
+            if (pact[i] && kk == 0 && c == 0)
+            {
+              const double wt = q.wght[p0[i]];
+              int          f  = q.apply_scaling ? (int)(sl[i] + sr[i]) : 0;
+              if (wt > kSmall)
+              {
+                if (q.invar_model)
+                { // src/lk.c:820-842, 1226-1273
+                  const int iv  = q.invar[p0[i]];
+                  double    inv = 0.0;
+                  bool      issue_ = false;
+                  if (iv >= 0)
+                  {
+                    inv = q.pi[iv];
+                    if (q.apply_scaling)
+                    {
+                      int e = f;
+                      do
+                      {
+                        const int piece = e < 63 ? e : 63;
+                        inv *= (double)(1ull << piece);
+                        e -= piece;
+                      } while (e != 0);
+                    }
+                    issue_ = isinf(inv);
+                  }
+                  if (issue_) { f = 0; site = q.pi[iv] * q.pinvar; }
+                  else site = site * (1. - q.pinvar) + inv * q.pinvar;
+                }
+                if (site < kSmall) { site = kSmall; raise_warn(q); }
+                const double lsl = log(site) - kLog2 * (double)f;
+                if (q.site_lnl) q.site_lnl[p0[i]] = lsl;
+                if (q.site_lk) q.site_lk[p0[i]] = exp(lsl);
+                contrib = wt * lsl;
+              }
+              q.fact[p0[i]] = f;
+            }
+            // this TILE's share: fixed shuffle tree -> deterministic, and the same double whichever wave shape computed it
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+            if (lane == 0 && w * NT + i < 16) s_wsum[w * NT + i] = contrib;
+          }
         }
         if (q.fence_post) __threadfence(); // every wave's stores are in memory before the workgroup's sum is posted
       }
@@ -772,8 +954,8 @@ __global__ __launch_bounds__(64 * (kAaMaxCons + 1)) void traverse_aa_kernel(cons
   if (wave == 0)
   { // the consumers' shares in wave order
     double tot = 0.0;
-    for (int i = 0; i < nw; ++i)
-      if ((size_t)blockIdx.x * nw + i < ntiles) tot += s_wsum[i];
+    for (int i = 0; i < tpw; ++i)
+      if ((size_t)blockIdx.x * tpw + i < ntiles) tot += s_wsum[i];
     publish_block_sum(q, tot, lane);
   }
 }

@@ -178,7 +178,8 @@ struct Instance
   bool        generic_loop = false; // PHYHIP_FLAG_GENERIC_LOOP: the reference's generic loop (`--cov`): plain kernel, no all-ones shortcut
   int         NE = 1;          // eigen systems / frequency vectors held: C with the class axis, else 1
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
-  int         aa_nw = 1;               // 20 states: consumer waves (= wave-tiles) per workgroup of traverse_aa_kernel
+  int         aa_nw = 1;               // 20 states: wave-tiles per workgroup of traverse_aa_kernel (= its consumer waves in the one-tile-per-wave forms)
+  int         aa_nt = 1;               // ... wave-tiles per consumer wave in list-form launches (2: alignments with enough tiles)
   bool        soa = false;     // 4-state buffers pattern-minor, lane-per-pattern kernel (phyhip_nt2.hpp)
   int         grid_nt2 = 0;
   int         nt_groups = 1; // lanes per pattern in the lane-per-pattern nucleotide kernel

@@ -163,6 +163,7 @@ struct TreeParams
   // 20-state kernel, lists with in-step tip x tip children (traverse_aa_kernel<..., INL>): where the evaluation edge's matrix
   // tables sit in the LDS ring (first table slot) and how many items must have been released before they may be written
   int             aa_e_slot, aa_e_need;
+  int             aa_tpw;   // wave-tiles per workgroup (traverse_aa_kernel with two tiles per consumer wave)
 };
 
 constexpr int kBigGroupWgs = 256; // workgroups of the large-grid resident evaluator when it adds per workgroup (phyhip_big.hpp)

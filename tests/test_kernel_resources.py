@@ -75,11 +75,15 @@ def test_default_traversal_kernels_keep_their_occupancy(product):
         n = f"_ZN6phyhip25traverse_nt2_mixed_kernelILi4ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdPKhi"
         assert waves_per_simd(product[n]["vgpr_count"]) >= 2 and product[n]["private_segment_fixed_size"] == 0, (n, product[n])
     # the 20-state kernel: 1 loader + 15 consumer waves per workgroup = four per SIMD
-    # (<C, DBG, ABL, ARGS, INL>: list form, argument form, and the list form with in-step tip x tip children)
+    # (<C, DBG, ABL, ARGS, INL, NT>: list form, argument form, and the list form with in-step tip x tip children) ...
     for c in (1, 2, 3, 4):
         for args, inl in ((0, 0), (1, 0), (0, 1)):
-            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb{args}ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
+            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb{args}ELb{inl}ELi1EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
             assert product[n]["vgpr_count"] <= 128, (n, product[n]["vgpr_count"])
+        # ... and the list forms with two wave-tiles per consumer wave: 1 loader + 7 consumers = two per SIMD
+        for inl in (0, 1):
+            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb0ELb{inl}ELi2EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
+            assert product[n]["vgpr_count"] <= 256 and product[n]["private_segment_fixed_size"] == 0, (n, product[n])
 
 
 def test_large_grid_resident_kernel_fits_its_waves(product):
