@@ -216,9 +216,16 @@ static int build_instance(Instance *I, const hipDeviceProp_t &prop)
     const long long cus    = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     I->aa_nw = (int)std::min<long long>(kAaMaxCons, std::max<long long>(1, (ntiles + cus - 1) / cus));
     if (const char *e = diag_env("PHYHIP_AA_NW")) { const int v = atoi(e); if (v >= 1 && v <= kAaMaxCons) I->aa_nw = v; }
-    // list-form launches of alignments with at least two consumer waves per SIMD: two wave-tiles per consumer wave (phyhip_aa.hpp:
-    // one read of the A operand and one set of per-step scalar work for both) -- at most 2 x kAaMaxCons2 tiles per workgroup then
-    I->aa_nt = I->aa_nw >= 8 ? 2 : 1;
+    // (diag build, PHYHIP_AA_NT=2: list-form launches with two wave-tiles per consumer wave -- phyhip_aa.hpp: one read of the A
+    // operand and one set of per-step scalar work for both, at most 2 x kAaMaxCons2 tiles per workgroup.  Built on the round-5
+    // verdict's advice and measured: slower, cfg3 432-435 against 368-378 us, 100 000 patterns 3.25 against 3.05-3.10 ms
+    // (profiles/r06_aa_kernel.md) -- five two-tile consumers per CU put four tile-steps on one SIMD where ten one-tile consumers
+    // put three)
+    // (diag build, PHYHIP_AA_D2=1: list-form launches of workgroups with at most kAaMaxConsD2 consumer waves request their children
+    // two operations ahead -- measured: no change, cfg3 366-377 us either way)
+    I->aa_d2 = false;
+    if (const char *e = diag_env("PHYHIP_AA_D2")) I->aa_d2 = atoi(e) != 0 && I->aa_nw <= kAaMaxConsD2;
+    I->aa_nt = 1;
     if (const char *e = diag_env("PHYHIP_AA_NT")) { const int v = atoi(e); if (v == 1 || v == 2) I->aa_nt = v; }
     if (I->aa_nt == 2) I->aa_nw = std::min(I->aa_nw, 2 * kAaMaxCons2);
     I->grid_aa = (int)((ntiles + I->aa_nw - 1) / I->aa_nw);

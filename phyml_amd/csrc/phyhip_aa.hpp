@@ -55,7 +55,11 @@ constexpr int kAaBlock  = 320;  // doubles per wave-tile block of a partials buf
 #define AA_RING 4
 #endif
 constexpr int kAaRing   = AA_RING;    // operations whose matrices the LDS ring holds (2 x 12.8 KB each)
-constexpr int kAaMaxCons = 15;  // consumer waves per workgroup (+ 1 loader = 16 waves = 4 per SIMD at <= 128 VGPRs)
+#ifndef AA_MAXCONS
+#define AA_MAXCONS 15
+#endif
+constexpr int kAaMaxCons = AA_MAXCONS;  // consumer waves per workgroup (+ 1 loader = 16 waves = 4 per SIMD at <= 128 VGPRs)
+constexpr int kAaMaxConsD2 = 11; // ... of the form that loads two operations ahead (+ 1 loader = 12 waves = 3 per SIMD at <= 168 VGPRs)
 constexpr int kAaMaxCons2 = 7;  // ... with two wave-tiles per consumer wave (+ 1 loader = 8 waves = 2 per SIMD at <= 256 VGPRs)
 
 
@@ -164,8 +168,12 @@ static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUp
 // rule) -- instead of that operation occupying a pipeline step of its own.
 // NT (list form only): wave-tiles per consumer wave, 1 or 2 (see the consumers below): at most kAaMaxCons2 consumer waves then -- eight
 // waves per workgroup, two per SIMD, 256 registers each.
-template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false, bool INL = false, int NT = 1>
-__global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2 + 1)) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+// D2 (list form only): the children of operation k + 2 are requested during step k, as soon as step k has taken its own operands
+// out of the registers they arrived in (the default requests operation k + 1's at the top of step k): a load has two steps to
+// arrive instead of one -- for alignments whose workgroups hold at most kAaMaxConsD2 consumer waves (three waves per SIMD: the
+// operands' second copy needs ~150 registers), where a step is too short to cover a trip to memory under load.
+template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false, bool INL = false, int NT = 1, bool D2 = false>
+__global__ __launch_bounds__(NT == 2 ? 64 * (kAaMaxCons2 + 1) : (D2 ? 64 * (kAaMaxConsD2 + 1) : 64 * (kAaMaxCons + 1))) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
                                                                             const ExecRec *__restrict__ xrec,
                                                                             const double *__restrict__ afrag, int n_frag_mats,
                                                                             const uint32_t *__restrict__ tip_masks,
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
   static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");
   static_assert(!INL || (!ARGS && !DBG && ABL == 0), "in-step tip x tip children: list form only");
   static_assert(NT == 1 || (NT == 2 && !ARGS && !DBG && ABL == 0), "two wave-tiles per wave: list form only");
+  static_assert(!D2 || (!ARGS && !DBG && ABL == 0), "loads two operations ahead: list form only");
 
   __shared__ __attribute__((aligned(16))) double ring[kAaRing][2][kAaMat];
   // (read and written with relaxed workgroup-scope atomics: those stay plain ds_read / ds_write instructions, whereas a
@@ -518,8 +527,29 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
         for (int i = 0; i < NT; ++i)
           if (take[i])
           {
+#ifdef AA_DEEP
+            // (experiment: every A value of the child requested before the first product)
+            v2d    a01[T], a23[T];
+            double a4[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+            {
+              const v2d *pr = reinterpret_cast<const v2d *>(A + t * kAaBlock) + lane;
+              a01[t] = pr[0]; a23[t] = pr[64]; a4[t] = A[t * kAaBlock + 256 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+            {
+              u[i][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01[t].x, x[i][t], u[i][0], 0, 0, 0);
+              u[i][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a01[t].y, x[i][t], u[i][1], 0, 0, 0);
+              u[i][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a23[t].x, x[i][t], u[i][2], 0, 0, 0);
+              u[i][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a23[t].y, x[i][t], u[i][3], 0, 0, 0);
+              u[i][4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[t], x[i][t], u[i][4], 0, 0, 0);
+            }
+#else
 #pragma unroll
             for (int t = 0; t < T; ++t) mfma_chunk(A, t, x[i][t], u[i]);
+#endif
           }
       };
 
@@ -553,6 +583,7 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
         ExecRec   cur = XR(0);
         IssueRec  nx1 = IR((1 < last) ? 1 : last);
         issue_children(IR(0), RA);
+        if constexpr (D2) issue_children(nx1, RB);
         {
           // The loop body sees [children loads of k+1][4 result stores of k] in flight (per tile) when step k+1 starts.  As many
           // stores through a zero-sized descriptor (dropped by the hardware, but counted) give the loop entry the same shape, so
@@ -578,9 +609,14 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
           PHY_STAMP(k, 0)
           // The loads of operation k+1 go out first (their registers were consumed by step k-1), then the records of
           // k+2 / k+1 are requested into the scalar registers the issue just freed: both have the whole step to arrive.
-          if (!ARGS || k < last) issue_children(nx1, Rn);
+          // (D2: the records first; the loads of operation k + 2 follow below, into the registers this step's operands arrived in)
+          if constexpr (!D2)
+            if (!ARGS || k < last) issue_children(nx1, Rn);
           const IssueRec nx2 = IR((k + 2 < last) ? k + 2 : last);
           const ExecRec  nxe = XR((k + 1 < last) ? k + 1 : last);
+          unsigned xa[NT], xb[NT], xt[NT]; // this step's auxiliary words (the register set is handed on below)
+#pragma unroll
+          for (int i = 0; i < NT; ++i) { xa[i] = R[i].xa; xb[i] = R[i].xb; xt[i] = INL ? R[i].xt : 0u; }
           // A tip child whose patterns all carry ONE state contributes a column of its matrix (the reference's Exex / Exin
           // kernels, src/avx.c:527-564): five values per lane straight from the ring, no product.  (Through the matrix
           // cores the result would be the same doubles -- the other 19 products are exact zeros -- at 25 MFMAs.)
@@ -593,12 +629,12 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
             m1[i] = m2[i] = 0; hot1[i] = hot2[i] = false;
             if (fl & kOpTip1)
             {
-              m1[i]   = R[i].xa ? R[i].xa : 1u; // (padding patterns carry no state: any column will do)
+              m1[i]   = xa[i] ? xa[i] : 1u; // (padding patterns carry no state: any column will do)
               hot1[i] = one_state(m1[i]);
             }
             if (fl & kOpTip2)
             {
-              m2[i]   = R[i].xb ? R[i].xb : 1u;
+              m2[i]   = xb[i] ? xb[i] : 1u;
               hot2[i] = one_state(m2[i]);
             }
             if (in1) s1[i] = 0;
@@ -615,7 +651,7 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
               for (int t = 0; t < T; ++t) x1[i][t] = Fout[i][t];
               s1[i] = scout[i];
             }
-            else { unpack(R[i].a, x1[i]); s1[i] = R[i].xa; }
+            else { unpack(R[i].a, x1[i]); s1[i] = xa[i]; }
             if (in2) s2[i] = 0;
             else if (fl & kOpTip2) { if (!hot2[i]) tip_vec(m2[i], x2[i]); s2[i] = 0; }
             else if (fl & kOpF21)
@@ -630,8 +666,9 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
               for (int t = 0; t < T; ++t) x2[i][t] = Fout[i][t];
               s2[i] = scout[i];
             }
-            else { unpack(R[i].b, x2[i]); s2[i] = R[i].xb; }
+            else { unpack(R[i].b, x2[i]); s2[i] = xb[i]; }
           }
+          if constexpr (D2) issue_children(nx2, R); // (clamped to the last operation near the end: harmless repeats)
           PHY_STAMP(k, 1)
           // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587 (never with a one-state tip)
           unsigned ones[NT];
@@ -670,7 +707,7 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
 #pragma unroll
                   for (int i = 0; i < NT; ++i)
                   {
-                    const unsigned ma = (in1 ? R[i].xa : R[i].xb) ? (in1 ? R[i].xa : R[i].xb) : 1u;
+                    const unsigned ma = (in1 ? xa[i] : xb[i]) ? (in1 ? xa[i] : xb[i]) : 1u;
                     hota[i] = one_state(ma); tk[i] = !hota[i]; onesab[i] = 1;
 #pragma unroll
                     for (int t = 0; t < T; ++t) ua[i][t] = 0.0;
@@ -689,7 +726,7 @@ __global__ __launch_bounds__(NT == 1 ? 64 * (kAaMaxCons + 1) : 64 * (kAaMaxCons2
 #pragma unroll
                   for (int i = 0; i < NT; ++i)
                   {
-                    const unsigned mb = R[i].xt ? R[i].xt : 1u;
+                    const unsigned mb = xt[i] ? xt[i] : 1u;
                     hotb[i] = one_state(mb); tk[i] = !hotb[i];
 #pragma unroll
                     for (int t = 0; t < T; ++t) ub[i][t] = 0.0;

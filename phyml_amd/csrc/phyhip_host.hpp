@@ -179,6 +179,7 @@ struct Instance
   int         NE = 1;          // eigen systems / frequency vectors held: C with the class axis, else 1
   bool        perm = false;    // 20-state buffers in the MFMA fragment-major layout (phyhip_aa.hpp)
   int         aa_nw = 1;               // 20 states: wave-tiles per workgroup of traverse_aa_kernel (= its consumer waves in the one-tile-per-wave forms)
+  bool        aa_d2 = false;           // ... list-form launches load two operations ahead (at most kAaMaxConsD2 consumer waves per workgroup)
   int         aa_nt = 1;               // ... wave-tiles per consumer wave in list-form launches (2: alignments with enough tiles)
   bool        soa = false;     // 4-state buffers pattern-minor, lane-per-pattern kernel (phyhip_nt2.hpp)
   int         grid_nt2 = 0;

@@ -936,8 +936,20 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         const dim3 blk(64 * (I->aa_nw + 1));
 #define AACASE(c_)                                                                                                          \
   case c_:                                                                                                                  \
-    named("traverse_aa_kernel<%d, false, 0, %s, %s, %d>", c_, q.recs_in_args ? "true" : "false", (!q.recs_in_args && has_inl) ? "true" : "false", \
-          q.recs_in_args ? 1 : I->aa_nt);                                                                                   \
+    named("traverse_aa_kernel<%d, false, 0, %s, %s, %d, %s>", c_, q.recs_in_args ? "true" : "false", (!q.recs_in_args && has_inl) ? "true" : "false", \
+          q.recs_in_args ? 1 : I->aa_nt, (!q.recs_in_args && I->aa_nt == 1 && I->aa_d2) ? "true" : "false");                \
+    if constexpr (kDiag) /* (measured variants of the list form, kept for A/B: profiles/r06_aa_kernel.md) */               \
+    if (!q.recs_in_args && I->aa_nt == 1 && I->aa_d2)                                                                       \
+    { /* few waves per SIMD: loads two operations ahead */                                                                  \
+      if (has_inl)                                                                                                          \
+        hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, false, true, 1, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec, \
+                           (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
+      else                                                                                                                  \
+        hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, false, false, 1, true>), dim3(I->grid_aa), blk, 0, I->stream, q, d_irec, d_xrec, \
+                           (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, (unsigned long long *)nullptr); \
+      return 0;                                                                                                             \
+    }                                                                                                                       \
+    if constexpr (kDiag)                                                                                                    \
     if (!q.recs_in_args && I->aa_nt == 2)                                                                                   \
     { /* two wave-tiles per consumer wave */                                                                                \
       const dim3 blk2(64 * ((I->aa_nw + 1) / 2 + 1));                                                                        \

@@ -21,7 +21,7 @@ DIAG = [{}, {"PHYHIP_NT_GROUPS": "1"}, {"PHYHIP_NT_GROUPS": "2"}, {"PHYHIP_NT_GR
         {"PHYHIP_BIG_GROUP_SUM": "0"}, {"PHYHIP_BIG_ONE_SHOT": "0"}, {"PHYHIP_PUSH_CMDS": "0"}, {"PHYHIP_PUSH_CMDS": "2"},
         {"PHYHIP_PUSH_NO_MOVDIR": "1"},
         {"PHYHIP_PMAT_THREADS": "1024"}, {"PHYHIP_RESIDENT_DIRECT": "4"}, {"PHYHIP_VIRT_INLINE": "0"}, {"PHYHIP_VIRT_MIN_OPS": "0"}, {"PHYHIP_NT_MIXED": "0"},
-        {"PHYHIP_PMAT20": "0"}, {"PHYHIP_PMAT20": "1"}]
+        {"PHYHIP_PMAT20": "0"}, {"PHYHIP_PMAT20": "1"}, {"PHYHIP_AA_NT": "2"}, {"PHYHIP_AA_D2": "1"}]
 PRODUCT = [{}, {"PHYHIP_RESIDENT": "0"}, {"PHYHIP_HOST_SUM": "0"}]
 _cache = {}
 
