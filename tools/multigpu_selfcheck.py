@@ -79,7 +79,8 @@ def main():
     print(json.dumps(out, indent=1))
     ok = out["lnL_rel_err_vs_shard_sum"] < 1e-12
     print("OK" if ok else "MISMATCH")
-    sys.exit(0 if ok else 1)
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0 if ok else 1)  # (RCCL prints a banner of its own on stdout while the interpreter shuts down)
 
 
 if __name__ == "__main__":
