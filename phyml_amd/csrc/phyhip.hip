@@ -602,6 +602,7 @@ static int small_upload(Instance *I, double *dst, const double *src, size_t n)
   HIPCHK(hipMemcpyAsync(dst, st, n * sizeof(double), hipMemcpyHostToDevice, I->stream));
   memcpy(I->h_model.data() + off, src, n * sizeof(double));
   I->h_model_set[off] = 1;
+  ++I->model_epoch;
   return PHYHIP_SUCCESS;
 }
 

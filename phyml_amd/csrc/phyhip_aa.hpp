@@ -172,13 +172,42 @@ static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUp
 // out of the registers they arrived in (the default requests operation k + 1's at the top of step k): a load has two steps to
 // arrive instead of one -- for alignments whose workgroups hold at most kAaMaxConsD2 consumer waves (three waves per SIMD: the
 // operands' second copy needs ~150 registers), where a step is too short to cover a trip to memory under load.
-template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false, bool INL = false, int NT = 1, bool D2 = false>
-__global__ __launch_bounds__(NT == 2 ? 64 * (kAaMaxCons2 + 1) : (D2 ? 64 * (kAaMaxConsD2 + 1) : 64 * (kAaMaxCons + 1))) void traverse_aa_kernel(const TreeParams q, const IssueRec *__restrict__ irec,
+// RES (argument form only): the RESIDENT evaluator of small 20-state alignments -- the workgroups stay on the device and take one
+// short evaluation after the other (an SPR regraft candidate: up to four matrices rebuilt, one or two partial updates, the edge
+// likelihood; src/spr.c:640-646) from the command record of phyhip_kernels.hpp's resident protocol, in resident_nt2_kernel's word
+// format (+ word 34: the model's epoch).  Per command every workgroup rebuilds the queued matrices itself -- pmat20_kernel's
+// arithmetic, four waves per matrix, straight into the ring slots its consumers read them from (workgroup 0 also stores them in
+// the two global tables) -- so a candidate is no launch at all instead of two; tables that were not rebuilt come from the global
+// table by LDS-DMA as usual.  Geometry: up to kAaMaxCons2 wave-tiles per workgroup (eight waves: a command's records and the
+// staged state live in registers for the whole loop -- 256 of them per lane); instances whose LAUNCHED form has one tile per
+// workgroup (aa_nw = 1, up to 256 tiles), so that one record per tile is one record per workgroup of the launched form and
+// the host's sum is the same double whoever served the evaluation.
+struct AaResident
+{
+  ResidentCtl   ctl;
+  const double *evec, *ivec, *eval, *rates; // U, U^-1, eigenvalues, category rates (device memory: re-read when the epoch changes)
+  double       *pmats_rw, *afrag_rw;        // the two global matrix tables
+};
+constexpr int kResidentAaWords = 10 + 2 * 12 + 1;
+
+template <int C_, bool DBG = false, int ABL = 0, bool ARGS = false, bool INL = false, int NT = 1, bool D2 = false, bool RES = false>
+__global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 64 * (kAaMaxConsD2 + 1) : 64 * (kAaMaxCons + 1))) void traverse_aa_kernel(const TreeParams q_in, const IssueRec *__restrict__ irec,
                                                                             const ExecRec *__restrict__ xrec,
                                                                             const double *__restrict__ afrag, int n_frag_mats,
                                                                             const uint32_t *__restrict__ tip_masks,
-                                                                            unsigned long long *dbg = nullptr)
+                                                                            unsigned long long *dbg = nullptr, const AaResident rs = AaResident())
 {
+  static_assert(!RES || (ARGS && !DBG && ABL == 0 && !INL && NT == 1 && !D2), "resident form: argument form only");
+  __shared__ __attribute__((aligned(16))) double ring[kAaRing][2][kAaMat];
+  // (read and written with relaxed workgroup-scope atomics: those stay plain ds_read / ds_write instructions, whereas a
+  // volatile access to LDS is compiled as a flat access behind a vmcnt(0) wait)
+  __shared__ int      s_ready;             // operations (+ the evaluation edge) whose matrices are in the ring
+  __shared__ int      s_done[16];          // per consumer wave: operations whose matrices it has finished reading
+  __shared__ double   s_wsum[16];          // per wave-tile of the workgroup: its share of the workgroup's sum
+  __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
+  __shared__ unsigned s_built;             // RES: bit 2 j + w: table w of item j was rebuilt into its ring slot by this workgroup
+  // One evaluation: everything a launched kernel does (the whole kernel in the launched forms; once per command in the resident one)
+  auto run = [&](const TreeParams &q) __attribute__((always_inline)) {
   constexpr int T   = kAaT;
   auto IR = [&](int i) -> IssueRec {
     if constexpr (ARGS) return i ? q.arg_ir[1] : q.arg_ir[0];
@@ -194,14 +223,6 @@ __global__ __launch_bounds__(NT == 2 ? 64 * (kAaMaxCons2 + 1) : (D2 ? 64 * (kAaM
   static_assert(!INL || (!ARGS && !DBG && ABL == 0), "in-step tip x tip children: list form only");
   static_assert(NT == 1 || (NT == 2 && !ARGS && !DBG && ABL == 0), "two wave-tiles per wave: list form only");
   static_assert(!D2 || (!ARGS && !DBG && ABL == 0), "loads two operations ahead: list form only");
-
-  __shared__ __attribute__((aligned(16))) double ring[kAaRing][2][kAaMat];
-  // (read and written with relaxed workgroup-scope atomics: those stay plain ds_read / ds_write instructions, whereas a
-  // volatile access to LDS is compiled as a flat access behind a vmcnt(0) wait)
-  __shared__ int      s_ready;             // operations (+ the evaluation edge) whose matrices are in the ring
-  __shared__ int      s_done[16];          // per consumer wave: operations whose matrices it has finished reading
-  __shared__ double   s_wsum[16];          // per wave-tile of the workgroup: its share of the workgroup's sum
-  __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -257,6 +278,32 @@ __global__ __launch_bounds__(NT == 2 ? 64 * (kAaMaxCons2 + 1) : (D2 ? 64 * (kAaM
       done_seen = need;
       return true;
     };
+    if constexpr (RES)
+    { // what the workgroup rebuilt itself sits in its slot already; every other table comes from the global table, one by one
+      const unsigned built = __builtin_amdgcn_readfirstlane(s_built);
+      auto table = [&](char *to, const unsigned off) { // one table: 12 pieces of 1 KiB and a half
+#pragma unroll
+        for (int g = 0; g < 12; ++g)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, (lds_ptr)(to + g * 1024), 16, (unsigned)g * 1024u + (unsigned)lane * 16u, off, 0, 0);
+        if (lane < 32)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, (lds_ptr)(to + 12 * 1024), 16, 12u * 1024u + (unsigned)lane * 16u, off, 0, 0);
+      };
+      for (int j = 0; j < n_items; ++j)
+      {
+        char *slot = reinterpret_cast<char *>(&ring[0][0][0]) + (size_t)(j % kAaRing) * 2 * kMatB;
+        if (j < n_ops)
+        {
+          const IssueRec rj = IR(j);
+          if (!((built >> (2 * j)) & 1u)) table(slot, rj.c1_data.x);
+          if (!((built >> (2 * j + 1)) & 1u)) table(slot + kMatB, rj.c2_data.x);
+        }
+        else if (!((built >> (2 * j)) & 1u)) table(slot, (unsigned)q.e_pm * kMatB);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+      asm volatile("" ::: "memory");
+      publish(n_items);
+    }
+    else
     for (int j = 0; j < ((ABL & 8) ? 0 : n_items); ++j)
     {
       unsigned off1, off2, off3 = 0, off4 = 0;
@@ -309,9 +356,12 @@ __global__ __launch_bounds__(NT == 2 ? 64 * (kAaMaxCons2 + 1) : (D2 ? 64 * (kAaM
         publish(j);
       }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    asm volatile("" ::: "memory");
-    publish(n_items);
+    if constexpr (!RES)
+    {
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+      asm volatile("" ::: "memory");
+      publish(n_items);
+    }
   }
   else
   {
@@ -987,14 +1037,161 @@ __global__ __launch_bounds__(NT == 2 ? 64 * (kAaMaxCons2 + 1) : (D2 ? 64 * (kAaM
   }
 #undef PHY_STAMP
   if (!q.edge_eval || q.class_axis) return;
+  if constexpr (RES) __threadfence(); // (what this wave stored -- results, workgroup 0's share of the rebuilt matrices -- is in memory before the records go out)
   __syncthreads();
   if (wave == 0)
-  { // the consumers' shares in wave order
-    double tot = 0.0;
-    for (int i = 0; i < tpw; ++i)
-      if ((size_t)blockIdx.x * tpw + i < ntiles) tot += s_wsum[i];
-    publish_block_sum(q, tot, lane);
+  {
+    if constexpr (RES)
+    { // one record per wave-tile: the launched form of such an instance has one tile per workgroup, the host adds the same terms
+      if (lane < tpw && (size_t)blockIdx.x * tpw + lane < ntiles)
+        post_host_block(q.host_blocks + (size_t)blockIdx.x * tpw + lane, s_wsum[lane], q.host_tag);
+    }
+    else
+    { // the consumers' shares in wave order
+      double tot = 0.0;
+      for (int i = 0; i < tpw; ++i)
+        if ((size_t)blockIdx.x * tpw + i < ntiles) tot += s_wsum[i];
+      publish_block_sum(q, tot, lane);
+    }
+  }
+  }; // (run)
+
+  if constexpr (!RES) run(q_in);
+  else
+  {
+    __shared__ unsigned long long sh_raw[64];
+    __shared__ __attribute__((aligned(16))) double sh_expt[4][4 * 20]; // [rebuilt matrix][category][eigenvalue]
+    __shared__ __attribute__((aligned(16))) double sh_U[400], sh_V[400];
+    __shared__ int sh_act;
+    const int          lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int)(blockDim.x >> 6);
+    unsigned long long last = rs.ctl.start_seq, t_last = wall_clock64(), model_seen = ~0ull;
+    bool               mail_open = false;
+    constexpr unsigned kMatB = kAaMat * 8;
+    for (;;)
+    {
+      if (wave == 0)
+      {
+        const int a = resident_poll_wave(rs.ctl, last, t_last, mail_open, sh_raw, 1, lane, blockIdx.x == 0);
+        if (lane == 0) sh_act = a;
+      }
+      __syncthreads();
+      const int act = __builtin_amdgcn_readfirstlane(sh_act);
+      if (act == 2) return;
+      if (act == 0)
+      {
+        __syncthreads(); // (sh_act / sh_raw are rewritten by the next poll)
+        continue;
+      }
+      // every word is the same for all lanes: make that known (descriptors and loop bounds belong in scalar registers)
+      auto word = [&](int k) {
+        const unsigned long long v = sh_raw[resident_slot(k)];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+      };
+      auto desc = [&](int k) {
+        Desc               d;
+        const unsigned long long b = word(k + 1);
+        d.base = word(k); d.bytes = (unsigned)b; d.x = (unsigned)(b >> 32);
+        return d;
+      };
+      const unsigned long long fl = word(1), ed = word(2), pm = word(3), epoch = word(34);
+      TreeParams               q = q_in;
+      q.host_tag = word(0);
+      q.n_fresh = (int)((fl >> 4) & 15); q.e_prefetch = (int)((fl >> 8) & 3);
+      q.edge_eval = 1; q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
+      q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
+      q.n_real_ops = (int)(fl & 3);
+      // what kernels on the stream wrote since the last command (the host says whether any did) is re-read from memory
+      if (fl & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // ---- the queued matrices, by this workgroup, into the ring slots its consumers will read them from ----------------------
+      const int nf = q.n_fresh;
+      if (nf > 0)
+      {
+        if (epoch != model_seen)
+        { // (the eigen system changes with the model only: staged once per epoch)
+          for (int t = threadIdx.x; t < 400; t += blockDim.x) { sh_U[t] = rs.evec[t]; sh_V[t] = rs.ivec[t]; }
+          model_seen = epoch;
+        }
+        for (int f = 0; f < nf; ++f)
+        {
+          double len;
+          const unsigned long long lb = word(6 + f);
+          __builtin_memcpy(&len, &lb, 8);
+          pmat20_exponentials(sh_expt[f], len, C_, false, rs.eval, rs.rates, q.br_len_mult, q.l_min, q.l_max, (int)threadIdx.x, (int)blockDim.x);
+        }
+      }
+      // where each rebuilt matrix is read in this command: the five places a command has -- table 0 / 1 of operation 0, of
+      // operation 1, table 0 of the evaluation edge's item -- or, read nowhere (the host sends at most two such), a table of the
+      // ring's spare item
+      const int n_ops_c = q.n_real_ops;
+      auto fidx = [&](int f) { return (int)(unsigned)(word(4 + f / 2) >> (32 * (f & 1))); };
+      // (the matrix offsets of the operations' children: the spare words of their data descriptors -- the descriptors themselves are
+      // taken out of the command behind the rebuild, where they are needed)
+      const unsigned used[5] = {n_ops_c > 0 ? (unsigned)(word(11) >> 32) : ~0u, n_ops_c > 0 ? (unsigned)(word(13) >> 32) : ~0u,
+                                n_ops_c > 1 ? (unsigned)(word(23) >> 32) : ~0u, n_ops_c > 1 ? (unsigned)(word(25) >> 32) : ~0u, (unsigned)q.e_pm * kMatB};
+      double *const eslot = n_ops_c == 0 ? &ring[0][0][0] : (n_ops_c == 1 ? &ring[1][0][0] : &ring[2][0][0]);
+      unsigned built = 0;
+      if (nf > 0)
+      {
+        if (C_ == 3)
+        { // (blocks beyond the category count stay zero in every table that is about to be filled: simplest, all of the ring)
+          double *rz = &ring[0][0][0];
+          for (int e = threadIdx.x; e < kAaRing * 2 * kAaMat; e += blockDim.x) rz[e] = 0.0;
+        }
+        __syncthreads();
+        // four waves per matrix where the workgroup has them (pmat20_kernel's shape), the groups taking the matrices in turn
+        const int wpm = nwaves >= 4 * nf ? 4 : (nwaves >= 2 * nf ? 2 : 1), groups = nwaves / wpm, g = wave / wpm;
+        double *const tabs[7] = {&ring[0][0][0], &ring[0][1][0], &ring[1][0][0], &ring[1][1][0], eslot, &ring[kAaRing - 1][0][0], &ring[kAaRing - 1][1][0]};
+#pragma unroll 1
+        for (int f = 0; f < nf; ++f)
+        {
+          const unsigned offb = (unsigned)fidx(f) * kMatB;
+          unsigned       m = 0;
+#pragma unroll
+          for (int y = 0; y < 5; ++y) m |= (used[y] == offb) ? (1u << y) : 0u;
+          // (bits of `built`: 2 j + w for table w of item j; the evaluation edge is item n_ops)
+          built |= (m & 15u) | ((m >> 4) << (2 * n_ops_c));
+          if (m == 0) m = 32u << (f & 1);
+          if (g < groups && (f % groups) == g)
+            pmat20_entries<7>(sh_expt[f], sh_U, sh_V, C_, false, lane, wave % wpm, wpm,
+                              blockIdx.x == 0 ? rs.pmats_rw + (size_t)fidx(f) * C_ * 400 : nullptr, tabs, m);
+        }
+        __syncthreads();
+        if (blockIdx.x == 0)
+        {
+#pragma unroll 1
+          for (int f = 0; f < nf; ++f)
+            { // the A-operand copies of the global table, from the first place each matrix was built into
+              const unsigned offb = (unsigned)fidx(f) * kMatB;
+              const double  *src = &ring[kAaRing - 1][f & 1][0];
+              if (used[4] == offb) src = eslot;
+              if (used[3] == offb) src = &ring[1][1][0];
+              if (used[2] == offb) src = &ring[1][0][0];
+              if (used[1] == offb) src = &ring[0][1][0];
+              if (used[0] == offb) src = &ring[0][0][0];
+              double2       *dst = reinterpret_cast<double2 *>(rs.afrag_rw + (size_t)fidx(f) * kAaMat);
+              const double2 *s2  = reinterpret_cast<const double2 *>(src);
+              for (int e = threadIdx.x; e < kAaMat / 2; e += blockDim.x) dst[e] = s2[e];
+            }
+        }
+      }
+      if (threadIdx.x == 0) s_built = built;
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+      {
+        q.arg_ir[o].c1_data = desc(10 + o * 12); q.arg_ir[o].c2_data = desc(12 + o * 12);
+        q.arg_ir[o].c1_scale = desc(14 + o * 12); q.arg_ir[o].c2_scale = desc(16 + o * 12);
+        q.arg_xr[o].dst_data = desc(18 + o * 12); q.arg_xr[o].dst_scale = desc(20 + o * 12);
+      }
+      run(q); // (starts with a workgroup barrier: s_built and the tables are in place for everybody)
+      __syncthreads();
+      last = last + 1; t_last = wall_clock64();
+    }
   }
 }
+
+// (defined in phyhip_big.hip, the translation unit compiled for kernels that are one loop around launched kernels' bodies)
+int launch_resident_aa(int C, int workgroups, int consumers, hipStream_t stream, const TreeParams &sq, const double *afrag, int n_frag_mats,
+                       const uint32_t *tip_masks, const AaResident &rs);
 
 } // namespace phyhip

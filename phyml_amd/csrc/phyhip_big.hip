@@ -5,6 +5,7 @@
 // per SIMD the kernel must run at that meant ~130 registers spilled to scratch (tools/kres.py on the listing); without the
 // pass: none.  Everything else of the library keeps the pass.
 #include "phyhip_big.hpp"
+#include "phyhip_aa.hpp"
 
 namespace phyhip
 {
@@ -43,6 +44,26 @@ int launch_resident_big(int C, int G, int workgroups, hipStream_t stream, const 
     default: return -1;
   }
 #undef BIGRES
+}
+
+// The resident form of the 20-state kernel (phyhip_aa.hpp: traverse_aa_kernel<..., RES>) is such a loop as well -- compiled with
+// the pass it spilled ~120 registers at its two waves per SIMD -- so its four instantiations live here too.  Returns 0, or -1 for
+// a category count without a kernel.
+int launch_resident_aa(int C, int workgroups, int consumers, hipStream_t stream, const TreeParams &sq, const double *afrag, int n_frag_mats,
+                       const uint32_t *tip_masks, const AaResident &rs)
+{
+  const dim3 blk(64 * (consumers + 1));
+#define AARES(c_)                                                                                                           \
+  case c_:                                                                                                                  \
+    hipLaunchKernelGGL((traverse_aa_kernel<c_, false, 0, true, false, 1, false, true>), dim3(workgroups), blk, 0, stream, sq, (const IssueRec *)nullptr, \
+                       (const ExecRec *)nullptr, afrag, n_frag_mats, tip_masks, (unsigned long long *)nullptr, rs);          \
+    return 0;
+  switch (C)
+  {
+    AARES(1) AARES(2) AARES(3) AARES(4)
+    default: return -1;
+  }
+#undef AARES
 }
 
 } // namespace phyhip

@@ -259,6 +259,7 @@ struct Instance
   // Lk(b) with update_eigen_lr (src/lk.c: Update_Eigen_Lr, then Lk_Core on the same edge) opens a chain of dLk calls: the
   // edge evaluation that directly follows an Update_Eigen_Lr makes its workgroups complete their stores before they post
   // their sums (TreeParams::fence_post), so that once the host has the scalar the whole stream is known to be finished.
+  unsigned long long model_epoch = 1; // bumped whenever the model block on the device changes (resident 20-state evaluator: its staged eigen system)
   unsigned long long api_no = 0, eig_api_no = 0; // entry-point calls so far; the call that queued the last eigen_lr kernel
   bool               fenced_eval = false;        // the evaluation in flight posts behind fences // stamps issued; the stamp whose arrival makes a non-dirty stream clean
   int          wall_khz = 0;          // rate of the device's wall_clock64()
@@ -593,6 +594,13 @@ inline bool resident_short_eligible(const Instance *I)
 {
   return I->resident && I->spin_wait && I->host_sum && I->soa && !I->co && !I->class_axis && I->grid_nt2 <= kResidentMaxGrid &&
          !I->ablate && I->nt_groups <= 2;
+}
+
+// ... and the resident form of the 20-state kernel (phyhip_aa.hpp, RES): instances whose launched form has one wave-tile per workgroup
+inline bool resident_aa_eligible(const Instance *I)
+{
+  return I->resident && I->spin_wait && I->host_sum && I->perm && !I->co && !I->class_axis && I->aa_nw == 1 && I->aa_nt == 1 && !I->ablate &&
+         I->grid_aa <= kResidentMaxGrid * kAaMaxCons2 && !(I->rt.n_silent > 16 && I->rt.n_silent * 4 > I->rt.n_cmd);
 }
 
 // ---- the large-grid resident evaluator (phyhip_big.hpp): host side ---------------------------------------------------

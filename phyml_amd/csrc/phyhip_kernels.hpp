@@ -1929,52 +1929,32 @@ __global__ __launch_bounds__(ST == 4 ? 64 : 1024) void pmat_kernel(const PmatPar
 // (tests/test_gpu_switches.py, PHYHIP_PMAT20).  Measured against pmat_kernel<20>: the three matrices of an SPR candidate 7.0
 // against 8.0 us (a short list is a chain of latencies either way: profiles/r05_aa_candidate.md), the 397 matrices of a
 // 200-taxon tree 15.2 against 16.8 us.
-static __global__ __launch_bounds__(256) void pmat20_kernel(const PmatParams q)
+// The exponentials of one matrix: expt[c][k] = exp(eigenvalue k x the clamped, rate-scaled length of category c), by the threads
+// tid, tid + nth, ... of whoever builds it (src/lk.c:2296-2300, src/models.c:275)
+__device__ __forceinline__ void pmat20_exponentials(double *expt, const double l, const int C, const bool cls, const double *R, const double *rates,
+                                                    const double br_len_mult, const double l_min, const double l_max, const int tid, const int nth)
 {
   constexpr int S = 20;
-  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S] | U [NE][S][S] | V [NE][S][S] | A-operand table [kAaMat]
-  const int m = blockIdx.x, C = q.C;
-  double l;
-  int    mat, shd;
-  if (q.indices) { l = q.lengths[m]; mat = q.indices[m]; shd = q.shadow ? q.shadow[m] : -1; }
-  else
-  {
-    l = q.small_len[0]; mat = q.small_idx[0]; shd = q.small_shadow[0];
-#pragma unroll
-    for (int k = 1; k < kSmallPm; ++k)
-      if (m == k) { l = q.small_len[k]; mat = q.small_idx[k]; shd = q.small_shadow[k]; }
-  }
-  if (shd >= 0)
-  { // the old value first (as in pmat_kernel: the barriers below come before any overwrite)
-    const double *src = q.pmats + (size_t)mat * C * S * S;
-    double       *dst = q.pmats + (size_t)shd * C * S * S;
-    for (int e = threadIdx.x; e < C * S * S; e += blockDim.x) dst[e] = src[e];
-    if (q.afrag)
-      for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) q.afrag[(size_t)shd * kAaMat + e] = q.afrag[(size_t)mat * kAaMat + e];
-  }
-  const bool cls = q.class_axis != 0;
-  const int  NE  = cls ? C : 1;
-  double *Us = expt + C * S, *Vs = Us + NE * S * S, *tab = q.afrag ? Vs + NE * S * S : nullptr;
-  for (int t = threadIdx.x; t < NE * S * S; t += blockDim.x)
-  {
-    Us[t] = q.U[t];
-    Vs[t] = q.V[t];
-  }
-  for (int t = threadIdx.x; t < C * S; t += blockDim.x)
+  for (int t = tid; t < C * S; t += nth)
   {
     const int c   = t / S, k = t % S;
-    double    len = (l > 0.0 ? l : 0.0) * q.rates[c]; // src/lk.c:2296
-    len *= q.br_len_mult;                             // :2297
-    if (len < q.l_min) len = q.l_min;                 // :2299-2300
-    else if (len > q.l_max) len = q.l_max;
-    expt[t] = exp(q.R[(cls ? c * S : 0) + k] * len);  // src/models.c:275
+    double    len = (l > 0.0 ? l : 0.0) * rates[c]; // src/lk.c:2296
+    len *= br_len_mult;                             // :2297
+    if (len < l_min) len = l_min;                   // :2299-2300
+    else if (len > l_max) len = l_max;
+    expt[t] = exp(R[(cls ? c * S : 0) + k] * len);  // src/models.c:275
   }
-  if (tab && C == 3) // (blocks beyond the category count -- C = 3: block 3 -- stay zero)
-    for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) tab[e] = 0.0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+}
+
+// The entries of one matrix from its staged exponentials and the staged eigen system, by the nwv waves wv = 0 .. nwv - 1 of
+// whoever builds it (every lane of each of them calls this): natural layout to `out` (or nowhere: nullptr), MFMA A-operand
+// order to those of the tables tabs[] (LDS) whose bit is set in `mask`.  A lane owns a 2 x 4 block of entries; see pmat20_kernel.
+template <int MAXTABS>
+__device__ __forceinline__ void pmat20_entries(const double *expt, const double *Us, const double *Vs, const int C, const bool cls, const int lane,
+                                               const int wv, const int nwv, double *out, double *const (&tabs)[MAXTABS], const unsigned mask)
+{
+  constexpr int S = 20;
   const int jq = lane % 5, cb = aa_cb(C);
-  double   *out = q.pmats + (size_t)mat * C * S * S;
   for (int g0 = wv * 12; g0 < C * 10; g0 += nwv * 12) // (uniform per wave: 12 row pairs of 5 lanes each, lanes 60-63 idle)
   {
     const int  grp  = g0 + lane / 5;
@@ -2016,22 +1996,69 @@ static __global__ __launch_bounds__(256) void pmat20_kernel(const PmatParams q)
       double r0[4], r1[4];
 #pragma unroll
       for (int x = 0; x < 4; ++x) { r0[x] = a0[x] / t0; r1[x] = a1[x] / t1; } // :298
-      double2 *o0 = reinterpret_cast<double2 *>(out + (size_t)(c * S + i0) * S + 4 * jq), *o1 = o0 + S / 2;
-      o0[0] = double2{r0[0], r0[1]}; o0[1] = double2{r0[2], r0[3]};
-      o1[0] = double2{r1[0], r1[1]}; o1[1] = double2{r1[2], r1[3]};
-      if (tab)
-      { // A-operand order (phyhip_aa.hpp): lane (k, b, i) of row group r, k-chunk t holds P[category of block b][4r + i][4t + k]
-        const int r = i0 >> 2, il = i0 & 3;
-        for (int b = c; b < 4; b += cb)
-#pragma unroll
-          for (int x = 0; x < 4; ++x)
-          {
-            tab[aa_a_slot(jq, r, 16 * x + 4 * b + il)]     = r0[x];
-            tab[aa_a_slot(jq, r, 16 * x + 4 * b + il + 1)] = r1[x];
-          }
+      if (out)
+      {
+        double2 *o0 = reinterpret_cast<double2 *>(out + (size_t)(c * S + i0) * S + 4 * jq), *o1 = o0 + S / 2;
+        o0[0] = double2{r0[0], r0[1]}; o0[1] = double2{r0[2], r0[3]};
+        o1[0] = double2{r1[0], r1[1]}; o1[1] = double2{r1[2], r1[3]};
       }
+      // A-operand order (phyhip_aa.hpp): lane (k, b, i) of row group r, k-chunk t holds P[category of block b][4r + i][4t + k]
+      const int r = i0 >> 2, il = i0 & 3;
+#pragma unroll
+      for (int y = 0; y < MAXTABS; ++y)
+        if ((mask >> y) & 1u)
+        {
+          double *const tab = tabs[y];
+          for (int b = c; b < 4; b += cb)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+            {
+              tab[aa_a_slot(jq, r, 16 * x + 4 * b + il)]     = r0[x];
+              tab[aa_a_slot(jq, r, 16 * x + 4 * b + il + 1)] = r1[x];
+            }
+        }
     }
   }
+}
+
+static __global__ __launch_bounds__(256) void pmat20_kernel(const PmatParams q)
+{
+  constexpr int S = 20;
+  extern __shared__ __attribute__((aligned(16))) double expt[]; // [C][S] | U [NE][S][S] | V [NE][S][S] | A-operand table [kAaMat]
+  const int m = blockIdx.x, C = q.C;
+  double l;
+  int    mat, shd;
+  if (q.indices) { l = q.lengths[m]; mat = q.indices[m]; shd = q.shadow ? q.shadow[m] : -1; }
+  else
+  {
+    l = q.small_len[0]; mat = q.small_idx[0]; shd = q.small_shadow[0];
+#pragma unroll
+    for (int k = 1; k < kSmallPm; ++k)
+      if (m == k) { l = q.small_len[k]; mat = q.small_idx[k]; shd = q.small_shadow[k]; }
+  }
+  if (shd >= 0)
+  { // the old value first (as in pmat_kernel: the barriers below come before any overwrite)
+    const double *src = q.pmats + (size_t)mat * C * S * S;
+    double       *dst = q.pmats + (size_t)shd * C * S * S;
+    for (int e = threadIdx.x; e < C * S * S; e += blockDim.x) dst[e] = src[e];
+    if (q.afrag)
+      for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) q.afrag[(size_t)shd * kAaMat + e] = q.afrag[(size_t)mat * kAaMat + e];
+  }
+  const bool cls = q.class_axis != 0;
+  const int  NE  = cls ? C : 1;
+  double *Us = expt + C * S, *Vs = Us + NE * S * S, *tab = q.afrag ? Vs + NE * S * S : nullptr;
+  for (int t = threadIdx.x; t < NE * S * S; t += blockDim.x)
+  {
+    Us[t] = q.U[t];
+    Vs[t] = q.V[t];
+  }
+  pmat20_exponentials(expt, l, C, cls, q.R, q.rates, q.br_len_mult, q.l_min, q.l_max, (int)threadIdx.x, (int)blockDim.x);
+  if (tab && C == 3) // (blocks beyond the category count -- C = 3: block 3 -- stay zero)
+    for (int e = threadIdx.x; e < kAaMat; e += blockDim.x) tab[e] = 0.0;
+  __syncthreads();
+  double *const tabs[1] = {tab};
+  pmat20_entries<1>(expt, Us, Vs, C, cls, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6), (int)(blockDim.x >> 6), q.pmats + (size_t)mat * C * S * S, tabs,
+                    tab ? 1u : 0u);
   if (tab)
   {
     __syncthreads();

@@ -344,8 +344,40 @@ int flush_impl(Instance *I, const EdgeEval *ee)
             (int)big_fit, (int)big_try, (int)big_eligible(I), n_ops, I->pm_idx.size(), I->up_idx.size(), (int)I->prof, (int)I->rt_skip, (int)I->dirty_prev,
             (int)I->touched_call, I->clean_after, *reinterpret_cast<volatile unsigned long long *>(I->h_result + 3), I->big_streak, (int)I->rb.launched,
             (void *)g_big_owner[I->dev < 64 ? I->dev : 0].load(), (void *)I);
-  const bool fold_pm = I->soa && I->fold_pmats && (I->grid_nt2 <= fold_grid_max || big_try || one_shot) && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
-                       I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8) && I->n_pm_shadow == 0;
+  // small 20-state alignments: an evaluation the resident workgroups of traverse_aa_kernel<..., RES> can take -- decided here, before
+  // the matrix queue is dealt with, because they rebuild the queued matrices themselves (a launched 20-state kernel cannot: without
+  // them the rebuild is pmat20_kernel's launch in front)
+  bool aa_take = false;
+  if (resident_aa_eligible(I) && ee && !ee->eigen && ee->to_host && !ee->dev_out && n_ops <= 2 && I->args_recs && I->fold_pmats &&
+      (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && I->n_pm_shadow == 0 && !I->prof && !I->rt_skip)
+  {
+    // (a rebuilt matrix the command does not read goes through the ring's spare item: two tables)
+    int unread = 0;
+    for (int m : I->pm_idx)
+    {
+      bool read = m == ee->pm;
+      for (const DevOp &o : I->pending) read = read || o.pm1 == m || o.pm2 == m;
+      unread += !read;
+    }
+    bool clean = unread <= 2 && !I->dirty_prev && !I->touched_call;
+    if (clean && I->clean_after)
+    { // the report of the last Update_Eigen_Lr (bounded wait, else the ordinary launch)
+      volatile unsigned long long *stamp = reinterpret_cast<volatile unsigned long long *>(I->h_result + 3);
+      struct timespec t0;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (long it = 1; *stamp < I->clean_after && clean; ++it)
+      {
+        __builtin_ia32_pause();
+        if ((it & 255) == 0 && ns_since(t0) > 200000.0) clean = false;
+      }
+      if (clean) { __atomic_thread_fence(__ATOMIC_ACQUIRE); I->clean_after = 0; ++I->clean_epoch; }
+    }
+    if (!clean) ++I->rt.n_busy;
+    aa_take = clean;
+  }
+  const bool fold_pm = (aa_take && !I->pm_idx.empty()) ||
+                       (I->soa && I->fold_pmats && (I->grid_nt2 <= fold_grid_max || big_try || one_shot) && !I->pm_idx.empty() && (int)I->pm_idx.size() <= 8 &&
+                        I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8) && I->n_pm_shadow == 0);
   // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
   // (TreeParams::n_up): no upload kernel in front of the traversal
   const bool arg_up = I->soa && I->arg_uploads && !I->up_idx.empty() && (int)I->up_idx.size() <= kArgUp && I->pm_idx.empty() &&
@@ -377,9 +409,12 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     q.n_fresh = (int)I->pm_idx.size();
     for (int k = 0; k < q.n_fresh; ++k) { q.fresh_idx[k] = I->pm_idx[k]; q.fresh_len[k] = I->pm_len[k]; }
     // (4 states, one eigen system, <= 4 categories: see fold_pm) the eigen system rides in the arguments as well
-    memcpy(q.m_evec, I->h_evec.data(), 16 * sizeof(double)); memcpy(q.m_ivec, I->h_ivec.data(), 16 * sizeof(double));
-    memcpy(q.m_eval, I->h_eval.data(), 4 * sizeof(double));
-    for (int c = 0; c < 4; ++c) q.m_rates[c] = c < I->C ? I->h_rates[c] : 0.0;
+    if (I->S == 4)
+    {
+      memcpy(q.m_evec, I->h_evec.data(), 16 * sizeof(double)); memcpy(q.m_ivec, I->h_ivec.data(), 16 * sizeof(double));
+      memcpy(q.m_eval, I->h_eval.data(), 4 * sizeof(double));
+      for (int c = 0; c < 4; ++c) q.m_rates[c] = c < I->C ? I->h_rates[c] : 0.0;
+    }
     q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max; q.pmats_rw = I->d_pmats;
     // (the matrix queue is cleared only after the launch that rebuilds it has been issued, see below)
   }
@@ -592,7 +627,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   {
     I->warn_current = false;
     q.edge_eval = 1; q.e_parent = ee->parent; q.e_child = ee->child; q.e_pm = ee->pm;
-    if (n_ops == 0 && fat && I->soa && I->args_recs) { q.recs_in_args = 1; q.n_real_ops = 0; } // (evaluation-only short launch)
+    if (n_ops == 0 && fat && (I->soa || aa_take) && I->args_recs) { q.recs_in_args = 1; q.n_real_ops = 0; } // (evaluation-only short launch)
     if (q.recs_in_args)
     { // short launch: the kernel fetches the sides of the evaluation edge that no queued operation writes up front
       auto untouched = [&](int idx) {
@@ -636,10 +671,73 @@ int flush_impl(Instance *I, const EdgeEval *ee)
             (int)rt_grid, (int)I->resident, (int)I->spin_wait, (int)I->host_sum, (int)I->soa, I->co != nullptr, (int)I->class_axis, I->grid_nt2,
             I->ablate, I->nt_groups, host_sum_n, q.recs_in_args, q.n_fresh, (int)I->want_site_outputs, (int)I->prof, (int)I->rt_skip,
             (int)I->dirty_prev, (int)I->touched_call);
-  if (rt_grid && host_sum_n > 0)
+  if ((rt_grid || resident_aa_eligible(I)) && host_sum_n > 0)
   { // every evaluation of such an instance completes its stores before it posts: the stream is clean once the scalar is back
     q.fence_post   = 1;
     I->fenced_eval = true;
+  }
+  // ---- small 20-state alignments: the resident form of traverse_aa_kernel (phyhip_aa.hpp) -------------------------------------
+  if (aa_take)
+  {
+    if (!(host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0))
+      return fail(PHYHIP_ERROR_GENERAL, "20-state resident evaluator: an evaluation it cannot take (%d records, %d matrices)", host_sum_n, q.n_fresh);
+    Resident  &R = I->rt;
+    // what the workgroups are launched with: everything of the launch form's arguments that does not change per call
+    TreeParams sq = base_params(I);
+    sq.host_blocks = I->h_blocks; sq.warn = I->h_warn; sq.fence_post = 1; sq.recs_in_args = 1; sq.edge_eval = 1;
+    sq.br_len_mult = I->br_len_mult; sq.l_min = I->l_min; sq.l_max = I->l_max; sq.pmats_rw = I->d_pmats;
+    if (I->want_site_outputs) { sq.site_lnl = I->d_site_lnl; sq.site_lk = I->d_site_lk; sq.site_cat = I->d_site_cat; }
+    // geometry: as few workgroups as hold every wave-tile with at most kAaMaxCons2 consumers each, the tiles spread evenly
+    const int ntl = I->grid_aa /* (aa_nw == 1: one tile per workgroup of the launched form) */, wgs = (ntl + kAaMaxCons2 - 1) / kAaMaxCons2,
+              nwr = (ntl + wgs - 1) / wgs;
+    if (!R.launched || R.grid != wgs || memcmp(&I->rt_static, &sq, sizeof sq) != 0 || resident_gone(R))
+    {
+      if (R.launched && (R.grid != wgs || memcmp(&I->rt_static, &sq, sizeof sq) != 0)) resident_stop(R);
+      AaResident  rs;
+      hipStream_t st;
+      if ((rc = resident_prepare(I, R, wgs, kResidentAaWords, R.seq, rs.ctl, &st))) return rc;
+      rs.evec = I->d_evec; rs.ivec = I->d_ivec; rs.eval = I->d_eval; rs.rates = I->d_catr; rs.pmats_rw = I->d_pmats; rs.afrag_rw = I->d_afrag;
+      if (launch_resident_aa(I->C, wgs, nwr, st, sq, (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, rs))
+        return fail(PHYHIP_ERROR_GENERAL, "20-state resident evaluator: no kernel for %d categories", I->C);
+      HIPCHK(hipGetLastError());
+      memcpy(&I->rt_static, &sq, sizeof sq);
+      resident_launched(R, wgs);
+    }
+    unsigned long long words[kResidentAaWords];
+    memset(words, 0, sizeof words);
+    const bool changed = I->clean_epoch != I->rt_epoch; // the stream ran something since the last command
+    words[0] = q.host_tag;
+    words[1] = (unsigned long long)q.n_real_ops | (changed ? 4ull : 0ull) | ((unsigned long long)q.n_fresh << 4) | ((unsigned long long)q.e_prefetch << 8);
+    words[2] = (unsigned long long)(unsigned)q.e_parent | ((unsigned long long)(unsigned)q.e_child << 32);
+    words[3] = (unsigned long long)(unsigned)q.e_pm | ((unsigned long long)(unsigned)q.last_dest << 32);
+    for (int k = 0; k < q.n_fresh; ++k)
+    {
+      words[4 + k / 2] |= (unsigned long long)(unsigned)q.fresh_idx[k] << (32 * (k & 1));
+      memcpy(&words[6 + k], &q.fresh_len[k], 8);
+    }
+    auto put = [&](int k, const Desc &d) { words[k] = d.base; words[k + 1] = (unsigned long long)d.bytes | ((unsigned long long)d.x << 32); };
+    for (int o = 0; o < q.n_real_ops; ++o)
+    {
+      put(10 + o * 12, q.arg_ir[o].c1_data); put(12 + o * 12, q.arg_ir[o].c2_data);
+      put(14 + o * 12, q.arg_ir[o].c1_scale); put(16 + o * 12, q.arg_ir[o].c2_scale);
+      put(18 + o * 12, q.arg_xr[o].dst_data); put(20 + o * 12, q.arg_xr[o].dst_scale);
+    }
+    words[34] = I->model_epoch;
+    // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (flush_and_wait)
+    I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
+    resident_send(I, R, words, kResidentAaWords);
+    I->rt_epoch = I->clean_epoch;
+    I->host_sum_n = host_sum_n; I->host_sum_ns = 1;
+    if (fold_pm)
+    {
+      for (int m : I->pm_idx) I->pm_slot[m] = -1;
+      I->pm_idx.clear();
+      I->pm_len.clear();
+      I->pm_shadow.clear();
+    }
+    I->pending.clear();
+    std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
+    return 0;
   }
   if (rt_grid && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0 && !I->prof && !I->rt_skip)
   {

@@ -308,3 +308,47 @@ def test_two_large_instances_share_one_device(monkeypatch):
     finally:
         for t, *_ in pairs:
             t.close()
+
+
+@pytest.mark.parametrize("P,C", [(60, 4), (429, 4), (1000, 4), (429, 2), (200, 3), (300, 1)])
+@pytest.mark.parametrize("host_pmat", [False, True])
+def test_20_state_resident_evaluator_is_the_launch_path_bit_for_bit(P, C, host_pmat, monkeypatch):
+    """Small 20-state alignments: SPR regraft candidates (src/spr.c:640-646: three matrices rebuilt, one partial update, the edge
+    likelihood) and plain Lk(b) are served by the resident form of traverse_aa_kernel -- the workgroups rebuild the queued matrices
+    themselves -- instead of pmat20_kernel + traverse_aa_kernel launches.  Every scalar is the launch path's double (PHYHIP_RESIDENT=0),
+    the oracle's to 1e-11, the matrices and partial vectors left behind are the launched ones bit for bit, and the resident
+    workgroups were the path that ran.  (Host-computed matrices -- the bit-exact route -- are uploads: those candidates are
+    launched, the evaluations without a matrix change are still served.)"""
+    from phyml_amd import replay
+    from replay_oracle import OracleReplayer
+    vals = {}
+    for res in ("0", "1"):
+        monkeypatch.setenv("PHYHIP_RESIDENT", res)
+        t, ot, tree, st = synthetic_pair(16, P, 20, C, seed=41, ambiguous_every=9, host_pmat=host_pmat)
+        try:
+            t.Set_Both_Sides(True)
+            ref0 = t.Lk(None)
+            ot.lk(None, both_sides=True)
+            tr = replay.make_trace(16, tree.edge_left, tree.edge_rght, tree.edge_len, 80, seed=13, walk_every=3, opt_every=5, n_dlk=3)
+            got, got2 = t.Replay_Surface_Trace(tr)
+            k = tr["kind"]
+            served, launches, silent, busy = t.inst.resident_stats(1)
+            if res == "1" and not host_pmat:
+                assert served >= 60 and silent == 0, (served, launches, silent, busy)
+            if res == "0":
+                assert served == 0
+            # what is left in device memory: matrices (both tables feed later launches) and the buffers the stream wrote
+            mats = [t.inst.get_transition_matrix(e).copy() for e in range(ot.ne)]
+            bufs = [t.partials(e, s).copy() for e in (0, 5, 11, ot.ne - 1) for s in (0, 1) if (e, s) in ot.plk]
+            after = t.Lk(None)   # a launched list-form traversal on whatever the residents left in the A-operand table
+            if res == "1":
+                oref, oref2 = OracleReplayer(ot).run(tr)
+                lnl_calls = (k == replay.EDGE_LNL) | (k == replay.DLK)
+                assert np.max(np.abs(got[lnl_calls] - oref[lnl_calls]) / np.abs(oref[lnl_calls])) < 1e-11
+            vals[res] = (got, got2, mats, bufs, after, ref0)
+        finally:
+            t.close()
+    a, b = vals["0"], vals["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2])) and all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    assert a[4] == b[4] and a[5] == b[5]
