@@ -35,11 +35,28 @@ static void release_instance(Instance *I)
                         "%.2f us from command to answer\n",
                 R == &I->rd ? "dLk evaluator" : (R == &I->rt ? "short-launch evaluator" : "large-grid evaluator"), R->n_cmd, R->n_launch,
                 R->n_silent, R->n_busy, R->n_cmd ? R->ns_wait * 1e-3 / (double)R->n_cmd : 0.0);
+  const bool aa_res_used = I->perm && I->rt.n_cmd > 0;
   resident_free(I->rd);
   resident_free(I->rt);
   big_release(I);
   const bool big_used = I->rb.n_cmd > 0;
   resident_free(I->rb);
+  if (I->d_big_stamps && aa_res_used)
+  { // resident 20-state evaluator: workgroup 0's phases, mean per command
+    unsigned long long h[32];
+    if (hipMemcpy(h, I->d_big_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[7])
+    {
+      const char *bn[5] = {"operands read", "products", "row sums", "divisions", "stored"};
+      for (int k = 0; k < 5; ++k)
+        fprintf(stderr, "    inside the matrix rebuild (wave 1, two units), after its start: %-16s %6.2f us\n", bn[k], (double)h[16 + k] * 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3) / (double)h[7]);
+      const char *in[6] = {"consumer wave 0 starts", "operations done", "evaluation edge's products done", "sums written", "fenced", "first operation's tables in the ring"};
+      for (int k = 0; k < 6; ++k)
+        fprintf(stderr, "    inside the evaluation, after its start: %-34s %6.2f us\n", in[k], (double)h[8 + k] * 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3) / (double)h[7]);
+      const char  *names[5] = {"command seen -> parsed", "-> eigen system, exponentials", "-> matrices built", "-> global copies, records", "-> evaluated, fenced, posted"};
+      const double us = 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3) / (double)h[7];
+      for (int k = 0; k < 5; ++k) fprintf(stderr, "  20-state resident, workgroup 0, mean of %llu commands: %-32s %6.2f us\n", h[7], names[k], (double)h[k] * us);
+    }
+  }
   if (I->d_big_stamps && big_used)
   { // where the last command's time went, per workgroup, relative to workgroup 0 seeing it (wall-clock ticks of 10 ns)
     std::vector<unsigned long long> h((size_t)8 * I->big_wgs);

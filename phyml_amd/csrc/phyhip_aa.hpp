@@ -49,6 +49,11 @@ namespace phyhip
 {
 
 typedef double v2d __attribute__((ext_vector_type(2)));
+#ifndef AA_RES_ABL
+#define AA_RES_ABL 0 // (timing-only cuts of the resident form, tools/build_big_variant.sh: 1 no wait for the stores, 2 no matrix rebuild, 4 no
+                     // exponentials, 8 no global copies, 64 the rebuild without its matrix-core products; 16: every
+                     // division the plain way -- valid results)
+#endif
 constexpr int kAaT      = 5;    // k-chunks of 4 input states = row groups of 4 output states
 constexpr int kAaBlock  = 320;  // doubles per wave-tile block of a partials buffer
 #ifndef AA_RING
@@ -182,11 +187,163 @@ static __global__ __launch_bounds__(256) void upload_matrices_kernel(const MatUp
 // staged state live in registers for the whole loop -- 256 of them per lane); instances whose LAUNCHED form has one tile per
 // workgroup (aa_nw = 1, up to 256 tiles), so that one record per tile is one record per workgroup of the launched form and
 // the host's sum is the same double whoever served the evaluation.
+// One (matrix, row group r) unit of a transition-matrix rebuild on the matrix cores, by ONE wave: the entries P_c[4r + i][.] of
+// every category c at once (block = category), written in MFMA A-operand order into the tables `tabs` whose bit is set in `mask`
+// (LDS) and, natural layout, to `out` (global; nullptr: nowhere).  P_c = (U diag(e_c)) V (src/models.c:275-298) is computed as its
+// transpose, D = V^T (U e_c)^T: with A = V^T's block (k-chunk kc, column chunk t) and B = the (U e_c) block of row group r, the D
+// fragment of lane 16 i' + 4 b + j' is P_c[4r + j'][4t + i'] -- exactly what lane (k = i', b, i = j') of the A-operand table holds for
+// (row group r, k-chunk t): no transposition, no exchange.  Arithmetic as pmat20_kernel's, bit for bit: the products U[i][k] e_c[k]
+// rounded first, one fused multiply-add per eigen index in ascending order from zero (five k-chunks of the 4x4x4 MFMA, whose four
+// terms accumulate in ascending k), the 1e-100 floor, the row sum over ascending columns (four lanes 16 apart per column chunk),
+// the division.
+// NU: units one wave works through side by side (their chains of dependent LDS reads, matrix-core accumulations, shuffles and
+// divisions interleave); unit u of the NU is (expt[u], r[u], out[u], mask[u]); a negative r[u] means "none".
+template <int C_, int NU>
+__device__ __forceinline__ void aa_build_units(const double *const (&expt)[NU] /* each [C][20] */, const double *Us, const double *Vs, const int (&r)[NU],
+                                               const int lane, double *const (&out)[NU], double *const tab0, const int (&ta)[NU], const int (&tb)[NU],
+                                               const unsigned (&more)[NU], unsigned long long *stamps = nullptr)
+{
+  // (PHYHIP_RESIDENT_STATS: [16 + k] the wave's wall-clock ticks up to -- 0 operands read, 1 products, 2 row sums, 3 divisions, 4 stored)
+  const unsigned long long t_in = stamps ? wall_clock64() : 0ull;
+  auto mark = [&](const int k, const double dep) {
+    if (stamps)
+    {
+      unsigned long long z;
+      __builtin_memcpy(&z, &dep, 8);
+      z = __builtin_amdgcn_readfirstlane((unsigned)z) & 0u; // (the stamp is taken behind what `dep` depends on)
+      if (lane == 0) (void)__hip_atomic_fetch_add(&stamps[16 + k], wall_clock64() - t_in + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  constexpr int CB = C_ == 1 ? 1 : (C_ == 2 ? 2 : 4);
+  const int k = lane >> 4, b = (lane >> 2) & 3, x = lane & 3, c = b % CB;
+  const bool idle = c >= C_; // (C = 3: block 3 carries no category -- its table entries are zeros)
+  // every operand out of LDS first, side by side (one wait), then the arithmetic
+  double uu[NU][kAaT], ee[NU][kAaT], vv[kAaT][kAaT];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int kc = 0; kc < kAaT; ++kc)
+    {
+      uu[u][kc] = Us[(4 * (r[u] < 0 ? 0 : r[u]) + x) * 20 + 4 * kc + k];
+      ee[u][kc] = expt[u][(idle ? 0 : c) * 20 + 4 * kc + k];
+    }
+#pragma unroll
+  for (int kc = 0; kc < kAaT; ++kc)
+#pragma unroll
+    for (int t = 0; t < kAaT; ++t) vv[kc][t] = Vs[(4 * kc + k) * 20 + 4 * t + x]; // (the same A operands for every unit)
+  double w[NU][kAaT], D[NU][kAaT], s[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int kc = 0; kc < kAaT; ++kc) w[u][kc] = uu[u][kc] * ee[u][kc];
+  mark(0, w[NU - 1][kAaT - 1] + vv[kAaT - 1][kAaT - 1]);
+#pragma unroll
+  for (int t = 0; t < kAaT; ++t)
+  {
+    double acc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = 0.0;
+#pragma unroll
+    for (int kc = 0; kc < kAaT; ++kc)
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        acc[u] = (AA_RES_ABL & 64) ? __builtin_fma(vv[kc][t], w[u][kc], acc[u]) : __builtin_amdgcn_mfma_f64_4x4x4f64(vv[kc][t], w[u][kc], acc[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) D[u][t] = (acc[u] < kSmallPij) ? kSmallPij : acc[u]; // src/models.c:293
+  }
+  mark(1, D[NU - 1][kAaT - 1] + D[0][0]);
+  // row sums in ascending column order (src/models.c:296-297), on the matrix cores as well: this lane's D fragment of column chunk t
+  // IS the B operand B[k = i'][j = j'] = P[4r + j'][4t + i'] of a product with an all-ones A -- D[i][j'] = C + 1 P[..][4t] + 1 P[..][4t + 1]
+  // + 1 P[..][4t + 2] + 1 P[..][4t + 3], one fused multiply-add per term in ascending k (the order the products above rest on), and a
+  // fused multiply-add by one is the addition: the chain over the five chunks is the reference's running sum, and it arrives in all
+  // four lanes (i) of row j' at once.  (Five matrix-core instructions per unit; gathering the four lanes' values by half-exchanges
+  // and adding them cost 50 vector instructions per unit -- a third of the rebuild, which is bound by what one CU's SIMDs can issue.)
+#pragma unroll
+  for (int u = 0; u < NU; ++u) s[u] = 0.0;
+#pragma unroll
+  for (int t = 0; t < kAaT; ++t)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) s[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, D[u][t], s[u], 0, 0, 0);
+  mark(2, s[0] + s[NU - 1]);
+  bool plain = false;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) plain = plain || !(s[u] > 0x1p-500 && s[u] < 0x1p500);
+  plain = (AA_RES_ABL & 16) || __builtin_amdgcn_ballot_w64(plain) != 0;
+  double P[NU][kAaT];
+  if (plain)
+  {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int t = 0; t < kAaT; ++t) P[u][t] = D[u][t] / s[u];
+  }
+  else
+  {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+    {
+      const double r0 = __builtin_amdgcn_rcp(s[u]);
+      const double e0 = __builtin_fma(-s[u], r0, 1.0), r1 = __builtin_fma(r0, e0, r0);
+      const double e1 = __builtin_fma(-s[u], r1, 1.0), rc = __builtin_fma(r1, e1, r1);
+#pragma unroll
+      for (int t = 0; t < kAaT; ++t)
+      {
+        const double q0 = D[u][t] * rc, rem = __builtin_fma(-s[u], q0, D[u][t]);
+        P[u][t] = __builtin_fma(rem, rc, q0);
+      }
+    }
+  }
+  mark(3, P[0][0] + P[NU - 1][kAaT - 1]);
+  // where the entries go: the unit's first two tables (numbers of kAaMat-sized tables from tab0; a matrix that is read in one place
+  // only has the same number twice -- the same value to the same address) without a test per entry; further tables (a matrix
+  // read in three places or more: bits of `more`) the slow way
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    if (r[u] >= 0)
+    {
+      double *const d0 = tab0 + (size_t)ta[u] * kAaMat, *const d1 = tab0 + (size_t)tb[u] * kAaMat;
+#pragma unroll
+      for (int t = 0; t < kAaT; ++t)
+      {
+        const double p = idle ? 0.0 : P[u][t];
+        const int    sl = aa_a_slot(t, r[u], lane);
+        d0[sl] = p;
+        if (tb[u] != ta[u]) d1[sl] = p;
+        for (unsigned m = more[u]; m; m &= m - 1) tab0[(size_t)__builtin_ctz(m) * kAaMat + sl] = p;
+      }
+      // natural layout [c][row][col]: the lanes of the first block of each category (C < 4: the other blocks repeat them);
+      // written through (device scope): see the resident form's stores below
+      if (out[u] && !idle && b < CB)
+#pragma unroll
+        for (int t = 0; t < kAaT; ++t)
+          __hip_atomic_store(&out[u][(size_t)(c * 20 + 4 * r[u] + x) * 20 + 4 * t + k], P[u][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  mark(4, 0.0);
+}
+
+// Resident form: one A-operand table (12.5 pieces of 1 KiB) from the global table into a ring slot by LDS-DMA, at device scope (what
+// another workgroup's loader wave wrote through a command ago is what arrives); by one wave, nothing waited for.
+__device__ __forceinline__ void aa_resident_table(const __amdgpu_buffer_rsrc_t af_rsrc, double *to_d, const unsigned off, const int lane)
+{
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  char *to = reinterpret_cast<char *>(to_d);
+#pragma unroll
+  for (int g = 0; g < 12; ++g)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, (lds_ptr)(to + g * 1024), 16, (unsigned)g * 1024u + (unsigned)lane * 16u, off, 0, 16);
+  if (lane < 32)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, (lds_ptr)(to + 12 * 1024), 16, 12u * 1024u + (unsigned)lane * 16u, off, 0, 16);
+}
+
 struct AaResident
 {
   ResidentCtl   ctl;
   const double *evec, *ivec, *eval, *rates; // U, U^-1, eigenvalues, category rates (device memory: re-read when the epoch changes)
   double       *pmats_rw, *afrag_rw;        // the two global matrix tables
+  // PHYHIP_RESIDENT_STATS: where workgroup 0's time goes per command, wall-clock ticks summed over the commands -- [0] command
+  // seen -> parsed, [1] -> eigen system / exponentials staged, [2] -> matrices built, [3] -> global copies issued + records taken out,
+  // [4] -> evaluation done and posted; [7] commands
+  unsigned long long *stamps;
+  int                 stamp_wg; // (the workgroup whose time is taken: PHYHIP_RESIDENT_STATS - 1)
 };
 constexpr int kResidentAaWords = 10 + 2 * 12 + 1;
 
@@ -205,6 +362,8 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
   __shared__ int      s_done[16];          // per consumer wave: operations whose matrices it has finished reading
   __shared__ double   s_wsum[16];          // per wave-tile of the workgroup: its share of the workgroup's sum
   __shared__ unsigned long long stamps[DBG ? 64 * 8 : 1];
+  __shared__ int      s_spare[2];          // RES: matrices rebuilt into the ring's spare item (read by nothing in this command), or -1
+  __shared__ unsigned long long s_t4;      // RES + PHYHIP_RESIDENT_STATS: when this command's evaluation began
   __shared__ unsigned s_built;             // RES: bit 2 j + w: table w of item j was rebuilt into its ring slot by this workgroup
   // One evaluation: everything a launched kernel does (the whole kernel in the launched forms; once per command in the resident one)
   auto run = [&](const TreeParams &q) __attribute__((always_inline)) {
@@ -219,6 +378,18 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
   };
   constexpr int CB  = C_ == 1 ? 1 : (C_ == 2 ? 2 : 4); // blocks (categories) per pattern
   constexpr int NPW = 16 / CB;                          // patterns per wave-tile
+  // Cache policy of what an evaluation stores.  Resident form: WRITTEN THROUGH at device scope (sc1, = a relaxed device-scope atomic
+  // store in the memory model) -- the workgroups never end, and what they store must be in memory, for kernels on other XCDs and
+  // for the host's copies, when the sums are posted.  Written through, a plain wait for the stores' acknowledgement is all the
+  // posting needs; the alternative -- a release fence per command -- writes the XCD's whole L2 back (buffer_wbl2: ~2 us each, two
+  // per command, of a 15 us command).  What the resident workgroups READ of each other's stores (the global A-operand tables
+  // workgroup 0 rewrites) they read at device scope likewise; what launched kernels or copies wrote in between is re-read behind the
+  // acquire fence the host asks for (command word 1, bit 2).
+  constexpr int kStAux = RES ? 16 : PHYHIP_STORE_AUX, kStAuxW = RES ? 16 : 0, kTabAux = RES ? 16 : 0;
+  auto gst = [](auto *ptr, const auto v) {
+    if constexpr (RES) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *ptr = v;
+  };
   static_assert(C_ >= 1 && C_ <= 4, "one MFMA block per category: at most four");
   static_assert(!INL || (!ARGS && !DBG && ABL == 0), "in-step tip x tip children: list form only");
   static_assert(NT == 1 || (NT == 2 && !ARGS && !DBG && ABL == 0), "two wave-tiles per wave: list form only");
@@ -281,27 +452,44 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
     if constexpr (RES)
     { // what the workgroup rebuilt itself sits in its slot already; every other table comes from the global table, one by one
       const unsigned built = __builtin_amdgcn_readfirstlane(s_built);
-      auto table = [&](char *to, const unsigned off) { // one table: 12 pieces of 1 KiB and a half
-#pragma unroll
-        for (int g = 0; g < 12; ++g)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, (lds_ptr)(to + g * 1024), 16, (unsigned)g * 1024u + (unsigned)lane * 16u, off, 0, 0);
-        if (lane < 32)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(af_rsrc, (lds_ptr)(to + 12 * 1024), 16, 12u * 1024u + (unsigned)lane * 16u, off, 0, 0);
-      };
       for (int j = 0; j < n_items; ++j)
       {
-        char *slot = reinterpret_cast<char *>(&ring[0][0][0]) + (size_t)(j % kAaRing) * 2 * kMatB;
+        double *slot = &ring[j % kAaRing][0][0];
         if (j < n_ops)
         {
           const IssueRec rj = IR(j);
-          if (!((built >> (2 * j)) & 1u)) table(slot, rj.c1_data.x);
-          if (!((built >> (2 * j + 1)) & 1u)) table(slot + kMatB, rj.c2_data.x);
+          if (!((built >> (2 * j)) & 1u)) aa_resident_table(af_rsrc, slot, rj.c1_data.x, lane);
+          if (!((built >> (2 * j + 1)) & 1u)) aa_resident_table(af_rsrc, slot + kAaMat, rj.c2_data.x, lane);
         }
-        else if (!((built >> (2 * j)) & 1u)) table(slot, (unsigned)q.e_pm * kMatB);
+        else if (!((built >> (2 * j)) & 1u)) aa_resident_table(af_rsrc, slot, (unsigned)q.e_pm * kMatB, lane);
       }
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
       asm volatile("" ::: "memory");
       publish(n_items);
+      if (blockIdx.x == 0 && !(AA_RES_ABL & 8))
+      { // while the consumers are at work: workgroup 0's copies of the rebuilt tables go to the global A-operand table (the
+        // launches that follow read them there), 16 bytes per lane and store
+        auto copy = [&](const double *src, const unsigned off) {
+          const u32x4 *s4 = reinterpret_cast<const u32x4 *>(src);
+          for (int e = lane; e < kAaMat / 2; e += 64) __builtin_amdgcn_raw_buffer_store_b128(s4[e], af_rsrc, (unsigned)e * 16u, off, kStAux);
+        };
+        for (int j = 0; j < n_items; ++j)
+        {
+          const double *slot = &ring[j % kAaRing][0][0];
+          if (j < n_ops)
+          {
+            const IssueRec rj = IR(j);
+            if ((built >> (2 * j)) & 1u) copy(slot, rj.c1_data.x);
+            if ((built >> (2 * j + 1)) & 1u) copy(slot + kAaMat, rj.c2_data.x);
+          }
+          else if ((built >> (2 * j)) & 1u) copy(slot, (unsigned)q.e_pm * kMatB);
+        }
+        for (int u = 0; u < 2; ++u)
+        {
+          const int m = __builtin_amdgcn_readfirstlane(s_spare[u]);
+          if (m >= 0) copy(&ring[kAaRing - 1][u][0], (unsigned)m * kMatB);
+        }
+      }
     }
     else
     for (int j = 0; j < ((ABL & 8) ? 0 : n_items); ++j)
@@ -381,6 +569,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
     }
     if (tact[0])
     {
+      if constexpr (RES) if (rs.stamps && (int)blockIdx.x == rs.stamp_wg && w == 0 && lane == 0) (void)__hip_atomic_fetch_add(&rs.stamps[8 + 0], wall_clock64() - s_t4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int kk = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3; // state residue / MFMA block / pattern within the group
       const int c  = b % CB;                                        // this lane's rate category
       const bool idle = c >= C_;                                    // C = 3: block 3 carries nothing
@@ -511,10 +700,21 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
           if (!cls) mx[0] = max_cats(mx[0]);
         }
       };
-      auto sum_states = [&](double v) { // (kk0 + kk1) + (kk2 + kk3), whichever lane asks
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        return v;
+      auto sum_states = [&](double v) { // (kk0 + kk1) + (kk2 + kk3), whichever lane asks: the four lanes' values by the half-exchange
+        unsigned w2[2], o[4][2];      // instructions (rows of 16 lanes [r0 r1 r2 r3] -> [r0 r0 r2 r2], [r1 r1 r3 r3] -> r0, r2 and r1, r3 everywhere)
+        __builtin_memcpy(w2, &v, 8);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+          const auto pp = __builtin_amdgcn_permlane16_swap(w2[h], w2[h], false, false);
+          const auto q0 = __builtin_amdgcn_permlane32_swap(pp[0], pp[0], false, false);
+          const auto q1 = __builtin_amdgcn_permlane32_swap(pp[1], pp[1], false, false);
+          o[0][h] = q0[0]; o[2][h] = q0[1]; o[1][h] = q1[0]; o[3][h] = q1[1];
+        }
+        double r4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_memcpy(&r4[i], o[i], 8);
+        return (r4[0] + r4[1]) + (r4[2] + r4[3]);
       };
       auto tip_vec = [&](unsigned word, double (&x)[T]) {
         const unsigned m = (word ? word : 1u) >> kk;
@@ -625,6 +825,49 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
         for (int t = 0; t < T; ++t) FA[i][t] = FB[i][t] = 0.0;
         scA[i] = scB[i] = 0;
       }
+
+      // argument form: a side of the evaluation edge that no operation of this launch writes (TreeParams::e_prefetch) is requested
+      // now, in front of the operations' own children -- one trip to memory less on the evaluation's chain
+      double   epx[NT][T], epy[NT][T];
+      unsigned eps[NT][2];
+      auto eval_fetch = [&](int i, int idx, double (&v)[T], unsigned &sc) {
+        const double *src = q.partials + (size_t)(idx - tips) * (ntiles * kAaBlock) + (size_t)tile[i] * kAaBlock;
+#pragma unroll
+        for (int t = 0; t < T; ++t) v[t] = src[aa_slot(t, lane)];
+        sc = (unsigned)q.scales[(size_t)(idx - tips) * (cls ? C : 1) * q.Ppad + voff_s[i] / 4];
+      };
+      // ... and so is everything else the site likelihoods read from memory (stationary frequencies, pattern weight, invariant-site
+      // state): four dependent trips on the evaluation's chain otherwise (2 us of a 7 us evaluation).  Same values, same arithmetic.
+      double pre_pi[T], pre_wt = 0.0, pre_cw[C_];
+      int    pre_iv = -1;
+#pragma unroll
+      for (int cc = 0; cc < C_; ++cc) pre_cw[cc] = 0.0;
+#pragma unroll
+      for (int t = 0; t < T; ++t) pre_pi[t] = 0.0;
+      if constexpr (ARGS)
+        if (q.edge_eval)
+        {
+          const double *pi_e = q.pi + ((cls && !idle) ? c * 20 : 0);
+#pragma unroll
+          for (int t = 0; t < T; ++t) pre_pi[t] = pi_e[4 * t + kk];
+#pragma unroll
+          for (int cc = 0; cc < C_; ++cc) pre_cw[cc] = q.cat_w[cc];
+          if (!cls && pact[0])
+          {
+            if (kk == 0 && c == 0) pre_wt = q.wght[p0[0]];
+            if (q.invar_model) pre_iv = q.invar[p0[0]];
+          }
+        }
+      if constexpr (ARGS)
+        if (q.edge_eval)
+        {
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+          {
+            if ((q.e_prefetch & 1) && tact[i]) eval_fetch(i, q.e_parent, epx[i], eps[i][0]);
+            if ((q.e_prefetch & 2) && tact[i]) eval_fetch(i, q.e_child, epy[i], eps[i][1]);
+          }
+        }
 
       if (n_ops > 0)
       {
@@ -743,6 +986,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
           {
             const double *A = wait_item(k, (int)cur.dst_scale.x);
             PHY_STAMP(k, 3)
+            if constexpr (RES) if (k == 0 && rs.stamps && (int)blockIdx.x == rs.stamp_wg && w == 0 && lane == 0) (void)__hip_atomic_fetch_add(&rs.stamps[8 + 5], wall_clock64() - s_t4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if constexpr (INL)
             {
               if (in1 || in2)
@@ -878,10 +1122,10 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
             }
             Frag wv;
             pack(o[i], wv);
-            __builtin_amdgcn_raw_buffer_store_b128(wv.p01, dr, voff_d16[i], 0, PHYHIP_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(wv.p23, dr, voff_d16[i] + 1024, 0, PHYHIP_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b64(wv.p4, dr, voff_d8[i], 0, PHYHIP_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_sst[i], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p01, dr, voff_d16[i], 0, kStAux);
+            __builtin_amdgcn_raw_buffer_store_b128(wv.p23, dr, voff_d16[i] + 1024, 0, kStAux);
+            __builtin_amdgcn_raw_buffer_store_b64(wv.p4, dr, voff_d8[i], 0, kStAux);
+            __builtin_amdgcn_raw_buffer_store_b32(sc, gr, voff_sst[i], 0, kStAuxW);
 #pragma unroll
             for (int t = 0; t < T; ++t) Fout[i][t] = o[i][t];
             scout[i] = sc;
@@ -917,12 +1161,19 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
 
       if (q.edge_eval)
       {
+        if constexpr (RES) if (rs.stamps && (int)blockIdx.x == rs.stamp_wg && w == 0 && lane == 0) (void)__hip_atomic_fetch_add(&rs.stamps[8 + 1], wall_clock64() - s_t4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- K2: site likelihood at the evaluation edge (src/lk.c:608-645, 767-861) -------------------------------
         double   x[NT][T], y[NT][T], u[NT][T];
         unsigned sl[NT], sr[NT];
         bool     tk[NT];
-        auto side = [&](int i, int idx, double (&v)[T], unsigned &sc) {
-          if (!tact[i])
+        auto side = [&](int i, int idx, double (&v)[T], unsigned &sc, const int which) {
+          if (ARGS && tact[i] && ((q.e_prefetch >> which) & 1))
+          { // (requested at the start)
+#pragma unroll
+            for (int t = 0; t < T; ++t) v[t] = which ? epy[i][t] : epx[i][t];
+            sc = eps[i][which];
+          }
+          else if (!tact[i])
           {
 #pragma unroll
             for (int t = 0; t < T; ++t) v[t] = 0.0;
@@ -939,19 +1190,13 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
             for (int t = 0; t < T; ++t) v[t] = FB[i][t];
             sc = scB[i];
           }
-          else
-          {
-            const double *src = q.partials + (size_t)(idx - tips) * (ntiles * kAaBlock) + (size_t)tile[i] * kAaBlock;
-#pragma unroll
-            for (int t = 0; t < T; ++t) v[t] = src[aa_slot(t, lane)];
-            sc = (unsigned)q.scales[(size_t)(idx - tips) * (cls ? C : 1) * q.Ppad + voff_s[i] / 4];
-          }
+          else eval_fetch(i, idx, v, sc);
         };
 #pragma unroll
         for (int i = 0; i < NT; ++i)
         {
-          side(i, q.e_parent, x[i], sl[i]);
-          side(i, q.e_child, y[i], sr[i]);
+          side(i, q.e_parent, x[i], sl[i], 0);
+          side(i, q.e_child, y[i], sr[i], 1);
           tk[i] = true;
 #pragma unroll
           for (int t = 0; t < T; ++t) u[i][t] = 0.0;
@@ -961,6 +1206,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
           mfma_tiles(A, x, u, tk); // rows: right-side state
           release_item(n_ops);
         }
+        if constexpr (RES) if (rs.stamps && (int)blockIdx.x == rs.stamp_wg && w == 0 && lane == 0) (void)__hip_atomic_fetch_add(&rs.stamps[8 + 2], wall_clock64() - s_t4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double *pi_c = q.pi + ((cls && !idle) ? c * 20 : 0);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -968,33 +1214,47 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
           double contrib = 0.0;
           double part = 0.0;
 #pragma unroll
-          for (int t = 0; t < T; ++t) part += u[i][t] * (y[i][t] * pi_c[4 * t + kk]);
+          for (int t = 0; t < T; ++t) part += u[i][t] * (y[i][t] * (ARGS ? pre_pi[t] : pi_c[4 * t + kk]));
+          // (argument form: pi[invariant state] out of the frequencies requested up front -- lane 16 (iv & 3) + ... holds pi[iv] in
+          // chunk iv >> 2)
+          double inv_pre = 0.0;
+          if constexpr (ARGS)
+            if (!cls && q.invar_model)
+            {
+              const int src = (lane & 15) | ((pre_iv < 0 ? kk : (pre_iv & 3)) << 4);
+#pragma unroll
+              for (int t = 0; t < T; ++t)
+              {
+                const double v = __shfl(pre_pi[t], src, 64);
+                if ((pre_iv >> 2) == t) inv_pre = v;
+              }
+            }
           const double lkc = sum_states(part);
-          if (pact[i] && kk == 0 && q.site_cat) q.site_cat[(size_t)p0[i] * C + c] = lkc;
+          if (pact[i] && kk == 0 && q.site_cat) gst(&q.site_cat[(size_t)p0[i] * C + c], lkc);
           if (cls)
           { // per class: its likelihood (above) and its scale exponent; the mixture is combined by class_combine_kernel
-            if (pact[i] && kk == 0) q.fact[(size_t)c * q.P + p0[i]] = q.apply_scaling ? (int)(sl[i] + sr[i]) : 0;
+            if (pact[i] && kk == 0) gst(&q.fact[(size_t)c * q.P + p0[i]], q.apply_scaling ? (int)(sl[i] + sr[i]) : 0);
           }
           else
           {
             // the categories of this lane's pattern, in category order (src/lk.c:816-818)
             double site = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < C_; ++cc) site += __shfl(lkc, (lane & ~(3 << 2)) | (((b / CB) * CB + cc) << 2), 64) * q.cat_w[cc];
+            for (int cc = 0; cc < C_; ++cc) site += __shfl(lkc, (lane & ~(3 << 2)) | (((b / CB) * CB + cc) << 2), 64) * (ARGS ? pre_cw[cc] : q.cat_w[cc]);
             if (pact[i] && kk == 0 && c == 0)
             {
-              const double wt = q.wght[p0[i]];
+              const double wt = ARGS ? pre_wt : q.wght[p0[i]];
               int          f  = q.apply_scaling ? (int)(sl[i] + sr[i]) : 0;
               if (wt > kSmall)
               {
                 if (q.invar_model)
                 { // src/lk.c:820-842, 1226-1273
-                  const int iv  = q.invar[p0[i]];
+                  const int iv  = ARGS ? pre_iv : q.invar[p0[i]];
                   double    inv = 0.0;
                   bool      issue_ = false;
                   if (iv >= 0)
                   {
-                    inv = q.pi[iv];
+                    inv = ARGS ? inv_pre : q.pi[iv];
                     if (q.apply_scaling)
                     {
                       int e = f;
@@ -1012,19 +1272,35 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
                 }
                 if (site < kSmall) { site = kSmall; raise_warn(q); }
                 const double lsl = log(site) - kLog2 * (double)f;
-                if (q.site_lnl) q.site_lnl[p0[i]] = lsl;
-                if (q.site_lk) q.site_lk[p0[i]] = exp(lsl);
+                if (q.site_lnl) gst(&q.site_lnl[p0[i]], lsl);
+                if (q.site_lk) gst(&q.site_lk[p0[i]], exp(lsl));
                 contrib = wt * lsl;
               }
-              q.fact[p0[i]] = f;
+              gst(&q.fact[p0[i]], f);
             }
             // this TILE's share: fixed shuffle tree -> deterministic, and the same double whichever wave shape computed it
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+            // (the tree contrib += shfl_down(contrib, 32 / 16 / 8 / 4 / 2 / 1) as lane 0 sees it, without the steps that can only add
+            // zeros -- contributions sit in the lanes with kk = 0, c = 0: lanes 0-15, of them block 0 (four categories), blocks 0 and
+            // 2 (two), all four (one) -- and with the last two steps, inside a quad, as DPP moves instead of trips through LDS)
+            if (CB <= 2) contrib += __shfl_down(contrib, 8, 64);
+            if (CB == 1) contrib += __shfl_down(contrib, 4, 64);
+            auto quad = [](const double v, const auto ctrl) { // lane i of a quad <- lane perm[i] of it
+              unsigned w2[2];
+              __builtin_memcpy(w2, &v, 8);
+              w2[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w2[0], decltype(ctrl)::value, 0xF, 0xF, false);
+              w2[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w2[1], decltype(ctrl)::value, 0xF, 0xF, false);
+              double r;
+              __builtin_memcpy(&r, w2, 8);
+              return r;
+            };
+            contrib += quad(contrib, std::integral_constant<int, 0xEE>()); // quad_perm [2, 3, 2, 3]: lanes 0, 1 <- lanes 2, 3
+            contrib += quad(contrib, std::integral_constant<int, 0xF5>()); // quad_perm [1, 1, 3, 3]: lane 0 <- lane 1
             if (lane == 0 && w * NT + i < 16) s_wsum[w * NT + i] = contrib;
           }
         }
-        if (q.fence_post) __threadfence(); // every wave's stores are in memory before the workgroup's sum is posted
+        if constexpr (RES) if (rs.stamps && (int)blockIdx.x == rs.stamp_wg && w == 0 && lane == 0) (void)__hip_atomic_fetch_add(&rs.stamps[8 + 3], wall_clock64() - s_t4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q.fence_post && !RES) __threadfence(); // every wave's stores are in memory before the workgroup's sum is posted (resident form: below)
+        if constexpr (RES) if (rs.stamps && (int)blockIdx.x == rs.stamp_wg && w == 0 && lane == 0) (void)__hip_atomic_fetch_add(&rs.stamps[8 + 4], wall_clock64() - s_t4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -1037,7 +1313,9 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
   }
 #undef PHY_STAMP
   if (!q.edge_eval || q.class_axis) return;
-  if constexpr (RES) __threadfence(); // (what this wave stored -- results, workgroup 0's share of the rebuilt matrices -- is in memory before the records go out)
+  // (resident form: what this wave stored -- results, its share of the rebuilt matrices -- is in memory before the records go out:
+  // written through, see kStAux above, so acknowledged = there)
+  if constexpr (RES && !(AA_RES_ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave == 0)
   {
@@ -1061,7 +1339,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
   {
     __shared__ unsigned long long sh_raw[64];
     __shared__ __attribute__((aligned(16))) double sh_expt[4][4 * 20]; // [rebuilt matrix][category][eigenvalue]
-    __shared__ __attribute__((aligned(16))) double sh_U[400], sh_V[400];
+    __shared__ __attribute__((aligned(16))) double sh_U[400], sh_V[400], sh_R[20], sh_rates[4];
     __shared__ int sh_act;
     const int          lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int)(blockDim.x >> 6);
     unsigned long long last = rs.ctl.start_seq, t_last = wall_clock64(), model_seen = ~0ull;
@@ -1082,10 +1360,13 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
         __syncthreads(); // (sh_act / sh_raw are rewritten by the next poll)
         continue;
       }
-      // every word is the same for all lanes: make that known (descriptors and loop bounds belong in scalar registers)
+      // the command's words: lane k of every wave reads word k (ONE trip to LDS for the whole record -- a read per word, each
+      // waited for, cost a microsecond per command), and a word is taken out of lane k's register: the same for all lanes and known
+      // to be (descriptors and loop bounds belong in scalar registers)
+      static_assert(kResidentAaWords <= 64, "one command word per lane");
+      const unsigned long long my_word = sh_raw[resident_slot(lane < kResidentAaWords ? lane : 0)];
       auto word = [&](int k) {
-        const unsigned long long v = sh_raw[resident_slot(k)];
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)my_word, k), hi = __builtin_amdgcn_readlane((unsigned)(my_word >> 32), k);
         return ((unsigned long long)hi << 32) | lo;
       };
       auto desc = [&](int k) {
@@ -1094,6 +1375,8 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
         d.base = word(k); d.bytes = (unsigned)b; d.x = (unsigned)(b >> 32);
         return d;
       };
+      unsigned long long tk[6];
+      tk[0] = rs.stamps ? wall_clock64() : 0ull;
       const unsigned long long fl = word(1), ed = word(2), pm = word(3), epoch = word(34);
       TreeParams               q = q_in;
       q.host_tag = word(0);
@@ -1103,6 +1386,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
       q.n_real_ops = (int)(fl & 3);
       // what kernels on the stream wrote since the last command (the host says whether any did) is re-read from memory
       if (fl & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      tk[1] = rs.stamps ? wall_clock64() : 0ull;
       // ---- the queued matrices, by this workgroup, into the ring slots its consumers will read them from ----------------------
       const int nf = q.n_fresh;
       if (nf > 0)
@@ -1110,14 +1394,21 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
         if (epoch != model_seen)
         { // (the eigen system changes with the model only: staged once per epoch)
           for (int t = threadIdx.x; t < 400; t += blockDim.x) { sh_U[t] = rs.evec[t]; sh_V[t] = rs.ivec[t]; }
+          if (threadIdx.x < 20) sh_R[threadIdx.x] = rs.eval[threadIdx.x];
+          if (threadIdx.x < C_) sh_rates[threadIdx.x] = rs.rates[threadIdx.x];
           model_seen = epoch;
+          __syncthreads();
         }
-        for (int f = 0; f < nf; ++f)
-        {
-          double len;
-          const unsigned long long lb = word(6 + f);
-          __builtin_memcpy(&len, &lb, 8);
-          pmat20_exponentials(sh_expt[f], len, C_, false, rs.eval, rs.rates, q.br_len_mult, q.l_min, q.l_max, (int)threadIdx.x, (int)blockDim.x);
+        if (!(AA_RES_ABL & 4))
+        { // (pmat20_exponentials' arithmetic, the matrices side by side: thread t takes (matrix t / 80, category, eigenvalue))
+          const int t = (int)threadIdx.x, f = t / (4 * 20), u = t % (4 * 20);
+          if (f < nf && u < C_ * 20)
+          {
+            double len;
+            const unsigned long long lb = sh_raw[resident_slot(6 + f)];
+            __builtin_memcpy(&len, &lb, 8);
+            pmat20_exponentials(sh_expt[f], len, C_, false, sh_R, sh_rates, q.br_len_mult, q.l_min, q.l_max, u, 4 * 20);
+          }
         }
       }
       // where each rebuilt matrix is read in this command: the five places a command has -- table 0 / 1 of operation 0, of
@@ -1133,49 +1424,66 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
       unsigned built = 0;
       if (nf > 0)
       {
-        if (C_ == 3)
-        { // (blocks beyond the category count stay zero in every table that is about to be filled: simplest, all of the ring)
-          double *rz = &ring[0][0][0];
-          for (int e = threadIdx.x; e < kAaRing * 2 * kAaMat; e += blockDim.x) rz[e] = 0.0;
+        __syncthreads(); // (exponentials and eigen system staged)
+        tk[2] = rs.stamps ? wall_clock64() : 0ull;
+        // where each rebuilt matrix goes: table numbers of the ring (table w of item j = 2 j + w; the evaluation edge is item n_ops,
+        // table 0; the spare item's two tables take what nothing reads in this command); bits of `built` likewise
+        int      fi[4], fta[4], ftb[4];
+        unsigned fmore[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+        {
+          fi[f] = 0; fta[f] = ftb[f] = 2 * (kAaRing - 1) + (f & 1); fmore[f] = 0;
+          if (f < nf)
+          {
+            fi[f] = fidx(f);
+            const unsigned offb = (unsigned)fi[f] * kMatB;
+            unsigned       m = 0; // (bit = table number)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) m |= (used[y] == offb) ? (1u << y) : 0u;
+            if (used[4] == offb) m |= 1u << (2 * n_ops_c);
+            built |= m;
+            if (m)
+            {
+              fta[f] = __builtin_ctz(m); m &= m - 1;
+              ftb[f] = m ? __builtin_ctz(m) : fta[f];
+              fmore[f] = m ? (m & (m - 1)) : 0u;
+            }
+          }
         }
+        auto pick = [](const int f, const auto (&v)[4]) { return f == 0 ? v[0] : (f == 1 ? v[1] : (f == 2 ? v[2] : v[3])); };
+        // one wave per (matrix, row group) unit, the units dealt out over the workgroup's waves; a wave with two units (three
+        // matrices x five row groups on eight waves) works through them side by side
+        if (!(AA_RES_ABL & 2))
+          for (int u0 = wave; u0 < nf * kAaT; u0 += 2 * nwaves)
+          {
+            const int u1 = u0 + nwaves, f0 = u0 / kAaT, f1 = u1 < nf * kAaT ? u1 / kAaT : f0;
+            const int           rr[2] = {u0 % kAaT, u1 < nf * kAaT ? u1 % kAaT : -1};
+            const double *const ex[2] = {sh_expt[f0], sh_expt[f1]};
+            // (the natural-layout copy of matrix f in the global table: by workgroup (f + 1) mod the grid -- workgroup 0's loader wave
+            // writes the A-operand copies)
+            double *const       oo[2] = {(int)blockIdx.x == (f0 + 1) % (int)gridDim.x ? rs.pmats_rw + (size_t)pick(f0, fi) * C_ * 400 : nullptr,
+                                         (int)blockIdx.x == (f1 + 1) % (int)gridDim.x ? rs.pmats_rw + (size_t)pick(f1, fi) * C_ * 400 : nullptr};
+            const int           ta[2] = {pick(f0, fta), pick(f1, fta)}, tb[2] = {pick(f0, ftb), pick(f1, ftb)};
+            const unsigned      mo[2] = {pick(f0, fmore), pick(f1, fmore)};
+            aa_build_units<C_, 2>(ex, sh_U, sh_V, rr, lane, oo, &ring[0][0][0], ta, tb, mo, (rs.stamps && (int)blockIdx.x == rs.stamp_wg && wave == 1) ? rs.stamps : nullptr);
+          }
         __syncthreads();
-        // four waves per matrix where the workgroup has them (pmat20_kernel's shape), the groups taking the matrices in turn
-        const int wpm = nwaves >= 4 * nf ? 4 : (nwaves >= 2 * nf ? 2 : 1), groups = nwaves / wpm, g = wave / wpm;
-        double *const tabs[7] = {&ring[0][0][0], &ring[0][1][0], &ring[1][0][0], &ring[1][1][0], eslot, &ring[kAaRing - 1][0][0], &ring[kAaRing - 1][1][0]};
-#pragma unroll 1
+        tk[3] = rs.stamps ? wall_clock64() : 0ull;
+      }
+      if (threadIdx.x == 0)
+      {
+        s_built = built;
+        s_spare[0] = s_spare[1] = -1;
         for (int f = 0; f < nf; ++f)
         {
           const unsigned offb = (unsigned)fidx(f) * kMatB;
-          unsigned       m = 0;
+          bool           rd = false;
 #pragma unroll
-          for (int y = 0; y < 5; ++y) m |= (used[y] == offb) ? (1u << y) : 0u;
-          // (bits of `built`: 2 j + w for table w of item j; the evaluation edge is item n_ops)
-          built |= (m & 15u) | ((m >> 4) << (2 * n_ops_c));
-          if (m == 0) m = 32u << (f & 1);
-          if (g < groups && (f % groups) == g)
-            pmat20_entries<7>(sh_expt[f], sh_U, sh_V, C_, false, lane, wave % wpm, wpm,
-                              blockIdx.x == 0 ? rs.pmats_rw + (size_t)fidx(f) * C_ * 400 : nullptr, tabs, m);
-        }
-        __syncthreads();
-        if (blockIdx.x == 0)
-        {
-#pragma unroll 1
-          for (int f = 0; f < nf; ++f)
-            { // the A-operand copies of the global table, from the first place each matrix was built into
-              const unsigned offb = (unsigned)fidx(f) * kMatB;
-              const double  *src = &ring[kAaRing - 1][f & 1][0];
-              if (used[4] == offb) src = eslot;
-              if (used[3] == offb) src = &ring[1][1][0];
-              if (used[2] == offb) src = &ring[1][0][0];
-              if (used[1] == offb) src = &ring[0][1][0];
-              if (used[0] == offb) src = &ring[0][0][0];
-              double2       *dst = reinterpret_cast<double2 *>(rs.afrag_rw + (size_t)fidx(f) * kAaMat);
-              const double2 *s2  = reinterpret_cast<const double2 *>(src);
-              for (int e = threadIdx.x; e < kAaMat / 2; e += blockDim.x) dst[e] = s2[e];
-            }
+          for (int y = 0; y < 5; ++y) rd = rd || used[y] == offb;
+          if (!rd) s_spare[f & 1] = fidx(f);
         }
       }
-      if (threadIdx.x == 0) s_built = built;
 #pragma unroll
       for (int o = 0; o < 2; ++o)
       {
@@ -1183,8 +1491,18 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
         q.arg_ir[o].c1_scale = desc(14 + o * 12); q.arg_ir[o].c2_scale = desc(16 + o * 12);
         q.arg_xr[o].dst_data = desc(18 + o * 12); q.arg_xr[o].dst_scale = desc(20 + o * 12);
       }
+      tk[4] = rs.stamps ? wall_clock64() : 0ull;
+      if (rs.stamps && threadIdx.x == 0) s_t4 = tk[4];
       run(q); // (starts with a workgroup barrier: s_built and the tables are in place for everybody)
       __syncthreads();
+      if (rs.stamps && (int)blockIdx.x == rs.stamp_wg && threadIdx.x == 0)
+      {
+        tk[5] = wall_clock64();
+        if (nf == 0) tk[2] = tk[3] = tk[1];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) (void)__hip_atomic_fetch_add(&rs.stamps[i], tk[i + 1] - tk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(&rs.stamps[7], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       last = last + 1; t_last = wall_clock64();
     }
   }

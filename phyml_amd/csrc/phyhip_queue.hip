@@ -697,6 +697,18 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       hipStream_t st;
       if ((rc = resident_prepare(I, R, wgs, kResidentAaWords, R.seq, rs.ctl, &st))) return rc;
       rs.evec = I->d_evec; rs.ivec = I->d_ivec; rs.eval = I->d_eval; rs.rates = I->d_catr; rs.pmats_rw = I->d_pmats; rs.afrag_rw = I->d_afrag;
+      rs.stamps = nullptr; rs.stamp_wg = 0;
+      if (getenv("PHYHIP_RESIDENT_STATS"))
+      { // (where workgroup 0's time goes per command: printed when the instance goes)
+        if (!I->d_big_stamps)
+        {
+          HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 32));
+          HIPCHK(hipMemsetAsync(I->d_big_stamps, 0, sizeof(unsigned long long) * 16, I->stream));
+          HIPCHK(hipStreamSynchronize(I->stream));
+        }
+        rs.stamps = I->d_big_stamps;
+        rs.stamp_wg = std::min(wgs - 1, std::max(0, atoi(getenv("PHYHIP_RESIDENT_STATS")) - 1));
+      }
       if (launch_resident_aa(I->C, wgs, nwr, st, sq, (const double *)I->d_afrag, I->nmat_all, (const uint32_t *)I->d_tipmasks, rs))
         return fail(PHYHIP_ERROR_GENERAL, "20-state resident evaluator: no kernel for %d categories", I->C);
       HIPCHK(hipGetLastError());

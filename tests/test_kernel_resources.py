@@ -75,11 +75,14 @@ def test_default_traversal_kernels_keep_their_occupancy(product):
         n = f"_ZN6phyhip25traverse_nt2_mixed_kernelILi4ELb{inl}EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdPKhi"
         assert waves_per_simd(product[n]["vgpr_count"]) >= 2 and product[n]["private_segment_fixed_size"] == 0, (n, product[n])
     # the 20-state kernel: 1 loader + 15 consumer waves per workgroup = four per SIMD
-    # (<C, DBG, ABL, ARGS, INL, NT, D2>: list form, argument form, and the list form with in-step tip x tip children)
+    # (<C, DBG, ABL, ARGS, INL, NT, D2, RES>: list form, argument form, and the list form with in-step tip x tip children)
     for c in (1, 2, 3, 4):
         for args, inl in ((0, 0), (1, 0), (0, 1)):
-            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb{args}ELb{inl}ELi1ELb0EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
+            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb{args}ELb{inl}ELi1ELb0ELb0EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPyNS_10AaResidentE"
             assert product[n]["vgpr_count"] <= 128, (n, product[n]["vgpr_count"])
+        # the resident form (<..., RES>): 1 loader + 7 consumers = two waves per SIMD
+        n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb1ELb0ELi1ELb0ELb1EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPyNS_10AaResidentE"
+        assert product[n]["vgpr_count"] <= 256 and product[n]["private_segment_fixed_size"] == 0, (n, product[n])
 
 
 def test_measured_variants_of_the_20_state_kernel_fit_their_waves(tmp_path):
@@ -91,9 +94,9 @@ def test_measured_variants_of_the_20_state_kernel_fit_their_waves(tmp_path):
     k = kernels_of(diag, str(tmp_path))
     for c in (1, 2, 3, 4):
         for inl in (0, 1):
-            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb0ELb{inl}ELi2ELb0EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
+            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb0ELb{inl}ELi2ELb0ELb0EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPyNS_10AaResidentE"
             assert k[n]["vgpr_count"] <= 256 and k[n]["private_segment_fixed_size"] == 0, (n, k[n])
-            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb0ELb{inl}ELi1ELb1EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPy"
+            n = f"_ZN6phyhip18traverse_aa_kernelILi{c}ELb0ELi0ELb0ELb{inl}ELi1ELb1ELb0EEEvNS_10TreeParamsEPKNS_8IssueRecEPKNS_7ExecRecEPKdiPKjPyNS_10AaResidentE"
             assert k[n]["vgpr_count"] <= 168 and k[n]["private_segment_fixed_size"] == 0, (n, k[n])
 
 
