@@ -58,7 +58,7 @@ int phyhip_update_eigen_lr(int instance, int left, int rght)
   I->touched_call = true;
   EigenParams e;
   e.t = base_params(I); e.ro = base_ro(I, nullptr); e.left = left; e.rght = rght; e.r_e_vect = I->d_evec; e.l_e_vect = I->d_ivec; e.dot_prod = I->d_dot;
-  const bool report = I->resident && I->S == 4 && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co; // (see eigen_eval)
+  const bool report = I->resident && (I->S == 4 || dlk_from_len(I)) && I->host_sum && I->spin_wait && I->grid <= kResidentMaxGrid && !I->co; // (see eigen_eval)
   e.tickets = report ? I->d_tickets : nullptr;
   e.stamp_host = reinterpret_cast<unsigned long long *>(I->h_result + 3); e.stamp = report ? ++I->stamp_seq : 0ull;
   AuxProf ap(I, 0);
@@ -93,6 +93,10 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   memset(&q, 0, sizeof q);
   q.dot_prod = I->d_dot; q.wght = I->d_wght; q.fact = I->d_fact; q.cat_w = I->d_catw; q.pi = I->d_pi; q.invar = I->d_invar;
   q.P = I->P; q.C = I->C; q.invar_model = I->invar_model; q.apply_scaling = I->apply_scaling; q.with_derivative = deriv ? 1 : 0;
+  // 20 states: the workgroups build the expl table from the edge length themselves (DlkParams::from_len)
+  const bool from_len = dlk_from_len(I) && expl_in_args;
+  q.eval_dev = I->d_eval; q.rates_dev = I->d_catr; q.br_len_mult = I->br_len_mult; q.l_min = I->l_min; q.l_max = I->l_max;
+  q.from_len = from_len ? 1 : 0; q.len = from_len ? l : 0.0;
   // grid-stride kernel.  Measured (us per dLk incl. launch and host hand-over): 512 workgroups + fused final sum win up to
   // ~100 MB of dot_prod (20 states x 100 k patterns: 33 vs 48); beyond, filling every wave slot (2048 workgroups, separate
   // final sum) streams better (4 states x 1 M patterns: 45 vs 64; the one-workgroup-per-256-lanes form took 75)
@@ -118,7 +122,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
     q.fin.seq = dev_out ? 0ull : ++I->seq; q.fin.warn_out = warn_out;
   }
   double *const xp = expl_in_args ? q.expl : expl_big.data();
-  for (int c = 0; c < I->C; ++c)
+  for (int c = 0; c < (from_len ? 0 : I->C); ++c)
   {
     if (deriv)
     { // src/lk.c:688-726
@@ -206,7 +210,7 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
   // (20 states, re-measured in round 4 with compact commands -- exp() values only, two 512-byte reads instead of four, ONE
   // polling workgroup, the others on the device-memory mailbox: 10.7 us from command to answer on the recorded proteic search,
   // 18.2 against 17.5 us per scalar-returning call, 13.2 against 13.4 us per dLk at 2 000 patterns -- still no gain: removed)
-  if (!big && hsum && I->resident && I->S == 4 && dgrid <= kResidentMaxGrid && I->spin_wait && expl_in_args)
+  if (!big && hsum && I->resident && (I->S == 4 || from_len) && dgrid <= kResidentMaxGrid && I->spin_wait && expl_in_args)
   {
     bool idle = !I->stream_dirty;
     if (idle && I->clean_after)
@@ -225,13 +229,15 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
     if (idle)
     {
       DlkParams qs = q; // what stays the same from call to call
-      qs.with_derivative = 0; qs.invar_model = 0; qs.apply_scaling = 0; qs.pinvar = 0.0; qs.fin.host_tag = 0;
+      qs.with_derivative = 0; qs.invar_model = 0; qs.apply_scaling = 0; qs.pinvar = 0.0; qs.fin.host_tag = 0; qs.len = 0.0;
       memset(qs.expl, 0, sizeof qs.expl);
       const DlkParams &o = I->r_static;
       Resident  &R = I->rd;
       const bool same = R.launched && R.grid == dgrid && o.dot_prod == qs.dot_prod && o.wght == qs.wght && o.fact == qs.fact &&
                         o.cat_w == qs.cat_w && o.pi == qs.pi && o.invar == qs.invar && o.P == qs.P && o.C == qs.C &&
-                        o.fin.host_blocks == qs.fin.host_blocks && o.fin.stride == qs.fin.stride && o.fin.warn == qs.fin.warn;
+                        o.fin.host_blocks == qs.fin.host_blocks && o.fin.stride == qs.fin.stride && o.fin.warn == qs.fin.warn &&
+                        o.from_len == qs.from_len && o.eval_dev == qs.eval_dev && o.rates_dev == qs.rates_dev && o.br_len_mult == qs.br_len_mult &&
+                        o.l_min == qs.l_min && o.l_max == qs.l_max;
       if (!same)
       {
         resident_stop(R);
@@ -242,12 +248,13 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
         if ((rc = resident_launch_dlk(I, qs, dgrid, R.seq))) return rc;
       }
       unsigned long long words[kResidentWords];
-      const int          n_words = 3 + I->C * 2 * I->S;
+      const int          n_words = from_len ? 4 : 3 + I->C * 2 * I->S;
       const bool         changed = I->api_no != R.api_no + 1; // something else was called since the last command
       words[0] = q.fin.host_tag;
-      words[1] = (q.with_derivative ? 1u : 0u) | (q.invar_model ? 2u : 0u) | (q.apply_scaling ? 4u : 0u) | (changed ? 8u : 0u);
+      words[1] = (q.with_derivative ? 1u : 0u) | (q.invar_model ? 2u : 0u) | (q.apply_scaling ? 4u : 0u) | (changed ? 8u : 0u) | (from_len ? 16u : 0u);
       memcpy(&words[2], &q.pinvar, 8);
-      memcpy(&words[3], q.expl, sizeof(double) * (size_t)(n_words - 3));
+      if (from_len) memcpy(&words[3], &l, 8);
+      else memcpy(&words[3], q.expl, sizeof(double) * (size_t)(n_words - 3));
       resident_send(I, R, words, n_words);
       I->host_sum_n = dgrid; I->host_sum_ns = 2;
       rc = wait_result(I);

@@ -562,6 +562,9 @@ void rewrite_pending(Instance *I, const EdgeEval *ee, bool may_virtualise);
 
 // ---- resident evaluators: host side -----------------------------------------------------------------------------
 constexpr int kResidentMaxGrid = 64;   // resident evaluator: alignments of up to this many dLk workgroups
+// 20 states, one eigen system, categories on their own axis: eigen-basis evaluations described by the edge length, the expl table
+// built by the workgroups (DlkParams::from_len, phyhip_kernels.hpp) -- launched and resident alike
+inline bool dlk_from_len(const Instance *I) { return I->S == 20 && I->NE == 1 && !I->class_axis && I->C <= 8; }
 constexpr int kResidentSilent = -4242; // wait_host_sum: the resident workgroups did not answer (not an error)
 static double ns_since(const struct timespec &t0)
 {

@@ -1223,7 +1223,45 @@ struct DlkParams
   FinishParams  fin;             // block_sums [2][stride], warn, and (optionally) the fused final sum
   double        expl[kMaxExpl];
   const double *expl_dev;        // more than 8 categories: the table in device memory instead (kernel arguments hold 4 KiB)
+  // 20 states, one eigen system: the evaluation is described by the edge LENGTH and the workgroups build the table themselves
+  // (dlk_expl_from_len: the arithmetic of src/lk.c:594-602 / :688-726 with the device's exp) -- a resident command of four words
+  // instead of 163 (one 512-byte read per poll instead of four: what made the 20-state resident dLk lose to the launch in rounds 3
+  // and 4), and the launched form takes the same route so that both give the same doubles.
+  int           from_len;        // != 0: build the table from `len`
+  double        len;
+  const double *eval_dev, *rates_dev; // eigenvalues [S], category rates [C]
+  double        br_len_mult, l_min, l_max;
 };
+
+// The expl table of an eigen-basis evaluation from the edge length (src/lk.c:594-602 without, :688-726 with the derivative;
+// the host's version: eigen_eval, phyhip_eigen.hip), entry by entry over the calling threads.
+template <int S>
+__device__ __forceinline__ void dlk_expl_from_len(double *tab, const double l, const bool deriv, const int C, const double *ev, const double *rates,
+                                                  const double mult, const double l_min, const double l_max, const int tid, const int nth)
+{
+  for (int e = tid; e < C * S; e += nth)
+  {
+    const int c = e / S, s = e % S;
+    if (deriv)
+    {
+      const double rr  = rates[c] * mult;
+      double       len = l * rr;
+      if (len < l_min) len = l_min;
+      else if (len > l_max) len = l_max;
+      const double v = ev[s], ex = exp(v * len);
+      tab[c * 2 * S + 2 * s]     = ex;
+      tab[c * 2 * S + 2 * s + 1] = ex * v * rr;
+    }
+    else
+    {
+      double len = (l > 0.0 ? l : 0.0) * rates[c];
+      len *= mult;
+      if (len < l_min) len = l_min;
+      else if (len > l_max) len = l_max;
+      tab[c * S + s] = exp(ev[s] * len);
+    }
+  }
+}
 
 // What varies from one evaluation to the next on one edge (the rest of DlkParams is fixed while the instance lives)
 struct DlkCall
@@ -1446,6 +1484,17 @@ __global__ __launch_bounds__(256) void dlk_kernel(const DlkParams q)
 {
   const DlkCall k = {q.with_derivative, q.invar_model, q.apply_scaling, q.pinvar};
   double        v[2];
+  if constexpr (S == 20)
+  {
+    if (q.from_len)
+    { // (every workgroup builds the table: 160 exponentials over 256 threads)
+      __shared__ double sh_tab[kMaxExpl];
+      dlk_expl_from_len<S>(sh_tab, q.len, q.with_derivative != 0, q.C, q.eval_dev, q.rates_dev, q.br_len_mult, q.l_min, q.l_max, (int)threadIdx.x, (int)blockDim.x);
+      __syncthreads();
+      if (dlk_block<S, CP>(q, k, sh_tab, q.fin.warn, v)) finish_sums<2>(q.fin, v, (int)(threadIdx.x & 63));
+      return;
+    }
+  }
   if (dlk_block<S, CP>(q, k, q.expl_dev ? q.expl_dev : q.expl, q.fin.warn, v)) finish_sums<2>(q.fin, v, (int)(threadIdx.x & 63));
 }
 
@@ -1620,6 +1669,14 @@ __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, co
     }
     const DlkCall k = {(int)(flags & 1), (int)((flags >> 1) & 1), (int)((flags >> 2) & 1), pinvar};
     const int     ne = q.C * (k.with_derivative ? 2 : 1) * S;
+    if (flags & 16)
+    { // the table from the edge length (word 3): DlkParams::from_len
+      double                   l;
+      const unsigned long long b = word(3);
+      __builtin_memcpy(&l, &b, 8);
+      dlk_expl_from_len<S>(sh_expl, l, k.with_derivative != 0, q.C, q.eval_dev, q.rates_dev, q.br_len_mult, q.l_min, q.l_max, (int)threadIdx.x, (int)blockDim.x);
+    }
+    else
     for (int e = threadIdx.x; e < ne; e += blockDim.x)
     {
       const unsigned long long b = word(3 + e);

@@ -190,7 +190,7 @@ int resident_launch_dlk(Instance *I, const DlkParams &qs, int dgrid, unsigned lo
 {
   ResidentCtl r;
   hipStream_t st;
-  int rc = resident_prepare(I, I->rd, dgrid, 3 + I->C * 2 * I->S, served, r, &st);
+  int rc = resident_prepare(I, I->rd, dgrid, qs.from_len ? 4 : 3 + I->C * 2 * I->S, served, r, &st);
   if (rc) return rc;
   rc = dispatch_shape(I, [&](auto s, auto cp) {
     constexpr int S_ = decltype(s)::value, CP_ = decltype(cp)::value;

@@ -335,8 +335,13 @@ def test_20_state_resident_evaluator_is_the_launch_path_bit_for_bit(P, C, host_p
             served, launches, silent, busy = t.inst.resident_stats(1)
             if res == "1" and not host_pmat:
                 assert served >= 60 and silent == 0, (served, launches, silent, busy)
+            # the branch-length chains' dLk calls (src/optimiz.c:607-663): resident too -- a four-word command (the edge length; the
+            # workgroups build the exponential table, as the launched 20-state dlk_kernel does: the same doubles)
+            d_served, _, d_silent, _ = t.inst.resident_stats(0)
+            if res == "1":
+                assert d_served >= 30 and d_silent == 0, (d_served, d_silent)
             if res == "0":
-                assert served == 0
+                assert served == 0 and d_served == 0
             # what is left in device memory: matrices (both tables feed later launches) and the buffers the stream wrote
             mats = [t.inst.get_transition_matrix(e).copy() for e in range(ot.ne)]
             bufs = [t.partials(e, s).copy() for e in (0, 5, 11, ot.ne - 1) for s in (0, 1) if (e, s) in ot.plk]

@@ -1,11 +1,9 @@
 export TMPDIR=/tmp
-B="python tools/bench_spr.py --taxa 37 --patterns 429 --states 20 --candidates 3000"
-P='import json,sys; d=json.loads(sys.stdin.read()); print("  us/candidate %.2f"%d["us_per_candidate"])'
-for wg in 1; do
-echo "resident, stats of workgroup $wg:"; PHYHIP_RESIDENT_STATS=$wg timeout 120 $B 2> gpurun_out/aa_res_stats_$wg.err | python -c "$P"
-grep -E "inside|20-state res|from command" gpurun_out/aa_res_stats_$wg.err
-done
+P='import json,sys; d=json.loads(sys.stdin.read()); print("  us/candidate %.2f  calls %d  dlk %d"%(d["us_per_candidate"], d["surface_calls"], d["dlk"]))'
+timeout 300 python -m pytest tests/test_gpu_resident.py -x -q 2>&1 | tail -5
 for rep in 1 2; do
-echo "lib:"; timeout 120 $B | python -c "$P"
+echo "aa launch + brlen:"; PHYHIP_RESIDENT=0 timeout 120 python tools/bench_spr.py --taxa 37 --patterns 429 --states 20 --candidates 2000 --opt-every 4 | python -c "$P"
+echo "aa resident + brlen:"; PHYHIP_RESIDENT_STATS=1 timeout 120 python tools/bench_spr.py --taxa 37 --patterns 429 --states 20 --candidates 2000 --opt-every 4 2> gpurun_out/aa_res_stats.err | python -c "$P"
+grep -E "from command" gpurun_out/aa_res_stats.err
+echo "aa resident:"; timeout 120 python tools/bench_spr.py --taxa 37 --patterns 429 --states 20 --candidates 2000 | python -c "$P"
 done
-timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/full_gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/full_gpu_tests.log
