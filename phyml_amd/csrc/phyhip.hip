@@ -49,8 +49,8 @@ static void release_instance(Instance *I)
       const char *bn[5] = {"operands read", "products", "row sums", "divisions", "stored"};
       for (int k = 0; k < 5; ++k)
         fprintf(stderr, "    inside the matrix rebuild (wave 1, two units), after its start: %-16s %6.2f us\n", bn[k], (double)h[16 + k] * 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3) / (double)h[7]);
-      const char *in[6] = {"consumer wave 0 starts", "operations done", "evaluation edge's products done", "sums written", "fenced", "first operation's tables in the ring"};
-      for (int k = 0; k < 6; ++k)
+      const char *in[7] = {"consumer wave 0 starts", "operations done", "evaluation edge's products done", "sums written", "fenced", "first operation's tables in the ring", "loader has published"};
+      for (int k = 0; k < 7; ++k)
         fprintf(stderr, "    inside the evaluation, after its start: %-34s %6.2f us\n", in[k], (double)h[8 + k] * 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3) / (double)h[7]);
       const char  *names[5] = {"command seen -> parsed", "-> eigen system, exponentials", "-> matrices built", "-> global copies, records", "-> evaluated, fenced, posted"};
       const double us = 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3) / (double)h[7];

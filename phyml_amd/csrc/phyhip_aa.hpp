@@ -365,6 +365,12 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
   __shared__ int      s_spare[2];          // RES: matrices rebuilt into the ring's spare item (read by nothing in this command), or -1
   __shared__ unsigned long long s_t4;      // RES + PHYHIP_RESIDENT_STATS: when this command's evaluation began
   __shared__ unsigned s_built;             // RES: bit 2 j + w: table w of item j was rebuilt into its ring slot by this workgroup
+  // Resident form: the first operation's children, requested by the command loop (end of the kernel) when the command is parsed --
+  // in front of the matrix rebuild, ~3 us in which nothing else needs them -- instead of by the evaluation when it starts: a trip
+  // to memory (1.3 us, the longest single wait of a resident evaluation) less on its chain.  The evaluation takes them from here.
+  u32x4    ext_a01 = {0u, 0u, 0u, 0u}, ext_a23 = {0u, 0u, 0u, 0u}, ext_b01 = {0u, 0u, 0u, 0u}, ext_b23 = {0u, 0u, 0u, 0u};
+  u32x2    ext_a4 = {0u, 0u}, ext_b4 = {0u, 0u};
+  unsigned ext_xa = 0, ext_xb = 0;
   // One evaluation: everything a launched kernel does (the whole kernel in the launched forms; once per command in the resident one)
   auto run = [&](const TreeParams &q) __attribute__((always_inline)) {
   constexpr int T   = kAaT;
@@ -466,6 +472,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
       asm volatile("" ::: "memory");
       publish(n_items);
+      if (rs.stamps && (int)blockIdx.x == rs.stamp_wg && lane == 0) (void)__hip_atomic_fetch_add(&rs.stamps[8 + 6], wall_clock64() - s_t4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (blockIdx.x == 0 && !(AA_RES_ABL & 8))
       { // while the consumers are at work: workgroup 0's copies of the rebuilt tables go to the global A-operand table (the
         // launches that follow read them there), 16 bytes per lane and store
@@ -844,6 +851,9 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
       for (int cc = 0; cc < C_; ++cc) pre_cw[cc] = 0.0;
 #pragma unroll
       for (int t = 0; t < T; ++t) pre_pi[t] = 0.0;
+      // (resident form with operations: requested inside the first step, behind its operands' wait -- the operands were requested
+      // when the command was parsed, and a wave's loads complete in order: in front of that wait these would be waited for too)
+      auto request_eval_inputs = [&]() {
       if constexpr (ARGS)
         if (q.edge_eval)
         {
@@ -868,6 +878,8 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
             if ((q.e_prefetch & 2) && tact[i]) eval_fetch(i, q.e_child, epy[i], eps[i][1]);
           }
         }
+      };
+      if (!RES || n_ops == 0) request_eval_inputs();
 
       if (n_ops > 0)
       {
@@ -875,7 +887,13 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
         Raw       RA[NT], RB[NT];
         ExecRec   cur = XR(0);
         IssueRec  nx1 = IR((1 < last) ? 1 : last);
-        issue_children(IR(0), RA);
+        if constexpr (RES)
+        { // (requested when the command was parsed: see ext_a01)
+          RA[0].a.p01 = ext_a01; RA[0].a.p23 = ext_a23; RA[0].a.p4 = ext_a4;
+          RA[0].b.p01 = ext_b01; RA[0].b.p23 = ext_b23; RA[0].b.p4 = ext_b4;
+          RA[0].xa = ext_xa; RA[0].xb = ext_xb;
+        }
+        else issue_children(IR(0), RA);
         if constexpr (D2) issue_children(nx1, RB);
         {
           // The loop body sees [children loads of k+1][4 result stores of k] in flight (per tile) when step k+1 starts.  As many
@@ -962,6 +980,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
             else { unpack(R[i].b, x2[i]); s2[i] = xb[i]; }
           }
           if constexpr (D2) issue_children(nx2, R); // (clamped to the last operation near the end: harmless repeats)
+          if constexpr (RES) if (k == 0) request_eval_inputs();
           PHY_STAMP(k, 1)
           // all-ones shortcut of the Inin kernel, per (pattern, category): src/avx.c:575-587 (never with a one-state tip)
           unsigned ones[NT];
@@ -1387,6 +1406,27 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
       // what kernels on the stream wrote since the last command (the host says whether any did) is re-read from memory
       if (fl & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       tk[1] = rs.stamps ? wall_clock64() : 0ull;
+      if (wave != 0 && q.n_real_ops > 0)
+      { // the consumers' first loads (issue_children's, for operation 0 of the command): see ext_a01
+        constexpr int CBr = C_ == 1 ? 1 : (C_ == 2 ? 2 : 4), NPWr = 16 / CBr;
+        const int       nwr = (int)(blockDim.x >> 6) - 1;
+        const long long tl = (long long)blockIdx.x * nwr + (wave - 1);
+        const bool      ta = (wave - 1 < nwr) && tl < (long long)(q_in.Ppad / NPWr);
+        const unsigned  nowhere = 0x7fff0000u, blk = (unsigned)((size_t)tl * kAaBlock * 8);
+        const unsigned  v16 = ta ? blk + lane * 16 : nowhere, v8 = ta ? blk + 2048 + lane * 8 : nowhere;
+        const unsigned  vp = ta ? (unsigned)(tl * NPWr + ((lane >> 2) & 3) / CBr * 4 + (lane & 3)) * 4u : nowhere; // (scale word / tip mask of the lane's pattern)
+        const Desc d1 = desc(10), d2 = desc(12), g1 = desc(14), g2 = desc(16);
+        auto rs4 = [](const Desc &d) { return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(d.base), 0, (int)d.bytes, 0x00020000); };
+        const __amdgpu_buffer_rsrc_t r1 = rs4(d1), r2 = rs4(d2), r3 = rs4(g1), r4 = rs4(g2);
+        ext_a01 = __builtin_amdgcn_raw_buffer_load_b128(r1, v16, 0, PHYHIP_LOAD_AUX);
+        ext_a23 = __builtin_amdgcn_raw_buffer_load_b128(r1, v16 + 1024, 0, PHYHIP_LOAD_AUX);
+        ext_a4  = __builtin_amdgcn_raw_buffer_load_b64(r1, v8, 0, PHYHIP_LOAD_AUX);
+        ext_b01 = __builtin_amdgcn_raw_buffer_load_b128(r2, v16, 0, PHYHIP_LOAD_AUX);
+        ext_b23 = __builtin_amdgcn_raw_buffer_load_b128(r2, v16 + 1024, 0, PHYHIP_LOAD_AUX);
+        ext_b4  = __builtin_amdgcn_raw_buffer_load_b64(r2, v8, 0, PHYHIP_LOAD_AUX);
+        ext_xa  = __builtin_amdgcn_raw_buffer_load_b32(r3, vp, 0, 0);
+        ext_xb  = __builtin_amdgcn_raw_buffer_load_b32(r4, vp, 0, 0);
+      }
       // ---- the queued matrices, by this workgroup, into the ring slots its consumers will read them from ----------------------
       const int nf = q.n_fresh;
       if (nf > 0)
