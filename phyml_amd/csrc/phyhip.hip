@@ -59,7 +59,7 @@ static void release_instance(Instance *I)
   }
   if (I->d_big_stamps && big_used)
   { // where the last command's time went, per workgroup, relative to workgroup 0 seeing it (wall-clock ticks of 10 ns)
-    std::vector<unsigned long long> h((size_t)8 * I->big_wgs);
+    std::vector<unsigned long long> h((size_t)16 * I->big_wgs);
     if (hipMemcpy(h.data(), I->d_big_stamps, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
     {
       const char *names[6] = {"command seen", "after the barrier", "wave 0 through", "all waves through", "ticket drawn", "final sum posted"};
@@ -69,13 +69,26 @@ static void release_instance(Instance *I)
         double mn = 1e30, mx = -1e30, sum = 0.0; int n = 0;
         for (int w = 0; w < I->big_wgs; ++w)
         {
-          const unsigned long long v = h[(size_t)w * 8 + k];
+          const unsigned long long v = h[(size_t)w * 16 + k];
           if (!v || v < t0) continue;
           const double d = (double)(v - t0) * 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3);
           mn = std::min(mn, d); mx = std::max(mx, d); sum += d; ++n;
         }
         if (n) fprintf(stderr, "  big resident, last command: %-18s min %7.2f  mean %7.2f  max %7.2f us after workgroup 0 saw it (%d workgroups)\n",
                        names[k], mn, sum / n, mx, n);
+      }
+      for (int k = 1; k < 6; ++k)
+      { // the same per workgroup as a mean over ITS commands, after its own `command seen'
+        double mn = 1e30, mx = -1e30, sum = 0.0; int n = 0;
+        for (int w = 0; w < I->big_wgs; ++w)
+        {
+          const unsigned long long c = h[(size_t)w * 16 + 8], v = h[(size_t)w * 16 + 8 + k];
+          if (!c || !v) continue;
+          const double d = (double)v / (double)c * 1e6 / ((double)(I->wall_khz > 0 ? I->wall_khz : 100000) * 1e3);
+          mn = std::min(mn, d); mx = std::max(mx, d); sum += d; ++n;
+        }
+        if (n) fprintf(stderr, "  big resident, mean of %llu commands: %-18s min %7.2f  mean %7.2f  max %7.2f us after the workgroup saw it (%d workgroups)\n",
+                       h[8], names[k], mn, sum / n, mx, n);
       }
     }
   }
@@ -919,6 +932,18 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
 {
   (void)cs;
   Group *G = get_group(instance);
+  if (G && count == 1 && group_combines_on_host(G, true))
+  { // every shard answers as a plain instance (its resident evaluators included), the shard sums are added here in shard order
+    std::vector<double> part(G->sub.size(), 0.0);
+    int rc = group_parallel(G, [&](int g) -> int {
+      return phyhip_calculate_edge_log_likelihoods(G->sub_id[g], parent, child, pm, d1, d2, cw, sf, cs, count, &part[g], outD1, outD2);
+    });
+    if (rc) return rc;
+    double sum = 0.0;
+    for (double v : part) sum += v;
+    *outSum = sum;
+    return group_collect_warning(G);
+  }
   GET_INST_RES(I, G ? G->sub_id[0] : instance);
   if (count != 1) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "count must be 1");
   if (d1 || d2 || outD1 || outD2)
@@ -1170,8 +1195,15 @@ int phyhip_profile_read(int instance, double *ms, int *launches, double *updates
 int phyhip_get_resident_stats(int instance, long long out[8])
 {
   if (Group *G = get_group(instance))
-  { // (sharded instances hand their sums to the collective on the device: never resident)
+  { // (sharded instances: what their shards' evaluators served -- host-combined short calls, Group::host_combine)
     for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int id : G->sub_id)
+    {
+      long long o[8];
+      const int rc = phyhip_get_resident_stats(id, o);
+      if (rc) return rc;
+      for (int k = 0; k < 8; ++k) out[k] += o[k];
+    }
     return PHYHIP_SUCCESS;
   }
   GET_INST_RES(I, instance);
@@ -1188,7 +1220,17 @@ int phyhip_get_resident_stats(int instance, long long out[8])
 int phyhip_get_big_resident_stats(int instance, long long out[4])
 {
   for (int k = 0; k < 4; ++k) out[k] = 0;
-  if (get_group(instance)) return PHYHIP_SUCCESS; // (sharded instances: never resident)
+  if (Group *G = get_group(instance))
+  {
+    for (int id : G->sub_id)
+    {
+      long long o[4];
+      const int rc = phyhip_get_big_resident_stats(id, o);
+      if (rc) return rc;
+      for (int k = 0; k < 4; ++k) out[k] += o[k];
+    }
+    return PHYHIP_SUCCESS;
+  }
   GET_INST_RES(I, instance);
   I_call.leave_query();
   const Resident *R = &I->rb;

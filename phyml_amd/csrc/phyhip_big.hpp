@@ -57,7 +57,7 @@ struct BigCtl
   unsigned     *tickets;   // device [1 + kTicketGroups], zero between commands
   const double *dot_prod;  // the eigen products (Update_Eigen_Lr's output, dLk's input)
   HostBlock    *wg_recs;   // device [2][kBigGroupWgs] {sum, tag}: a workgroup's partial sums (kBigGroupSum), tags never 0
-  // PHYHIP_RESIDENT_STATS: wall-clock stamps of the last command per workgroup, [workgroup][8]: 0 command seen, 1 after the
+  // PHYHIP_RESIDENT_STATS: wall-clock stamps per workgroup, [workgroup][16]: of the last command 0 command seen, 1 after the
   // workgroup's barrier, 2 wave 0 through with its tiles, 3 all waves through, 4 ticket drawn, 5 final sum posted (nullptr: none)
   unsigned long long *stamps;
 };
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
     const BigCtl            &b = cm.b;
     HostBlock *const         host_blocks = cm.host_blocks;
     auto stamp = [&](int i, unsigned long long t) {
-      if (b.stamps && tid == 0) b.stamps[(size_t)bid * 8 + i] = t;
+      if (b.stamps && tid == 0) { b.stamps[(size_t)bid * 16 + i] = t; b.stamps[(size_t)bid * 16 + 8 + i] += i ? t - st0 : 1ull; }
     };
     stamp(0, st0);
     stamp(1, wall_clock64());
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
     const BigCtl            &b = cm.b;
     HostBlock *const         host_blocks = cm.host_blocks;
     auto stamp = [&](int i, unsigned long long t) {
-      if (b.stamps && tid == 0) b.stamps[(size_t)bid * 8 + i] = t;
+      if (b.stamps && tid == 0) { b.stamps[(size_t)bid * 16 + i] = t; b.stamps[(size_t)bid * 16 + 8 + i] += t - st0; }
     };
     if (gsum)
     { // ---- the final sum on the device, one partial sum per workgroup (kBigGroupSum above) ----

@@ -334,6 +334,20 @@ static int eigen_eval(Instance *I, double l, bool deriv, double *lnl, double *dl
 // dLk / eigen-basis Lk on the shards + the collective (count 3: warning, lnL, dlnL)
 static int group_eigen_eval(Group *G, double l, bool deriv, double *lnl, double *dlnl)
 {
+  if (group_combines_on_host(G, false))
+  { // shard by shard through the plain entry points (resident dLk evaluators included), added here in shard order
+    std::vector<double> pl(G->sub.size(), 0.0), pd(G->sub.size(), 0.0);
+    int rc = group_parallel(G, [&](int g) -> int {
+      double lg = l; // (clamped by the entry point: the same value on every shard)
+      return deriv ? phyhip_calculate_eigen_lnl_dlnl(G->sub_id[g], &lg, &pl[g], &pd[g]) : phyhip_calculate_eigen_lnl(G->sub_id[g], l, &pl[g]);
+    });
+    if (rc) return rc;
+    double a = 0.0, b = 0.0;
+    for (size_t g = 0; g < pl.size(); ++g) { a += pl[g]; b += pd[g]; }
+    *lnl = a;
+    if (dlnl) *dlnl = b;
+    return group_collect_warning(G);
+  }
   int rc = group_parallel(G, [&](int g) -> int {
     double *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
     return eigen_eval(G->sub[g], l, deriv, nullptr, nullptr, slot + 1, slot);
@@ -360,13 +374,19 @@ static int rank_eigen_eval(Instance *I, double l, bool deriv, double *lnl, doubl
 
 int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, double *outDLnL)
 {
-  Group *G = get_group(instance);
-  GET_INST_RES(I, G ? G->sub_id[0] : instance);
+  if (Group *G = get_group(instance))
+  { // (no call is entered on a shard here: the shards' own entry points or the group's launches below do that)
+    if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN");
+    const Instance *I0 = G->sub[0];
+    if (*l < I0->l_min) *l = I0->l_min;
+    else if (*l > I0->l_max) *l = I0->l_max;
+    return group_eigen_eval(G, *l, true, outLnL, outDLnL);
+  }
+  GET_INST_RES(I, instance);
   I_call.leave_untouched(); // (queues nothing by itself; flush() says so if it does)
   if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN"); // src/lk.c:671
   if (*l < I->l_min) *l = I->l_min;                                                     // src/lk.c:673-674
   else if (*l > I->l_max) *l = I->l_max;
-  if (G) return group_eigen_eval(G, *l, true, outLnL, outDLnL);
   if (I->co) return rank_eigen_eval(I, *l, true, outLnL, outDLnL);
   return eigen_eval(I, *l, true, outLnL, outDLnL);
 }

@@ -293,8 +293,8 @@ static int big_alloc(Instance *I)
   HIPCHK(hipMemsetAsync(I->d_big_recs, 0, sizeof(HostBlock) * 2 * kBigGroupWgs, I->stream)); // (tag 0: no evaluation's)
   if (getenv("PHYHIP_RESIDENT_STATS"))
   {
-    HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs));
-    HIPCHK(hipMemsetAsync(I->d_big_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)I->big_wgs, I->stream));
+    HIPCHK(hipMalloc((void **)&I->d_big_stamps, sizeof(unsigned long long) * 16 * (size_t)I->big_wgs));
+    HIPCHK(hipMemsetAsync(I->d_big_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)I->big_wgs, I->stream));
   }
   HIPCHK(hipStreamSynchronize(I->stream));
   return 0;

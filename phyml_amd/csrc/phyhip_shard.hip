@@ -239,6 +239,7 @@ int create_group(int tipCount, int partialsBufferCount, int stateCount, int patt
     release_group(G);
     return PHYHIP_ERROR_GENERAL;
   }
+  if (const char *e = getenv("PHYHIP_SHARD_HOST_COMBINE")) G->host_combine = atoi(e);
   {
     const char *e = getenv("PHYHIP_SHARD_THREADS");
     if (e ? atoi(e) != 0 : nctx > 1)
@@ -258,6 +259,34 @@ int create_group(int tipCount, int partialsBufferCount, int stateCount, int patt
     }
   g_groups.push_back(G);
   return kGroupBase + (int)g_groups.size() - 1;
+}
+
+// Does this evaluation go shard by shard through the plain entry points, the calling thread adding the shard sums
+// (Group::host_combine)?  queue_counts: an edge evaluation -- short when no shard has more than two operations queued (what the
+// resident evaluators and the records-in-the-arguments launches take).
+bool group_combines_on_host(const Group *G, bool queue_counts)
+{
+  if (G->host_combine <= 0) return false;
+  if (G->host_combine >= 2 || !queue_counts) return true;
+  for (const Instance *I : G->sub)
+    if (I->pending.size() > 2) return false;
+  return true;
+}
+
+// after a host-combined evaluation: the warning flag of src/lk.c:847-851 over all shards (each shard's own last evaluation)
+int group_collect_warning(Group *G)
+{
+  int w = 0;
+  for (int id : G->sub_id)
+  {
+    int      ws = 0;
+    const int rc = phyhip_get_numerical_warning(id, &ws);
+    if (rc) return rc;
+    w = std::max(w, ws);
+  }
+  G->last_warn  = w;
+  G->warn_valid = true;
+  return PHYHIP_SUCCESS;
 }
 
 // Lk(b) / Lk(NULL) on a sharded instance: every shard's traversal + edge evaluation (no host synchronisation), then the

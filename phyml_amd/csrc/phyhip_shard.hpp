@@ -127,6 +127,13 @@ struct Group
   int                     last_warn = 0;
   bool                    warn_valid = false;
   std::vector<ShardWorker *> workers; // one per shard when the shards sit on more than one device (or PHYHIP_SHARD_THREADS=1)
+  // Scalar-returning SHORT calls (Lk(b) behind at most two queued operations, dLk, Lk in the eigen basis: the call patterns of
+  // src/spr.c:640-646 and src/optimiz.c:607-663) answered shard by shard as plain instances answer them -- each shard's resident
+  // evaluators included -- and added by the calling thread in shard order, instead of a launch per shard + the collective
+  // (~35 us of pure latency for 16-24 bytes the host is waiting for anyway).  The process owns every shard, so the host IS the
+  // place where the shard sums meet; whole-tree evaluations keep the RCCL all-reduce, and so does the one-process-per-GPU form
+  // for everything.  PHYHIP_SHARD_HOST_COMBINE: 0 never, 1 short calls (default), 2 every evaluation.
+  int                     host_combine = 1;
 };
 
 Group *get_group(int id);
@@ -173,3 +180,5 @@ int  mixture_groups(const int *instances, int count, std::vector<Group *> &Gs);
 int  create_group(int tipCount, int partialsBufferCount, int stateCount, int patternCount, int matrixBufferCount, int categoryCount,
                   const int *resourceList, int resourceCount, phyhip_instance_details *returnInfo, long classAxisFlag = 0);
 int  group_edge_lnl(Group *G, int parent, int child, int pm, double *out);
+bool group_combines_on_host(const Group *G, bool queue_counts);
+int  group_collect_warning(Group *G);

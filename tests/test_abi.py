@@ -143,7 +143,7 @@ def test_every_environment_switch_is_documented():
     # the product library reads only these; every other switch goes through diag_env (diag build only)
     product = set(re.findall(r'[^_a-z]getenv\("(PHYHIP_[A-Z0-9_]+)"\)', src))
     assert product <= {"PHYHIP_DEVICE", "PHYHIP_RESIDENT", "PHYHIP_RESIDENT_IDLE_US", "PHYHIP_RESIDENT_STATS", "PHYHIP_HOST_SUM",
-                       "PHYHIP_SHARD_THREADS", "PHYHIP_HOSTPROF", "PHYHIP_RESIDENT_DEBUG"}, product  # (the last two: behind kDiag)
+                       "PHYHIP_SHARD_THREADS", "PHYHIP_SHARD_HOST_COMBINE", "PHYHIP_HOSTPROF", "PHYHIP_RESIDENT_DEBUG"}, product  # (the last two: behind kDiag)
     missing = [n for n in names if n not in docs]
     assert not missing, missing
 

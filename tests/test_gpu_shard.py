@@ -88,17 +88,22 @@ def test_sharded_instance_spr_call_pattern_matches_single_device(monkeypatch):
     """A seeded SPR / Br_Len_Opt call stream (phyml_amd/replay.py) through a sharded instance returns the scalars the
     single-device instance returns (1e-12; the shard sums are added in a different order) -- with the shards driven from
     the calling thread and from the per-shard helper threads (what a multi-device group uses; PHYHIP_SHARD_THREADS=1
-    forces them for shards that share a device)."""
+    forces them for shards that share a device), and with the short calls answered shard by shard and added on the host
+    (PHYHIP_SHARD_HOST_COMBINE=1, the default: each shard's resident evaluators serve them), through the collective
+    only (0) and with every evaluation added on the host (2)."""
     from phyml_amd import replay
-    res = []
-    for devs, threads in ((None, "0"), ([0, 0, 0], "0"), ([0, 0, 0], "1")):
+    res, served = [], []
+    runs = ((None, "0", "1"), ([0, 0, 0], "0", "1"), ([0, 0, 0], "1", "1"), ([0, 0, 0], "0", "0"), ([0, 0, 0], "1", "0"), ([0, 0, 0], "1", "2"))
+    for devs, threads, combine in runs:
         monkeypatch.setenv("PHYHIP_SHARD_THREADS", threads)
+        monkeypatch.setenv("PHYHIP_SHARD_HOST_COMBINE", combine)
         t, ot, tree, st = synthetic_pair(40, 3000, 4, 4, seed=77, devices=devs)
         try:
             t.Set_Both_Sides(True)
             t.Lk(None)
             tr = replay.make_trace(40, tree.edge_left, tree.edge_rght, tree.edge_len, 60, seed=5, walk_every=3, opt_every=4, n_dlk=4)
             res.append(t.Replay_Surface_Trace(tr))
+            served.append(t.inst.resident_stats(0)[0] + t.inst.resident_stats(1)[0])
         finally:
             t.close()
     (a, a2) = res[0]
@@ -108,6 +113,10 @@ def test_sharded_instance_spr_call_pattern_matches_single_device(monkeypatch):
         assert np.max(np.abs(a[m] - b[m]) / np.abs(a[m])) < 1e-12
         assert np.max(np.abs(a2 - b2) / np.maximum(1.0, np.abs(a2))) < 1e-9
     assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1], res[2][1])  # threads change nothing
+    assert np.array_equal(res[3][0], res[4][0]) and np.array_equal(res[3][1], res[4][1])
+    # the shards' resident evaluators serve the host-combined short calls, and only those
+    assert served[1] > 0 and served[2] > 0 and served[5] > 0, served
+    assert served[3] == 0 and served[4] == 0, served
 
 
 def test_numerical_warning_rides_in_the_all_reduce():
