@@ -875,6 +875,7 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
   }
   if (!shadow.empty() && shadow[0] >= 0) { I->up_shadow[I->up_slot[matrixIndex]] = shadow[0]; ++I->n_up_shadow; }
   if ((int)I->up_idx.size() >= 4 * kUploadBatch && (rc = flush_uploads(I))) return rc;
+  I_call.leave_queued_only(); // (a flush above -- flush_pmats, flush_uploads, also through the staging ring's rotation -- says so itself)
   return PHYHIP_SUCCESS;
 }
 

@@ -31,7 +31,8 @@ namespace phyhip
 //   dLk command: 2 pinvar, 3.. the expl table (C x 2 x 4 doubles).
 // flags: bits 0-1 operations, 2 device data changed since the last command, 4-7 matrices to rebuild, 8-9 evaluation sides to
 // fetch early, 10 eigen products instead of the sum, 11 dLk command, 12 with derivative, 13 invariant-site model, 14 scaling,
-// 15 final sum on the device, 16 (with 15) through one partial sum per workgroup.
+// 15 final sum on the device, 16 (with 15) through one partial sum per workgroup, 17-18 host-computed matrices waiting in
+// ResidentCtl::up_area (their indices in words 4-5; never together with matrices to rebuild).
 constexpr int kBigWords = kResidentNtWords > 3 + 32 ? kResidentNtWords : 3 + 32;
 static_assert((kBigWords + kResidentPay - 1) / kResidentPay <= 15, "a command must fit the one 512-byte read of a poll");
 enum : unsigned long long
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
         karg_copy(q, &A2->t);
         q.host_tag = word(0);
         q.n_fresh = first ? (int)((fl2 >> 4) & 15) : 0; // (a wave rebuilds the command's matrices with its first tile)
+        q.n_up = first ? (int)((fl2 >> 17) & 3) : 0;     // (... or takes the host-computed ones to their slots)
         const bool mid = passes == 2 && pass == 0;      // the first of two operations: no evaluation behind it
         q.e_prefetch = mid ? 0 : (int)((fl2 >> 8) & 3);
         q.edge_eval = mid ? 0 : ((fl2 & kBigEigen) ? 2 : 1); q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
         // a model change makes the host launch a new generation)
         const char *kt = (const char *)ka2 + offsetof(BigArgs, t);
         fr.idx = sh_idx; fr.len = sh_len;
+        fr.up_idx = sh_idx; fr.up_val = as_global(A2->r.up_area); fr.up_sys = true;
         fr.evec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_evec));
         fr.ivec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_ivec));
         fr.eval = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_eval));

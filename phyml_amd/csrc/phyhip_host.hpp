@@ -144,6 +144,7 @@ struct Resident
   ResidentCmd        *cmd = nullptr;
   ResidentCmd        *shadow = nullptr;
   bool                pushed = false;
+  double             *up_area = nullptr; // pushed records only: device memory for a command's host-computed matrices (ResidentCtl::up_area)
   unsigned long long *report = nullptr; // host-mapped: the generation whose workgroups have left (written by workgroup 0)
   unsigned long long *mail = nullptr;  // device mailbox (word 0: what workgroup 0 decided; relayed commands)
   hipStream_t         stream[2] = {nullptr, nullptr};
@@ -245,6 +246,9 @@ struct Instance
   TreeParams   rt_static;
   // the evaluation last handed to resident_nt2_kernel, kept until it is answered (unanswered: it is launched instead)
   std::vector<DevOp>  rt_ops;
+  int                 rt_up_n = 0;      // ... and the host-computed matrices it carried (ResidentCtl::up_area)
+  int                 rt_up_idx[kArgUp] = {0, 0, 0};
+  double              rt_up_val[kArgUp][64];
   std::vector<int>    rt_pm_idx;
   std::vector<double> rt_pm_len;
   bool         rt_skip = false;       // the evaluation being repeated after an unanswered command goes the ordinary way
@@ -581,6 +585,7 @@ int        resident_prepare(Instance *I, Resident &R, int grid, int n_words, uns
 void       resident_launched(Resident &R, int grid);
 bool       resident_gone(const Resident &R);
 void       resident_send(Instance *I, Resident &R, const unsigned long long *words, int n_words);
+bool       resident_push_uploads(Resident &R, int n, const double (*vals)[64], int doubles_each);
 int        resident_launch_dlk(Instance *I, const DlkParams &qs, int dgrid, unsigned long long served);
 bool       big_clean(Instance *I);
 int        stamp_stream(Instance *I);

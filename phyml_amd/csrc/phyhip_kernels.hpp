@@ -1559,6 +1559,11 @@ struct ResidentCtl
   // host-mapped: the generation whose workgroups have left (not in the record: the record may live in DEVICE memory, where the
   // host pushes the commands through the BAR -- every workgroup then polls it locally, no relay, phyhip_resident.hip)
   unsigned long long *report;
+  // Host-computed transition matrices of a command (the bit-exact route: the host layer's PMat() + phyhip_set_transition_matrix,
+  // src/lk.c:2360): device memory the host stores into through the BAR BEFORE it pushes the command -- posted writes stay in
+  // order, so a workgroup that sees the command finds them there -- [kArgUp][64] doubles, read past the caches (the same
+  // lines carried the previous command's matrices).  nullptr: the record is host memory, such commands are launched instead.
+  const double       *up_area;
   // Workgroup 0 alone decides when a generation leaves (idle time-out): it says so in the mailbox's word 0, which the others
   // watch, and reports to the host -- which therefore KNOWS whether anybody is there instead of guessing from elapsed time.
 };

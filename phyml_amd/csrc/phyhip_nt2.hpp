@@ -55,6 +55,7 @@ struct NtFresh
   const double *evec, *ivec, *eval, *rates;  // U, U^-1, eigenvalues, category rates
   const int    *up_idx = nullptr;            // [n_up] host-computed matrices of this launch (TreeParams::up_idx / up_val)
   const double *up_val = nullptr;            // [n_up][64]
+  bool          up_sys = false;              // up_val is device memory the HOST wrote (resident commands, ResidentCtl::up_area): read past the caches
 };
 
 // One workgroup's (= one wave's) share of a launch: the whole kernel body, callable from a kernel that stays resident.
@@ -253,7 +254,17 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
   if (q.n_up > 0)
   { // host-computed matrices from the arguments to their slots (see TreeParams::n_up)
     for (int m = 0; m < q.n_up; ++m)
-      if (lane < C * 16) q.pmats_rw[(size_t)fr.up_idx[m] * (C * 16) + lane] = fr.up_val[m * 64 + lane];
+      if (lane < C * 16)
+      {
+        double v;
+        if (fr.up_sys)
+        {
+          const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(fr.up_val) + m * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __builtin_memcpy(&v, &b, 8);
+        }
+        else v = fr.up_val[m * 64 + lane];
+        q.pmats_rw[(size_t)fr.up_idx[m] * (C * 16) + lane] = v;
+      }
     asm volatile("" ::: "memory"); // (as below: this wave's later loads see these stores)
     __builtin_amdgcn_wave_barrier();
   }
@@ -756,7 +767,8 @@ __global__ __launch_bounds__(64, 2) void traverse_nt2_mixed_kernel(const TreePar
 // is on its stream, the one-wave workgroups of this kernel stay on the device and take those evaluations from the command
 // record: payload words 0 tag, 1 flags (bits 0-1 operations, bit 2 device data changed, bits 4-7 matrices to rebuild, bits
 // 8-9 evaluation sides to fetch early, bit 10 the eigen products of the edge -- Update_Eigen_Lr -- instead of its sum), 2 evaluation edge (parent | child << 32), 3 its matrix | last destination << 32,
-// 4-5 matrix indices, 6-9 their edge lengths, then per operation 12 words: the four child descriptors and the two
+// 4-5 matrix indices (of the matrices to rebuild, or -- bits 17-18 of the flags: how many -- of the host-computed matrices waiting in
+// ResidentCtl::up_area), 6-9 their edge lengths, then per operation 12 words: the four child descriptors and the two
 // destination descriptors of the launch form's records.  Everything else is the launch's TreeParams, fixed at launch.
 // A workgroup completes and writes back its stores before it posts its sum (fence_post), so kernels launched afterwards
 // -- on whichever XCD -- find them in memory.
@@ -796,7 +808,7 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     const unsigned long long fl = word(1), ed = word(2), pm = word(3);
     TreeParams               q = sq;
     q.host_tag = word(0);
-    q.n_fresh = (int)((fl >> 4) & 15); q.e_prefetch = (int)((fl >> 8) & 3);
+    q.n_fresh = (int)((fl >> 4) & 15); q.e_prefetch = (int)((fl >> 8) & 3); q.n_up = (int)((fl >> 17) & 3);
     q.edge_eval = (fl >> 10) & 1 ? 2 : 1; q.e_parent = (int)(unsigned)ed; q.e_child = (int)(unsigned)(ed >> 32);
     q.e_pm = (int)(unsigned)pm; q.last_dest = (int)(unsigned)(pm >> 32);
     if (lane < 4)
@@ -819,6 +831,7 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     __builtin_amdgcn_wave_barrier();
     NtFresh fr;
     fr.idx = sh_idx; fr.len = sh_len; fr.evec = evec; fr.ivec = ivec; fr.eval = eval; fr.rates = rates;
+    fr.up_idx = sh_idx; fr.up_val = r.up_area; fr.up_sys = true;
     if (n_ops == 1) nt2_run<C, G, false, 1>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
     else if (n_ops == 2) nt2_run<C, G, false, 2>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
     else nt2_run<C, G, false, 3>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);

@@ -299,6 +299,17 @@ bool fuse_reduce(const Instance *I, int nblocks)
   return nblocks <= 512;
 }
 
+// The host-computed matrices a resident command carries, kept until it is answered (see flush_and_wait)
+static void keep_uploads(Instance *I, const TreeParams &q)
+{
+  I->rt_up_n = q.n_up;
+  for (int k = 0; k < q.n_up; ++k)
+  {
+    I->rt_up_idx[k] = q.up_idx[k];
+    memcpy(I->rt_up_val[k], q.up_val[k], sizeof(double) * 64);
+  }
+}
+
 // Launch the queued operations (and optionally the fused edge evaluation) as one traversal kernel.
 int flush_impl(Instance *I, const EdgeEval *ee)
 {
@@ -320,9 +331,16 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // large grids: an evaluation the large-grid resident workgroups can take (phyhip_big.hpp) carries its matrices in the command
   // (host-computed matrices -- the bit-exact route -- stay with the one-wave launch that takes them in its arguments: the
   // large-grid kernel launched with them in ITS arguments was measured, 30-31 against 28.4 us per candidate at 500 x 100 000)
-  const bool big_form = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
-                        (int)I->pm_idx.size() <= 4 && I->up_idx.empty() && !I->rt_skip; // (an evaluation that kernel can take)
-  const bool big_fit = big_form && big_eligible(I) && !I->prof;
+  // Host-computed matrices that can travel with the evaluation (kernel arguments of a launch: TreeParams::n_up; a resident
+  // command: ResidentCtl::up_area)
+  const bool up_ride = I->soa && I->arg_uploads && !I->up_idx.empty() && (int)I->up_idx.size() <= kArgUp && I->pm_idx.empty() &&
+                       (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8) && I->n_up_shadow == 0;
+  // ... in a resident command: where the host stores into device memory (a pushed record)
+  auto up_resident = [&](const Resident &R) { return up_ride && I->push_cmds != 0 && (R.cmd ? R.pushed && R.up_area != nullptr : true); };
+  const bool big_form0 = ee && (ee->eigen || (ee->to_host && !ee->dev_out)) && n_ops <= 2 && I->args_recs && I->fold_pmats &&
+                         (int)I->pm_idx.size() <= 4 && !I->rt_skip; // (an evaluation that kernel can take)
+  const bool big_form = big_form0 && I->up_idx.empty();
+  const bool big_fit = big_form0 && (I->up_idx.empty() || up_resident(I->rb)) && big_eligible(I) && !I->prof;
   const bool big_try = big_fit && big_ready(I);
   // ... and they are there (or launched now): decided before the records are built -- a resident command of two operations runs
   // them one after the other per tile, without register forwarding between them (phyhip_big.hpp)
@@ -331,7 +349,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   {
     const int brc = big_ensure(I);
     if (brc < 0) return brc;
-    big_take = brc == 0;
+    big_take = brc == 0 && (I->up_idx.empty() || up_resident(I->rb)); // (a record that turned out to live in host memory: launch)
   }
   // ... or they are not, and the same kernel is LAUNCHED for this one evaluation (BigArgs::n_one_shot) instead of pmat_kernel +
   // a traversal of one-wave workgroups + a record per workgroup: where the final sum can run through one partial sum per
@@ -380,8 +398,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
                         I->up_idx.empty() && (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8) && I->n_pm_shadow == 0);
   // a short list of HOST-computed matrices rides in the arguments of the lane-per-pattern nucleotide kernel at every grid size
   // (TreeParams::n_up): no upload kernel in front of the traversal
-  const bool arg_up = I->soa && I->arg_uploads && !I->up_idx.empty() && (int)I->up_idx.size() <= kArgUp && I->pm_idx.empty() &&
-                      (n_ops > 0 || ee) && I->C <= 4 && !I->class_axis && !(I->ablate & 8) && I->n_up_shadow == 0;
+  const bool arg_up = up_ride;
   if (!fold_pm && !arg_up && (!I->pm_idx.empty() || !I->up_idx.empty()) && (rc = flush_pmats(I))) return rc;
   if (n_ops == 0 && !ee) return 0;
   rc = upload_masks(I);
@@ -751,7 +768,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
     std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
     return 0;
   }
-  if (rt_grid && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0 && !I->prof && !I->rt_skip)
+  if (rt_grid && host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && (q.n_up == 0 || up_resident(I->rt)) && !I->prof && !I->rt_skip)
   {
     bool clean = !I->dirty_prev && !I->touched_call;
     if (clean && I->clean_after)
@@ -802,12 +819,15 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         memcpy(&I->rt_static, &sq, sizeof sq);
         resident_launched(R, I->grid_nt2);
       }
+      // (host-computed matrices and a record that turned out to live in host memory: the launch below takes them in its arguments)
+      if (q.n_up == 0 || resident_push_uploads(R, q.n_up, q.up_val, 16 * I->C))
+      {
       unsigned long long words[kResidentNtWords];
       memset(words, 0, sizeof words);
       const bool changed = I->clean_epoch != I->rt_epoch; // the stream ran something since the last command
       words[0] = q.host_tag;
       words[1] = (unsigned long long)q.n_real_ops | (changed ? 4ull : 0ull) | ((unsigned long long)q.n_fresh << 4) |
-                 ((unsigned long long)q.e_prefetch << 8) | (q.edge_eval == 2 ? 1ull << 10 : 0ull);
+                 ((unsigned long long)q.e_prefetch << 8) | (q.edge_eval == 2 ? 1ull << 10 : 0ull) | ((unsigned long long)q.n_up << 17);
       words[2] = (unsigned long long)(unsigned)q.e_parent | ((unsigned long long)(unsigned)q.e_child << 32);
       words[3] = (unsigned long long)(unsigned)q.e_pm | ((unsigned long long)(unsigned)q.last_dest << 32);
       for (int k = 0; k < q.n_fresh; ++k)
@@ -815,6 +835,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         words[4 + k / 2] |= (unsigned long long)(unsigned)q.fresh_idx[k] << (32 * (k & 1));
         memcpy(&words[6 + k], &q.fresh_len[k], 8);
       }
+      for (int k = 0; k < q.n_up; ++k) words[4 + k / 2] |= (unsigned long long)(unsigned)q.up_idx[k] << (32 * (k & 1)); // (never both kinds: up_ride)
       auto put = [&](int k, const Desc &d) { words[k] = d.base; words[k + 1] = (unsigned long long)d.bytes | ((unsigned long long)d.x << 32); };
       for (int o = 0; o < q.n_real_ops; ++o)
       {
@@ -824,6 +845,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       }
       // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (phyhip_calculate_edge_log_likelihoods)
       I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
+      keep_uploads(I, q);
       resident_send(I, R, words, kResidentNtWords); // (every sector the workgroups wait for carries the command's number)
       I->rt_epoch = I->clean_epoch;
       I->host_sum_n = host_sum_n; I->host_sum_ns = 1;
@@ -837,6 +859,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       I->pending.clear();
       std::fill(I->mat_in_queue.begin(), I->mat_in_queue.end(), 0);
       return 0;
+      }
     }
   }
   // ---- large nucleotide alignments: the large-grid resident evaluator (resident_big_kernel) -------------------------------
@@ -844,8 +867,10 @@ int flush_impl(Instance *I, const EdgeEval *ee)
   // write-back per wave costs more than the launch; whether the stream is idle again is found by querying it, big_clean)
   if (big_cmd)
   {
-    if (!(host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && q.n_up == 0))
+    if (!(host_sum_n > 0 && q.recs_in_args && q.n_fresh <= 4 && (q.n_up == 0 || (big_take && q.n_fresh == 0))))
       return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: an evaluation it cannot take (%d records, %d matrices)", host_sum_n, q.n_fresh);
+    if (q.n_up > 0 && !resident_push_uploads(I->rb, q.n_up, q.up_val, 16 * I->C))
+      return fail(PHYHIP_ERROR_GENERAL, "large-grid resident evaluator: no upload area for %d host-computed matrices", q.n_up);
     {
       Resident &R = I->rb;
       unsigned long long words[kBigWords];
@@ -855,7 +880,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       words[0] = q.host_tag;
       words[1] = (unsigned long long)q.n_real_ops | (changed ? kBigChanged : 0ull) | ((unsigned long long)q.n_fresh << 4) |
                  ((unsigned long long)q.e_prefetch << 8) | (q.edge_eval == 2 ? kBigEigen : 0ull) | (dsum ? kBigDeviceSum : 0ull) |
-                 (dsum && big_sum_by_group(I, host_sum_n) ? kBigGroupSum : 0ull);
+                 (dsum && big_sum_by_group(I, host_sum_n) ? kBigGroupSum : 0ull) | ((unsigned long long)q.n_up << 17);
       words[2] = (unsigned long long)(unsigned)q.e_parent | ((unsigned long long)(unsigned)q.e_child << 32);
       words[3] = (unsigned long long)(unsigned)q.e_pm | ((unsigned long long)(unsigned)q.last_dest << 32);
       for (int k = 0; k < q.n_fresh; ++k)
@@ -863,6 +888,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
         words[4 + k / 2] |= (unsigned long long)(unsigned)q.fresh_idx[k] << (32 * (k & 1));
         memcpy(&words[6 + k], &q.fresh_len[k], 8);
       }
+      for (int k = 0; k < q.n_up; ++k) words[4 + k / 2] |= (unsigned long long)(unsigned)q.up_idx[k] << (32 * (k & 1));
       auto put = [&](int k, const Desc &d) { words[k] = d.base; words[k + 1] = (unsigned long long)d.bytes | ((unsigned long long)d.x << 32); };
       for (int o = 0; o < q.n_real_ops; ++o)
       {
@@ -899,6 +925,7 @@ int flush_impl(Instance *I, const EdgeEval *ee)
       else
       { // kept until the answer is in: an evaluation nobody answers is launched the ordinary way (flush_and_wait)
         I->rt_ops = I->pending; I->rt_pm_idx = I->pm_idx; I->rt_pm_len = I->pm_len;
+        keep_uploads(I, q);
         resident_send(I, R, words, kBigWords);
         I->rt_epoch = I->clean_epoch;
         I->host_sum_n = dsum ? 1 : host_sum_n; I->host_sum_ns = 1;
@@ -1388,6 +1415,20 @@ int flush_and_wait(Instance *I, EdgeEval &ee, bool flushed)
         I->pm_len.push_back(I->rt_pm_len[k]);
         I->pm_shadow.push_back(-1);
       }
+    for (int k = 0; k < I->rt_up_n; ++k)
+    { // ... and its host-computed matrices: queued again as phyhip_set_transition_matrix queued them
+      const int    m = I->rt_up_idx[k];
+      const size_t bytes = (size_t)I->C * I->S * I->S * sizeof(double);
+      void        *st = nullptr;
+      if ((rc = I->ring.alloc(bytes, I->stream, &st))) return rc;
+      memcpy(st, I->rt_up_val[k], bytes);
+      if (I->up_slot[m] >= 0) continue; // (cannot be: the command took every queued upload)
+      I->up_slot[m] = (int)I->up_idx.size();
+      I->up_idx.push_back(m);
+      I->up_src.push_back((const double *)st);
+      I->up_shadow.push_back(-1);
+    }
+    I->rt_up_n = 0;
     I->rt_skip = true;
     rc = flush(I, &ee);
     I->rt_skip = false;

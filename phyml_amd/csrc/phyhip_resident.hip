@@ -52,6 +52,27 @@ static void push_lines(Resident &R, int first_sector, int last_sector) // sector
   }
   _mm_sfence();
 }
+// A command's host-computed matrices into ResidentCtl::up_area, in front of the command itself (posted writes arrive in order)
+bool resident_push_uploads(Resident &R, int n, const double (*vals)[64], int doubles_each)
+{
+  if (!R.pushed || !R.up_area) return false;
+  alignas(64) double line[8];
+  char *dst = reinterpret_cast<char *>(R.up_area);
+  for (int m = 0; m < n; ++m)
+    for (int l = 0; l * 8 < doubles_each; ++l)
+    {
+      if (cpu_has_movdir64b())
+      {
+        memcpy(line, vals[m] + l * 8, 64);
+        store64_direct(dst + (size_t)m * 512 + 64 * l, line);
+      }
+      else
+        for (int k = 0; k < 8; ++k) reinterpret_cast<volatile double *>(dst + (size_t)m * 512 + 64 * l)[k] = vals[m][l * 8 + k];
+    }
+  _mm_sfence();
+  return true;
+}
+
 // control word 0 (generation in charge) / 1 (leave)
 static void set_ctl(Resident &R, int word, unsigned long long v)
 {
@@ -85,6 +106,7 @@ void resident_free(Resident &R)
   }
   resident_stop(R);
   if (R.cmd) (void)(R.pushed ? hipFree(R.cmd) : hipHostFree(R.cmd));
+  if (R.up_area) (void)hipFree(R.up_area);
   if (R.shadow) free(R.shadow);
   if (R.report) (void)hipHostFree(R.report);
   if (R.mail) (void)hipFree(R.mail);
@@ -114,6 +136,12 @@ int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned l
         // instances' resident workgroups, which only leave after their idle time -- a mixture of 64 class instances met that
         // stall on every instance's first use)
         HIPCHK(hipMemsetAsync(R.cmd, 0, bytes, I->stream));
+        // (the matrices a command may bring along, same kind of memory; without it such commands are launched)
+        const size_t ub = sizeof(double) * 64 * kArgUp;
+        const hipError_t e2 = I->push_cmds == 1 ? hipMalloc((void **)&R.up_area, ub)
+                                                : hipExtMallocWithFlags((void **)&R.up_area, ub, I->push_cmds == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+        if (e2 != hipSuccess) { (void)hipGetLastError(); R.up_area = nullptr; }
+        else HIPCHK(hipMemsetAsync(R.up_area, 0, ub, I->stream));
         HIPCHK(hipStreamSynchronize(I->stream));
         memset(R.shadow, 0, bytes);
         R.pushed = true;
@@ -141,7 +169,7 @@ int resident_prepare(Instance *I, Resident &R, int grid, int n_words, unsigned l
   ++R.gen;
   set_ctl(R, 0, R.gen);
   r.cmd = R.cmd; r.gen = R.gen; r.start_seq = served; r.n_sectors = (n_words + kResidentPay - 1) / kResidentPay;
-  r.mail = R.mail; r.report = R.report;
+  r.mail = R.mail; r.report = R.report; r.up_area = R.up_area;
   r.relay = (!R.pushed && grid > I->resident_direct) ? 1 : 0; // (a pushed record is polled locally: by everybody)
   if (I->wall_khz <= 0)
   {

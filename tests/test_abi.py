@@ -173,7 +173,7 @@ def test_resident_choke_point():
                        "phyhip_update_eigen_lr", "phyhip_calculate_edge_log_likelihoods", "phyhip_calculate_eigen_lnl_dlnl",
                        "phyhip_calculate_eigen_lnl", "phyhip_get_numerical_warning", "phyhip_get_resident_stats",
                        "phyhip_get_big_resident_stats", "phyhip_get_virtual_stats", "phyhip_profile_read_kernel"}, sorted(keepers)
-    REVIEWED = {"leave_queued_only": {"phyhip_update_transition_matrices", "phyhip_update_partials"},
+    REVIEWED = {"leave_queued_only": {"phyhip_update_transition_matrices", "phyhip_set_transition_matrix", "phyhip_update_partials"},
                 "leave_untouched": {"phyhip_calculate_eigen_lnl_dlnl", "phyhip_calculate_eigen_lnl"},
                 "leave_query": {"phyhip_get_numerical_warning", "phyhip_get_resident_stats", "phyhip_get_big_resident_stats",
                                 "phyhip_get_virtual_stats", "phyhip_profile_read_kernel"}}

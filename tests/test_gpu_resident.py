@@ -187,6 +187,46 @@ def test_resident_protocol_under_stress(monkeypatch):
         assert np.array_equal(a, b) and np.array_equal(a2, b2), k
 
 
+@pytest.mark.parametrize("taxa,patterns,categories", [(40, 382, 4), (30, 1500, 4), (20, 700, 1), (16, 5000, 4), (12, 40000, 4), (12, 7000, 3)])
+def test_host_computed_matrices_ride_in_resident_commands(taxa, patterns, categories, monkeypatch):
+    """The bit-exact matrix route -- the host layer's PMat() + phyhip_set_transition_matrix (src/lk.c:2360), what PhyML's glue uses by
+    default -- in the search's call pattern: the three matrices of an SPR candidate travel to ResidentCtl::up_area through the BAR
+    in front of the command, the resident workgroups (short-launch evaluator up to 2 048 patterns, large-grid evaluator beyond) take
+    them to their slots as a launch takes them from its arguments.  The launch path's doubles, scalar by scalar; the oracle's to
+    1e-12 (host matrices: no device exp); the candidates are served, not launched; the workgroups leaving all the time (commands
+    that go unanswered are launched with their matrices queued again) changes nothing."""
+    from phyml_amd import replay
+    import replay_oracle
+    big = patterns > 2048
+    res, stats = {}, {}
+    for r, idle in (("0", "1000"), ("1", "1000"), ("1", "5")):
+        monkeypatch.setenv("PHYHIP_RESIDENT", r)
+        monkeypatch.setenv("PHYHIP_RESIDENT_IDLE_US", idle)
+        t, ot, tree, st = synthetic_pair(taxa, patterns, 4, categories, seed=63, host_pmat=True, ambiguous_every=13)
+        try:
+            t.Set_Both_Sides(True)
+            t.Lk(None)
+            tr = replay.make_trace(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, 80, seed=8, walk_every=3, opt_every=4, n_dlk=4)
+            res[(r, idle)] = t.Replay_Surface_Trace(tr)
+            stats[(r, idle)] = t.inst.resident_stats(2 if big else 1)
+            if (r, idle) == ("1", "1000"):
+                ot.lk(None, both_sides=True)
+                ref, ref2 = replay_oracle.OracleReplayer(ot).run(tr)
+                m = ref != 0
+                assert np.max(np.abs(res[(r, idle)][0][m] - ref[m]) / np.abs(ref[m])) < 1e-12
+        finally:
+            t.close()
+    a, a2 = res[("0", "1000")]
+    for k, (b, b2) in res.items():
+        assert np.array_equal(a, b) and np.array_equal(a2, b2), k
+    served, launches, silent, busy = stats[("1", "1000")]
+    assert stats[("0", "1000")][0] == 0
+    # (needs the host's stores into device memory -- a large BAR, as on every MI355X box of this pool; without it such commands are launched)
+    assert served >= 80 and silent == 0, stats  # every candidate's Lk(b) (+ the eigen products of the branch-length chains)
+    s2 = stats[("1", "5")]
+    assert s2[0] + s2[2] > 0 and s2[1] > 1, s2
+
+
 # ---- the large-grid resident evaluator (phyml_amd/csrc/phyhip_big.hpp) ----------------------------------------------------
 
 @pytest.mark.parametrize("taxa,patterns,categories", [(16, 5000, 4), (12, 40000, 4), (12, 9000, 2), (12, 7000, 3), (12, 6000, 1),

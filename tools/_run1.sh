@@ -1,6 +1,10 @@
 export TMPDIR=/tmp
-P='import json,sys; d=json.loads(sys.stdin.read()); print("  us/candidate %.2f  calls %d  dlk %d"%(d["us_per_candidate"], d["surface_calls"], d["dlk"]))'
-echo "cfg5 resident:"; PHYHIP_RESIDENT_STATS=1 timeout 300 python tools/bench_spr.py --candidates 3000 2> gpurun_out/big_stats.err | python -c "$P"
-grep -vE "^\s*$" gpurun_out/big_stats.err | head -40
-echo "dlk:"; PHYHIP_RESIDENT_STATS=1 timeout 300 python tools/bench_dlk.py 2>&1 | tail -30
-echo "stamps cfg2:"; PHYHIP_LIBDIR=phyml_amd/lib_diag PHYHIP_ABLATE=8 timeout 300 python bench.py --workload cfg2_nt_100x50k --steps 10 --warmup 3 2>&1 | grep -E "^step" | head -70
+P='import json,sys; d=json.loads(sys.stdin.read()); print("  us/candidate %.2f  calls %d  dlk %d served %s"%(d["us_per_candidate"], d["surface_calls"], d["dlk"], d["served_by_resident_workgroups"]))'
+timeout 900 python -m pytest tests/test_gpu_resident.py tests/test_gpu_cfg5.py tests/test_gpu_replay.py tests/test_gpu_trace.py -x -q 2>&1 | tail -6
+for hp in "" "--host-pmat"; do
+echo "54x382 $hp:"; timeout 300 python tools/bench_spr.py --taxa 54 --patterns 382 --candidates 3000 $hp | grep "^{" | python -c "$P"
+echo "54x382 brlen $hp:"; timeout 300 python tools/bench_spr.py --taxa 54 --patterns 382 --candidates 3000 --opt-every 4 $hp | grep "^{" | python -c "$P"
+echo "500x100k $hp:"; timeout 300 python tools/bench_spr.py --candidates 2000 $hp | grep "^{" | python -c "$P"
+done
+echo "host-pmat, residents off:"; PHYHIP_RESIDENT=0 timeout 300 python tools/bench_spr.py --taxa 54 --patterns 382 --candidates 3000 --host-pmat | grep "^{" | python -c "$P"
+PHYHIP_RESIDENT=0 timeout 300 python tools/bench_spr.py --candidates 2000 --host-pmat | grep "^{" | python -c "$P"

@@ -22,13 +22,15 @@ def main():
     ap.add_argument("--opt-every", type=int, default=0)
     ap.add_argument("--states", type=int, default=4, choices=(4, 20))
     ap.add_argument("--host-pmat", action="store_true", help="transition matrices computed by the host layer's PMat() (bit-exact route)")
+    ap.add_argument("--devices", default="", help="comma-separated device list: a sharded instance (repeat a device for several shards on it)")
     args = ap.parse_args()
     from phyml_amd import lktree, replay, synth, workloads
     blk = workloads.model_block("model_gtr_g4" if args.states == 4 else "model_lg_g4")
     tree = synth.random_tree(args.taxa, 9, 0.02, 0.15)   # defaults = workloads cfg5_nt_500x100k (tests/test_gpu_cfg5.py checks
     st = synth.simulate_states(tree, args.patterns, args.states, 9)  # every scalar of this call pattern against the oracle at this size)
     C = int(blk["ncatg"][0])
-    t = lktree.LkTree(args.taxa, tree.edge_left, tree.edge_rght, tree.edge_len, args.patterns, args.states, C, host_pmat=args.host_pmat)
+    t = lktree.LkTree(args.taxa, tree.edge_left, tree.edge_rght, tree.edge_len, args.patterns, args.states, C, host_pmat=args.host_pmat,
+                      devices=[int(x) for x in args.devices.split(",")] if args.devices else None)
     t.set_model(blk["pi"], blk["gamma_rr"], blk["gamma_r_proba"], blk["e_val"], blk["r_e_vect"], blk["l_e_vect"])
     t.Make_Tree_For_Lk(np.ones(args.patterns))
     t.set_tips(tip_states=st.astype(np.int32))
@@ -48,7 +50,8 @@ def main():
                       "us_per_candidate": dt / args.candidates * 1e6, "candidates_per_s": args.candidates / dt,
                       "surface_calls": int(len(k)), "updates": n_upd, "edge_lnl": n_lnl, "dlk": n_dlk,
                       "incremental_M_site_updates_per_s": n_upd * args.patterns / dt / 1e6,
-                      "finite": bool(np.isfinite(out).all())}))
+                      "finite": bool(np.isfinite(out).all()),
+                      "devices": args.devices or None, "served_by_resident_workgroups": [int(t.inst.resident_stats(k)[0]) for k in (0, 1, 2)]}))
     t.close()
 
 

@@ -68,6 +68,19 @@ def main():
     d0, _ = bench.timed_steps(t0, args.steps, 3, lambda: torch.cuda.synchronize(devs[0]))
     t0.close()
     out["one_shard_with_collective_ms"] = d0 / args.steps * 1e3
+    # the search's call pattern on the sharded instance (src/spr.c:640-646, src/optimiz.c:607-663): short scalar-returning calls are
+    # answered shard by shard (each shard's resident evaluators) and added by the host -- no launch, no collective per call
+    from phyml_amd import replay
+    tree = wl["tree"]
+    t.Set_Both_Sides(True); t.Lk(None)
+    tr = replay.make_trace(wl["states"].shape[0], tree.edge_left, tree.edge_rght, tree.edge_len, 400, seed=3,
+                           walk_every=3, opt_every=4, n_dlk=5)
+    t.Replay_Surface_Trace({k: v[:100] for k, v in tr.items()})
+    c0 = time.perf_counter()
+    vals, _ = t.Replay_Surface_Trace(tr)
+    out["call_pattern_us_per_candidate"] = (time.perf_counter() - c0) / 400 * 1e6
+    out["call_pattern_served_by_resident_workgroups"] = [int(t.inst.resident_stats(k)[0]) for k in (0, 1, 2)]
+    out["call_pattern_finite"] = bool(np.isfinite(vals).all())
     t.close()
     if len(set(devs)) == len(devs):
         wl1 = workloads.make(name, n_pattern=P)
@@ -77,7 +90,7 @@ def main():
         out["one_gpu_ms_per_step"] = d1 / args.steps * 1e3
         out["speedup"] = out["one_gpu_ms_per_step"] / out["sharded_ms_per_step"]
     print(json.dumps(out, indent=1))
-    ok = out["lnL_rel_err_vs_shard_sum"] < 1e-12
+    ok = out["lnL_rel_err_vs_shard_sum"] < 1e-12 and out["call_pattern_finite"]
     print("OK" if ok else "MISMATCH")
     sys.stdout.flush(); sys.stderr.flush()
     os._exit(0 if ok else 1)  # (RCCL prints a banner of its own on stdout while the interpreter shuts down)
