@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
     const BigCtl            &b = cm.b;
     HostBlock *const         host_blocks = cm.host_blocks;
     auto stamp = [&](int i, unsigned long long t) {
-      if (b.stamps && tid == 0) { b.stamps[(size_t)bid * 16 + i] = t; b.stamps[(size_t)bid * 16 + 8 + i] += i ? t - st0 : 1ull; }
+      // (the sums as atomics whose result nobody waits for: a read-modify-write would hold wave 0 for a trip to memory per stamp)
+      if (b.stamps && tid == 0) { b.stamps[(size_t)bid * 16 + i] = t; (void)__hip_atomic_fetch_add(&b.stamps[(size_t)bid * 16 + 8 + i], i ? t - st0 : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     };
     stamp(0, st0);
     stamp(1, wall_clock64());
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
     const BigCtl            &b = cm.b;
     HostBlock *const         host_blocks = cm.host_blocks;
     auto stamp = [&](int i, unsigned long long t) {
-      if (b.stamps && tid == 0) { b.stamps[(size_t)bid * 16 + i] = t; b.stamps[(size_t)bid * 16 + 8 + i] += t - st0; }
+      if (b.stamps && tid == 0) { b.stamps[(size_t)bid * 16 + i] = t; (void)__hip_atomic_fetch_add(&b.stamps[(size_t)bid * 16 + 8 + i], t - st0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     };
     if (gsum)
     { // ---- the final sum on the device, one partial sum per workgroup (kBigGroupSum above) ----
