@@ -173,7 +173,8 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
                                       const double *edgeLengths, int count);
 
 /* replaces beagleSetTransitionMatrix, src/lk.c:2360: upload b->Pij_rr ([category][from][to]) as computed
-   by the host's own PMat() -- the bit-exact route. */
+   by the host's own PMat() -- bit-exact by construction.  (phyhip_update_transition_matrices above builds the
+   same doubles on the device: its exp() is the reference's libm's, phyml_amd/csrc/phyhip_exp.hpp.) */
 int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *inMatrix, double paddedValue);
 
 /* replaces beagleGetTransitionMatrix, src/lk.c:2351 */

@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
                 if (site < kSmall) { site = kSmall; raise_warn(q); }
                 const double lsl = log(site) - kLog2 * (double)f;
                 if (q.site_lnl) gst(&q.site_lnl[p0[i]], lsl);
-                if (q.site_lk) gst(&q.site_lk[p0[i]], exp(lsl));
+                if (q.site_lk) gst(&q.site_lk[p0[i]], dev_exp(lsl));
                 contrib = wt * lsl;
               }
               gst(&q.fact[p0[i]], f);
@@ -1360,6 +1360,8 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
     __shared__ __attribute__((aligned(16))) double sh_expt[4][4 * 20]; // [rebuilt matrix][category][eigenvalue]
     __shared__ __attribute__((aligned(16))) double sh_U[400], sh_V[400], sh_R[20], sh_rates[4];
     __shared__ int sh_act;
+    __shared__ unsigned long long sh_exp[256]; // the exp table (dev_exp), copied once per launch
+    exp_tab_to_lds(sh_exp, (int)threadIdx.x, (int)blockDim.x);
     const int          lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int)(blockDim.x >> 6);
     unsigned long long last = rs.ctl.start_seq, t_last = wall_clock64(), model_seen = ~0ull;
     bool               mail_open = false;
@@ -1447,7 +1449,7 @@ __global__ __launch_bounds__((NT == 2 || RES) ? 64 * (kAaMaxCons2 + 1) : (D2 ? 6
             double len;
             const unsigned long long lb = sh_raw[resident_slot(6 + f)];
             __builtin_memcpy(&len, &lb, 8);
-            pmat20_exponentials(sh_expt[f], len, C_, false, sh_R, sh_rates, q.br_len_mult, q.l_min, q.l_max, u, 4 * 20);
+            pmat20_exponentials(sh_expt[f], len, C_, false, sh_R, sh_rates, q.br_len_mult, q.l_min, q.l_max, u, 4 * 20, sh_exp);
           }
         }
       }

@@ -125,6 +125,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
   __shared__ __attribute__((aligned(16))) double sh_dot[NW][(64 / G) * C * 4]; // per wave: staging of a tile's eigen products
   __shared__ double             sh_red[2][256];                                // the final sum's accumulators
   __shared__ int                sh_late;
+  __shared__ unsigned long long sh_exp[256]; // the exp table (dev_exp): every wave rebuilds the command's matrices
+  exp_tab_to_lds(sh_exp, (int)threadIdx.x, 64 * NW);
   unsigned long long last = args_.r.start_seq, t_last = wall_clock64();
   bool               mail_open = false, served = false;
   for (;;)
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void resident_big_kernel(con
         // a model change makes the host launch a new generation)
         const char *kt = (const char *)ka2 + offsetof(BigArgs, t);
         fr.idx = sh_idx; fr.len = sh_len;
-        fr.up_idx = sh_idx; fr.up_val = as_global(A2->r.up_area); fr.up_sys = true;
+        fr.up_idx = sh_idx; fr.up_val = as_global(A2->r.up_area); fr.up_sys = true; fr.exp_lds = sh_exp;
         fr.evec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_evec));
         fr.ivec = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_ivec));
         fr.eval = reinterpret_cast<const double *>(kt + offsetof(TreeParams, m_eval));

@@ -17,8 +17,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "phyhip_exp.hpp"
+
 namespace phyhip
 {
+
+// exp() wherever the reference calls its libm's on this path (transition matrices, the eigen-basis tables, cur_site_lk): the
+// reference's doubles (phyhip_exp.hpp)
+// (resident kernels keep a copy of the 2 KB table in LDS, copied once per launch: thousands of waves gathering from the global
+// table in their matrix rebuild cost an SPR candidate 1.5 us at 500 x 100 000, measured; exp_tab_to_lds / dev_exp(x, lds table))
+typedef const __attribute__((address_space(3))) unsigned long long *ExpLdsTab;
+#ifdef PHYHIP_OCML_EXP // (A/B builds only, tools/build_variant.sh: the device library's exp -- a few ulp from the reference's)
+__device__ __forceinline__ double dev_exp(const double x, const unsigned long long * = nullptr) { return exp(x); }
+#else
+__device__ __forceinline__ double dev_exp(const double x) { return phyhip_exp_ref(x, phyhip_exp_tab); }
+// lds: a copy of the table in LDS (generic pointer to it), or nullptr
+__device__ __forceinline__ double dev_exp(const double x, const unsigned long long *lds)
+{
+  return lds ? phyhip_exp_ref(x, (ExpLdsTab)lds) : phyhip_exp_ref(x, phyhip_exp_tab);
+}
+#endif
+__device__ __forceinline__ void exp_tab_to_lds(unsigned long long *lds, const int tid, const int nth)
+{
+  for (int i = tid; i < 256; i += nth) lds[i] = phyhip_exp_tab[i];
+}
 
 constexpr int    kLarge         = 256;                         // src/utilities.h:507
 constexpr double kTwoToLarge    = 0x1p256;                     // TWO_TO_THE_LARGE
@@ -701,7 +723,7 @@ __global__ __launch_bounds__(256) void traverse_kernel(const TreeParams q, const
         }
         const double lsl = log(site) - kLog2 * (double)f; // src/lk.c:854
         if (q.site_lnl) q.site_lnl[p] = lsl;
-        if (q.site_lk) q.site_lk[p] = exp(lsl);
+        if (q.site_lk) q.site_lk[p] = dev_exp(lsl);
         contrib = w * lsl; // src/lk.c:856
       }
       q.fact[p] = f;
@@ -1034,7 +1056,7 @@ __global__ __launch_bounds__(256, (DIST == 2 ? 3 : 4)) void traverse_nt_kernel(c
         if (site < kSmall) { site = kSmall; raise_warn(q); }
         const double lsl = log(site) - kLog2 * (double)f;
         if (q.site_lnl) q.site_lnl[p] = lsl;
-        if (q.site_lk) q.site_lk[p] = exp(lsl);
+        if (q.site_lk) q.site_lk[p] = dev_exp(lsl);
         contrib = w * lsl;
       }
       q.fact[p] = f;
@@ -1237,7 +1259,7 @@ struct DlkParams
 // the host's version: eigen_eval, phyhip_eigen.hip), entry by entry over the calling threads.
 template <int S>
 __device__ __forceinline__ void dlk_expl_from_len(double *tab, const double l, const bool deriv, const int C, const double *ev, const double *rates,
-                                                  const double mult, const double l_min, const double l_max, const int tid, const int nth)
+                                                  const double mult, const double l_min, const double l_max, const int tid, const int nth, const unsigned long long *exp_lds = nullptr)
 {
   for (int e = tid; e < C * S; e += nth)
   {
@@ -1248,7 +1270,7 @@ __device__ __forceinline__ void dlk_expl_from_len(double *tab, const double l, c
       double       len = l * rr;
       if (len < l_min) len = l_min;
       else if (len > l_max) len = l_max;
-      const double v = ev[s], ex = exp(v * len);
+      const double v = ev[s], ex = dev_exp(v * len, exp_lds);
       tab[c * 2 * S + 2 * s]     = ex;
       tab[c * 2 * S + 2 * s + 1] = ex * v * rr;
     }
@@ -1258,7 +1280,7 @@ __device__ __forceinline__ void dlk_expl_from_len(double *tab, const double l, c
       len *= mult;
       if (len < l_min) len = l_min;
       else if (len > l_max) len = l_max;
-      tab[c * S + s] = exp(ev[s] * len);
+      tab[c * S + s] = dev_exp(ev[s] * len, exp_lds);
     }
   }
 }
@@ -1647,6 +1669,8 @@ __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, co
   __shared__ unsigned long long sh_raw[(1 + kResidentSectors + 15) / 16 * 64];
   __shared__ double             sh_expl[kMaxExpl];
   __shared__ unsigned long long sh_ctl[1];
+  __shared__ unsigned long long sh_exp[256]; // the exp table (dev_exp), copied once per launch
+  exp_tab_to_lds(sh_exp, (int)threadIdx.x, (int)blockDim.x);
   unsigned long long last = r.start_seq, t_last = wall_clock64();
   const int          n_loads = (1 + r.n_sectors + 15) / 16;
   bool               mail_open = false; // workgroup 0: the mailbox carries this generation's control line
@@ -1679,7 +1703,7 @@ __global__ __launch_bounds__(256) void resident_dlk_kernel(const DlkParams q, co
       double                   l;
       const unsigned long long b = word(3);
       __builtin_memcpy(&l, &b, 8);
-      dlk_expl_from_len<S>(sh_expl, l, k.with_derivative != 0, q.C, q.eval_dev, q.rates_dev, q.br_len_mult, q.l_min, q.l_max, (int)threadIdx.x, (int)blockDim.x);
+      dlk_expl_from_len<S>(sh_expl, l, k.with_derivative != 0, q.C, q.eval_dev, q.rates_dev, q.br_len_mult, q.l_min, q.l_max, (int)threadIdx.x, (int)blockDim.x, sh_exp);
     }
     else
     for (int e = threadIdx.x; e < ne; e += blockDim.x)
@@ -1929,7 +1953,7 @@ __global__ __launch_bounds__(ST == 4 ? 64 : 1024) void pmat_kernel(const PmatPar
     len *= q.br_len_mult;                             // :2297
     if (len < q.l_min) len = q.l_min;                 // :2299-2300
     else if (len > q.l_max) len = q.l_max;
-    expt[t] = exp(q.R[(q.class_axis ? c * S : 0) + k] * len); // src/models.c:275
+    expt[t] = dev_exp(q.R[(q.class_axis ? c * S : 0) + k] * len); // src/models.c:275
   }
   __syncthreads();
   if (PRE)
@@ -1994,7 +2018,8 @@ __global__ __launch_bounds__(ST == 4 ? 64 : 1024) void pmat_kernel(const PmatPar
 // The exponentials of one matrix: expt[c][k] = exp(eigenvalue k x the clamped, rate-scaled length of category c), by the threads
 // tid, tid + nth, ... of whoever builds it (src/lk.c:2296-2300, src/models.c:275)
 __device__ __forceinline__ void pmat20_exponentials(double *expt, const double l, const int C, const bool cls, const double *R, const double *rates,
-                                                    const double br_len_mult, const double l_min, const double l_max, const int tid, const int nth)
+                                                    const double br_len_mult, const double l_min, const double l_max, const int tid, const int nth,
+                                                    const unsigned long long *exp_lds = nullptr)
 {
   constexpr int S = 20;
   for (int t = tid; t < C * S; t += nth)
@@ -2004,7 +2029,7 @@ __device__ __forceinline__ void pmat20_exponentials(double *expt, const double l
     len *= br_len_mult;                             // :2297
     if (len < l_min) len = l_min;                   // :2299-2300
     else if (len > l_max) len = l_max;
-    expt[t] = exp(R[(cls ? c * S : 0) + k] * len);  // src/models.c:275
+    expt[t] = dev_exp(R[(cls ? c * S : 0) + k] * len, exp_lds);  // src/models.c:275
   }
 }
 

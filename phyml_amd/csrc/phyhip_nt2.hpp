@@ -56,6 +56,7 @@ struct NtFresh
   const int    *up_idx = nullptr;            // [n_up] host-computed matrices of this launch (TreeParams::up_idx / up_val)
   const double *up_val = nullptr;            // [n_up][64]
   bool          up_sys = false;              // up_val is device memory the HOST wrote (resident commands, ResidentCtl::up_area): read past the caches
+  const unsigned long long *exp_lds = nullptr; // resident kernels: their LDS copy of the exp table (dev_exp)
 };
 
 // One workgroup's (= one wave's) share of a launch: the whole kernel body, callable from a kernel that stays resident.
@@ -285,7 +286,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         len *= q.br_len_mult;
         if (len < q.l_min) len = q.l_min;
         else if (len > q.l_max) len = q.l_max;
-        ex = exp(fr.eval[ek] * len);
+        ex = dev_exp(fr.eval[ek] * len, fr.exp_lds);
       }
       // entry (c, i, j) of a matrix = lane (C <= 4: one pass); idle lanes compute entry 0 and store nothing, so that every
       // shuffle below runs with the whole wave active
@@ -690,7 +691,7 @@ __device__ __forceinline__ void nt2_run(const TreeParams &q, const IssueRec *__r
         if (site < kSmall) { site = kSmall; raise_warn(q); }
         const double lsl = log(site) - kLog2 * (double)f;
         if (q.site_lnl) q.site_lnl[p] = lsl;
-        if (q.site_lk) q.site_lk[p] = exp(lsl);
+        if (q.site_lk) q.site_lk[p] = dev_exp(lsl);
         contrib = w * lsl;
       }
       q.fact[p] = f;
@@ -784,9 +785,12 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
   __shared__ int                sh_idx[4];
   __shared__ double             sh_len[4];
   __shared__ __attribute__((aligned(16))) double sh_dot[(64 / G) * C * 4];
+  __shared__ unsigned long long sh_exp[256];
   const int          lane = threadIdx.x;
   unsigned long long last = r.start_seq, t_last = wall_clock64();
   bool               mail_open = false;
+  exp_tab_to_lds(sh_exp, lane, 64);
+  __builtin_amdgcn_wave_barrier();
   for (;;)
   {
     const int act = resident_poll_wave(r, last, t_last, mail_open, sh_raw, 1, lane, blockIdx.x == 0);
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(64, 1) void resident_nt2_kernel(const TreeParams sq
     __builtin_amdgcn_wave_barrier();
     NtFresh fr;
     fr.idx = sh_idx; fr.len = sh_len; fr.evec = evec; fr.ivec = ivec; fr.eval = eval; fr.rates = rates;
-    fr.up_idx = sh_idx; fr.up_val = r.up_area; fr.up_sys = true;
+    fr.up_idx = sh_idx; fr.up_val = r.up_area; fr.up_sys = true; fr.exp_lds = sh_exp;
     if (n_ops == 1) nt2_run<C, G, false, 1>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
     else if (n_ops == 2) nt2_run<C, G, false, 2>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
     else nt2_run<C, G, false, 3>(q, nullptr, nullptr, pmats, tip_codes, nullptr, fr, blockIdx.x, threadIdx.x, sh_dot);
