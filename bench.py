@@ -216,7 +216,9 @@ def materialise_after_traversal(wl, torch, reps=6):
         b = t.Lk(e_c)
         t2 = time.perf_counter()
         v1 = t.inst.virtual_stats()
-        assert abs(a - ref) <= 1e-9 * abs(ref) and a == b, (ref, a, b)
+        # (a: a list-form launch -- the stored definitions in front -- adds its block sums in the two-wave-shape partition, b: a short
+        # evaluation in the one-shape partition: the same tree state to the last bits, not necessarily the same double)
+        assert abs(a - ref) <= 1e-9 * abs(ref) and abs(a - b) <= 1e-12 * abs(ref), (ref, a, b)
         if k >= 2:  # (the first rounds load code objects)
             first.append((t1 - t0) * 1e6); again.append((t2 - t1) * 1e6); virt.append((v0[0], v1[0], v1[3] - v0[3]))
     t.close()
