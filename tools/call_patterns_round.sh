@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/call_patterns_round.sh : the round's call-pattern evidence in ONE gpurun call -- per-phase statistics of the resident commands
+# (gpurun_out/r06/call_patterns.txt -> profiles/r06_call_patterns_raw.txt), then tools/profile_round.sh r06 and tools/profile_r05_extra.sh r06
 export TMPDIR=/tmp
 P='import json,sys; d=json.loads(sys.stdin.read()); print("  us/candidate %.2f  calls %d  dlk %d served %s"%(d["us_per_candidate"], d["surface_calls"], d["dlk"], d["served_by_resident_workgroups"]))'
 mkdir -p gpurun_out/r06
