@@ -84,7 +84,8 @@ def test_sharded_instance_matches_reference(name, layout, golden):
         t.close()
 
 
-def test_sharded_instance_spr_call_pattern_matches_single_device(monkeypatch):
+@pytest.mark.parametrize("ns,taxa,P", [(4, 40, 3000), (20, 24, 700)])
+def test_sharded_instance_spr_call_pattern_matches_single_device(ns, taxa, P, monkeypatch):
     """A seeded SPR / Br_Len_Opt call stream (phyml_amd/replay.py) through a sharded instance returns the scalars the
     single-device instance returns (1e-12; the shard sums are added in a different order) -- with the shards driven from
     the calling thread and from the per-shard helper threads (what a multi-device group uses; PHYHIP_SHARD_THREADS=1
@@ -97,11 +98,11 @@ def test_sharded_instance_spr_call_pattern_matches_single_device(monkeypatch):
     for devs, threads, combine in runs:
         monkeypatch.setenv("PHYHIP_SHARD_THREADS", threads)
         monkeypatch.setenv("PHYHIP_SHARD_HOST_COMBINE", combine)
-        t, ot, tree, st = synthetic_pair(40, 3000, 4, 4, seed=77, devices=devs)
+        t, ot, tree, st = synthetic_pair(taxa, P, ns, 4, seed=77, devices=devs, host_pmat=(ns == 4))
         try:
             t.Set_Both_Sides(True)
             t.Lk(None)
-            tr = replay.make_trace(40, tree.edge_left, tree.edge_rght, tree.edge_len, 60, seed=5, walk_every=3, opt_every=4, n_dlk=4)
+            tr = replay.make_trace(taxa, tree.edge_left, tree.edge_rght, tree.edge_len, 60, seed=5, walk_every=3, opt_every=4, n_dlk=4)
             res.append(t.Replay_Surface_Trace(tr))
             served.append(t.inst.resident_stats(0)[0] + t.inst.resident_stats(1)[0])
         finally:
