@@ -97,7 +97,16 @@ PHYHIP_EXP_FN double phyhip_exp_asdouble(uint64_t b) { double d; __builtin_memcp
 PHYHIP_EXP_FN uint64_t phyhip_exp_asuint(double d) { uint64_t b; __builtin_memcpy(&b, &d, 8); return b; }
 
 // T: the table (phyhip_exp_tab, or a copy of it nearer to the lanes: on the device any pointer type, so that a copy in LDS is
-// read with LDS instructions)
+// read with LDS instructions).
+// Written without divergent branches: the common path is computed by every lane, the rare results (|x| < 2^-54, |x| >= 512,
+// infinities, NaN) are selected over it -- the subnormal-result arithmetic behind ONE wave-uniform test -- because nested divergent
+// branches cost the two-operation short-launch kernels the scalar registers of their execution-mask saves (they reserved scratch:
+// tests/test_kernel_resources.py).  Every selected value is the value the branch of the original computes.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PHYHIP_EXP_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#else
+#define PHYHIP_EXP_ANY(c) (c)
+#endif
 #if defined(__HIPCC__) || defined(__HIP__)
 template <typename TabPtr>
 PHYHIP_EXP_FN double phyhip_exp_ref(double x, TabPtr T)
@@ -108,55 +117,51 @@ PHYHIP_EXP_FN double phyhip_exp_ref(double x, const uint64_t *T)
   const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47,
                C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
   const uint64_t xb = phyhip_exp_asuint(x);
-  uint32_t abstop = (uint32_t)(xb >> 52) & 0x7ff;
-  if (abstop - 0x3c9u > 0x3eu)
-  {
-    if ((int32_t)(abstop - 0x3c9u) < 0) return 1.0 + x; // |x| < 2^-54
-    if (abstop > 0x408u)
-    { // |x| >= 1024, infinities, NaN
-      if (xb == 0xfff0000000000000ull) return 0.0;
-      if (abstop == 0x7ffu) return 1.0 + x;
-      if (xb >> 63) return 0.0;                             // underflow
-      return phyhip_exp_asdouble(0x7ff0000000000000ull);    // overflow
-    }
-    abstop = 0; // 512 <= |x| < 1024: the scale may not be representable
-  }
-  double kd = PHYHIP_EXP_FMA(x, InvLn2N, Shift);
+  const uint32_t abstop = (uint32_t)(xb >> 52) & 0x7ff;
+  const int      tiny = abstop < 0x3c9u;   // |x| < 2^-54: 1 + x
+  const int      far = abstop > 0x408u;    // |x| >= 1024, infinities, NaN
+  const int      edge = abstop == 0x408u;  // 512 <= |x| < 1024: the scale may not be representable
+  // (lanes whose result is selected below compute on a harmless argument)
+  const double xs = (tiny || far) ? 0.0 : x;
+  double kd = PHYHIP_EXP_FMA(xs, InvLn2N, Shift);
   const uint64_t ki = phyhip_exp_asuint(kd);
   kd -= Shift;
-  double r = PHYHIP_EXP_FMA(kd, NegLn2hiN, x);
+  double r = PHYHIP_EXP_FMA(kd, NegLn2hiN, xs);
   r = PHYHIP_EXP_FMA(kd, NegLn2loN, r);
   const uint64_t idx = 2 * (ki & 127), top = ki << 45;
   const double   tail = phyhip_exp_asdouble(T[idx]);
-  uint64_t       sbits = T[idx + 1] + top;
+  const uint64_t sbits = T[idx + 1] + top;
   const double   p23 = PHYHIP_EXP_FMA(C3, r, C2), tr = r + tail, r2 = r * r, p45 = PHYHIP_EXP_FMA(r, C5, C4);
   double         tmp = PHYHIP_EXP_FMA(p23, r2, tr);
   tmp = PHYHIP_EXP_FMA(r2 * r2, p45, tmp);
-  if (abstop == 0)
-  {
-    if ((ki & 0x80000000ull) == 0)
-    { // k > 0: the exponent of scale might have overflowed
-      sbits -= 1009ull << 52;
-      const double scale = phyhip_exp_asdouble(sbits);
-      return 0x1p1009 * PHYHIP_EXP_FMA(scale, tmp, scale);
-    }
-    sbits += 1022ull << 52; // k < 0: the result may be subnormal
-    const double scale = phyhip_exp_asdouble(sbits), st = tmp * scale;
-    double       y = scale + st;
-    if (y < 1.0)
+  const double scale = phyhip_exp_asdouble(edge ? 0x3ff0000000000000ull : sbits);
+  double       res = PHYHIP_EXP_FMA(scale, tmp, scale);
+  if (PHYHIP_EXP_ANY(edge))
+  { // specialcase() of the original, both signs of k side by side
+    const double sp = phyhip_exp_asdouble(sbits - (1009ull << 52));
+    const double yp = 0x1p1009 * PHYHIP_EXP_FMA(sp, tmp, sp);          // k > 0: the exponent of scale might have overflowed
+    const double sn = phyhip_exp_asdouble(sbits + (1022ull << 52));    // k < 0: the result may be subnormal
+    const double st = tmp * sn;
+    double       y = sn + st;
     {
       const double hi = y + 1.0;
-      double       lo = scale - y;
+      double       lo = sn - y;
       lo = lo + st;
       double t = 1.0 - hi;
       t = t + y;
       t = t + lo;
       t = t + hi;
-      y = t - 1.0;
-      if (y == 0.0) y = 0.0;
+      double y2 = t - 1.0;
+      y2 = (y2 == 0.0) ? 0.0 : y2;
+      y = (y < 1.0) ? y2 : y;
     }
-    return 0x1p-1022 * y;
+    const double yn = 0x1p-1022 * y;
+    const double e = (ki & 0x80000000ull) ? yn : yp;
+    res = edge ? e : res;
   }
-  const double scale = phyhip_exp_asdouble(sbits);
-  return PHYHIP_EXP_FMA(scale, tmp, scale);
+  // |x| >= 1024: -inf -> 0, NaN / +inf -> 1 + x, negative -> 0 (underflow), positive -> +inf (overflow)
+  const double f = (xb == 0xfff0000000000000ull) ? 0.0 : (abstop == 0x7ffu) ? 1.0 + x : (xb >> 63) ? 0.0 : phyhip_exp_asdouble(0x7ff0000000000000ull);
+  res = far ? f : res;
+  res = tiny ? 1.0 + x : res;
+  return res;
 }
