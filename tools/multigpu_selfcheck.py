@@ -81,6 +81,8 @@ def main():
     out["call_pattern_us_per_candidate"] = (time.perf_counter() - c0) / 400 * 1e6
     out["call_pattern_served_by_resident_workgroups"] = [int(t.inst.resident_stats(k)[0]) for k in (0, 1, 2)]
     out["call_pattern_finite"] = bool(np.isfinite(vals).all())
+    out["call_pattern_route"] = ("every shard's resident evaluators, shard sums added on the host" if sum(out["call_pattern_served_by_resident_workgroups"]) > 0
+                                 else "a launch per shard + the collective (large shards that share a device, or PHYHIP_SHARD_HOST_COMBINE=0)")
     t.close()
     if len(set(devs)) == len(devs):
         wl1 = workloads.make(name, n_pattern=P)
