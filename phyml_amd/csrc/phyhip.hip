@@ -805,11 +805,26 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
                                       const int *firstDerivativeIndices, const int *secondDerivativeIndices,
                                       const double *edgeLengths, int count)
 {
-  if (Group *G = get_group(instance)) // (a whole-tree batch launches the rebuild at once: on the shard's helper thread)
+  if (Group *G = get_group_nodrain(instance))
+  {
+    // a short list on a group with helper threads is only recorded (Group::deferred): validated here as the shards would
+    if (G->defers() && count > 0 && count < kEagerPmBatch && eigenIndex == 0 && !firstDerivativeIndices && !secondDerivativeIndices && probabilityIndices && edgeLengths)
+    {
+      for (int i = 0; i < count; ++i)
+        if (probabilityIndices[i] < 0 || probabilityIndices[i] >= G->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", probabilityIndices[i]);
+      GroupDeferred d;
+      d.kind = 1; d.idx.assign(probabilityIndices, probabilityIndices + count); d.val.assign(edgeLengths, edgeLengths + count);
+      G->deferred.push_back(std::move(d));
+      return PHYHIP_SUCCESS;
+    }
+    int rc = group_drain(G);
+    if (rc) return group_take_drain_error(G);
+    // (a whole-tree batch launches the rebuild at once: on the shard's helper thread)
     return group_parallel(G, [&](int g) {
       return phyhip_update_transition_matrices(G->sub_id[g], eigenIndex, probabilityIndices, firstDerivativeIndices,
                                                secondDerivativeIndices, edgeLengths, count);
     });
+  }
   GET_INST_RES(I, instance);
   if (eigenIndex != 0) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "eigenIndex must be 0");
   if (firstDerivativeIndices || secondDerivativeIndices)
@@ -849,8 +864,20 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
 
 int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *inMatrix, double paddedValue)
 {
-  if (Group *G = get_group(instance))
+  if (Group *G = get_group_nodrain(instance))
+  {
+    if (G->defers() && inMatrix)
+    {
+      if (matrixIndex < 0 || matrixIndex >= G->nmat) return fail(PHYHIP_ERROR_OUT_OF_RANGE, "matrix index %d", matrixIndex);
+      GroupDeferred d;
+      d.kind = 2; d.idx.assign(1, matrixIndex); d.val.assign(inMatrix, inMatrix + (size_t)G->C * G->S * G->S);
+      G->deferred.push_back(std::move(d));
+      return PHYHIP_SUCCESS;
+    }
+    int rc = group_drain(G);
+    if (rc) return group_take_drain_error(G);
     return group_each(G, [&](int id, long long, long long) { return phyhip_set_transition_matrix(id, matrixIndex, inMatrix, paddedValue); });
+  }
   (void)paddedValue;
   GET_INST_RES(I, instance);
   // (a virtual buffer defined on the old value: the upload kernel moves that into the buffer's snapshot slot first -- the host
@@ -895,8 +922,31 @@ int phyhip_get_transition_matrix(int instance, int matrixIndex, double *outMatri
 
 int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int cumulativeScaleIndex)
 {
-  if (Group *G = get_group(instance))
+  if (Group *G = get_group_nodrain(instance))
+  {
+    if (G->defers() && n > 0 && n <= 2 && ops)
+    { // (short lists: the search's; a whole-tree list goes to the shards at once) -- validated here as the shards would
+      for (int i = 0; i < n; ++i)
+      {
+        const phyhip_operation &o = ops[i];
+        if (o.destinationPartials < G->tips || o.destinationPartials >= G->nbuf || o.child1Partials < 0 || o.child1Partials >= G->nbuf ||
+            o.child2Partials < 0 || o.child2Partials >= G->nbuf)
+          return fail(PHYHIP_ERROR_OUT_OF_RANGE, "operation %d: partials buffer index out of range", i);
+        if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= G->nmat || o.child2TransitionMatrix < 0 || o.child2TransitionMatrix >= G->nmat)
+          return fail(PHYHIP_ERROR_OUT_OF_RANGE, "operation %d: matrix index out of range", i);
+        if (o.destinationPartials == o.child1Partials || o.destinationPartials == o.child2Partials)
+          return fail(PHYHIP_ERROR_OUT_OF_RANGE, "operation %d: buffer %d is both destination and child", i, o.destinationPartials);
+      }
+      GroupDeferred d;
+      d.kind = 0; d.ops.assign(ops, ops + n);
+      G->deferred.push_back(std::move(d));
+      G->deferred_ops += (size_t)n;
+      return PHYHIP_SUCCESS;
+    }
+    int rc = group_drain(G);
+    if (rc) return group_take_drain_error(G);
     return group_each(G, [&](int id, long long, long long) { return phyhip_update_partials(id, ops, n, cumulativeScaleIndex); });
+  }
   (void)cumulativeScaleIndex;
   GET_INST_RES(I, instance);
   for (int i = 0; i < n; ++i)
@@ -932,19 +982,26 @@ int phyhip_calculate_edge_log_likelihoods(int instance, const int *parent, const
                                           double *outSum, double *outD1, double *outD2)
 {
   (void)cs;
-  Group *G = get_group(instance);
+  Group *G = get_group_nodrain(instance);
   if (G && count == 1 && group_combines_on_host(G, true))
-  { // every shard answers as a plain instance (its resident evaluators included), the shard sums are added here in shard order
+  { // every shard answers as a plain instance (its resident evaluators included), the shard sums are added here in shard order;
+    // the queue-only calls recorded since the last evaluation (Group::deferred) are replayed by the same job
     std::vector<double> part(G->sub.size(), 0.0);
+    std::vector<int>    warn(G->sub.size(), 0);
     int rc = group_parallel(G, [&](int g) -> int {
-      return phyhip_calculate_edge_log_likelihoods(G->sub_id[g], parent, child, pm, d1, d2, cw, sf, cs, count, &part[g], outD1, outD2);
+      int r = group_replay(G, g);
+      if (r) return r;
+      r = phyhip_calculate_edge_log_likelihoods(G->sub_id[g], parent, child, pm, d1, d2, cw, sf, cs, count, &part[g], outD1, outD2);
+      return r ? r : phyhip_get_numerical_warning(G->sub_id[g], &warn[g]);
     });
+    G->deferred.clear(); G->deferred_ops = 0;
     if (rc) return rc;
     double sum = 0.0;
     for (double v : part) sum += v;
     *outSum = sum;
-    return group_collect_warning(G);
+    return group_collect_warning(G, warn);
   }
+  if (G && group_drain(G)) return group_take_drain_error(G); // (the collective route: the shards' queues first)
   GET_INST_RES(I, G ? G->sub_id[0] : instance);
   if (count != 1) return fail(PHYHIP_ERROR_NO_IMPLEMENTATION, "count must be 1");
   if (d1 || d2 || outD1 || outD2)

@@ -22,7 +22,15 @@ extern "C" {
 
 int phyhip_update_eigen_lr(int instance, int left, int rght)
 {
-  if (Group *G = get_group(instance)) return group_parallel(G, [&](int g) { return phyhip_update_eigen_lr(G->sub_id[g], left, rght); });
+  if (Group *G = get_group_nodrain(instance))
+  { // (the recorded queue-only calls -- the partial update in front of the products -- are replayed by the same job)
+    const int rc = group_parallel(G, [&](int g) -> int {
+      const int r = group_replay(G, g);
+      return r ? r : phyhip_update_eigen_lr(G->sub_id[g], left, rght);
+    });
+    G->deferred.clear(); G->deferred_ops = 0;
+    return rc;
+  }
   GET_INST_RES(I, instance);
   int rc = check_partial_index(I, left, true);
   if (rc) return rc;
@@ -337,17 +345,23 @@ static int group_eigen_eval(Group *G, double l, bool deriv, double *lnl, double 
   if (group_combines_on_host(G, false))
   { // shard by shard through the plain entry points (resident dLk evaluators included), added here in shard order
     std::vector<double> pl(G->sub.size(), 0.0), pd(G->sub.size(), 0.0);
+    std::vector<int>    warn(G->sub.size(), 0);
     int rc = group_parallel(G, [&](int g) -> int {
       double lg = l; // (clamped by the entry point: the same value on every shard)
-      return deriv ? phyhip_calculate_eigen_lnl_dlnl(G->sub_id[g], &lg, &pl[g], &pd[g]) : phyhip_calculate_eigen_lnl(G->sub_id[g], l, &pl[g]);
+      int    r = group_replay(G, g);
+      if (r) return r;
+      r = deriv ? phyhip_calculate_eigen_lnl_dlnl(G->sub_id[g], &lg, &pl[g], &pd[g]) : phyhip_calculate_eigen_lnl(G->sub_id[g], l, &pl[g]);
+      return r ? r : phyhip_get_numerical_warning(G->sub_id[g], &warn[g]);
     });
+    G->deferred.clear(); G->deferred_ops = 0;
     if (rc) return rc;
     double a = 0.0, b = 0.0;
     for (size_t g = 0; g < pl.size(); ++g) { a += pl[g]; b += pd[g]; }
     *lnl = a;
     if (dlnl) *dlnl = b;
-    return group_collect_warning(G);
+    return group_collect_warning(G, warn);
   }
+  if (group_drain(G)) return group_take_drain_error(G);
   int rc = group_parallel(G, [&](int g) -> int {
     double *slot = shard_slot(G->co->ctx[G->ctx_of[g]], G->k_of[g]);
     return eigen_eval(G->sub[g], l, deriv, nullptr, nullptr, slot + 1, slot);
@@ -374,7 +388,7 @@ static int rank_eigen_eval(Instance *I, double l, bool deriv, double *lnl, doubl
 
 int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, double *outDLnL)
 {
-  if (Group *G = get_group(instance))
+  if (Group *G = get_group_nodrain(instance))
   { // (no call is entered on a shard here: the shards' own entry points or the group's launches below do that)
     if (std::isnan(*l)) return fail(PHYHIP_ERROR_FLOATING_POINT, "branch length is NaN");
     const Instance *I0 = G->sub[0];
@@ -393,7 +407,7 @@ int phyhip_calculate_eigen_lnl_dlnl(int instance, double *l, double *outLnL, dou
 
 int phyhip_calculate_eigen_lnl(int instance, double l, double *outLnL)
 {
-  if (Group *G = get_group(instance)) return group_eigen_eval(G, l, false, outLnL, nullptr);
+  if (Group *G = get_group_nodrain(instance)) return group_eigen_eval(G, l, false, outLnL, nullptr);
   GET_INST_RES(I, instance);
   I_call.leave_untouched();
   if (I->co) return rank_eigen_eval(I, l, false, outLnL, nullptr);

@@ -112,13 +112,44 @@ void release_collective(Collective *co)
 std::mutex           g_groups_mu;
 std::vector<Group *> g_groups;
 
-Group *get_group(int id)
+Group *get_group_nodrain(int id)
 {
   if (id < kGroupBase) return nullptr;
   std::lock_guard<std::mutex> lk(g_groups_mu);
   const int k = id - kGroupBase;
   if (k >= (int)g_groups.size()) return nullptr;
   return g_groups[k];
+}
+Group *get_group(int id)
+{
+  Group *G = get_group_nodrain(id);
+  if (G && !G->deferred.empty()) (void)group_drain(G); // (a failure is kept in Group::drain_rc for the caller's group_each / group_parallel)
+  return G;
+}
+
+// the recorded queue-only calls, on shard g through its plain entry points (its helper thread, or the calling thread)
+int group_replay(Group *G, int g)
+{
+  const int id = G->sub_id[g];
+  for (const GroupDeferred &d : G->deferred)
+  {
+    int rc = PHYHIP_SUCCESS;
+    if (d.kind == 0) rc = phyhip_update_partials(id, d.ops.data(), (int)d.ops.size(), 0);
+    else if (d.kind == 1) rc = phyhip_update_transition_matrices(id, 0, d.idx.data(), nullptr, nullptr, d.val.data(), (int)d.idx.size());
+    else rc = phyhip_set_transition_matrix(id, d.idx[0], d.val.data(), 0.0);
+    if (rc) return rc;
+  }
+  return PHYHIP_SUCCESS;
+}
+
+int group_drain(Group *G)
+{
+  if (G->deferred.empty()) return PHYHIP_SUCCESS;
+  const int rc = group_parallel(G, [&](int g) -> int { return group_replay(G, g); });
+  G->deferred.clear();
+  G->deferred_ops = 0;
+  if (rc) { G->drain_rc = rc; G->drain_err = g_err; }
+  return rc;
 }
 void forget_group(int id)
 {
@@ -273,21 +304,16 @@ bool group_combines_on_host(const Group *G, bool queue_counts)
   if (G->co->ctx.size() < G->sub.size() && big_shape(G->sub[0])) return false;
   if (!queue_counts) return true;
   for (const Instance *I : G->sub)
-    if (I->pending.size() > 2) return false;
+    if (I->pending.size() + G->deferred_ops > 2) return false;
   return true;
 }
 
-// after a host-combined evaluation: the warning flag of src/lk.c:847-851 over all shards (each shard's own last evaluation)
-int group_collect_warning(Group *G)
+// after a host-combined evaluation: the warning flag of src/lk.c:847-851 over all shards -- each shard's own last evaluation, read
+// by the thread that ran it (its device is current there: from the calling thread every shard would cost a device switch)
+int group_collect_warning(Group *G, const std::vector<int> &shard_warn)
 {
   int w = 0;
-  for (int id : G->sub_id)
-  {
-    int      ws = 0;
-    const int rc = phyhip_get_numerical_warning(id, &ws);
-    if (rc) return rc;
-    w = std::max(w, ws);
-  }
+  for (int ws : shard_warn) w = std::max(w, ws);
   G->last_warn  = w;
   G->warn_valid = true;
   return PHYHIP_SUCCESS;

@@ -115,6 +115,16 @@ struct ShardWorker
 
 constexpr int kGroupBase = 1 << 20; // instance ids >= kGroupBase name sharded instances
 
+// A queue-only call on a sharded instance that has helper threads, kept until something needs the shards to have seen it
+// (Group::deferred): 0 phyhip_update_partials, 1 phyhip_update_transition_matrices, 2 phyhip_set_transition_matrix
+struct GroupDeferred
+{
+  int                           kind;
+  std::vector<phyhip_operation> ops;
+  std::vector<int>              idx;
+  std::vector<double>           val;
+};
+
 struct Group
 {
   int                     S = 0, C = 0, tips = 0, nbuf = 0, nmat = 0;
@@ -134,13 +144,37 @@ struct Group
   // place where the shard sums meet; whole-tree evaluations keep the RCCL all-reduce, and so does the one-process-per-GPU form
   // for everything.  PHYHIP_SHARD_HOST_COMBINE: 0 never, 1 short calls (default), 2 every evaluation.
   int                     host_combine = 1;
+  // The queue-only calls of a search (three matrix refreshes and a partial update per SPR candidate, src/spr.c:640-646) do no device
+  // work, but entering a shard's entry point from the calling thread makes that shard's device current -- a device switch per shard
+  // and call, ~1 us each: 8 shards x 4 calls would cost a candidate more than its evaluation.  With helper threads (every shard's
+  // device stays current on its own thread) such calls are only RECORDED here, validated against the group's dimensions, and
+  // replayed by each shard's helper thread in front of the next thing that needs them: the evaluation's own job (one round trip to
+  // the helpers per scalar-returning call) or, for every other entry point, get_group() itself, which drains the list first.
+  std::vector<GroupDeferred> deferred;
+  size_t                  deferred_ops = 0; // partial updates among them (group_combines_on_host counts them)
+  int                     drain_rc = 0;     // a replay that failed: returned (once) by the next group_each / group_parallel
+  std::string             drain_err;
+  bool defers() const { return !workers.empty(); }
 };
 
-Group *get_group(int id);
+Group *get_group(int id);          // (drains Group::deferred first: what the caller does next sees every queued call)
+Group *get_group_nodrain(int id);  // the entry points that record, and the evaluations that replay inside their own jobs
+int    group_replay(Group *G, int g);
+int    group_drain(Group *G);
 void   forget_group(int id);
+
+inline int group_take_drain_error(Group *G)
+{
+  if (!G->drain_rc) return 0;
+  const int rc = G->drain_rc;
+  g_err = G->drain_err;
+  G->drain_rc = 0;
+  return rc;
+}
 
 template <typename F> int group_each(Group *G, F &&f)
 {
+  if (const int rc = group_take_drain_error(G)) return rc;
   for (size_t g = 0; g < G->sub_id.size(); ++g)
   {
     const int rc = f(G->sub_id[g], G->lo[g], G->n[g]);
@@ -152,6 +186,7 @@ template <typename F> int group_each(Group *G, F &&f)
 // run f(g) for every shard g: on the helper threads when the group has them, else in the calling thread
 template <typename F> int group_parallel(Group *G, F &&f)
 {
+  if (const int rc = group_take_drain_error(G)) return rc;
   if (G->workers.empty())
   {
     for (size_t g = 0; g < G->sub.size(); ++g)
@@ -181,4 +216,4 @@ int  create_group(int tipCount, int partialsBufferCount, int stateCount, int pat
                   const int *resourceList, int resourceCount, phyhip_instance_details *returnInfo, long classAxisFlag = 0);
 int  group_edge_lnl(Group *G, int parent, int child, int pm, double *out);
 bool group_combines_on_host(const Group *G, bool queue_counts);
-int  group_collect_warning(Group *G);
+int  group_collect_warning(Group *G, const std::vector<int> &shard_warn);
