@@ -815,6 +815,7 @@ int phyhip_update_transition_matrices(int instance, int eigenIndex, const int *p
       GroupDeferred d;
       d.kind = 1; d.idx.assign(probabilityIndices, probabilityIndices + count); d.val.assign(edgeLengths, edgeLengths + count);
       G->deferred.push_back(std::move(d));
+      if (G->deferred.size() >= 4096 && group_drain(G)) return group_take_drain_error(G); // (a caller that only ever queues)
       return PHYHIP_SUCCESS;
     }
     int rc = group_drain(G);
@@ -872,6 +873,7 @@ int phyhip_set_transition_matrix(int instance, int matrixIndex, const double *in
       GroupDeferred d;
       d.kind = 2; d.idx.assign(1, matrixIndex); d.val.assign(inMatrix, inMatrix + (size_t)G->C * G->S * G->S);
       G->deferred.push_back(std::move(d));
+      if (G->deferred.size() >= 4096 && group_drain(G)) return group_take_drain_error(G); // (a caller that only ever queues)
       return PHYHIP_SUCCESS;
     }
     int rc = group_drain(G);
@@ -924,8 +926,8 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
 {
   if (Group *G = get_group_nodrain(instance))
   {
-    if (G->defers() && n > 0 && n <= 2 && ops)
-    { // (short lists: the search's; a whole-tree list goes to the shards at once) -- validated here as the shards would
+    if (G->defers() && n > 0 && ops)
+    { // (any list: a whole tree's is then queued on the shards side by side, by their helper threads) -- validated here as the shards would
       for (int i = 0; i < n; ++i)
       {
         const phyhip_operation &o = ops[i];
@@ -941,6 +943,7 @@ int phyhip_update_partials(int instance, const phyhip_operation *ops, int n, int
       d.kind = 0; d.ops.assign(ops, ops + n);
       G->deferred.push_back(std::move(d));
       G->deferred_ops += (size_t)n;
+      if (G->deferred.size() >= 4096 && group_drain(G)) return group_take_drain_error(G); // (a caller that only ever queues)
       return PHYHIP_SUCCESS;
     }
     int rc = group_drain(G);

@@ -65,6 +65,47 @@ def test_virtual_buffers_per_shard_under_helper_threads(ns, P):
             t.close(); t1.close()
 
 
+def test_recorded_queue_only_calls_reach_the_shards_in_order():
+    """A group with helper threads records the queue-only calls (phyhip_shard.hpp: Group::deferred) and replays them on the shards' own
+    threads in front of whatever needs them.  Thousands of them without an evaluation in between (the list drains itself), matrix
+    refreshes and partial updates interleaved, a getter right behind a recorded update (drained by get_group), argument errors
+    reported at the call: the sharded instance ends where the plain instance ends, buffer for buffer."""
+    t, ot, tree, st = synthetic_pair(20, 900, 4, 4, seed=5, host_pmat=False, devices=[0, 0, 0])
+    t1, _, _, _ = synthetic_pair(20, 900, 4, 4, seed=5, host_pmat=False)
+    try:
+        for x in (t, t1):
+            x.Set_Both_Sides(True)
+            x.Lk(None)
+        order = []
+        ot.post_order(ot.tip_root, ot.adj[ot.tip_root][0][0], ops=order)
+        rng = np.random.default_rng(3)
+        n_calls = 0
+        while n_calls < 5000:
+            e = int(rng.integers(0, ot.ne))
+            l = float(10.0 ** rng.uniform(-3, 0))
+            for x in (t, t1):
+                x.inst.update_transition_matrices(np.array([e], np.int32), np.array([l]))
+            n_calls += 1
+            for (b, dd) in order[:: max(1, len(order) // 3)]:
+                for x in (t, t1):
+                    x.Update_Partial_Lk(b, dd)
+                n_calls += 1
+        b, dd = order[-1]
+        side = 0 if dd == ot.el[b] else 1
+        assert np.array_equal(t.partials(b, side), t1.partials(b, side))          # a getter behind recorded updates
+        for (b, dd) in order:
+            for x in (t, t1):
+                x.Update_Partial_Lk(b, dd)
+        e = ot.root_edge()
+        a, c = t.Lk(e), t1.Lk(e)
+        assert abs(a - c) <= 1e-12 * abs(c)
+        with pytest.raises(Exception):
+            t.inst.update_partials([(t.inst.nbuf + 5, 0, 0, 1, 1)])               # reported at the call, not at the replay
+        assert abs(t.Lk(e) - c) <= 1e-12 * abs(c)
+    finally:
+        t.close(); t1.close()
+
+
 def test_sharded_mixtures_under_helper_threads():
     """The mixture tests' sharded layouts (class instances and the class axis, lnL and dLk) once more with the helper threads on."""
     import test_gpu_mixture as tm
