@@ -265,14 +265,20 @@ static double one_class(const double *left, const double *rght, const double *Pi
       const double *row = Pij + state * ns;
       if (ns == 4)
       { /* :121-123: elementwise product, then AVX_Vect_Norm = (x0+x2)+(x1+x3) (src/avx.c:281-289) */
-        double q0 = row[0] * left[0], q1 = row[1] * left[1], q2 = row[2] * left[2], q3 = row[3] * left[3];
+        /* (volatile: the reference multiplies as a vector and hands the products to AVX_Vect_Norm, a call -- its binary has no fused
+           multiply-add here, and this restatement must not grow one under -mfma) */
+        volatile double q0 = row[0] * left[0], q1 = row[1] * left[1], q2 = row[2] * left[2], q3 = row[3] * left[3];
         return pi[state] * ((q0 + q2) + (q1 + q3));
       }
-      /* :163-176: per-lane sums of the blockwise products, then the horizontal norm.  (Whether the
-         reference's multiply+add pairs were fused is the compiler's choice; tests allow 1e-14.) */
+      /* :163-176: the blockwise products (stored, in the reference's binary, before they are added: no fused multiply-add), their
+         per-lane sums in block order, then the horizontal norm */
       double lane[4] = {0., 0., 0., 0.};
       for (int b = 0; b < ns / 4; ++b)
-        for (int k = 0; k < 4; ++k) lane[k] = lane[k] + row[b * 4 + k] * left[b * 4 + k];
+        for (int k = 0; k < 4; ++k)
+        {
+          volatile double prod = row[b * 4 + k] * left[b * 4 + k];
+          lane[k] = lane[k] + prod;
+        }
       return pi[state] * ((lane[0] + lane[2]) + (lane[1] + lane[3]));
     }
     else

@@ -71,9 +71,11 @@ def test_lnl_and_site_outputs(name, evaluated):
     w = d["wght"] > 0
     assert abs(lnl - d["lnL"][0]) / abs(d["lnL"][0]) < 1e-14
     assert np.array_equal(fact[w], d["fact_sum_scale"][w])
-    assert np.max(np.abs(site[w] - d["c_lnL_sorted"][w])) < 1e-12
-    assert np.allclose(unscaled[w], d["unscaled_site_lk_cat"][w], rtol=1e-13, atol=0)
-    assert np.allclose(cur[w], d["cur_site_lk"][w], rtol=1e-12, atol=0)
+    # every per-site output the reference keeps, bit for bit (round 6: the tip branch of one_class no longer lets the compiler fuse
+    # a multiply-add the reference's binary does not have)
+    assert np.array_equal(site[w], d["c_lnL_sorted"][w])
+    assert np.array_equal(unscaled[w], d["unscaled_site_lk_cat"][w])
+    assert np.array_equal(cur[w], d["cur_site_lk"][w])
 
 
 @pytest.mark.parametrize("name", FIXTURES)
